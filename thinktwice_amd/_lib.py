@@ -1,0 +1,55 @@
+"""ctypes binding of libthinktwice_hip.so -- the ONLY compute backend.
+
+There is deliberately no CPU or eager-PyTorch fallback: if the library is not
+built, or a call fails, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libthinktwice_hip.so")
+
+TT_F32, TT_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU, ACT_SOFTPLUS = 0, 1, 2, 3, 4
+
+_lib = None
+
+
+class TTError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raise loudly if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TTError(
+                f"{LIB_PATH} is missing: run `python -m thinktwice_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no fallback path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.tt_last_error.restype = ctypes.c_char_p
+        _lib.tt_version.restype = ctypes.c_int
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise TTError(f"{what} failed (rc={rc}): {lib().tt_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or NULL)."""
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def cur_stream(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise TTError("thinktwice_amd ops need device tensors (MI355X); got a CPU tensor. "
+                          "There is no CPU path in the product -- see oracle/ for the checker.")

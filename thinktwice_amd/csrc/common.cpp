@@ -1,0 +1,19 @@
+// Error reporting + version for libthinktwice_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/thinktwice_hip.h"
+
+namespace tt {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace tt
+
+extern "C" const char* tt_last_error(void) { return tt::g_err; }
+extern "C" int tt_version(void) { return 100; }

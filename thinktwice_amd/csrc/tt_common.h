@@ -1,0 +1,69 @@
+// Shared host/device helpers for libthinktwice_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/thinktwice_hip.h"
+
+namespace tt {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return -2;
+    }
+    return 0;
+}
+
+#define TT_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            ::tt::set_error(__VA_ARGS__);     \
+            return -1;                        \
+        }                                     \
+    } while (0)
+
+constexpr int kWave = 64;
+constexpr int kNumCU = 256;
+
+static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// bf16 <-> f32 bit helpers (round-to-nearest-even), usable on device.
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) {
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kVec = 4;  // elements per 16-byte vector
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<uint16_t> {  // bf16 storage
+    static constexpr int kVec = 8;
+    __device__ static __forceinline__ float ld(const uint16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case TT_ACT_RELU: return v > 0.f ? v : 0.f;
+        case TT_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case TT_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case TT_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
+        default: return v;
+    }
+}
+
+}  // namespace tt

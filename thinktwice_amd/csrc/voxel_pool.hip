@@ -1,0 +1,452 @@
+// Lift-Splat "splat" kernels for gfx950 (wave64).
+//
+//  tt_voxel_pool_fwd       op-boundary drop-in for the reference CUDA kernel
+//                          (ops/voxel_pooling/src/voxel_pooling_forward_cuda.cu:9-36).
+//  tt_voxel_pool_bwd       VoxelPooling.backward (ops/voxel_pooling/voxel_pooling.py:57-69).
+//  tt_frustum_voxel_index  LSS.get_geometry + voxel index (backbones/lss.py:474-512,629-631).
+//  tt_lift_splat_fwd       fused depth-softmax (x) context -> BEV (lss.py:583-615 + splat).
+//
+// Design (HBM-bound): the reference walks one point per THREAD
+// (64 lanes 1 KiB apart => every load and atomic uncoalesced).  Here one WAVE
+// owns a point row: 64 lanes x float4 = one fully coalesced 1 KiB row load,
+// rows of out-of-range points are never fetched, consecutive points that fall
+// in the same BEV cell are summed in registers and flushed with one atomic per
+// channel (wave-level pre-reduction), and 4 row loads are kept in flight per wave.
+#include "tt_common.h"
+
+namespace tt {
+
+// ---------------------------------------------------------------------------
+// forward, C % 4 == 0.  NV = float4 chunks per lane = ceil(C / 256).
+// ---------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void voxel_pool_rows_kernel(
+    long long total_points, int num_points, int C, int X, int Y, int Z,
+    const int32_t* __restrict__ geom, const float* __restrict__ feats,
+    float* __restrict__ out, int32_t* __restrict__ pos_memo) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long nchunks = (total_points + 63) >> 6;
+    const int c4 = C >> 2;
+
+    for (long long chunk = wave; chunk < nchunks; chunk += nwaves) {
+        const long long p = chunk * 64 + lane;
+        int cell = -1;
+        if (p < total_points) {
+            const int x = geom[p * 3 + 0];
+            const int y = geom[p * 3 + 1];
+            const int z = geom[p * 3 + 2];
+            if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {
+                const int b = (int)(p / num_points);
+                cell = (b * Y + y) * X + x;
+                if (pos_memo) {
+                    pos_memo[p * 3 + 0] = b;
+                    pos_memo[p * 3 + 1] = y;
+                    pos_memo[p * 3 + 2] = x;
+                }
+            }
+        }
+        unsigned long long mask = __ballot(cell >= 0);
+        int cur = -1;
+        float4 acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        while (mask) {
+            // up to 4 valid points per round: issue all row loads first.
+            int idx[4];
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (mask) {
+                    idx[j] = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    cnt = j + 1;
+                } else {
+                    idx[j] = 0;
+                }
+            }
+            float4 row[4][NV];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < cnt) {
+                    const float4* src =
+                        reinterpret_cast<const float4*>(feats + (chunk * 64 + idx[j]) * (long long)C);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const int ch = lane + 64 * v;
+                        row[j][v] = (ch < c4) ? src[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < cnt) {
+                    const int c = __builtin_amdgcn_readlane(cell, idx[j]);
+                    if (c != cur) {
+                        if (cur >= 0) {
+#pragma unroll
+                            for (int v = 0; v < NV; ++v) {
+                                const int ch = lane + 64 * v;
+                                if (ch < c4) {
+                                    float* dst = out + (long long)cur * C + ch * 4;
+                                    unsafeAtomicAdd(dst + 0, acc[v].x);
+                                    unsafeAtomicAdd(dst + 1, acc[v].y);
+                                    unsafeAtomicAdd(dst + 2, acc[v].z);
+                                    unsafeAtomicAdd(dst + 3, acc[v].w);
+                                }
+                            }
+                        }
+                        cur = c;
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) acc[v] = row[j][v];
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) {
+                            acc[v].x += row[j][v].x;
+                            acc[v].y += row[j][v].y;
+                            acc[v].z += row[j][v].z;
+                            acc[v].w += row[j][v].w;
+                        }
+                    }
+                }
+            }
+        }
+        if (cur >= 0) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int ch = lane + 64 * v;
+                if (ch < c4) {
+                    float* dst = out + (long long)cur * C + ch * 4;
+                    unsafeAtomicAdd(dst + 0, acc[v].x);
+                    unsafeAtomicAdd(dst + 1, acc[v].y);
+                    unsafeAtomicAdd(dst + 2, acc[v].z);
+                    unsafeAtomicAdd(dst + 3, acc[v].w);
+                }
+            }
+        }
+    }
+}
+
+// Generic fallback (any C): one thread per (point, channel).  Correctness path
+// for odd channel counts only.
+__global__ __launch_bounds__(256) void voxel_pool_scalar_kernel(
+    long long total_points, int num_points, int C, int X, int Y, int Z,
+    const int32_t* __restrict__ geom, const float* __restrict__ feats,
+    float* __restrict__ out, int32_t* __restrict__ pos_memo) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long p = t / C;
+    const int c = (int)(t % C);
+    if (p >= total_points) return;
+    const int x = geom[p * 3 + 0], y = geom[p * 3 + 1], z = geom[p * 3 + 2];
+    if (x < 0 || x >= X || y < 0 || y >= Y || z < 0 || z >= Z) return;
+    const int b = (int)(p / num_points);
+    if (pos_memo && c == 0) {
+        pos_memo[p * 3 + 0] = b;
+        pos_memo[p * 3 + 1] = y;
+        pos_memo[p * 3 + 2] = x;
+    }
+    unsafeAtomicAdd(out + ((long long)(b * Y + y) * X + x) * C + c, feats[p * C + c]);
+}
+
+// ---------------------------------------------------------------------------
+// backward: pure gather, one float4 per thread.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void voxel_pool_bwd_kernel(
+    long long total_points, int C, int X, int Y, const int32_t* __restrict__ pos_memo,
+    const float* __restrict__ grad_out, float* __restrict__ grad_in) {
+    const int c4 = C >> 2;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long p = t / c4;
+    const int ch = (int)(t % c4);
+    if (p >= total_points) return;
+    const int b = pos_memo[p * 3 + 0];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b != -1) {
+        const int y = pos_memo[p * 3 + 1], x = pos_memo[p * 3 + 2];
+        v = reinterpret_cast<const float4*>(grad_out + ((long long)(b * Y + y) * X + x) * C)[ch];
+    }
+    reinterpret_cast<float4*>(grad_in + p * C)[ch] = v;
+}
+
+__global__ __launch_bounds__(256) void voxel_pool_bwd_scalar_kernel(
+    long long total_points, int C, int X, int Y, const int32_t* __restrict__ pos_memo,
+    const float* __restrict__ grad_out, float* __restrict__ grad_in) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long p = t / C;
+    const int c = (int)(t % C);
+    if (p >= total_points) return;
+    const int b = pos_memo[p * 3 + 0];
+    float v = 0.f;
+    if (b != -1) {
+        const int y = pos_memo[p * 3 + 1], x = pos_memo[p * 3 + 2];
+        v = grad_out[((long long)(b * Y + y) * X + x) * C + c];
+    }
+    grad_in[p * C + c] = v;
+}
+
+// ---------------------------------------------------------------------------
+// frustum -> ego -> voxel index.  Products and sums are written as separate
+// IEEE roundings in k order (no FMA contraction) so the oracle can restate the
+// exact same arithmetic.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dot4_seq(const float* m, float a, float b, float c, float d) {
+    float s = __fmul_rn(m[0], a);
+    s = __fadd_rn(s, __fmul_rn(m[1], b));
+    s = __fadd_rn(s, __fmul_rn(m[2], c));
+    s = __fadd_rn(s, __fmul_rn(m[3], d));
+    return s;
+}
+
+__global__ __launch_bounds__(256) void frustum_voxel_index_kernel(
+    int B, int ncam, int D, int fH, int fW, const float* __restrict__ frustum,
+    const float* __restrict__ mats, float lox, float loy, float loz, float sx, float sy, float sz,
+    int32_t* __restrict__ geom_xyz, float* __restrict__ geom_f32) {
+    const long long per_cam = (long long)D * fH * fW;
+    const long long total = (long long)B * ncam * per_cam;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const long long bc = t / per_cam;
+    const long long q = t % per_cam;
+    const float* iida = mats + bc * 32;
+    const float* comb = iida + 16;
+    const float4 f = reinterpret_cast<const float4*>(frustum)[q];
+    float p0 = dot4_seq(iida + 0, f.x, f.y, f.z, f.w);
+    float p1 = dot4_seq(iida + 4, f.x, f.y, f.z, f.w);
+    float p2 = dot4_seq(iida + 8, f.x, f.y, f.z, f.w);
+    float p3 = dot4_seq(iida + 12, f.x, f.y, f.z, f.w);
+    p0 = __fmul_rn(p0, p2);
+    p1 = __fmul_rn(p1, p2);
+    const float gx = dot4_seq(comb + 0, p0, p1, p2, p3);
+    const float gy = dot4_seq(comb + 4, p0, p1, p2, p3);
+    const float gz = dot4_seq(comb + 8, p0, p1, p2, p3);
+    if (geom_f32) {
+        geom_f32[t * 3 + 0] = gx;
+        geom_f32[t * 3 + 1] = gy;
+        geom_f32[t * 3 + 2] = gz;
+    }
+    // (geom - lo) / size, truncated toward zero like Tensor.int() (lss.py:630-631)
+    geom_xyz[t * 3 + 0] = (int)__fdiv_rn(__fsub_rn(gx, lox), sx);
+    geom_xyz[t * 3 + 1] = (int)__fdiv_rn(__fsub_rn(gy, loy), sy);
+    geom_xyz[t * 3 + 2] = (int)__fdiv_rn(__fsub_rn(gz, loz), sz);
+}
+
+// ---------------------------------------------------------------------------
+// fused lift-splat: one wave per image pixel (b, cam, h, w).
+//   prob[d] = softmax_d(depth_logits[pix, :]);  out[cell(pix,d), :] += prob[d] * ctx[pix, :]
+// Consecutive depth bins of one ray that fall in the same BEV cell are merged
+// (sum of probabilities) before touching memory.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void lift_splat_kernel(
+    int B, int ncam, int D, int fH, int fW, int C, int X, int Y, int Z,
+    const T* __restrict__ depth_logits, const T* __restrict__ ctx,
+    const int32_t* __restrict__ geom, float* __restrict__ out, int out_cstride, int out_coff,
+    int rot_flip) {
+    const int lane = threadIdx.x & 63;
+    const long long pix = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long npix = (long long)B * ncam * fH * fW;
+    if (pix >= npix) return;
+    const int hw = (int)(pix % ((long long)fH * fW));
+    const int bc = (int)(pix / ((long long)fH * fW));
+    const int b = bc / ncam;
+    const int cam = bc % ncam;
+
+    // ---- softmax over D (D <= 128: two bins per lane)
+    const T* lg = depth_logits + pix * D;
+    float l0 = (lane < D) ? Elem<T>::ld(lg + lane) : -INFINITY;
+    float l1 = (lane + 64 < D) ? Elem<T>::ld(lg + lane + 64) : -INFINITY;
+    float m = fmaxf(l0, l1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float e0 = (lane < D) ? expf(l0 - m) : 0.f;
+    float e1 = (lane + 64 < D) ? expf(l1 - m) : 0.f;
+    float s = e0 + e1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float inv = 1.f / s;
+    e0 *= inv;
+    e1 *= inv;
+
+    // ---- cell per depth bin
+    const long long per_cam = (long long)D * fH * fW;
+    const int32_t* g = geom + ((long long)b * ncam * per_cam + (long long)cam * per_cam) * 3;
+    int cell0 = -1, cell1 = -1;
+    if (lane < D) {
+        const int32_t* q = g + ((long long)lane * fH * fW + hw) * 3;
+        const int x = q[0], y = q[1], z = q[2];
+        if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) cell0 = y * X + x;
+    }
+    if (lane + 64 < D) {
+        const int32_t* q = g + ((long long)(lane + 64) * fH * fW + hw) * 3;
+        const int x = q[0], y = q[1], z = q[2];
+        if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) cell1 = y * X + x;
+    }
+
+    // ---- context row in registers (C <= 1024: up to 4 float4-chunks per lane)
+    const int c4 = C >> 2;
+    float4 cv[4];
+    const T* crow = ctx + pix * C;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int ch = lane + 64 * v;
+        if (ch < c4) {
+            cv[v].x = Elem<T>::ld(crow + ch * 4 + 0);
+            cv[v].y = Elem<T>::ld(crow + ch * 4 + 1);
+            cv[v].z = Elem<T>::ld(crow + ch * 4 + 2);
+            cv[v].w = Elem<T>::ld(crow + ch * 4 + 3);
+        } else {
+            cv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
+    int cur = -1;
+    float w = 0.f;
+    auto flush = [&](int cell, float wsum) {
+        int y = cell / X, x = cell % X;
+        int oi = y, oj = x;
+        if (rot_flip) {  // rot90(flip(bev,[2]),1,[2,3]): out[i][j] = bev[Y-1-j][X-1-i]
+            oi = X - 1 - x;
+            oj = Y - 1 - y;
+        }
+        const int OW = rot_flip ? Y : X;
+        const int OH = rot_flip ? X : Y;
+        float* dst = out + (((long long)b * OH + oi) * OW + oj) * out_cstride + out_coff;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int ch = lane + 64 * v;
+            if (ch < c4) {
+                unsafeAtomicAdd(dst + ch * 4 + 0, wsum * cv[v].x);
+                unsafeAtomicAdd(dst + ch * 4 + 1, wsum * cv[v].y);
+                unsafeAtomicAdd(dst + ch * 4 + 2, wsum * cv[v].z);
+                unsafeAtomicAdd(dst + ch * 4 + 3, wsum * cv[v].w);
+            }
+        }
+    };
+    for (int d = 0; d < D; ++d) {
+        const int src_lane = d & 63;
+        const int c = (d < 64) ? __builtin_amdgcn_readlane(cell0, src_lane)
+                               : __builtin_amdgcn_readlane(cell1, src_lane);
+        const float pr = __uint_as_float(
+            (d < 64) ? __builtin_amdgcn_readlane(__float_as_uint(e0), src_lane)
+                     : __builtin_amdgcn_readlane(__float_as_uint(e1), src_lane));
+        if (c != cur) {
+            if (cur >= 0) flush(cur, w);
+            cur = c;
+            w = 0.f;
+        }
+        w += pr;
+    }
+    if (cur >= 0) flush(cur, w);
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" int tt_voxel_pool_fwd(int batch_size, int num_points, int num_channels,
+                                 int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                 const int32_t* geom_xyz, const float* input_features,
+                                 float* output_features, int32_t* pos_memo, void* stream) {
+    TT_REQUIRE(batch_size >= 0 && num_points >= 0 && num_channels > 0,
+               "tt_voxel_pool_fwd: bad sizes B=%d Np=%d C=%d", batch_size, num_points, num_channels);
+    TT_REQUIRE(num_voxel_x > 0 && num_voxel_y > 0 && num_voxel_z > 0,
+               "tt_voxel_pool_fwd: bad voxel grid");
+    const long long total = (long long)batch_size * num_points;
+    if (total == 0) return 0;
+    TT_REQUIRE(geom_xyz && input_features && output_features, "tt_voxel_pool_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int C = num_channels;
+    if (C % 4 == 0 && C <= 1024 &&
+        (reinterpret_cast<uintptr_t>(input_features) & 15) == 0) {
+        const long long nchunks = (total + 63) / 64;
+        // ~8 chunks per wave keeps 2048+ blocks on big inputs and still fills the chip on small ones
+        long long blocks = (nchunks + 4 * 8 - 1) / (4 * 8);
+        if (blocks < 1) blocks = 1;
+        if (blocks > kNumCU * 16) blocks = kNumCU * 16;
+        const int nv = (C / 4 + 63) / 64;
+#define LAUNCH(NV)                                                                             \
+    hipLaunchKernelGGL(voxel_pool_rows_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st,  \
+                       total, num_points, C, num_voxel_x, num_voxel_y, num_voxel_z, geom_xyz, \
+                       input_features, output_features, pos_memo)
+        switch (nv) {
+            case 1: LAUNCH(1); break;
+            case 2: LAUNCH(2); break;
+            case 3: LAUNCH(3); break;
+            default: LAUNCH(4); break;
+        }
+#undef LAUNCH
+    } else {
+        const long long threads = total * C;
+        hipLaunchKernelGGL(voxel_pool_scalar_kernel, dim3((unsigned)div_up(threads, 256)), dim3(256),
+                           0, st, total, num_points, C, num_voxel_x, num_voxel_y, num_voxel_z,
+                           geom_xyz, input_features, output_features, pos_memo);
+    }
+    return check_launch("tt_voxel_pool_fwd");
+}
+
+extern "C" int tt_voxel_pool_bwd(int batch_size, int num_points, int num_channels,
+                                 int num_voxel_x, int num_voxel_y, const int32_t* pos_memo,
+                                 const float* grad_out_bhwc, float* grad_in, void* stream) {
+    const long long total = (long long)batch_size * num_points;
+    if (total == 0) return 0;
+    TT_REQUIRE(pos_memo && grad_out_bhwc && grad_in, "tt_voxel_pool_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int C = num_channels;
+    if (C % 4 == 0) {
+        const long long threads = total * (C / 4);
+        hipLaunchKernelGGL(voxel_pool_bwd_kernel, dim3((unsigned)div_up(threads, 256)), dim3(256), 0,
+                           st, total, C, num_voxel_x, num_voxel_y, pos_memo, grad_out_bhwc, grad_in);
+    } else {
+        const long long threads = total * C;
+        hipLaunchKernelGGL(voxel_pool_bwd_scalar_kernel, dim3((unsigned)div_up(threads, 256)),
+                           dim3(256), 0, st, total, C, num_voxel_x, num_voxel_y, pos_memo,
+                           grad_out_bhwc, grad_in);
+    }
+    return check_launch("tt_voxel_pool_bwd");
+}
+
+extern "C" int tt_frustum_voxel_index(int batch_size, int num_cams, int D, int fH, int fW,
+                                      const float* frustum, const float* mats,
+                                      const float* voxel_lo, const float* voxel_size,
+                                      int32_t* geom_xyz, float* geom_f32_or_null, void* stream) {
+    TT_REQUIRE(frustum && mats && voxel_lo && voxel_size && geom_xyz,
+               "tt_frustum_voxel_index: null pointer");
+    const long long total = (long long)batch_size * num_cams * D * fH * fW;
+    if (total == 0) return 0;
+    // voxel_lo / voxel_size are HOST pointers (3 floats each): module constants.
+    hipLaunchKernelGGL(frustum_voxel_index_kernel, dim3((unsigned)div_up(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, batch_size, num_cams, D, fH, fW, frustum, mats,
+                       voxel_lo[0], voxel_lo[1], voxel_lo[2], voxel_size[0], voxel_size[1],
+                       voxel_size[2], geom_xyz, geom_f32_or_null);
+    return check_launch("tt_frustum_voxel_index");
+}
+
+extern "C" int tt_lift_splat_fwd(int batch_size, int num_cams, int D, int fH, int fW, int C,
+                                 int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                 const void* depth_logits, const void* context, int dtype,
+                                 const int32_t* geom_xyz, float* out, int out_cstride, int out_coff,
+                                 int rot_flip, void* stream) {
+    TT_REQUIRE(depth_logits && context && geom_xyz && out, "tt_lift_splat_fwd: null pointer");
+    TT_REQUIRE(D > 0 && D <= 128, "tt_lift_splat_fwd: D=%d unsupported (1..128)", D);
+    TT_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "tt_lift_splat_fwd: C=%d unsupported", C);
+    const long long npix = (long long)batch_size * num_cams * fH * fW;
+    if (npix == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)div_up(npix, 4);
+    if (dtype == TT_F32) {
+        hipLaunchKernelGGL(lift_splat_kernel<float>, dim3(blocks), dim3(256), 0, st, batch_size,
+                           num_cams, D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z,
+                           (const float*)depth_logits, (const float*)context, geom_xyz, out,
+                           out_cstride, out_coff, rot_flip);
+    } else if (dtype == TT_BF16) {
+        hipLaunchKernelGGL(lift_splat_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, batch_size,
+                           num_cams, D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z,
+                           (const uint16_t*)depth_logits, (const uint16_t*)context, geom_xyz, out,
+                           out_cstride, out_coff, rot_flip);
+    } else {
+        TT_REQUIRE(false, "tt_lift_splat_fwd: bad dtype %d", dtype);
+    }
+    return check_launch("tt_lift_splat_fwd");
+}

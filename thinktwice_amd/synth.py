@@ -1,0 +1,67 @@
+"""Seeded synthetic inputs with the shapes/dtypes of the reference's `forward_inference`
+batch (input contract: open_loop_training/code/datasets/carla_dataset.py:263-334,
+leaderboard/team_code/thinktwice_agent.py:444-454).  SURVEY.md section 8(d)."""
+import numpy as np
+import torch
+
+from . import calib
+
+
+def make_img_metas(batch_size, num_sweeps=2, curr2key=None):
+    """img_metas[b][t] dicts with the keys LSS.forward reads (backbones/lss.py:667-707)."""
+    intr, l2c, l2i = calib.camera_tables()
+    ida = np.stack([calib.eval_ida_mat() for _ in range(4)])
+    metas = []
+    for _ in range(batch_size):
+        per_sweep = []
+        for t in range(num_sweeps):
+            c2k = np.eye(4, dtype=np.float32)
+            if curr2key is not None and t < num_sweeps - 1:
+                c2k = np.asarray(curr2key, dtype=np.float32)
+            per_sweep.append({
+                "cam_intrinsic": torch.from_numpy(intr.copy()),
+                "ida_mats": torch.from_numpy(ida.copy()),
+                # carla_dataset.py:290,312: lidar2cam @ curr2key (key frame: identity)
+                "currlidar2keycam": torch.from_numpy(l2c @ c2k),
+                "lidar2cam": torch.from_numpy(l2c.copy()),
+                "lidar2img": torch.from_numpy(l2i.copy()),
+            })
+        metas.append(per_sweep)
+    return metas
+
+
+def make_batch(batch_size, seed=1234, num_points=65536, img_hw=(calib.FINAL_H, calib.FINAL_W),
+               device="cpu", with_img=True):
+    """Synthetic `forward_inference` batch: img N(0,1) (B,2,4,3,H,W); points (B,1,Np,5)
+    uniform in the point-cloud range with z<4; speed/target_point/command."""
+    imgs, pts, speed, tp, cmd = [], [], [], [], []
+    for i in range(batch_size):
+        g = torch.Generator().manual_seed(seed + i)
+        if with_img:
+            imgs.append(torch.randn(2, 4, 3, img_hw[0], img_hw[1], generator=g))
+        u = torch.rand(num_points, 5, generator=g)
+        p = torch.empty(num_points, 5)
+        p[:, 0] = -8.0 + u[:, 0] * 38.4
+        p[:, 1] = -19.2 + u[:, 1] * 38.4
+        p[:, 2] = -4.0 + u[:, 2] * 8.0
+        p[:, 3] = u[:, 3]
+        p[:, 4] = 0.0
+        p[num_points // 2:, 4] = -1.0
+        pts.append(p[None])
+        speed.append(torch.rand(1, generator=g) * 12.0)
+        tp.append(torch.randn(2, generator=g) * 10.0)
+        c = int(torch.randint(0, 6, (1,), generator=g))
+        oh = torch.zeros(6)
+        oh[c] = 1.0
+        cmd.append(oh)
+    batch = {
+        "points": torch.stack(pts).to(device),
+        "speed": torch.cat(speed).to(device),
+        "target_point": torch.stack(tp).to(device),
+        "target_command": torch.stack(cmd).to(device),
+        "target_command_raw": torch.stack(cmd).argmax(-1).to(device),
+        "img_metas": make_img_metas(batch_size),
+    }
+    if with_img:
+        batch["img"] = torch.stack(imgs).to(device)
+    return batch

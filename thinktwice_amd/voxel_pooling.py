@@ -1,0 +1,92 @@
+"""`voxel_pooling(geom_xyz, input_features, voxel_num)` -- host-side mirror of the
+reference operator (open_loop_training/ops/voxel_pooling/voxel_pooling.py:8-72),
+backed by the hand-written gfx950 kernel behind `tt_voxel_pool_fwd`.
+
+Same argument meaning, same return layout ([B, C, Y, X] view of a channel-last
+buffer), same error behaviour (asserts on non-contiguous inputs; device tensors
+required).  Differences that do not change results:
+  * no 514 MB `zeros_like(input_features)` is allocated in inference
+    (reference: voxel_pooling.py:29) -- the gradient buffer is created in backward;
+  * `voxel_num` entries are read once on the host (the reference converts three
+    0-dim tensors through pybind on every call: voxel_pooling.py:45-47).
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+
+def _voxel_num_tuple(voxel_num):
+    if isinstance(voxel_num, torch.Tensor):
+        voxel_num = voxel_num.detach().cpu().tolist()
+    vx, vy, vz = (int(v) for v in voxel_num)
+    return vx, vy, vz
+
+
+class VoxelPooling(Function):
+    @staticmethod
+    def forward(ctx, geom_xyz, input_features, voxel_num):
+        assert geom_xyz.is_contiguous()
+        assert input_features.is_contiguous()
+        _lib.require_cuda(geom_xyz, input_features)
+        if geom_xyz.dtype != torch.int32:
+            raise _lib.TTError("geom_xyz must be int32 (reference: lss.py:630-631 `.int()`)")
+        if input_features.dtype != torch.float32:
+            raise _lib.TTError("input_features must be float32")
+        ctx.mark_non_differentiable(geom_xyz)
+        in_shape = input_features.shape
+        geom_xyz = geom_xyz.reshape(geom_xyz.shape[0], -1, geom_xyz.shape[-1])
+        input_features = input_features.reshape(geom_xyz.shape[0], -1, input_features.shape[-1])
+        assert geom_xyz.shape[1] == input_features.shape[1]
+        B, Np, C = input_features.shape
+        vx, vy, vz = _voxel_num_tuple(voxel_num)
+        out = input_features.new_zeros(B, vy, vx, C)
+        need_memo = input_features.requires_grad
+        pos_memo = geom_xyz.new_full((B, Np, 3), -1) if need_memo else None
+        rc = _lib.lib().tt_voxel_pool_fwd(
+            ctypes.c_int(B), ctypes.c_int(Np), ctypes.c_int(C), ctypes.c_int(vx), ctypes.c_int(vy),
+            ctypes.c_int(vz), _lib.ptr(geom_xyz), _lib.ptr(input_features), _lib.ptr(out),
+            _lib.ptr(pos_memo), _lib.cur_stream(input_features.device))
+        _lib.check(rc, "tt_voxel_pool_fwd")
+        if need_memo:
+            ctx.save_for_backward(pos_memo)
+        ctx.in_shape = in_shape
+        ctx.vxy = (vx, vy)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_output_features):
+        (pos_memo,) = ctx.saved_tensors
+        B, Np, _ = pos_memo.shape
+        C = grad_output_features.shape[1]
+        vx, vy = ctx.vxy
+        g = grad_output_features.permute(0, 2, 3, 1).contiguous()  # [B,Y,X,C]
+        grad_in = g.new_empty(B, Np, C)
+        rc = _lib.lib().tt_voxel_pool_bwd(
+            ctypes.c_int(B), ctypes.c_int(Np), ctypes.c_int(C), ctypes.c_int(vx), ctypes.c_int(vy),
+            _lib.ptr(pos_memo), _lib.ptr(g), _lib.ptr(grad_in), _lib.cur_stream(g.device))
+        _lib.check(rc, "tt_voxel_pool_bwd")
+        return None, grad_in.reshape(ctx.in_shape), None
+
+
+def voxel_pooling(geom_xyz, input_features, voxel_num):
+    return VoxelPooling.apply(geom_xyz, input_features, voxel_num)
+
+
+def voxel_pooling_forward_wrapper(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y,
+                                  num_voxel_z, geom_xyz, input_features, output_features, pos_memo):
+    """Argument-for-argument mirror of the reference extension symbol
+    (ops/voxel_pooling/src/voxel_pooling_forward.cpp:24-37); returns 1."""
+    _lib.require_cuda(geom_xyz, input_features, output_features, pos_memo)
+    for name, t in (("geom_xyz", geom_xyz), ("input_features", input_features)):
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} must be contiguous ")
+    rc = _lib.lib().tt_voxel_pool_fwd(
+        ctypes.c_int(int(batch_size)), ctypes.c_int(int(num_points)), ctypes.c_int(int(num_channels)),
+        ctypes.c_int(int(num_voxel_x)), ctypes.c_int(int(num_voxel_y)), ctypes.c_int(int(num_voxel_z)),
+        _lib.ptr(geom_xyz), _lib.ptr(input_features), _lib.ptr(output_features), _lib.ptr(pos_memo),
+        _lib.cur_stream(input_features.device))
+    _lib.check(rc, "tt_voxel_pool_fwd")
+    return 1
