@@ -1,0 +1,129 @@
+"""Implicit-GEMM conv / linear kernel (tt_conv2d_fwd) vs a plain PyTorch fp32 reference of the
+same op on CPU.  Tolerances: f32 mode 1e-4 relative-to-max (exact-f32 MFMA, different sum order);
+bf16 mode 2e-2 (inputs rounded to bf16; reference evaluated on the same rounded inputs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, g, scale=1.0):
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _run(dt, N, H, W, Cin, Cout, k, stride=1, pad=0, dil=1, act=0, use_bn=True, res=0, seed=0):
+    from thinktwice_amd import ops, weights
+    g = torch.Generator().manual_seed(seed)
+    x = _mk((N, Cin, H, W), g)
+    w = _mk((Cout, Cin, k, k), g, (Cin * k * k) ** -0.5)
+    scale = (torch.rand(Cout, generator=g) + 0.5) if use_bn else None
+    shift = _mk((Cout,), g, 0.3)
+    xq = weights.to_channel_last(x, dt).cuda()
+    wq = weights.prep_conv_weight(w, dt).cuda()
+    x_ref = xq.float().cpu()[..., :Cin].permute(0, 3, 1, 2)
+    w_ref = wq.float().cpu()[..., :Cin].permute(0, 3, 1, 2)
+    ref = F.conv2d(x_ref, w_ref, None, stride, pad, dil)
+    if scale is not None:
+        ref = ref * scale.view(1, -1, 1, 1)
+    ref = ref + shift.view(1, -1, 1, 1)
+    r1 = r2 = None
+    if res >= 1:
+        r1 = _mk(tuple(ref.shape), g).permute(0, 2, 3, 1).contiguous().to(dt)
+        ref = ref + r1.float().permute(0, 3, 1, 2)
+    if res >= 2:
+        r2 = _mk(tuple(ref.shape), g).permute(0, 2, 3, 1).contiguous().to(dt)
+        ref = ref + r2.float().permute(0, 3, 1, 2)
+    ref = {0: lambda t: t, 1: F.relu, 2: torch.sigmoid, 3: F.gelu, 4: F.softplus}[act](ref)
+    out = ops.conv2d(xq, wq, stride=stride, pad=pad, dil=dil,
+                     scale=None if scale is None else scale.cuda(), shift=shift.cuda(), act=act,
+                     res1=None if r1 is None else r1.cuda(), res2=None if r2 is None else r2.cuda())
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    err = float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+    assert got.shape == ref.shape
+    assert err < tol, err
+
+
+CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil, act, bn, res
+    (2, 13, 17, 64, 128, 3, 1, 1, 1, 1, True, 1),     # ragged M, BasicBlock-like epilogue
+    (1, 28, 56, 256, 80, 1, 1, 0, 1, 0, False, 0),    # 1x1, Cout tail in a 128 tile
+    (2, 40, 48, 3, 64, 7, 2, 3, 1, 1, True, 0),       # ResNet stem (Cin 3 -> padded)
+    (1, 21, 21, 512, 256, 3, 2, 1, 1, 1, True, 0),    # stride 2
+    (1, 28, 56, 64, 64, 3, 1, 6, 6, 1, True, 0),      # ASPP dilation 6
+    (1, 30, 30, 64, 64, 3, 1, 18, 18, 1, True, 0),    # ASPP dilation 18
+    (2, 16, 16, 64, 12, 1, 1, 0, 1, 0, False, 0),     # seg head Cout=12
+    (2, 9, 9, 512, 18, 3, 1, 1, 1, 0, False, 0),      # DCN offset conv Cout=18
+    (3, 21, 21, 38, 32, 3, 1, 1, 1, 1, False, 0),     # SpatialGRU conv, Cin=38 (padded)
+    (2, 21, 21, 256, 256, 3, 1, 1, 1, 1, True, 2),    # conv_fusion: two residuals
+    (5, 1, 1, 1543, 512, 1, 1, 0, 1, 3, False, 0),    # linear 1543->512 + GELU, 5 rows
+    (300, 1, 1, 256, 1024, 1, 1, 0, 1, 2, False, 0),  # linear + sigmoid
+    (1, 7, 7, 128, 256, 3, 1, 0, 1, 4, False, 0),     # valid conv, softplus
+]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_matches_torch(dt, case):
+    N, H, W, Cin, Cout, k, s, p, d, act, bn, res = case
+    _run(dt, N, H, W, Cin, Cout, k, s, p, d, act, bn, res, seed=Cin + Cout + k)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_deconv2x2_pixel_shuffle(dt):
+    from thinktwice_amd import ops, weights
+    g = torch.Generator().manual_seed(3)
+    x = _mk((2, 256, 7, 14), g)
+    w = _mk((256, 128, 2, 2), g, 256 ** -0.5)
+    b = _mk((128,), g, 0.2)
+    xq = weights.to_channel_last(x, dt).cuda()
+    wq = weights.prep_deconv2x2_weight(w, dt).cuda()
+    ref = F.conv_transpose2d(xq.float().cpu().permute(0, 3, 1, 2),
+                             w.to(dt).float(), b, stride=2)
+    # write into the first 128 channels of a 384-channel concat buffer (UnetLayer.forward: cat)
+    buf = torch.zeros(2, 14, 28, 384, dtype=dt).cuda()
+    ops.conv2d(xq, wq, shift=b.cuda(), pixel_shuffle2=True, out=buf, out_coff=0)
+    got = buf.float().cpu()[..., :128].permute(0, 3, 1, 2)
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    assert float((got - ref).abs().max() / ref.abs().max()) < tol
+    assert float(buf[..., 128:].abs().max()) == 0.0
+
+
+def test_channel_offsets_strided_output_and_per_image_shift():
+    from thinktwice_amd import ops, weights
+    dt = torch.float32
+    g = torch.Generator().manual_seed(4)
+    x = _mk((8, 96, 6, 5), g)                      # use channels [32, 96) only
+    w = _mk((256, 64, 1, 1), g, 0.1)
+    b = _mk((256,), g, 0.2)
+    cam = _mk((4, 256), g)                          # per-camera embedding (DEC:392), image n -> cam n%4
+    xq = weights.to_channel_last(x, dt).cuda()
+    wq = weights.prep_conv_weight(w, dt).cuda()
+    ref = F.conv2d(x[:, 32:], w, b) + cam[torch.arange(8) % 4][:, :, None, None]
+    # value-buffer layout: [image][total_positions=50][256], this level occupies rows [20, 50)
+    val = torch.zeros(8, 50, 256).cuda()
+    flat = val.view(-1)
+    out_view = torch.as_strided(flat, (8, 6, 5, 256), (50 * 256, 5 * 256, 256, 1), 20 * 256)
+    import ctypes
+    d = ops._ConvDesc()
+    d.in_ = xq.data_ptr(); d.N = 8; d.H = 6; d.W = 5; d.Cin = 64; d.in_cstride = 96; d.in_coff = 32
+    d.weight = wq.data_ptr(); d.Cout = 256; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0; d.dil = 1
+    d.out = out_view.data_ptr(); d.OH = 6; d.OW = 5; d.out_cstride = 256; d.out_coff = 0
+    d.out_nstride = 50 * 256
+    bc, cc = b.cuda(), cam.cuda().contiguous()
+    d.shift = bc.data_ptr(); d.shift_n = cc.data_ptr(); d.shift_n_mod = 4
+    d.act = 0; d.dtype = 0; d.out_dtype = 0
+    ops.check(ops.lib().tt_conv2d_fwd(ctypes.byref(d), ops.cur_stream(xq.device)), "conv")
+    got = out_view.cpu().permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-4
+    assert float(val[:, :20].abs().max()) == 0.0
+
+
+def test_conv_rejects_unpadded_channels():
+    from thinktwice_amd import _lib, ops
+    x = torch.zeros(1, 4, 4, 6).cuda()
+    w = torch.zeros(8, 1, 1, 6).cuda()
+    with pytest.raises(_lib.TTError):
+        ops.conv2d(x, w)

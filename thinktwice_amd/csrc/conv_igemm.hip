@@ -1,0 +1,346 @@
+// Implicit-GEMM convolution / linear on gfx950 MFMA (wave64), channel-last activations.
+//
+//   C[M = N*OH*OW, Cout] = A[M, K = KH*KW*Cin] (gathered on the fly) x W[Cout, K]^T
+//
+// Replaces the cuDNN / cuBLAS calls behind every nn.Conv2d / nn.Linear / ConvTranspose2d(k2,s2)
+// of the reference forward: ResNet-50 + PAFPN (mmdet), DepthNet / UNet /
+// seg->feature / merge convs (backbones/lss.py:161-282,409-439), SECOND / SECONDFPN,
+// BEV fusion neck (encoder_decoder_framework.py:81-138) and the decoder's 1x1 / 3x3 convs
+// and row-batched linears (dense_heads/).
+//
+// Tiling (MI355X-first, not a warp-tile port):
+//   * 256 threads = 4 waves per workgroup, block tile BM x BN, K-tile = 64 B (f32) / 128 B
+//     (bf16) of contiguous K per row, both operands K-contiguous in LDS with a 16 B row pad
+//     (row stride 80 / 144 B => the four 16-lane groups of ds_read_b128 are conflict-free).
+//   * each wave owns TM x TN tiles of 32x32; f32 mode uses v_mfma_f32_32x32x2_f32 (exact
+//     f32, 157 TF peak), bf16 mode v_mfma_f32_32x32x16_bf16 (2.5 PF peak), f32 accumulate.
+//     One ds_read_b128 per operand feeds 4 (f32) or 1 (bf16) MFMA per k-chunk.
+//   * global->register->LDS double buffering: tile k+1 is fetched (16 B per lane, coalesced
+//     along Cin) while tile k is on the matrix pipe; one barrier per K-tile.
+//   * fused epilogue: BN/bias scale+shift, per-image shift, up to two residuals, activation,
+//     channel-offset / strided output (concat-free), ConvTranspose k2s2 pixel shuffle.
+#include "tt_common.h"
+
+namespace tt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvArgs {
+    const void* in;
+    const void* weight;
+    void* out;
+    const float* scale;
+    const float* shift;
+    const float* shift_n;
+    const void* res1;
+    const void* res2;
+    long long in_nstride, out_nstride;
+    int N, H, W, Cin, in_cstride, in_coff;
+    int Cout, KH, KW, stride, pad, dil;
+    int OH, OW, out_cstride, out_coff;
+    int pixel_shuffle2, shift_n_mod;
+    int res1_cstride, res1_coff, res2_cstride, res2_coff;
+    int act, out_dtype;
+    int M, K;            // GEMM sizes
+    int cin_fast;        // 1 if Cin % BK == 0 (tap uniform per K tile)
+    int out_fast;        // 1 if plain [M][out_cstride] addressing
+    int tiles_n;
+};
+
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+    // one 16 B vector (4 floats) per lane = 4 MFMAs of K=2 (lanes 0-31: k, lanes 32-63: k+4)
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<uint16_t> {
+    // one 16 B vector (8 bf16) per lane = 1 MFMA of K=16
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                    __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr int VEC = Elem<T>::kVec;               // elements per 16 B
+    constexpr int BKB = (sizeof(T) == 4) ? 64 : 128; // K bytes per row per tile
+    constexpr int BK = BKB / (int)sizeof(T);
+    constexpr int VPR = BKB / 16;                    // 16 B vectors per row
+    constexpr int ROWB = BKB + 16;                   // padded LDS row stride (bytes)
+    constexpr int NVA = (BM * VPR + 255) / 256;
+    constexpr int NVB = (BN * VPR + 255) / 256;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                          // [2][BM][ROWB]
+    unsigned char* sB = smem + 2 * BM * ROWB;          // [2][BN][ROWB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int tile_n = blockIdx.x % p.tiles_n;
+    const int tile_m = blockIdx.x / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(p.weight);
+
+    // ---- per-thread gather rows (fixed over the K loop)
+    int a_row[NVA], a_vc[NVA], a_h0[NVA], a_w0[NVA];
+    long long a_base[NVA];
+    bool a_ok[NVA];
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+        const int idx = tid + 256 * i;
+        a_row[i] = idx / VPR;
+        a_vc[i] = idx % VPR;
+        const int m = m0 + a_row[i];
+        a_ok[i] = (m < p.M) && (idx < BM * VPR);
+        const int mm = a_ok[i] ? m : 0;
+        const int n = mm / (p.OH * p.OW);
+        const int r = mm - n * (p.OH * p.OW);
+        const int oh = r / p.OW, ow = r - oh * p.OW;
+        a_h0[i] = oh * p.stride - p.pad;
+        a_w0[i] = ow * p.stride - p.pad;
+        a_base[i] = (long long)n * p.in_nstride + p.in_coff;
+    }
+    int b_row[NVB], b_vc[NVB];
+    bool b_ok[NVB];
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+        const int idx = tid + 256 * i;
+        b_row[i] = idx / VPR;
+        b_vc[i] = idx % VPR;
+        b_ok[i] = ((n0 + b_row[i]) < p.Cout) && (idx < BN * VPR);
+    }
+
+    const int nk = (p.K + BK - 1) / BK;
+    uint4 ra[NVA], rb[NVB];
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        int tap_u = 0, ci_u = 0, kh_u = 0, kw_u = 0;
+        if (p.cin_fast) {
+            tap_u = k0 / p.Cin;
+            ci_u = k0 - tap_u * p.Cin;
+            kh_u = tap_u / p.KW;
+            kw_u = tap_u - kh_u * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            int kh, kw, ci;
+            const int k = k0 + a_vc[i] * VEC;
+            if (p.cin_fast) {
+                kh = kh_u; kw = kw_u; ci = ci_u + a_vc[i] * VEC;
+            } else {
+                const int tap = k / p.Cin;
+                ci = k - tap * p.Cin;
+                kh = tap / p.KW;
+                kw = tap - kh * p.KW;
+            }
+            const int ih = a_h0[i] + kh * p.dil;
+            const int iw = a_w0[i] + kw * p.dil;
+            const bool ok = a_ok[i] && (k < p.K) && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            if (ok) {
+                const T* src = in + a_base[i] + ((long long)ih * p.W + iw) * p.in_cstride + ci;
+                ra[i] = *reinterpret_cast<const uint4*>(src);
+            } else {
+                ra[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int k = k0 + b_vc[i] * VEC;
+            if (b_ok[i] && k < p.K) {
+                rb[i] = *reinterpret_cast<const uint4*>(wgt + (long long)(n0 + b_row[i]) * p.K + k);
+            } else {
+                rb[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i)
+            if (tid + 256 * i < BM * VPR)
+                *reinterpret_cast<uint4*>(sA + (buf * BM + a_row[i]) * ROWB + a_vc[i] * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NVB; ++i)
+            if (tid + 256 * i < BN * VPR)
+                *reinterpret_cast<uint4*>(sB + (buf * BN + b_row[i]) * ROWB + b_vc[i] * 16) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frag_off = (lane & 31) * ROWB + (lane >> 5) * 16;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const unsigned char* tA = sA + (buf * BM + wm * WTM) * ROWB + frag_off;
+        const unsigned char* tB = sB + (buf * BN + wn * WTN) * ROWB + frag_off;
+#pragma unroll
+        for (int kc = 0; kc < BKB / 32; ++kc) {
+            uint4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const uint4*>(tA + i * 32 * ROWB + kc * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const uint4*>(tB + j * 32 * ROWB + kc * 32);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int cout_real = p.pixel_shuffle2 ? (p.Cout >> 2) : p.Cout;
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WTN + j * 32 + (lane & 31);
+        if (col >= p.Cout) continue;
+        int co = col, q = 0;
+        if (p.pixel_shuffle2) {
+            q = col / cout_real;
+            co = col - q * cout_real;
+        }
+        const float sc = p.scale ? p.scale[co] : 1.f;
+        const float sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] * sc + sh;
+                long long o;
+                int n = 0;
+                if (p.out_fast) {
+                    o = (long long)m * p.out_cstride + p.out_coff + co;
+                } else {
+                    n = m / ohw;
+                    const int rem = m - n * ohw;
+                    int oh = rem / p.OW, ow = rem - oh * p.OW;
+                    int OWo = p.OW;
+                    if (p.pixel_shuffle2) {
+                        oh = 2 * oh + (q >> 1);
+                        ow = 2 * ow + (q & 1);
+                        OWo = 2 * p.OW;
+                    }
+                    o = (long long)n * p.out_nstride + ((long long)oh * OWo + ow) * p.out_cstride +
+                        p.out_coff + co;
+                }
+                if (p.shift_n) {
+                    if (p.out_fast) n = m / ohw;
+                    v += p.shift_n[(n % p.shift_n_mod) * cout_real + co];
+                }
+                if (p.res1)
+                    v += Elem<T>::ld(reinterpret_cast<const T*>(p.res1) +
+                                     (long long)m * p.res1_cstride + p.res1_coff + co);
+                if (p.res2)
+                    v += Elem<T>::ld(reinterpret_cast<const T*>(p.res2) +
+                                     (long long)m * p.res2_cstride + p.res2_coff + co);
+                v = apply_act(v, p.act);
+                if (p.out_dtype == TT_F32)
+                    reinterpret_cast<float*>(p.out)[o] = v;
+                else
+                    reinterpret_cast<uint16_t*>(p.out)[o] = f32_to_bf16(v);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_conv(ConvArgs& a, hipStream_t st) {
+    constexpr int BKB = (sizeof(T) == 4) ? 64 : 128;
+    constexpr int BK = BKB / (int)sizeof(T);
+    constexpr int ROWB = BKB + 16;
+    const int tiles_m = div_up(a.M, BM);
+    a.tiles_n = div_up(a.Cout, BN);
+    a.cin_fast = (a.Cin % BK == 0) ? 1 : 0;
+    const size_t smem = (size_t)2 * (BM + BN) * ROWB;
+    auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+    static bool attr_set = false;
+    if (!attr_set && smem > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * a.tiles_n)), dim3(256), smem, st, a);
+    return check_launch("tt_conv2d_fwd");
+}
+
+template <typename T>
+static int dispatch_conv(ConvArgs& a, hipStream_t st) {
+    if (a.Cout > 64) return launch_conv<T, 128, 128, 2, 2>(a, st);
+    if (a.Cout > 32) return launch_conv<T, 128, 64, 2, 2>(a, st);
+    return launch_conv<T, 128, 32, 4, 1>(a, st);
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
+    TT_REQUIRE(d && d->in && d->weight && d->out, "tt_conv2d_fwd: null pointer");
+    TT_REQUIRE(d->dtype == TT_F32 || d->dtype == TT_BF16, "tt_conv2d_fwd: bad dtype %d", d->dtype);
+    TT_REQUIRE(d->out_dtype == TT_F32 || d->out_dtype == TT_BF16, "tt_conv2d_fwd: bad out_dtype");
+    const int vec = d->dtype == TT_F32 ? 4 : 8;
+    TT_REQUIRE(d->Cin > 0 && d->Cin % vec == 0 && d->in_cstride % vec == 0 && d->in_coff % vec == 0,
+               "tt_conv2d_fwd: Cin=%d in_cstride=%d in_coff=%d must be multiples of %d (pad channels)",
+               d->Cin, d->in_cstride, d->in_coff, vec);
+    TT_REQUIRE((reinterpret_cast<uintptr_t>(d->in) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(d->weight) & 15) == 0,
+               "tt_conv2d_fwd: in/weight must be 16-byte aligned");
+    TT_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 &&
+                   d->stride > 0 && d->dil > 0 && d->OH > 0 && d->OW > 0,
+               "tt_conv2d_fwd: bad geometry");
+    TT_REQUIRE(!d->pixel_shuffle2 || d->Cout % 4 == 0, "tt_conv2d_fwd: pixel_shuffle2 needs Cout%%4==0");
+    ConvArgs a;
+    a.in = d->in; a.weight = d->weight; a.out = d->out;
+    a.scale = d->scale; a.shift = d->shift; a.shift_n = d->shift_n;
+    a.res1 = d->res1; a.res2 = d->res2;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_cstride = d->in_cstride; a.in_coff = d->in_coff;
+    a.in_nstride = d->in_nstride ? d->in_nstride : (long long)d->H * d->W * d->in_cstride;
+    a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+    a.OH = d->OH; a.OW = d->OW; a.out_cstride = d->out_cstride; a.out_coff = d->out_coff;
+    const long long def_on = (long long)d->OH * d->OW * d->out_cstride * (d->pixel_shuffle2 ? 4 : 1);
+    a.out_nstride = d->out_nstride ? d->out_nstride : def_on;
+    a.pixel_shuffle2 = d->pixel_shuffle2;
+    a.shift_n_mod = d->shift_n_mod > 0 ? d->shift_n_mod : 1;
+    a.res1_cstride = d->res1_cstride; a.res1_coff = d->res1_coff;
+    a.res2_cstride = d->res2_cstride; a.res2_coff = d->res2_coff;
+    a.act = d->act; a.out_dtype = d->out_dtype;
+    a.M = d->N * d->OH * d->OW;
+    a.K = d->KH * d->KW * d->Cin;
+    a.out_fast = (!d->pixel_shuffle2 && a.out_nstride == (long long)d->OH * d->OW * d->out_cstride) ? 1 : 0;
+    TT_REQUIRE(!(d->pixel_shuffle2 && (d->res1 || d->res2)),
+               "tt_conv2d_fwd: residuals are not supported with pixel_shuffle2");
+    a.tiles_n = 1; a.cin_fast = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == TT_F32) return dispatch_conv<float>(a, st);
+    return dispatch_conv<uint16_t>(a, st);
+}

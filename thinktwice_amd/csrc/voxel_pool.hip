@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void voxel_pool_bwd_scalar_kernel(
 // exact same arithmetic.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float dot4_seq(const float* m, float a, float b, float c, float d) {
+#pragma clang fp contract(off)
     float s = __fmul_rn(m[0], a);
     s = __fadd_rn(s, __fmul_rn(m[1], b));
     s = __fadd_rn(s, __fmul_rn(m[2], c));
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(256) void frustum_voxel_index_kernel(
     int B, int ncam, int D, int fH, int fW, const float* __restrict__ frustum,
     const float* __restrict__ mats, float lox, float loy, float loz, float sx, float sy, float sz,
     int32_t* __restrict__ geom_xyz, float* __restrict__ geom_f32) {
+#pragma clang fp contract(off)
     const long long per_cam = (long long)D * fH * fW;
     const long long total = (long long)B * ncam * per_cam;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;

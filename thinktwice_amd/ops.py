@@ -57,3 +57,64 @@ def lift_splat(depth_logits, context, geom_xyz, voxel_num, batch_size, num_cams,
                                  cur_stream(context.device))
     check(rc, "tt_lift_splat_fwd")
     return out
+
+
+# ----------------------------------------------------------------------------- conv / linear
+class _ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("in_", ctypes.c_void_p), ("N", _c), ("H", _c), ("W", _c), ("Cin", _c), ("in_cstride", _c),
+        ("in_coff", _c), ("in_nstride", ctypes.c_longlong),
+        ("weight", ctypes.c_void_p), ("Cout", _c), ("KH", _c), ("KW", _c), ("stride", _c),
+        ("pad", _c), ("dil", _c),
+        ("out", ctypes.c_void_p), ("OH", _c), ("OW", _c), ("out_cstride", _c), ("out_coff", _c),
+        ("out_nstride", ctypes.c_longlong),
+        ("pixel_shuffle2", _c),
+        ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
+        ("shift_n", ctypes.c_void_p), ("shift_n_mod", _c),
+        ("res1", ctypes.c_void_p), ("res1_cstride", _c), ("res1_coff", _c),
+        ("res2", ctypes.c_void_p), ("res2_cstride", _c), ("res2_coff", _c),
+        ("act", _c), ("dtype", _c), ("out_dtype", _c),
+    ]
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=None, res1_coff=0,
+           res2=None, res2_coff=0, out=None, out_coff=0, in_coff=0, cin=None, pixel_shuffle2=False,
+           shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None):
+    """Channel-last implicit-GEMM convolution on MFMA (tt_conv2d_fwd).
+
+    x   [N,H,W,Cs]  (f32 or bf16); channels [in_coff, in_coff+cin) are convolved
+    w   [Cout,KH,KW,cin] same dtype (for pixel_shuffle2: [4*Cout_real,1,1,cin])
+    out [N,OH,OW,Ct] written at channel offset out_coff (allocated if None)
+    """
+    require_cuda(x, w)
+    assert x.is_contiguous() and w.is_contiguous() and x.dim() == 4 and w.dim() == 4
+    N, H, W, Cs = x.shape
+    Cout, KH, KW, Cin = w.shape
+    if cin is None:
+        cin = Cin
+    assert cin == Cin, (cin, Cin)
+    OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    cr = Cout // 4 if pixel_shuffle2 else Cout
+    if out is None:
+        odt = out_dtype or x.dtype
+        oh, ow = (2 * OH, 2 * OW) if pixel_shuffle2 else (OH, OW)
+        out = torch.empty(N, oh, ow, cr, dtype=odt, device=x.device)
+    d = _ConvDesc()
+    d.in_ = x.data_ptr(); d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.in_cstride = Cs; d.in_coff = in_coff
+    d.in_nstride = 0
+    d.weight = w.data_ptr(); d.Cout = Cout; d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad; d.dil = dil
+    d.out = out.data_ptr(); d.OH = OH; d.OW = OW
+    d.out_cstride = out.shape[-1]; d.out_coff = out_coff; d.out_nstride = out_nstride
+    d.pixel_shuffle2 = 1 if pixel_shuffle2 else 0
+    d.scale = _dp(scale); d.shift = _dp(shift); d.shift_n = _dp(shift_n); d.shift_n_mod = shift_n_mod
+    d.res1 = _dp(res1); d.res1_cstride = 0 if res1 is None else res1.shape[-1]; d.res1_coff = res1_coff
+    d.res2 = _dp(res2); d.res2_cstride = 0 if res2 is None else res2.shape[-1]; d.res2_coff = res2_coff
+    d.act = act; d.dtype = dtype_code(x); d.out_dtype = dtype_code(out)
+    rc = lib().tt_conv2d_fwd(ctypes.byref(d), cur_stream(x.device))
+    check(rc, "tt_conv2d_fwd")
+    return out

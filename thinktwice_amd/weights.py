@@ -1,0 +1,57 @@
+"""Checkpoint-tensor -> kernel-layout conversion (one-off, at load time; plumbing).
+
+The reference keeps PyTorch layouts in its state_dict ([Cout,Cin,KH,KW] convs, [out,in] linears,
+[Cin,Cout,2,2] transposed convs).  The MFMA kernels want K-contiguous rows
+[Cout][KH][KW][Cin_padded]; BatchNorm (eval) folds into a per-channel f32 scale/shift that the
+conv epilogue applies.
+"""
+import torch
+
+
+def vec_of(dtype):
+    return 4 if dtype == torch.float32 else 8
+
+
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def prep_conv_weight(w, dtype, cin_pad=None):
+    """[Cout,Cin,KH,KW] -> [Cout,KH,KW,Cin_p] contiguous in `dtype` (zero-padded input channels)."""
+    Cout, Cin, KH, KW = w.shape
+    cp = cin_pad or pad_to(Cin, vec_of(dtype))
+    out = torch.zeros(Cout, KH, KW, cp, dtype=dtype, device=w.device)
+    out[..., :Cin] = w.permute(0, 2, 3, 1).to(dtype)
+    return out.contiguous()
+
+
+def prep_linear_weight(w, dtype, in_pad=None):
+    """[out,in] -> [out,1,1,in_p]."""
+    return prep_conv_weight(w[:, :, None, None], dtype, in_pad)
+
+
+def prep_deconv2x2_weight(w, dtype):
+    """ConvTranspose2d(k=2,s=2) weight [Cin,Cout,2,2] -> [(dh*2+dw)*Cout+co, 1, 1, Cin_p]."""
+    Cin, Cout, KH, KW = w.shape
+    assert KH == 2 and KW == 2
+    m = w.permute(2, 3, 1, 0).reshape(4 * Cout, Cin)
+    return prep_linear_weight(m, dtype)
+
+
+def fold_bn(bn_weight, bn_bias, running_mean, running_var, eps, conv_bias=None):
+    """eval-mode BatchNorm after a conv -> (scale, shift) f32 with y = conv_nobias * scale + shift."""
+    scale = bn_weight.float() / torch.sqrt(running_var.float() + eps)
+    shift = bn_bias.float() - running_mean.float() * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.float() * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def to_channel_last(x, dtype=None, c_pad=None):
+    """[N,C,H,W] -> [N,H,W,Cp] contiguous (zero-padded channels)."""
+    N, C, H, W = x.shape
+    dtype = dtype or x.dtype
+    cp = c_pad or pad_to(C, vec_of(dtype))
+    out = torch.zeros(N, H, W, cp, dtype=dtype, device=x.device)
+    out[..., :C] = x.permute(0, 2, 3, 1).to(dtype)
+    return out
