@@ -147,7 +147,174 @@ def gen_f12():
           idx_mismatch_vs_oracle=np.array([mism]))
 
 
-FIXTURES = {"F3": gen_f3, "F12": gen_f12}
+# ---------------------------------------------------------------------------
+# F7: the reference EncoderDecoder (in-repo modules imported unmodified; third-party
+#     arithmetic adapted onto the oracle restatements) vs the oracle, end to end.
+# ---------------------------------------------------------------------------
+def build_reference_model(cfg, sd):
+    """Instantiate the reference EncoderDecoder under the import shims and load `sd`."""
+    import torch.nn as nn
+    from oracle import c_ref
+    from oracle import model_ref as M
+
+    class FnModule(nn.Module):
+        def __init__(self, fn):
+            super().__init__()
+            self.fn = fn
+
+        def forward(self, *a, **k):
+            return self.fn(*a, **k)
+
+        def init_weights(self):
+            pass
+
+    class BasicBlock(nn.Module):          # [3P] mmdet BasicBlock(inplanes, planes)
+        def __init__(self, inplanes, planes):
+            super().__init__()
+            self.conv1 = nn.Conv2d(inplanes, planes, 3, padding=1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+
+        def forward(self, x):
+            return M.basic_block({"b." + k: v for k, v in self.state_dict().items()}, "b", x)
+
+    class DCN(nn.Module):                 # [3P] mmcv DeformConv2dPack
+        def __init__(self, in_channels, out_channels, kernel_size, padding, groups, im2col_step=128):
+            super().__init__()
+            self.weight = nn.Parameter(torch.zeros(out_channels, in_channels // groups, 3, 3))
+            self.conv_offset = nn.Conv2d(in_channels, 18, 3, padding=1)
+            self.groups = groups
+
+        def forward(self, x):
+            return M.dcn({"d." + k: v for k, v in self.state_dict().items()}, "d", x, self.groups)
+
+    def ext_fwd(batch_size, num_points, num_channels, vx, vy, vz, geom, feats, out, memo):
+        o, m = c_ref.voxel_pool_fwd(geom.numpy(), feats.detach().numpy(), (int(vx), int(vy), int(vz)),
+                                    acc64=False)
+        out += torch.from_numpy(o)
+        return 1
+
+    def msda_core(value, spatial_shapes, loc, attw):
+        return M.msda_core(value, [tuple(int(v) for v in s) for s in spatial_shapes], loc, attw)
+
+    holder = {}
+
+    def build_backbone(c):
+        c = dict(c)
+        t = c.pop("type")
+        if t == "LSS":
+            return holder["lss"].LSS(**c)
+        if t == "ResNet":
+            return FnModule(lambda x: tuple(M.resnet50(sd, "img_encoder.img_backbone", x)))
+        if t == "LidarNet":
+            return FnModule(lambda pts: M.lidar_net(sd, "lidar_encoder", cfg, pts))
+        raise KeyError(t)
+
+    def build_neck(c):
+        return FnModule(lambda feats: tuple(M.pafpn(sd, "img_encoder.img_neck", list(feats))))
+
+    def build_head(c):
+        c = dict(c)
+        c.pop("type")
+        return holder["dec"].ThinkTwiceDecoder(**c)
+
+    def build_conv_layer(c, *a, **k):
+        c = dict(c)
+        assert c.pop("type") == "DCN"
+        return DCN(**c)
+
+    ref_stubs.install({"voxel_pooling_ext_fwd": ext_fwd, "msda_core": msda_core, "BasicBlock": BasicBlock,
+                       "build_conv_layer": build_conv_layer, "build_backbone": build_backbone,
+                       "build_neck": build_neck, "build_head": build_head})
+    holder["lss"] = ref_stubs.ref_import("model_code.backbones.lss")
+    holder["dec"] = ref_stubs.ref_import("model_code.dense_heads.thinktwice_decoder")
+    edf = ref_stubs.ref_import("encoder_decoder_framework")
+    tcfg = ref_stubs.ConfigDict(cfg["cfg"])
+    enc = dict(cfg["img_encoder"])
+    enc["final_dim"] = tuple(enc["final_dim"])
+    model = edf.EncoderDecoder(
+        img_encoder=enc,
+        decoder=dict(type="ThinkTwiceDecoder", config=tcfg, bev_h=21, bev_w=21),
+        lidar_encoder=dict(cfg["lidar_encoder"]), num_cams=4, use_depth=True, train_cfg=tcfg, test_cfg=tcfg)
+    res = model.load_state_dict(sd, strict=False)
+    third_party = ("img_encoder.img_backbone.", "img_encoder.img_neck.", "lidar_encoder.")
+    unexpected = [k for k in res.unexpected_keys if not k.startswith(third_party)]
+    assert not res.missing_keys, f"param_spec misses reference keys: {res.missing_keys[:10]}"
+    assert not unexpected, f"param_spec has keys the reference lacks: {unexpected[:10]}"
+    model.eval()
+    return model
+
+
+def _pack_pred(pred, sample_gen):
+    out = {}
+    for k, v in pred.items():
+        if not torch.is_tensor(v):
+            continue
+        v = v.detach().float()
+        if v.numel() <= 4096:
+            out[k] = v.numpy()
+        else:
+            idx = torch.randint(0, v.numel(), (256,), generator=sample_gen)
+            out[k + "__idx"] = idx.numpy()
+            out[k + "__val"] = v.reshape(-1)[idx].numpy()
+            out[k + "__stats"] = np.array([float(v.mean()), float(v.abs().mean()), float(v.abs().max())])
+    return out
+
+
+def _gen_forward(name, B, hw, npts, seed=0):
+    import json
+    import time
+    from oracle import model_ref as M
+    from thinktwice_amd import config, params, synth
+    cfg = config.model_config(final_dim=hw)
+    sd = params.init_params(cfg, seed=seed)
+    model = build_reference_model(cfg, sd)
+    # reference state_dict names/shapes of the in-repo modules (Appendix B check)
+    ref_keys = {k: list(v.shape) for k, v in model.state_dict().items()}
+    batch = synth.make_batch(B, img_hw=hw, num_points=npts)
+    t0 = time.time()
+    with torch.no_grad():
+        ref = model.forward_inference(batch)
+        t1 = time.time()
+        ora = M.forward_inference(sd, cfg, batch, return_intermediates=True)
+    t2 = time.time()
+    print(f"reference forward {t1 - t0:.1f}s, oracle forward {t2 - t1:.1f}s")
+    worst = 0.0
+    for k, v in ref.items():
+        if torch.is_tensor(v):
+            e = float((v - ora[k]).abs().max() / v.abs().max().clamp_min(1e-6))
+            worst = max(worst, e)
+            print(f"  {k:34s} shape {tuple(v.shape)}  rel-max err oracle vs reference {e:.2e}")
+    assert worst < 1e-4, worst
+    g = torch.Generator().manual_seed(99)
+    pack = _pack_pred(ref, g)
+    g = torch.Generator().manual_seed(98)
+    inter = _pack_pred({"cam_bev": ora["_cam_bev"], "lidar_bev": ora["_lidar_bev"], "flat": ora["_flat"],
+                        "seg": ora["_cam"]["seg"], "depth": ora["_cam"]["depth"],
+                        "context": ora["_cam"]["context"],
+                        "fpn0": ora["_cam"]["fpn_feats"][0], "fpn3": ora["_cam"]["fpn_feats"][3]}, g)
+    pack.update({"inter__" + k: v for k, v in inter.items()})
+    pack["look_max_len"] = np.array([i["max_len"] for i in ora["_look_info"]])
+    pack["look_count"] = torch.stack([i["count"] for i in ora["_look_info"]]).numpy()
+    pack["meta"] = np.array([B, hw[0], hw[1], npts, seed])
+    pack["oracle_vs_reference_worst_rel_err"] = np.array([worst])
+    _save(name, **pack)
+    return ref_keys
+
+
+def gen_f7():
+    import json
+    keys = _gen_forward("f7_forward_small_b2.npz", 2, (128, 256), 20000)
+    with open(os.path.join(HERE, "reference_state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+
+
+def gen_f8():
+    _gen_forward("f8_forward_full_b1.npz", 1, (448, 896), 65536)
+
+
+FIXTURES = {"F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8}
 
 
 def main():

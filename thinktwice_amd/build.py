@@ -25,6 +25,7 @@ def _sources():
 def _deps_mtime():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(HERE, "..", "include", "thinktwice_hip.h"))
+    hdrs.append(os.path.abspath(__file__))  # flag changes rebuild everything
     return max(os.path.getmtime(h) for h in hdrs)
 
 

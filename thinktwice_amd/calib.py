@@ -32,13 +32,14 @@ IMG_H, IMG_W = 900, 1600          # raw camera size (configs/thinktwice.py:116-1
 FINAL_H, FINAL_W = 448, 896       # network input (configs/thinktwice.py:113)
 
 
-def eval_ida_mat():
+def eval_ida_mat(final_dim=(FINAL_H, FINAL_W)):
     """IDAImageTransform.sample_ida_augmentation, is_train=False branch (transform.py:264-273)
     followed by img_transform's matrix (transform.py:346-378): resize 0.56, crop rows 56:504."""
-    resize = max(FINAL_H / IMG_H, FINAL_W / IMG_W)
+    fh, fw = final_dim
+    resize = max(fh / IMG_H, fw / IMG_W)
     new_w, new_h = int(IMG_W * resize), int(IMG_H * resize)
-    crop_h = int(new_h) - FINAL_H
-    crop_w = int(max(0, new_w - FINAL_W) / 2)
+    crop_h = int(new_h) - fh
+    crop_w = int(max(0, new_w - fw) / 2)
     m = np.eye(4, dtype=np.float32)
     m[0, 0] = m[1, 1] = np.float32(resize)
     m[0, 3] = -float(crop_w)

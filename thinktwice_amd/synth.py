@@ -7,10 +7,10 @@ import torch
 from . import calib
 
 
-def make_img_metas(batch_size, num_sweeps=2, curr2key=None):
+def make_img_metas(batch_size, num_sweeps=2, curr2key=None, final_dim=(calib.FINAL_H, calib.FINAL_W)):
     """img_metas[b][t] dicts with the keys LSS.forward reads (backbones/lss.py:667-707)."""
     intr, l2c, l2i = calib.camera_tables()
-    ida = np.stack([calib.eval_ida_mat() for _ in range(4)])
+    ida = np.stack([calib.eval_ida_mat(final_dim) for _ in range(4)])
     metas = []
     for _ in range(batch_size):
         per_sweep = []
@@ -60,7 +60,7 @@ def make_batch(batch_size, seed=1234, num_points=65536, img_hw=(calib.FINAL_H, c
         "target_point": torch.stack(tp).to(device),
         "target_command": torch.stack(cmd).to(device),
         "target_command_raw": torch.stack(cmd).argmax(-1).to(device),
-        "img_metas": make_img_metas(batch_size),
+        "img_metas": make_img_metas(batch_size, final_dim=img_hw),
     }
     if with_img:
         batch["img"] = torch.stack(imgs).to(device)
