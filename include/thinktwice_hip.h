@@ -63,7 +63,7 @@ int tt_voxel_pool_bwd(int batch_size, int num_points, int num_channels,
  * mats: per (b,cam) two 4x4 row-major f32 matrices: inv(ida) and
  * sensor2ego @ inv(intrin)   [B*ncam][2][16].
  * frustum f32 [D,fH,fW,4]; geom_xyz out int32 [B, ncam*D*fH*fW, 3].
- * voxel_lo[3] = voxel_coord - voxel_size/2, voxel_size[3]. */
+ * voxel_lo[3] = voxel_coord - voxel_size/2, voxel_size[3]: HOST pointers (module constants). */
 int tt_frustum_voxel_index(int batch_size, int num_cams, int D, int fH, int fW,
                            const float* frustum, const float* mats,
                            const float* voxel_lo, const float* voxel_size,
@@ -112,6 +112,53 @@ typedef struct tt_conv_desc {
 } tt_conv_desc;
 
 int tt_conv2d_fwd(const tt_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------
+ * HBM-bound glue of the forward (channel-last; `dtype` = storage type of the activation).
+ * Each replaces a torch call of the reference forward (call sites cited).
+ * ---------------------------------------------------------------------- */
+/* img (B*T*N,3,H,W) f32 NCHW -> channel-last with zero-padded channels (lss.py:517-519) */
+int tt_nchw_to_nhwc_pad(const float* in, void* out, int N, int C, int H, int W, int Cp,
+                        int out_dtype, void* stream);
+/* channel-last -> NCHW f32 (outputs returned in the reference layout) */
+int tt_nhwc_to_nchw(const void* in, float* out, int N, int C, int H, int W, int cstride, int coff,
+                    int in_dtype, void* stream);
+/* F.max_pool2d(x,3,2,1): mmdet ResNet stem (lss.py:401 -> [3P]) */
+int tt_maxpool3x3s2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
+/* dst += F.interpolate(src, size=dst.shape, mode='nearest'): PAFPN top-down (lss.py:301-305) */
+int tt_upsample_nearest_add(void* dst, const void* src, int N, int H, int W, int C, int h, int w,
+                            int dtype, void* stream);
+/* nn.Upsample(scale_factor=2, bilinear, align_corners=True): UNet (lss.py:267) */
+int tt_bilinear_up2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
+/* mode 0: AdaptiveAvgPool2d(1) (lss.py:80); mode 1: 0.5*mean+0.5*max (code/utils.py:91-92); out f32 [N,C] */
+int tt_spatial_pool(const void* in, float* out, int N, int HW, int C, int cstride, int coff, int mode,
+                    int dtype, void* stream);
+/* out = out_act(x * gate_act(gate[n,c]) + res): SELayer (lss.py:158), SEModule+residual (utils.py:96,117-119) */
+int tt_channel_gate(const void* x, const float* gate, const void* res, void* out, int N, int HW, int C,
+                    int gate_act, int out_act, int dtype, void* stream);
+/* rows: out = act(x*scale[c] + shift[c]): eval BatchNorm1d (lss.py:232, encoder_decoder_framework.py:134) */
+int tt_affine_rows(const void* x, const float* scale, const float* shift, void* out, long long R, int C,
+                   int x_stride, int out_stride, int act, int dtype, void* stream);
+/* nn.LayerNorm over the last dim (MSDA:252,201,262; thinktwice_decoder.py:197) */
+int tt_layernorm_rows(const void* x, const float* gamma, const float* beta, void* out, long long R,
+                      int D, int x_stride, int out_stride, float eps, int dtype, void* stream);
+/* strided channel-offset copy (torch.cat assembly); rot_flip!=0: torch.rot90(torch.flip(x,[2]),1,[2,3])
+ * (encoder_decoder_framework.py:241,246) */
+int tt_copy_nhwc(const void* in, void* out, int N, int H, int W, int C, int in_cstride, int in_coff,
+                 int out_cstride, int out_coff, int rot_flip, int in_dtype, int out_dtype, void* stream);
+/* out[n,p,coff+c] = v[n,c]: `.unsqueeze(-1).unsqueeze(-1).repeat` (thinktwice_decoder.py:42,257) */
+int tt_broadcast_rows(const void* v, void* out, int N, int HW, int C, int v_stride, int out_cstride,
+                      int out_coff, int dtype, void* stream);
+/* op 0: a+b; 1: (1-b)*a; 2: (1-g)*a+g*b; 3: act(a)   (SpatialGRU.gru_cell, dense_heads/utils.py:93-106) */
+int tt_ew(const void* a, const void* b, const void* g, void* out, long long R, int C, int a_stride,
+          int a_coff, int b_stride, int b_coff, int g_stride, int g_coff, int o_stride, int o_coff,
+          int op, int act, int dtype, void* stream);
+
+/* mmcv DeformConv2dPack (DCN v1, 3x3, stride 1, deform_groups 1) column builder (lss.py:189-197):
+ * cols [N*H*W, 9, C] = bilinear samples of x [N,H,W,C] at the offset taps; offsets f32
+ * [N,H,W,off_cstride] with channels [dy_0,dx_0,...,dy_8,dx_8].  The grouped GEMM runs on tt_conv2d_fwd. */
+int tt_deform_im2col3x3(const void* x, const float* offsets, void* cols, int N, int H, int W, int C,
+                        int off_cstride, int pad, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

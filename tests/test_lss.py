@@ -1,0 +1,47 @@
+"""Camera encoder: HIP `LSS` vs the oracle restatement on the same seeded
+inputs/weights at a reduced image size (oracle runs in seconds).  f32 mode tolerance 1e-3 of the
+tensor's max (north_star), bf16 mode reported with a loose bound."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from oracle import model_ref as M
+    from thinktwice_amd import config, params, synth
+    hw = (128, 256)
+    cfg = config.model_config(final_dim=hw)
+    sd = params.init_params(cfg, seed=0, parts=("img_encoder",))
+    batch = synth.make_batch(2, img_hw=hw, num_points=1000)
+    with torch.no_grad():
+        ref = M.lss_forward(sd, "img_encoder", cfg, batch["img"], batch["img_metas"])
+    return cfg, sd, batch, ref
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 0.15)])
+def test_lss_forward_matches_oracle(setup, dt, tol):
+    from thinktwice_amd.lss import LSS
+    cfg, sd, batch, ref = setup
+    enc = dict(cfg["img_encoder"])
+    enc.pop("type")
+    m = LSS(**enc, dtype=dt).load_state_dict(sd)
+    out = m(batch["img"].cuda(), batch["img_metas"], is_return_depth=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out["_geom"].cpu().numpy(), ref["geom_idx"].reshape(2, -1, 3).numpy())
+    errs = {}
+    for i in range(4):
+        errs[f"fpn{i}"] = _rel(out["fpn_feats"][i].cpu(), ref["fpn_feats"][i])
+    errs["seg"] = _rel(out["seg"].cpu(), ref["seg"])
+    errs["depth"] = _rel(out["depth"].cpu(), ref["depth"])
+    errs["bev"] = _rel(out["bev"].cpu(), ref["bev"])
+    print(dt, errs)
+    for k, e in errs.items():
+        assert e < tol, (k, e, errs)
+    assert torch.equal(out["lidar2img"], ref["lidar2img"]) and torch.equal(out["ida_mat"], ref["ida_mat"])

@@ -62,3 +62,15 @@ def geometry_matrices(mats, sweep_index=-1):
     intrin = mats["intrin_mats"][:, sweep_index]
     pair = torch.stack([ida.inverse(), s2e.matmul(torch.inverse(intrin))], 2)
     return pair.reshape(-1, 2, 4, 4).contiguous()
+
+
+def depth_mlp_input(mats):
+    """(B*ncam, 22) camera-aware DepthNet input of the KEY frame (backbones/lss.py:206-231):
+    [fx, fy, cx, cy, ida00, ida01, ida03, ida10, ida11, ida13, sensor2ego[:3,:] (12)]."""
+    k = mats["intrin_mats"][:, -1]
+    a = mats["ida_mats"][:, -1]
+    s = mats["sensor2ego_mats"][:, -1][..., :3, :]
+    B, N = k.shape[:2]
+    head = torch.stack([k[..., 0, 0], k[..., 1, 1], k[..., 0, 2], k[..., 1, 2], a[..., 0, 0], a[..., 0, 1],
+                        a[..., 0, 3], a[..., 1, 0], a[..., 1, 1], a[..., 1, 3]], -1)
+    return torch.cat([head, s.reshape(B, N, 12)], -1).reshape(B * N, 22).contiguous()

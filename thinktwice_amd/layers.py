@@ -1,0 +1,82 @@
+"""Prepared layers: checkpoint tensors -> kernel-layout weights + fused epilogue parameters.
+
+A `Conv` is one launch of tt_conv2d_fwd (implicit GEMM on MFMA) with BN/bias/activation/residual
+fused; `Rows` are the same kernel used as a row-batched nn.Linear (always f32: tiny M).
+"""
+import torch
+
+from . import _lib, ops, weights
+
+ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "sigmoid": _lib.ACT_SIGMOID, "gelu": _lib.ACT_GELU,
+       "softplus": _lib.ACT_SOFTPLUS}
+
+
+class Conv:
+    def __init__(self, w, scale, shift, stride=1, pad=0, dil=1, act="none", pixel_shuffle2=False):
+        self.w, self.scale, self.shift = w, scale, shift
+        self.stride, self.pad, self.dil = stride, pad, dil
+        self.act = ACT[act]
+        self.ps2 = pixel_shuffle2
+        self.cin = w.shape[-1]
+
+    def __call__(self, x, **kw):
+        return ops.conv2d(x, self.w, stride=self.stride, pad=self.pad, dil=self.dil, scale=self.scale,
+                          shift=self.shift, act=self.act, pixel_shuffle2=self.ps2, **kw)
+
+
+def _dev(t, device):
+    return None if t is None else t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def conv_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, stride=1, pad=0, dil=1, act="none",
+                 cin_pad=None, weight=None):
+    """nn.Conv2d `name` (+ optional eval BatchNorm `bn`) -> Conv."""
+    w = sd[name + ".weight"] if weight is None else weight
+    bias = sd.get(name + ".bias")
+    wq = weights.prep_conv_weight(w.to(device), dtype, cin_pad)
+    if bn is not None:
+        scale, shift = weights.fold_bn(sd[bn + ".weight"], sd[bn + ".bias"], sd[bn + ".running_mean"],
+                                       sd[bn + ".running_var"], eps, bias)
+    else:
+        scale, shift = None, bias
+    return Conv(wq, _dev(scale, device), _dev(shift, device), stride, pad, dil, act)
+
+
+def linear_from_sd(sd, name, device, act="none", in_pad=None, dtype=torch.float32, bn=None, eps=1e-5):
+    """nn.Linear `name` -> Conv over rows ([R,1,1,in] input)."""
+    w = sd[name + ".weight"]
+    wq = weights.prep_linear_weight(w.to(device), dtype, in_pad)
+    bias = sd.get(name + ".bias")
+    if bn is not None:
+        scale, shift = weights.fold_bn(sd[bn + ".weight"], sd[bn + ".bias"], sd[bn + ".running_mean"],
+                                       sd[bn + ".running_var"], eps, bias)
+    else:
+        scale, shift = None, bias
+    return Conv(wq, _dev(scale, device), _dev(shift, device), act=act)
+
+
+def deconv2x2_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, act="none"):
+    """nn.ConvTranspose2d(k=2, s=2) -> 1x1 GEMM to 4*Cout + pixel shuffle in the epilogue."""
+    wq = weights.prep_deconv2x2_weight(sd[name + ".weight"].to(device), dtype)
+    bias = sd.get(name + ".bias")
+    if bn is not None:
+        scale, shift = weights.fold_bn(sd[bn + ".weight"], sd[bn + ".bias"], sd[bn + ".running_mean"],
+                                       sd[bn + ".running_var"], eps, bias)
+    else:
+        scale, shift = None, bias
+    return Conv(wq, _dev(scale, device), _dev(shift, device), act=act, pixel_shuffle2=True)
+
+
+def rows(x):
+    """(R, C) -> (R,1,1,C) view for the row-batched linear path."""
+    return x.view(x.shape[0], 1, 1, x.shape[1])
+
+
+def unrows(x):
+    return x.view(x.shape[0], x.shape[-1])
+
+
+def bn_affine(sd, bn, device, eps=1e-5):
+    s, t = weights.fold_bn(sd[bn + ".weight"], sd[bn + ".bias"], sd[bn + ".running_mean"],
+                           sd[bn + ".running_var"], eps)
+    return _dev(s, device), _dev(t, device)

@@ -1,0 +1,286 @@
+"""`LSS` camera encoder -- host-side mirror of the reference module
+(open_loop_training/code/model_code/backbones/lss.py:351-724), every tensor op on hand-written
+gfx950 kernels behind the C ABI.
+
+Same constructor arguments, same state_dict key names, same `forward(img, img_metas)` return
+dict (`bev`, `seg`, `fpn_feats`, `lidar2img`, `ida_mat`[, `depth`]) in the reference's NCHW f32
+layout.  Internally activations are channel-last; both sweeps go through the image trunk as ONE
+batch of B*T*4 images (BN is in eval mode, so per-image results are unchanged), concatenations are
+channel-offset writes, the depth softmax / outer product / permute / voxel pooling chain
+(lss.py:583-632) is one fused lift-splat kernel that never materialises the 514 MB/sample volume.
+"""
+import torch
+
+from . import _lib, camera, layers, ops
+from .layers import conv_from_sd, deconv2x2_from_sd, linear_from_sd, rows, unrows
+from .registry import BACKBONES
+
+
+class _ResNet50:
+    """[3P] mmdet ResNet(depth=50, out_indices 0-3) with eval BN folded into the conv epilogues."""
+
+    def __init__(self, sd, p, dtype, device):
+        vec = 4 if dtype == torch.float32 else 8
+        self.cin_pad = vec
+        self.stem = conv_from_sd(sd, p + ".conv1", dtype, device, bn=p + ".bn1", stride=2, pad=3, act="relu",
+                                 cin_pad=vec)
+        self.blocks = []
+        for li, nb in enumerate((3, 4, 6, 3), start=1):
+            stage = []
+            for b in range(nb):
+                q = f"{p}.layer{li}.{b}"
+                s = 2 if (b == 0 and li > 1) else 1
+                blk = {
+                    "c1": conv_from_sd(sd, q + ".conv1", dtype, device, bn=q + ".bn1", act="relu"),
+                    "c2": conv_from_sd(sd, q + ".conv2", dtype, device, bn=q + ".bn2", stride=s, pad=1, act="relu"),
+                    "c3": conv_from_sd(sd, q + ".conv3", dtype, device, bn=q + ".bn3", act="relu"),
+                    "ds": conv_from_sd(sd, q + ".downsample.0", dtype, device, bn=q + ".downsample.1", stride=s)
+                    if b == 0 else None,
+                }
+                stage.append(blk)
+            self.blocks.append(stage)
+
+    def __call__(self, x):
+        x = ops.maxpool3x3s2(self.stem(x))
+        outs = []
+        for stage in self.blocks:
+            for blk in stage:
+                idt = blk["ds"](x) if blk["ds"] is not None else x
+                y = blk["c2"](blk["c1"](x))
+                x = blk["c3"](y, res1=idt)          # relu(bn3(conv3) + identity)
+            outs.append(x)
+        return outs
+
+
+@BACKBONES.register_module()
+class LSS:
+    def __init__(self, x_bound, y_bound, z_bound, d_bound, final_dim, downsample_factor, output_channels,
+                 img_backbone_conf=None, img_neck_conf=None, depth_net_conf=None, seg_net_conf=None,
+                 queue_len=1, fpn_in_channels=(64, 128, 256, 512), dtype=torch.float32, device="cuda"):
+        self.grid = camera.VoxelGrid(x_bound, y_bound, z_bound)
+        self.d_bound = d_bound
+        self.final_dim = tuple(final_dim)
+        self.downsample_factor = downsample_factor
+        self.output_channels = output_channels
+        self.queue_len = queue_len
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.frustum = camera.make_frustum(self.final_dim, downsample_factor, d_bound)
+        self.depth_channels = self.frustum.shape[0]
+        self.voxel_num = self.grid.voxel_num
+        self._frustum_dev = None
+        self.loaded = False
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd, prefix="img_encoder"):
+        dt, dev, p = self.dtype, self.device, prefix
+        f32 = torch.float32
+        self.backbone = _ResNet50(sd, p + ".img_backbone", dt, dev)
+        n = p + ".img_neck"
+        self.lat = [conv_from_sd(sd, f"{n}.lateral_convs.{i}.conv", dt, dev) for i in range(4)]
+        self.fpn = [conv_from_sd(sd, f"{n}.fpn_convs.{i}.conv", dt, dev, pad=1) for i in range(4)]
+        self.down = [conv_from_sd(sd, f"{n}.downsample_convs.{i}.conv", dt, dev, stride=2, pad=1) for i in range(3)]
+        self.paf = [conv_from_sd(sd, f"{n}.pafpn_convs.{i}.conv", dt, dev, pad=1) for i in range(3)]
+        self.neck_conv = conv_from_sd(sd, p + ".neck_conv", dt, dev)
+        d = p + ".depth_net"
+        self.bn22 = layers.bn_affine(sd, d + ".bn", dev)
+        self.reduce = conv_from_sd(sd, d + ".reduce_conv.0", dt, dev, bn=d + ".reduce_conv.1", pad=1, act="relu")
+        self.se = {}
+        for name in ("depth", "context"):
+            self.se[name] = [
+                linear_from_sd(sd, f"{d}.{name}_mlp.fc1", dev, act="relu", in_pad=24),
+                linear_from_sd(sd, f"{d}.{name}_mlp.fc2", dev),
+                conv_from_sd(sd, f"{d}.{name}_se.conv_reduce", f32, dev, act="relu"),
+                conv_from_sd(sd, f"{d}.{name}_se.conv_expand", f32, dev),
+            ]
+        self.context_conv = conv_from_sd(sd, d + ".context_conv", dt, dev)
+        self.bb = []
+        for i in range(3):
+            q = f"{d}.depth_conv.{i}"
+            self.bb.append((conv_from_sd(sd, q + ".conv1", dt, dev, bn=q + ".bn1", pad=1, act="relu"),
+                            conv_from_sd(sd, q + ".conv2", dt, dev, bn=q + ".bn2", pad=1, act="relu")))
+        a = d + ".depth_conv.3"
+        self.aspp = [conv_from_sd(sd, a + ".aspp1.atrous_conv", dt, dev, bn=a + ".aspp1.bn", act="relu")]
+        for i, dil in ((2, 6), (3, 12), (4, 18)):
+            self.aspp.append(conv_from_sd(sd, f"{a}.aspp{i}.atrous_conv", dt, dev, bn=f"{a}.aspp{i}.bn", pad=dil,
+                                          dil=dil, act="relu"))
+        self.aspp_gap = conv_from_sd(sd, a + ".global_avg_pool.1", f32, dev, bn=a + ".global_avg_pool.2", act="relu")
+        w1 = sd[a + ".conv1.weight"]
+        mid = w1.shape[0]
+        self.aspp_out = conv_from_sd(sd, a + ".conv1", dt, dev, bn=a + ".bn1", act="relu",
+                                     weight=w1[:, : 4 * mid].contiguous())
+        # global-pool branch enters conv1 as a per-image shift: bn_scale * (W[:, 4*mid:] @ x5)
+        self.aspp_gapw = conv_from_sd(sd, a + ".conv1", f32, dev, weight=w1[:, 4 * mid:].contiguous())
+        self.aspp_gapw.scale, self.aspp_gapw.shift = self.aspp_out.scale, None
+        q = d + ".depth_conv.4"
+        self.dcn_off = conv_from_sd(sd, q + ".conv_offset", dt, dev, pad=1)
+        wd = sd[q + ".weight"]
+        self.dcn_groups = mid // wd.shape[1]
+        og = wd.shape[0] // self.dcn_groups
+        self.dcn_w = []
+        for g in range(self.dcn_groups):
+            wg = wd[g * og:(g + 1) * og].to(dev)                        # (og, cg, 3, 3)
+            wg = wg.permute(0, 2, 3, 1).reshape(og, 1, 9, wg.shape[1])  # [Cout][1][tap][cin]
+            self.dcn_w.append(wg.to(dt).contiguous())
+        self.depth_out = conv_from_sd(sd, d + ".depth_conv.5", dt, dev)
+        s = p + ".seg_net"
+        self.up = {k: deconv2x2_from_sd(sd, f"{s}.{k}.up", dt, dev) for k in ("unet_layer4", "unet_layer3", "unet_layer2")}
+        self.upc = {k: conv_from_sd(sd, f"{s}.{k}.conv_relu.0", dt, dev, pad=1, act="relu")
+                    for k in ("unet_layer4", "unet_layer3", "unet_layer2")}
+        self.u0a = conv_from_sd(sd, s + ".unet_layer0.1", dt, dev, pad=1, act="relu")
+        self.u0b = conv_from_sd(sd, s + ".unet_layer0.3", dt, dev, pad=1)
+        self.seg_cp = 12 if dt == f32 else 16
+        self.conv_last = conv_from_sd(sd, s + ".conv_last", dt, dev)
+        r = p + ".seg_res_to_image_feature"
+        self.seg2feat = []
+        for idx, (st, pd) in zip((0, 3, 6, 9, 12, 15, 18), ((1, 0), (1, 0), (2, 1), (1, 0), (2, 1), (1, 0), (2, 1))):
+            self.seg2feat.append(conv_from_sd(sd, f"{r}.{idx}", dt, dev, bn=f"{r}.{idx + 1}", stride=st, pad=pd,
+                                              act="relu", cin_pad=self.seg_cp if idx == 0 else None))
+        self.merge = conv_from_sd(sd, p + ".merge_seg_and_image", dt, dev, pad=1)
+        if self.queue_len != 1:
+            self.bev_merge = conv_from_sd(sd, p + ".bev_multiframe_merge", f32, dev, pad=1)
+        self._frustum_dev = self.frustum.to(dev)
+        self.loaded = True
+        return self
+
+    # ------------------------------------------------------------------ forward pieces
+    def _trunk(self, x):
+        """ResNet-50 + PAFPN + neck_conv on NI channel-last images.  FPN maps are produced directly
+        inside the UNet concat buffers (torch.cat of lss.py:256 becomes a channel offset)."""
+        NI = x.shape[0]
+        c = self.backbone(x)
+        lat = [self.lat[i](c[i]) for i in range(4)]
+        for i in range(3, 0, -1):
+            ops.upsample_nearest_add_(lat[i - 1], lat[i])
+        H0, W0 = lat[0].shape[1:3]
+        dt, dev = self.dtype, x.device
+        cat2 = torch.empty(NI, H0, W0, 384, dtype=dt, device=dev)            # [up(d3) 128 | e1 256]
+        cat3 = torch.empty(NI, H0 // 2, W0 // 2, 512, dtype=dt, device=dev)  # [up(d4) 256 | e2 256]
+        cat4 = torch.empty(NI, H0 // 4, W0 // 4, 512, dtype=dt, device=dev)  # [up(e4) 256 | e3 256]
+        # PAFPN out[0] == inter[0]: produced in place inside the UNet concat buffer
+        self.fpn[0](lat[0], out=cat2, out_coff=128)
+        inter = [None] + [self.fpn[i](lat[i]) for i in range(1, 4)]
+        self.down[0](cat2, in_coff=128, cin=256, res1=inter[1], out=inter[1])
+        for i in range(1, 3):
+            self.down[i](inter[i], res1=inter[i + 1], out=inter[i + 1])
+        self.paf[0](inter[1], out=cat3, out_coff=256)
+        self.paf[1](inter[2], out=cat4, out_coff=256)
+        e4 = self.paf[2](inter[3])
+        return (cat2, cat3, cat4, e4)
+
+    def _fpn_views(self, bufs):
+        """[(tensor, channel offset, channels)] of the 4 FPN maps."""
+        cat2, cat3, cat4, e4 = bufs
+        return [(cat2, 128, 256), (cat3, 256, 256), (cat4, 256, 256), (e4, 0, 256)]
+
+    def _se_gate(self, name, m):
+        fc1, fc2, cr, ce = self.se[name]
+        return unrows(ce(cr(fc2(fc1(rows(m))))))
+
+    def _depth_net(self, src, mlp_in, T):
+        """DepthNet.forward (lss.py:205-240): returns depth logits f32 (NI,h,w,D) and the merge
+        buffer whose channels [0:256] hold the context."""
+        NI, h, w, _ = src.shape
+        dev, dt = src.device, self.dtype
+        m24 = torch.zeros(mlp_in.shape[0], 24, dtype=torch.float32, device=dev)
+        ops.affine_rows(mlp_in, self.bn22[0], self.bn22[1], out=m24)
+        x = self.reduce(src)
+        g_ctx = self._se_gate("context", m24).repeat(T, 1)
+        g_dep = self._se_gate("depth", m24).repeat(T, 1)
+        merge_in = torch.empty(NI, h, w, 384, dtype=dt, device=dev)
+        self.context_conv(ops.channel_gate(x, g_ctx), out=merge_in, out_coff=0)
+        d = ops.channel_gate(x, g_dep)
+        for c1, c2 in self.bb:
+            d = c2(c1(d), res1=d)
+        mid = d.shape[-1]
+        cat = torch.empty(NI, h, w, 4 * mid, dtype=dt, device=dev)
+        for i, br in enumerate(self.aspp):
+            br(d, out=cat, out_coff=i * mid)
+        x5 = self.aspp_gap(rows(ops.spatial_pool(d, 0)))                 # (NI,1,1,mid) f32
+        shift_n = unrows(self.aspp_gapw(x5)).contiguous()                # bn_scale * (W5 @ x5)
+        d = self.aspp_out(cat, shift_n=shift_n, shift_n_mod=NI)
+        off = self.dcn_off(d, out_dtype=torch.float32)
+        cols = ops.deform_im2col3x3(d, off, pad=1)
+        dd = torch.empty(NI, h, w, mid, dtype=dt, device=dev)
+        cg = mid // self.dcn_groups
+        og = self.dcn_w[0].shape[0]
+        for g, wg in enumerate(self.dcn_w):
+            ops.conv2d(cols, wg, in_coff=g * cg, cin=cg, out=dd.view(NI * h * w, 1, 1, mid), out_coff=g * og)
+        depth = self.depth_out(dd, out_dtype=torch.float32)
+        return depth, merge_in
+
+    def _seg_net(self, bufs):
+        """UNet.forward (lss.py:275-282) -> seg logits (NI, H/2, W/2, seg_cp)."""
+        cat2, cat3, cat4, e4 = bufs
+        self.up["unet_layer4"](e4, out=cat4, out_coff=0)
+        d4 = self.upc["unet_layer4"](cat4)
+        self.up["unet_layer3"](d4, out=cat3, out_coff=0)
+        d3 = self.upc["unet_layer3"](cat3)
+        self.up["unet_layer2"](d3, out=cat2, out_coff=0)
+        d2 = self.upc["unet_layer2"](cat2)
+        d0 = self.u0b(self.u0a(ops.bilinear_up2(d2)))
+        NI, H, W, _ = d0.shape
+        seg = torch.zeros(NI, H, W, self.seg_cp, dtype=self.dtype, device=d0.device)
+        self.conv_last(d0, out=seg)
+        return seg
+
+    def geometry(self, mats, batch_size, num_cams):
+        gm = camera.geometry_matrices(mats, -1).to(self.device)
+        return ops.frustum_voxel_index(self._frustum_dev, gm, self.grid.lower, self.grid.voxel_size.tolist(),
+                                       batch_size, num_cams)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, img, img_metas, timestamps=None, is_return_depth=False, channel_last=False):
+        """img (B,T,N,3,H,W) f32 on device (key frame = last T index) -> dict like LSS.forward."""
+        if not self.loaded:
+            raise _lib.TTError("LSS: load_state_dict() first")
+        _lib.require_cuda(img)
+        if img.dim() == 5:
+            img = img.unsqueeze(1)
+        B, T, N, C, H, W = img.shape
+        assert T == self.queue_len, "LSS.queue_len must be set correctly in config!"
+        assert (H, W) == self.final_dim
+        mats = camera.stack_img_metas(img_metas, N)
+        NI = T * B * N
+        # sweep-major image order: key sweep first (index 0 == reference sweep index -1)
+        x = torch.empty(NI, H, W, self.backbone.cin_pad, dtype=self.dtype, device=img.device)
+        for s in range(T):
+            for b in range(B):
+                src = img[b, T - 1 - s].contiguous()
+                o = (s * B + b) * N
+                ops.check(ops.lib().tt_nchw_to_nhwc_pad(ops.ptr(src), ops.ptr(x[o:o + N]), N, C, H, W,
+                                                        x.shape[-1], ops.dtype_code(x),
+                                                        ops.cur_stream(img.device)), "tt_nchw_to_nhwc_pad")
+        bufs = self._trunk(x)
+        fpn2_buf, fpn2_off, _ = self._fpn_views(bufs)[2]
+        src = self.neck_conv(fpn2_buf, in_coff=fpn2_off, cin=256)
+        mlp_in = camera.depth_mlp_input(mats).to(img.device)
+        depth, merge_in = self._depth_net(src, mlp_in, T)
+        # keep FPN maps of the key sweep before the UNet overwrites nothing of them (offset slices)
+        seg = self._seg_net(bufs)
+        f = seg
+        for cv in self.seg2feat[:-1]:
+            f = cv(f)
+        self.seg2feat[-1](f, out=merge_in, out_coff=256)
+        ctx = self.merge(merge_in, out_dtype=torch.float32)
+        geom = self.geometry(mats, B, N)
+        vx, vy, vz = (int(v) for v in self.voxel_num)
+        bev_cat = torch.zeros(B, vy, vx, self.output_channels * T, dtype=torch.float32, device=img.device)
+        BN = B * N
+        for s in range(T):
+            ops.lift_splat(depth[s * BN:(s + 1) * BN], ctx[s * BN:(s + 1) * BN], geom, (vx, vy, vz), B, N,
+                           out=bev_cat, out_coff=s * self.output_channels)
+        bev = self.bev_merge(bev_cat) if T > 1 else bev_cat
+        fpn = [(t[:BN], off, c) for (t, off, c) in self._fpn_views(bufs)]
+        outs = {"lidar2img": mats["lidar2img"], "ida_mat": mats["ida_mat"], "_fpn_cl": fpn, "_bev_cl": bev,
+                "_geom": geom}
+        if channel_last:
+            return outs
+        outs["bev"] = ops.nhwc_to_nchw(bev)
+        outs["seg"] = ops.nhwc_to_nchw(seg[:BN], C=12)
+        outs["fpn_feats"] = tuple(ops.nhwc_to_nchw(t, C=c, coff=off) for (t, off, c) in fpn)
+        if is_return_depth:
+            outs["depth"] = ops.nhwc_to_nchw(depth[:BN])
+        return outs
+
+    __call__ = forward

@@ -118,3 +118,142 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     rc = lib().tt_conv2d_fwd(ctypes.byref(d), cur_stream(x.device))
     check(rc, "tt_conv2d_fwd")
     return out
+
+
+# ----------------------------------------------------------------------------- glue kernels
+_ll = ctypes.c_longlong
+_f = ctypes.c_float
+
+
+def _st(t):
+    return cur_stream(t.device)
+
+
+def nchw_to_nhwc_pad(x, dtype, c_pad):
+    """(N,C,H,W) f32 -> (N,H,W,c_pad) `dtype`, zero-padded channels."""
+    require_cuda(x)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    N, C, H, W = x.shape
+    out = torch.empty(N, H, W, c_pad, dtype=dtype, device=x.device)
+    check(lib().tt_nchw_to_nhwc_pad(ptr(x), ptr(out), _c(N), _c(C), _c(H), _c(W), _c(c_pad),
+                                    _c(dtype_code(out)), _st(x)), "tt_nchw_to_nhwc_pad")
+    return out
+
+
+def nhwc_to_nchw(x, C=None, coff=0):
+    """(N,H,W,Cs) -> (N,C,H,W) f32."""
+    require_cuda(x)
+    N, H, W, Cs = x.shape
+    C = C or Cs
+    out = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)
+    check(lib().tt_nhwc_to_nchw(ptr(x), ptr(out), _c(N), _c(C), _c(H), _c(W), _c(Cs), _c(coff),
+                                _c(dtype_code(x)), _st(x)), "tt_nhwc_to_nchw")
+    return out
+
+
+def maxpool3x3s2(x):
+    N, H, W, C = x.shape
+    out = torch.empty(N, (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1, C, dtype=x.dtype, device=x.device)
+    check(lib().tt_maxpool3x3s2(ptr(x), ptr(out), _c(N), _c(H), _c(W), _c(C), _c(dtype_code(x)), _st(x)),
+          "tt_maxpool3x3s2")
+    return out
+
+
+def upsample_nearest_add_(dst, src):
+    N, H, W, C = dst.shape
+    check(lib().tt_upsample_nearest_add(ptr(dst), ptr(src), _c(N), _c(H), _c(W), _c(C), _c(src.shape[1]),
+                                        _c(src.shape[2]), _c(dtype_code(dst)), _st(dst)),
+          "tt_upsample_nearest_add")
+    return dst
+
+
+def bilinear_up2(x):
+    N, H, W, C = x.shape
+    out = torch.empty(N, 2 * H, 2 * W, C, dtype=x.dtype, device=x.device)
+    check(lib().tt_bilinear_up2(ptr(x), ptr(out), _c(N), _c(H), _c(W), _c(C), _c(dtype_code(x)), _st(x)),
+          "tt_bilinear_up2")
+    return out
+
+
+def spatial_pool(x, mode, C=None, coff=0):
+    """(N,H,W,Cs) -> f32 (N,C): mode 0 mean, mode 1 (mean+max)/2."""
+    N, H, W, Cs = x.shape
+    C = C or Cs
+    out = torch.empty(N, C, dtype=torch.float32, device=x.device)
+    check(lib().tt_spatial_pool(ptr(x), ptr(out), _c(N), _c(H * W), _c(C), _c(Cs), _c(coff), _c(mode),
+                                _c(dtype_code(x)), _st(x)), "tt_spatial_pool")
+    return out
+
+
+def channel_gate(x, gate, res=None, gate_act=_lib.ACT_SIGMOID, out_act=_lib.ACT_NONE, out=None):
+    N, H, W, C = x.shape
+    assert gate.dtype == torch.float32 and gate.shape == (N, C) and gate.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    check(lib().tt_channel_gate(ptr(x), ptr(gate), ptr(res), ptr(out), _c(N), _c(H * W), _c(C), _c(gate_act),
+                                _c(out_act), _c(dtype_code(x)), _st(x)), "tt_channel_gate")
+    return out
+
+
+def affine_rows(x, scale, shift, act=0, out=None):
+    """x (R, C) possibly a row-strided 2-D view."""
+    R, C = x.shape
+    out = torch.empty(R, C, dtype=x.dtype, device=x.device) if out is None else out
+    check(lib().tt_affine_rows(ptr(x), ptr(scale), ptr(shift), ptr(out), _ll(R), _c(C), _c(x.stride(0)),
+                               _c(out.stride(0)), _c(act), _c(dtype_code(x)), _st(x)), "tt_affine_rows")
+    return out
+
+
+def layernorm_rows(x, gamma, beta, eps=1e-5, out=None, D=None):
+    """LayerNorm over the first D columns of each row of the 2-D (row-strided) x."""
+    R = x.shape[0]
+    D = D or x.shape[1]
+    out = torch.zeros(R, x.shape[1], dtype=x.dtype, device=x.device) if out is None else out
+    check(lib().tt_layernorm_rows(ptr(x), ptr(gamma), ptr(beta), ptr(out), _ll(R), _c(D), _c(x.stride(0)),
+                                  _c(out.stride(0)), _f(eps), _c(dtype_code(x)), _st(x)), "tt_layernorm_rows")
+    return out
+
+
+def copy_nhwc(x, out, C=None, in_coff=0, out_coff=0, rot_flip=False):
+    N, H, W, Cs = x.shape
+    C = C or Cs
+    check(lib().tt_copy_nhwc(ptr(x), ptr(out), _c(N), _c(H), _c(W), _c(C), _c(Cs), _c(in_coff),
+                             _c(out.shape[-1]), _c(out_coff), _c(1 if rot_flip else 0), _c(dtype_code(x)),
+                             _c(dtype_code(out)), _st(x)), "tt_copy_nhwc")
+    return out
+
+
+def broadcast_rows(v, out, out_coff=0):
+    """v (N, C) -> out (N,H,W,Ct)[..., out_coff:out_coff+C] = v[n, :]."""
+    N, C = v.shape
+    _, H, W, Ct = out.shape
+    check(lib().tt_broadcast_rows(ptr(v), ptr(out), _c(N), _c(H * W), _c(C), _c(v.stride(0)), _c(Ct),
+                                  _c(out_coff), _c(dtype_code(out)), _st(out)), "tt_broadcast_rows")
+    return out
+
+
+def ew(op, a, b=None, g=None, out=None, C=None, a_coff=0, b_coff=0, g_coff=0, out_coff=0, act=0):
+    """Row-wise elementwise op on 2-D (row-strided) views; see tt_ew."""
+    a2 = a.reshape(-1, a.shape[-1])
+    R = a2.shape[0]
+    C = C or a2.shape[1]
+    if out is None:
+        out = torch.empty(R, C, dtype=a.dtype, device=a.device)
+    o2 = out.reshape(-1, out.shape[-1])
+    b2 = None if b is None else b.reshape(-1, b.shape[-1])
+    g2 = None if g is None else g.reshape(-1, g.shape[-1])
+    check(lib().tt_ew(ptr(a2), ptr(b2), ptr(g2), ptr(o2), _ll(R), _c(C), _c(a2.stride(0)), _c(a_coff),
+                      _c(0 if b2 is None else b2.stride(0)), _c(b_coff), _c(0 if g2 is None else g2.stride(0)),
+                      _c(g_coff), _c(o2.stride(0)), _c(out_coff), _c(op), _c(act), _c(dtype_code(a)), _st(a)),
+          "tt_ew")
+    return out
+
+
+def deform_im2col3x3(x, offsets, pad=1):
+    """x (N,H,W,C), offsets f32 (N,H,W,>=18) -> cols (N*H*W, 1, 9, C) (a [M,1,9,C] "image" for conv2d)."""
+    N, H, W, C = x.shape
+    assert offsets.dtype == torch.float32 and offsets.is_contiguous()
+    cols = torch.empty(N * H * W, 1, 9, C, dtype=x.dtype, device=x.device)
+    check(lib().tt_deform_im2col3x3(ptr(x), ptr(offsets), ptr(cols), _c(N), _c(H), _c(W), _c(C),
+                                    _c(offsets.shape[-1]), _c(pad), _c(dtype_code(x)), _st(x)),
+          "tt_deform_im2col3x3")
+    return cols
