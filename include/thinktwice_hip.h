@@ -31,6 +31,7 @@ extern "C" {
 #define TT_ACT_SIGMOID 2
 #define TT_ACT_GELU 3
 #define TT_ACT_SOFTPLUS 4
+#define TT_ACT_SOFTPLUS_CLAMP 5  /* clamp(softplus(x), min=1e-3): thinktwice_decoder.py:484 */
 
 const char* tt_last_error(void);
 int tt_version(void);
@@ -159,6 +160,33 @@ int tt_ew(const void* a, const void* b, const void* g, void* out, long long R, i
  * [N,H,W,off_cstride] with channels [dy_0,dx_0,...,dy_8,dx_8].  The grouped GEMM runs on tt_conv2d_fwd. */
 int tt_deform_im2col3x3(const void* x, const float* offsets, void* cols, int N, int H, int W, int C,
                         int off_cstride, int pad, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Look module (dense_heads/thinktwice_decoder.py:88-187 + multi_scale_deformable_attn_function.py).
+ * All per-(sample,camera) query packing stays on the device (the reference does B*4 nonzero()
+ * host syncs per decoder layer, thinktwice_decoder.py:131-137).  120 slots are always computed;
+ * `max_len` (device int) bounds the final reduction exactly like the reference's padded length.
+ * ---------------------------------------------------------------------- */
+/* obtain_cam_ref_points_query (DEC:89-113,129-149): wp (B,4,2); lidar2img/ida_mat (B,4,4,4) f32.
+ * -> ref_packed (B,4,120,2), query_of_slot (B,4,120) (-1 = padded), count (B,4), max_len (1). */
+int tt_look_project_pack(int B, const float* wp, const float* lidar2img, const float* ida_mat,
+                         float img_h, float img_w, float* ref_packed, int* query_of_slot,
+                         int* count, int* max_len, void* stream);
+/* query rows (B*4*120, row_stride>=1543) f32 = [ctrl 4 | xyz 3 | emb 128 | meas 128 | flat 256 |
+ * F.grid_sample of the 4 fpn_linear maps (c*4+lvl) 1024] (DEC:119-127,148,164-171); padded slots = 0.
+ * level_maps: 4 HOST-array device pointers to [B*4,H_l,W_l,256] maps; level_hw: 8 host ints. */
+int tt_look_gather_query(int B, const int* query_of_slot, const float* ref_packed, const float* wp,
+                         const float* ctrl_softplus, const float* temporal_embedding,
+                         const float* static_embedding, const float* measurement_feat,
+                         const float* flattened_feat, const void* const* level_maps,
+                         const int* level_hw, int maps_dtype, float* out, int row_stride, void* stream);
+/* MSDeformableAttention3D core (MSDA:478-526 + mmcv multi_scale_deformable_attn_pytorch [3P]):
+ * value [B*4, sum(HW), 256] (8 heads x 32), offsets f32 [R,512], logits f32 [R,256], R = B*4*120. */
+int tt_msda_sample(int B, const void* value, int value_dtype, const float* offsets, const float* logits,
+                   const float* ref_packed, const int* level_hw, float* out, void* stream);
+/* SpatialCrossAttention "mask & average" incl. its batch-coupling bug (MSDA:338-342):
+ * out (B, 4*256) = sum_{s=B}^{max_len-1} x[b,cam,s,:] / B. */
+int tt_sca_reduce(int B, const float* x, const int* max_len, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libthinktwice_hip.so")
 
 TT_F32, TT_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU, ACT_SOFTPLUS = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU, ACT_SOFTPLUS, ACT_SOFTPLUS_CLAMP = 0, 1, 2, 3, 4, 5
 
 _lib = None
 

@@ -1,0 +1,284 @@
+// "Look" module kernels of the ThinkTwice decoder (dense_heads/thinktwice_decoder.py:88-187,
+// dense_heads/multi_scale_deformable_attn_function.py:279-344,423-526).
+//
+// The reference builds per-(sample, camera) query lists with B*4 host-synchronising nonzero()
+// calls per layer and pads them to a data-dependent max_len.  Here everything stays on the device:
+//   look_project_pack : project the 120 3-D look points into the 4 cameras, in-image mask, stable
+//                       left-packing per (sample, camera) by wave ballot, max_len by atomicMax.
+//   look_gather_query : assemble the 1543-wide query rows (519 base + 4 levels x 256 bilinear
+//                       samples of the FPN maps) for all 120 slots (padded slots = zero rows).
+//   msda_sample       : multi-scale deformable attention core (softmax over 32 (level, point) logits,
+//                       bilinear sampling with zero padding, align_corners=False).
+//   sca_reduce        : the reference's batch-coupled "mask & average" (first B slots zeroed, / B,
+//                       sum over slots < max_len) -- reproduced as is.
+#include "tt_common.h"
+
+namespace tt {
+
+constexpr int kQ = 120;     // 8 BEV points x 15 heights
+constexpr int kCams = 4;
+
+__device__ __forceinline__ float dot4(const float* m, float a, float b, float c, float d) {
+    float s = m[0] * a;
+    s = s + m[1] * b;
+    s = s + m[2] * c;
+    s = s + m[3] * d;
+    return s;
+}
+
+// one wave per (b, cam).  wp (B,4,2) f32; outputs: ref_packed (B,4,120,2), query_of_slot (B,4,120) int,
+// count (B,4) int, max_len (1) int (atomicMax; must be zeroed before launch).
+__global__ __launch_bounds__(64) void look_project_pack_kernel(
+    const float* __restrict__ wp, const float* __restrict__ lidar2img, const float* __restrict__ ida,
+    float img_h, float img_w, float* __restrict__ ref_packed, int* __restrict__ query_of_slot,
+    int* __restrict__ count, int* __restrict__ max_len, float* __restrict__ pts3d_out) {
+    const int bc = blockIdx.x;
+    const int b = bc / kCams;
+    const int lane = threadIdx.x;
+    const float* L = lidar2img + (long long)bc * 16;
+    const float* A = ida + (long long)bc * 16;
+    int base = 0;
+    for (int half = 0; half < 2; ++half) {
+        const int q = half * 64 + lane;
+        bool ok = false;
+        float rx = 0.f, ry = 0.f;
+        if (q < kQ) {
+            const int pt = q / 15, zi = q % 15;
+            float X, Y;
+            if (pt < 4) {
+                X = wp[(b * 4 + pt) * 2 + 0];
+                Y = wp[(b * 4 + pt) * 2 + 1];
+            } else {   // static look points (DEC:157)
+                const float sx[4] = {5.f, 0.f, 0.f, -5.f};
+                const float sy[4] = {0.f, -5.f, 5.f, 0.f};
+                X = sx[pt - 4];
+                Y = sy[pt - 4];
+            }
+            const float Z = (float)(-4.0 + (double)zi * (14.0 / 14.0));   // linspace(-4, 10, 15)
+            if (pts3d_out && (bc % kCams) == 0) {
+                pts3d_out[(b * kQ + q) * 3 + 0] = X;
+                pts3d_out[(b * kQ + q) * 3 + 1] = Y;
+                pts3d_out[(b * kQ + q) * 3 + 2] = Z;
+            }
+            const float cx = dot4(L + 0, X, Y, Z, 1.f);
+            const float cy = dot4(L + 4, X, Y, Z, 1.f);
+            const float cz = dot4(L + 8, X, Y, Z, 1.f);
+            const float cw = dot4(L + 12, X, Y, Z, 1.f);
+            const float eps = 1e-5f;
+            const float zz = fmaxf(cz, eps);
+            const float ux = cx / zz, uy = cy / zz;
+            const float ix = dot4(A + 0, ux, uy, cz, cw);
+            const float iy = dot4(A + 4, ux, uy, cz, cw);
+            const float iz = dot4(A + 8, ux, uy, cz, cw);
+            rx = ix / img_w;
+            ry = iy / img_h;
+            ok = (iz > eps) && (ry > 0.f) && (ry < 1.f) && (rx < 1.f) && (rx > 0.f);
+        }
+        const unsigned long long m = __ballot(ok);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (ok) {
+            query_of_slot[(long long)bc * kQ + pos] = q;
+            ref_packed[((long long)bc * kQ + pos) * 2 + 0] = rx;
+            ref_packed[((long long)bc * kQ + pos) * 2 + 1] = ry;
+        }
+        base += __popcll(m);
+    }
+    // padded slots
+    for (int s = base + lane; s < kQ; s += 64) {
+        query_of_slot[(long long)bc * kQ + s] = -1;
+        ref_packed[((long long)bc * kQ + s) * 2 + 0] = 0.f;
+        ref_packed[((long long)bc * kQ + s) * 2 + 1] = 0.f;
+    }
+    if (lane == 0) {
+        count[bc] = base;
+        atomicMax(max_len, base);
+    }
+}
+
+// bilinear sample of a channel-last map at normalised (x, y), align_corners=False, zero padding
+template <typename T>
+__device__ __forceinline__ float bilinear_cl(const T* __restrict__ map, int H, int W, int cstride, int c,
+                                             float nx, float ny) {
+    const float x = nx * (float)W - 0.5f, y = ny * (float)H - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float lx = x - fx, ly = y - fy;
+    float v = 0.f;
+    if (y0 >= 0 && y0 < H) {
+        if (x0 >= 0 && x0 < W) v += (1.f - ly) * (1.f - lx) * Elem<T>::ld(map + ((long long)y0 * W + x0) * cstride + c);
+        if (x0 + 1 >= 0 && x0 + 1 < W) v += (1.f - ly) * lx * Elem<T>::ld(map + ((long long)y0 * W + x0 + 1) * cstride + c);
+    }
+    if (y0 + 1 >= 0 && y0 + 1 < H) {
+        if (x0 >= 0 && x0 < W) v += ly * (1.f - lx) * Elem<T>::ld(map + ((long long)(y0 + 1) * W + x0) * cstride + c);
+        if (x0 + 1 >= 0 && x0 + 1 < W) v += ly * lx * Elem<T>::ld(map + ((long long)(y0 + 1) * W + x0 + 1) * cstride + c);
+    }
+    return v;
+}
+
+struct LevelMaps {
+    const void* p[4];
+    int H[4], W[4];
+};
+
+// one block (256 threads) per (b, cam, slot): query row = [ctrl4 | xyz3 | emb128 | meas128 | flat256 | samp 1024]
+template <typename T>
+__global__ __launch_bounds__(256) void look_gather_query_kernel(
+    const int* __restrict__ query_of_slot, const float* __restrict__ ref_packed, const float* __restrict__ wp,
+    const float* __restrict__ ctrl_sp, const float* __restrict__ temporal, const float* __restrict__ stat,
+    const float* __restrict__ meas, const float* __restrict__ flat, LevelMaps maps, float* __restrict__ out,
+    int row_stride) {
+    const long long row = blockIdx.x;               // (b*4+cam)*120 + slot
+    const int bc = (int)(row / kQ);
+    const int b = bc / kCams;
+    const int q = query_of_slot[row];
+    float* o = out + row * row_stride;
+    const int t = threadIdx.x;
+    if (q < 0) {
+        for (int i = t; i < row_stride; i += 256) o[i] = 0.f;
+        return;
+    }
+    const int pt = q / 15, zi = q % 15;
+    if (t < 4) o[t] = (pt < 4) ? ctrl_sp[(b * 4 + pt) * 4 + t] : 0.f;
+    if (t == 4) {
+        const float sx[4] = {5.f, 0.f, 0.f, -5.f};
+        const float sy[4] = {0.f, -5.f, 5.f, 0.f};
+        o[4] = (pt < 4) ? wp[(b * 4 + pt) * 2 + 0] : sx[pt - 4];
+        o[5] = (pt < 4) ? wp[(b * 4 + pt) * 2 + 1] : sy[pt - 4];
+        o[6] = (float)(-4.0 + (double)zi);
+    }
+    if (t < 128) {
+        o[7 + t] = (pt < 4) ? temporal[pt * 128 + t] : stat[(pt - 4) * 128 + t];
+        o[135 + t] = meas[b * 128 + t];
+    }
+    o[263 + t] = flat[b * 256 + t];
+    const float rx = ref_packed[row * 2 + 0], ry = ref_packed[row * 2 + 1];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const T* map = reinterpret_cast<const T*>(maps.p[l]) + (long long)bc * maps.H[l] * maps.W[l] * 256;
+        o[519 + t * 4 + l] = bilinear_cl<T>(map, maps.H[l], maps.W[l], 256, t, rx, ry);
+    }
+    if (t < row_stride - 1543) o[1543 + t] = 0.f;
+}
+
+// one block per (bc, slot): thread = head*32 + channel.  value [B*4][S][256] (T), offsets f32 [R][512]
+// ((head, level, point, xy)), logits f32 [R][256] ((head, level*point)), ref f32 [R][2] -> out f32 [R][256]
+template <typename T>
+__global__ __launch_bounds__(256) void msda_sample_kernel(const T* __restrict__ value,
+                                                          const float* __restrict__ offsets,
+                                                          const float* __restrict__ logits,
+                                                          const float* __restrict__ ref, LevelMaps lv,
+                                                          int S, float* __restrict__ out) {
+    const long long row = blockIdx.x;
+    const int bc = (int)(row / kQ);
+    const int t = threadIdx.x, head = t >> 5;
+    const float* lg = logits + row * 256 + head * 32;
+    float mx = -INFINITY;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) mx = fmaxf(mx, lg[i]);
+    float den = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) den += expf(lg[i] - mx);
+    const float rx = ref[row * 2 + 0], ry = ref[row * 2 + 1];
+    const float* of = offsets + row * 512 + head * 64;
+    float acc = 0.f;
+    long long start = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const int H = lv.H[l], W = lv.W[l];
+        const T* map = value + ((long long)bc * S + start) * 256;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const float w = expf(lg[l * 8 + p] - mx) / den;
+            const float nx = rx + of[(l * 8 + p) * 2 + 0] / (float)W;
+            const float ny = ry + of[(l * 8 + p) * 2 + 1] / (float)H;
+            acc += w * bilinear_cl<T>(map, H, W, 256, t, nx, ny);
+        }
+        start += (long long)H * W;
+    }
+    out[row * 256 + t] = acc;
+}
+
+// out[b, cam*256 + c] = (1/B) * sum_{s = B}^{max_len-1} x[(b*4+cam)*120 + s, c]
+__global__ __launch_bounds__(256) void sca_reduce_kernel(const float* __restrict__ x, const int* __restrict__ max_len,
+                                                         int B, float* __restrict__ out) {
+    const int bc = blockIdx.x, c = threadIdx.x;
+    const int ml = min(*max_len, kQ);
+    float s = 0.f;
+    for (int k = B; k < ml; ++k) s += x[((long long)bc * kQ + k) * 256 + c] / (float)B;
+    out[(long long)bc * 256 + c] = s;
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" int tt_look_project_pack(int B, const float* wp, const float* lidar2img, const float* ida_mat,
+                                    float img_h, float img_w, float* ref_packed, int* query_of_slot,
+                                    int* count, int* max_len, void* stream) {
+    TT_REQUIRE(wp && lidar2img && ida_mat && ref_packed && query_of_slot && count && max_len,
+               "tt_look_project_pack: null");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(max_len, 0, sizeof(int), st) != hipSuccess) {
+        set_error("tt_look_project_pack: memset failed");
+        return -2;
+    }
+    hipLaunchKernelGGL(look_project_pack_kernel, dim3(B * kCams), dim3(64), 0, st, wp, lidar2img, ida_mat, img_h,
+                       img_w, ref_packed, query_of_slot, count, max_len, (float*)nullptr);
+    return check_launch("tt_look_project_pack");
+}
+
+static int fill_levels(LevelMaps& m, const void* const* maps, const int* hw) {
+    for (int l = 0; l < 4; ++l) {
+        m.p[l] = maps ? maps[l] : nullptr;
+        m.H[l] = hw[2 * l];
+        m.W[l] = hw[2 * l + 1];
+    }
+    return 0;
+}
+
+extern "C" int tt_look_gather_query(int B, const int* query_of_slot, const float* ref_packed, const float* wp,
+                                    const float* ctrl_softplus, const float* temporal_embedding,
+                                    const float* static_embedding, const float* measurement_feat,
+                                    const float* flattened_feat, const void* const* level_maps,
+                                    const int* level_hw, int maps_dtype, float* out, int row_stride, void* stream) {
+    TT_REQUIRE(query_of_slot && ref_packed && wp && ctrl_softplus && level_maps && level_hw && out,
+               "tt_look_gather_query: null");
+    TT_REQUIRE(row_stride >= 1543 && row_stride <= 1543 + 256, "tt_look_gather_query: row_stride %d", row_stride);
+    LevelMaps m;
+    fill_levels(m, level_maps, level_hw);
+    const unsigned rows_n = (unsigned)(B * kCams * kQ);
+    hipStream_t st = (hipStream_t)stream;
+    if (maps_dtype == TT_F32)
+        hipLaunchKernelGGL(look_gather_query_kernel<float>, dim3(rows_n), dim3(256), 0, st, query_of_slot, ref_packed,
+                           wp, ctrl_softplus, temporal_embedding, static_embedding, measurement_feat,
+                           flattened_feat, m, out, row_stride);
+    else
+        hipLaunchKernelGGL(look_gather_query_kernel<uint16_t>, dim3(rows_n), dim3(256), 0, st, query_of_slot,
+                           ref_packed, wp, ctrl_softplus, temporal_embedding, static_embedding, measurement_feat,
+                           flattened_feat, m, out, row_stride);
+    return check_launch("tt_look_gather_query");
+}
+
+extern "C" int tt_msda_sample(int B, const void* value, int value_dtype, const float* offsets, const float* logits,
+                              const float* ref_packed, const int* level_hw, float* out, void* stream) {
+    TT_REQUIRE(value && offsets && logits && ref_packed && level_hw && out, "tt_msda_sample: null");
+    LevelMaps m;
+    fill_levels(m, nullptr, level_hw);
+    int S = 0;
+    for (int l = 0; l < 4; ++l) S += m.H[l] * m.W[l];
+    const unsigned rows_n = (unsigned)(B * kCams * kQ);
+    hipStream_t st = (hipStream_t)stream;
+    if (value_dtype == TT_F32)
+        hipLaunchKernelGGL(msda_sample_kernel<float>, dim3(rows_n), dim3(256), 0, st, (const float*)value, offsets,
+                           logits, ref_packed, m, S, out);
+    else
+        hipLaunchKernelGGL(msda_sample_kernel<uint16_t>, dim3(rows_n), dim3(256), 0, st, (const uint16_t*)value,
+                           offsets, logits, ref_packed, m, S, out);
+    return check_launch("tt_msda_sample");
+}
+
+extern "C" int tt_sca_reduce(int B, const float* x, const int* max_len, float* out, void* stream) {
+    TT_REQUIRE(x && max_len && out, "tt_sca_reduce: null");
+    hipLaunchKernelGGL(sca_reduce_kernel, dim3(B * kCams), dim3(256), 0, (hipStream_t)stream, x, max_len, B, out);
+    return check_launch("tt_sca_reduce");
+}

@@ -62,6 +62,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case TT_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         case TT_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
         case TT_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
+        case TT_ACT_SOFTPLUS_CLAMP: return fmaxf(v > 20.f ? v : log1pf(expf(v)), 1e-3f);
         default: return v;
     }
 }

@@ -1,0 +1,273 @@
+"""`ThinkTwiceDecoder` -- host-side mirror of the reference head
+(open_loop_training/code/model_code/dense_heads/thinktwice_decoder.py:262-533, inference path),
+with its LookModule / SpatialCrossAttention / MSDeformableAttention3D / SpatialGRU sub-modules
+(thinktwice_decoder.py:26-260, multi_scale_deformable_attn_function.py:197-526, utils.py:53-106).
+
+Same state_dict keys and the same output dict (keys/shapes of SURVEY 8a A22).  All query packing is
+done on the device (no host sync inside the 5-layer loop); dead branches of the reference
+(LiDAR look features zeroed at DEC:186, PredictionModule.ffn discarded at DEC:44-46) are not
+computed -- their parameters are accepted and ignored.
+"""
+import torch
+
+from . import _lib, ops
+from .layers import conv_from_sd, linear_from_sd, rows, unrows
+from .registry import HEADS
+
+F32 = torch.float32
+
+
+def _mlp(sd, name, idx, dev, last_act=False, in_pad=None):
+    out = []
+    for n, j in enumerate(idx):
+        act = "relu" if (n < len(idx) - 1 or last_act) else "none"
+        out.append(linear_from_sd(sd, f"{name}.{j}", dev, act=act, in_pad=in_pad if n == 0 else None))
+    return out
+
+
+def _run(seq, x):
+    for l in seq:
+        x = l(x)
+    return x
+
+
+class _GRU:
+    """SpatialGRU (utils.py:53-106): conv-GRU over 4 steps, input constant over the map."""
+
+    def __init__(self, sd, p, dev):
+        def two(name):
+            return (conv_from_sd(sd, f"{p}.{name}.0", F32, dev, pad=1, act="relu", cin_pad=40),
+                    conv_from_sd(sd, f"{p}.{name}.2", F32, dev, pad=1))
+        self.update, self.reset, self.tilde = two("conv_update"), two("conv_reset"), two("conv_state_tilde")
+        self.dec0 = conv_from_sd(sd, p + ".conv_decoder.0", F32, dev, pad=1, act="relu")
+        self.dec2 = conv_from_sd(sd, p + ".conv_decoder.2", F32, dev, pad=1)
+        for pair in (self.update, self.reset):
+            pair[1].act = _lib.ACT_SIGMOID
+
+    def __call__(self, inp6, state, fut):
+        """inp6 (B,4,6) f32; state (B,H,W,32); fut (B,4,H,W,32) output buffer."""
+        B, H, W, _ = state.shape
+        dev = state.device
+        xs = torch.zeros(B, H, W, 40, dtype=F32, device=dev)      # [x 6 | state 32 | pad 2]
+        xr = torch.zeros(B, H, W, 40, dtype=F32, device=dev)
+        for t in range(4):
+            x_t = inp6[:, t]                                       # (B,6) row-strided view
+            ops.broadcast_rows(x_t, xs, out_coff=0)
+            ops.broadcast_rows(x_t, xr, out_coff=0)
+            ops.ew(3, state, out=xs, C=32, out_coff=6)
+            u = self.update[1](self.update[0](xs))
+            r = self.reset[1](self.reset[0](xs))
+            ops.ew(1, state, b=r, out=xr, C=32, out_coff=6)        # (1 - r) * state
+            cand = self.tilde[1](self.tilde[0](xr))
+            new_state = torch.empty_like(state)
+            ops.ew(2, state, b=cand, g=u, out=new_state, C=32)     # (1-u)*state + u*cand
+            state = new_state
+            self.dec2(self.dec0(state), out=fut[:, t])
+        return fut
+
+
+class _Layer:
+    def __init__(self, sd, p, dev, dtype):
+        self.gru = _GRU(sd, p + ".prediction_module.spatial_gru", dev)
+        c = p + ".look_module.cam_look_module"
+        self.q_ln = (sd[c + ".query_linear.0.weight"].to(dev, F32).contiguous(),
+                     sd[c + ".query_linear.0.bias"].to(dev, F32).contiguous())
+        self.q1 = linear_from_sd(sd, c + ".query_linear.1", dev, act="gelu", in_pad=1544)
+        self.q3 = linear_from_sd(sd, c + ".query_linear.3", dev, act="gelu")
+        d = c + ".deformable_attention"
+        self.off = linear_from_sd(sd, d + ".sampling_offsets", dev)
+        self.aw = linear_from_sd(sd, d + ".attention_weights", dev)
+        self.vproj = linear_from_sd(sd, d + ".value_proj", dev, dtype=dtype)
+        self.vproj_w = sd[d + ".value_proj.weight"].to(dev, F32)
+        self.vproj_b = sd[d + ".value_proj.bias"].to(dev, F32)
+        self.ffn_ln = (sd[c + ".ffn.norm.weight"].to(dev, F32).contiguous(), sd[c + ".ffn.norm.bias"].to(dev, F32).contiguous())
+        self.ffn1 = linear_from_sd(sd, c + ".ffn.w_1", dev, act="gelu")
+        self.ffn2 = linear_from_sd(sd, c + ".ffn.w_2", dev)
+        self.o_ln = (sd[c + ".output_proj.0.weight"].to(dev, F32).contiguous(),
+                     sd[c + ".output_proj.0.bias"].to(dev, F32).contiguous())
+        self.o1 = linear_from_sd(sd, c + ".output_proj.1", dev, act="gelu")
+        self.o3 = linear_from_sd(sd, c + ".output_proj.3", dev)
+        self.mlp_ln = (sd[p + ".mlp.0.weight"].to(dev, F32).contiguous(), sd[p + ".mlp.0.bias"].to(dev, F32).contiguous())
+        self.mlp1 = linear_from_sd(sd, p + ".mlp.1", dev, act="relu")
+        self.mlp4 = linear_from_sd(sd, p + ".mlp.4", dev, act="relu")
+        self.traj = _mlp(sd, p + ".traj_offset_module", (0, 2, 4), dev, in_pad=516)
+        self.ctrl = _mlp(sd, p + ".ctrl_offset_module", (0, 2, 4), dev)
+        self.bev0 = conv_from_sd(sd, p + ".BEV_feat_update_module.0", F32, dev, pad=1, act="relu")
+        self.bev2 = conv_from_sd(sd, p + ".BEV_feat_update_module.2", F32, dev, pad=1)
+        self.flat0 = linear_from_sd(sd, p + ".flattened_BEV_feat_update_module.0", dev, act="relu")
+        self.flat2 = linear_from_sd(sd, p + ".flattened_BEV_feat_update_module.2", dev)
+
+
+@HEADS.register_module()
+class ThinkTwiceDecoder:
+    def __init__(self, config=None, bev_h=None, bev_w=None, BEV_feat_dim=256, flattened_BEV_feat_dim=256,
+                 dtype=torch.float32, device="cuda", **kwargs):
+        self.config = config
+        self.bev_h, self.bev_w = bev_h, bev_w
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.refine_num = config["refine_num"]
+        self.loaded = False
+
+    def load_state_dict(self, sd, prefix="decoder"):
+        p, dev = prefix, self.device
+        self.speed = _mlp(sd, p + ".speed_branch", (0, 2, 4), dev)
+        self.join_traj = _mlp(sd, p + ".join_traj", (0, 2, 4), dev, last_act=True)
+        self.value_traj = _mlp(sd, p + ".value_branch_traj", (0, 2, 4), dev)
+        self.output_traj = _mlp(sd, p + ".output_traj", (0, 2), dev)
+        self.join_ctrl = _mlp(sd, p + ".join_ctrl", (0, 2, 4), dev, last_act=True)
+        self.value_ctrl = _mlp(sd, p + ".value_branch_ctrl", (0, 2, 4), dev)
+        self.policy = _mlp(sd, p + ".policy_head", (0, 2), dev, last_act=True)
+        self.dist_mu = _mlp(sd, p + ".dist_mu", (0, 2), dev)
+        self.dist_sigma = _mlp(sd, p + ".dist_sigma", (0, 2), dev)
+        self.fpn_linear = [conv_from_sd(sd, f"{p}.fpn_linear{i}", self.dtype, dev) for i in range(4)]
+        self.temporal = sd[p + ".temporal_embedding"].to(dev, F32).contiguous()
+        self.static = sd[p + ".static_embedding"].to(dev, F32).contiguous()
+        cams = sd[p + ".cams_embeds"].to(dev, F32)
+        lvls = sd[p + ".level_embeds"].to(dev, F32)
+        self.layers = [_Layer(sd, f"{p}.decoder_layers.{L}", dev, self.dtype) for L in range(self.refine_num)]
+        # value_proj(feat + cam_embed + level_embed) = value_proj(feat) + per-(level, cam) shift  (DEC:392-393)
+        for lay in self.layers:
+            emb = cams.view(1, 4, 256) + lvls.view(4, 1, 256)                       # (lvl, cam, 256)
+            lay.vshift = [torch.addmm(lay.vproj_b.new_zeros(256), emb[l], lay.vproj_w.t()).contiguous()
+                          for l in range(4)]                                         # W e (bias added by shift)
+        self.loaded = True
+        return self
+
+    # ------------------------------------------------------------------ look module
+    def _look(self, lay, B, wp, ctrl_sp, meas, flat, lidar2img, ida_mat, mlvl, level_hw, S):
+        ref, qos, count, max_len = ops.look_project_pack(wp, lidar2img, ida_mat, self.config["img_size"])
+        qrows = ops.look_gather_query(qos, ref, wp, ctrl_sp, self.temporal, self.static, meas, flat, mlvl)
+        R = qrows.shape[0]
+        qn = torch.zeros_like(qrows)
+        ops.layernorm_rows(qrows, lay.q_ln[0], lay.q_ln[1], out=qn, D=1543)
+        q = lay.q3(lay.q1(rows(qn)))                                                # (R,1,1,256)
+        off = unrows(lay.off(q))
+        aw = unrows(lay.aw(q))
+        value = torch.empty(B * 4, S, 256, dtype=self.dtype, device=wp.device)
+        start = 0
+        for l, m in enumerate(mlvl):
+            hw = m.shape[1] * m.shape[2]
+            ops.conv2d(m, lay.vproj.w, shift=lay.vproj.shift, shift_n=lay.vshift[l], shift_n_mod=4,
+                       out=value[:, start:start + hw].unflatten(1, (m.shape[1], m.shape[2])), out_nstride=S * 256)
+            start += hw
+        att = ops.msda_sample(value, off, aw, ref, level_hw, B)                      # (R,256)
+        an = ops.layernorm_rows(att, lay.ffn_ln[0], lay.ffn_ln[1])
+        y = unrows(lay.ffn2(lay.ffn1(rows(an)), res1=att.view(R, 1, 1, 256)))
+        red = ops.sca_reduce(y, max_len, B)                                          # (B,1024)
+        rn = ops.layernorm_rows(red, lay.o_ln[0], lay.o_ln[1])
+        return unrows(lay.o3(lay.o1(rows(rn)))), (count, max_len)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, flattend_BEV_feat, BEV_feat, measurement_feat, target_point, parent_module,
+                teacher_forcing_data=None, look_feature_metadata=None, channel_last_out=False):
+        """flattend_BEV_feat (B,256), BEV_feat channel-last (B,21,21,32), measurement_feat (B,128) f32 on
+        device; look_feature_metadata = [lidar2img (B,4,4,4), ida_mat (B,4,4,4), fpn (4 x (tensor, coff, C))
+        channel-last, lidar feature (unused: the LiDAR look branch is zeroed, DEC:186)]."""
+        if teacher_forcing_data is not None:
+            raise _lib.TTError("teacher forcing (training path) is not part of this build")
+        flat, bev, meas = flattend_BEV_feat, BEV_feat, measurement_feat
+        B = flat.shape[0]
+        dev = flat.device
+        outs = {}
+        outs["pred_speed"] = unrows(_run(self.speed, rows(flat)))
+        fm = torch.empty(B, 384, dtype=F32, device=dev)
+        ops.ew(3, flat, out=fm, C=256, out_coff=0)
+        ops.ew(3, meas, out=fm, C=128, out_coff=256)
+        jt = _run(self.join_traj, rows(fm))
+        outs["pred_value_traj"] = unrows(_run(self.value_traj, jt))
+        outs["pred_features_traj"] = unrows(jt)
+        wp0 = unrows(_run(self.output_traj, jt)).view(B, 4, 2)
+        jc = _run(self.join_ctrl, rows(fm))
+        outs["pred_value_ctrl"] = unrows(_run(self.value_ctrl, jc))
+        outs["pred_features_ctrl"] = unrows(jc)
+        pol = _run(self.policy, jc)
+        R1 = self.refine_num + 1
+        wp_all = torch.empty(B, R1, 4, 2, dtype=F32, device=dev)
+        ctrl_all = torch.empty(B, R1, 4, 4, dtype=F32, device=dev)
+        # coarse outputs written straight into the stacked result buffers (torch.stack of DEC:483-484)
+        ops.ew(3, wp0.reshape(B, 8), out=wp_all.view(B, R1 * 8), C=8, out_coff=0)
+        mu = unrows(_run(self.dist_mu, pol))
+        sg = unrows(_run(self.dist_sigma, pol))
+        c0 = ctrl_all.view(B, R1 * 16)
+        for t in range(4):   # cat([mu, sigma], -1) per time step
+            ops.ew(3, mu, out=c0, C=2, a_coff=2 * t, out_coff=4 * t)
+            ops.ew(3, sg, out=c0, C=2, a_coff=2 * t, out_coff=4 * t + 2)
+
+        lidar2img = look_feature_metadata[0].to(dev, F32).contiguous()
+        ida_mat = look_feature_metadata[1].to(dev, F32).contiguous()
+        fpn = look_feature_metadata[2]
+        mlvl = [self.fpn_linear[i](t, in_coff=off, cin=c) for i, (t, off, c) in enumerate(fpn)]
+        level_hw = [(m.shape[1], m.shape[2]) for m in mlvl]
+        S = sum(h * w for h, w in level_hw)
+
+        H, W = bev.shape[1:3]
+        s_bev = torch.empty(B, self.refine_num, H, W, 32, dtype=F32, device=dev)
+        s_flat = torch.empty(B, self.refine_num, 256, dtype=F32, device=dev)
+        s_fut = torch.empty(B, self.refine_num, 4, H, W, 32, dtype=F32, device=dev)
+        cur_bev, cur_flat = bev, flat
+        look_info = []
+        for L, lay in enumerate(self.layers):
+            wp = wp_all[:, L].contiguous()
+            ctrl = ctrl_all[:, L].contiguous()
+            sp = ops.ew(3, ctrl.view(B * 4, 4), act=_lib.ACT_SOFTPLUS).view(B, 4, 4)
+            inp6 = torch.empty(B, 4, 6, dtype=F32, device=dev)
+            ops.ew(3, wp.view(B * 4, 2), out=inp6.view(B * 4, 6), C=2, out_coff=0)
+            ops.ew(3, sp.view(B * 4, 4), out=inp6.view(B * 4, 6), C=4, out_coff=2)
+            fut = torch.empty(B, 4, H, W, 32, dtype=F32, device=dev)
+            lay.gru(inp6, cur_bev, fut)
+            fflat = parent_module.flatten_tail(fut.view(B * 4, H, W, 32))            # (B*4,256)
+            look, info = self._look(lay, B, wp, sp, meas, cur_flat, lidar2img, ida_mat, mlvl, level_hw, S)
+            look_info.append(info)
+            # [future flat 256 | look 256 | zeros 256 (LiDAR look) | temporal 128 | meas 128]
+            hin = torch.zeros(B * 4, 1024, dtype=F32, device=dev)
+            ops.ew(3, fflat, out=hin, C=256, out_coff=0)
+            hv = hin.view(B, 4, 1024)
+            for t in range(4):
+                ops.ew(3, look, out=hv[:, t], C=256, out_coff=256)
+                ops.ew(3, meas, out=hv[:, t], C=128, out_coff=896)
+                ops.ew(3, self.temporal[t:t + 1].expand(B, 128), out=hv[:, t], C=128, out_coff=768)
+            hn = ops.layernorm_rows(hin, lay.mlp_ln[0], lay.mlp_ln[1])
+            h = unrows(lay.mlp4(lay.mlp1(rows(hn))))                                 # (B*4,512)
+            tin = torch.zeros(B * 4, 516, dtype=F32, device=dev)
+            ops.ew(3, wp.view(B * 4, 2), out=tin, C=2, out_coff=0)
+            ops.ew(3, h, out=tin, C=512, out_coff=2)
+            d_wp = unrows(_run(lay.traj, rows(tin)))                                  # (B*4,2)
+            cin = torch.empty(B * 4, 516, dtype=F32, device=dev)
+            ops.ew(3, ctrl.view(B * 4, 4), out=cin, C=4, out_coff=0)
+            ops.ew(3, h, out=cin, C=512, out_coff=4)
+            d_ctrl = unrows(_run(lay.ctrl, rows(cin)))                                # (B*4,4)
+            ops.ew(0, d_wp, b=wp.view(B * 4, 2), out=wp_all[:, L + 1].view(B * 4, 2))
+            ops.ew(0, d_ctrl, b=ctrl.view(B * 4, 4), out=ctrl_all[:, L + 1].view(B * 4, 4))
+            hb = h.view(B, 2048)
+            xb = torch.empty(B, H, W, 2080, dtype=F32, device=dev)
+            ops.copy_nhwc(cur_bev, xb, out_coff=0)
+            ops.broadcast_rows(hb, xb, out_coff=32)
+            new_bev = lay.bev2(lay.bev0(xb), res1=cur_bev)
+            ops.ew(3, new_bev.view(B, -1), out=s_bev[:, L].view(B, -1))
+            fin = torch.empty(B, 2304, dtype=F32, device=dev)
+            ops.ew(3, cur_flat, out=fin, C=256, out_coff=0)
+            ops.ew(3, hb, out=fin, C=2048, out_coff=256)
+            new_flat = unrows(lay.flat2(lay.flat0(rows(fin)), res1=rows(cur_flat)))
+            ops.ew(3, new_flat, out=s_flat[:, L])
+            ops.ew(3, fut.view(B, -1), out=s_fut[:, L].view(B, -1))
+            cur_bev, cur_flat = new_bev, new_flat
+        ct = ops.ew(3, ctrl_all.view(B * R1 * 4, 4), act=_lib.ACT_SOFTPLUS_CLAMP).view(B, R1, 4, 4)
+        outs["pred_wp"] = wp_all
+        outs["mu_branches"], outs["sigma_branches"] = ct[:, :, 0, :2], ct[:, :, 0, 2:]
+        outs["future_mu"], outs["future_sigma"] = ct[:, :, 1:, :2], ct[:, :, 1:, 2:]
+        outs["refine_flattned_BEV_feature"] = s_flat
+        outs["_look_info"] = look_info
+        if channel_last_out:
+            outs["_bev_cl"], outs["_refine_bev_cl"], outs["_refine_fut_cl"] = bev, s_bev, s_fut
+            return outs
+        outs["bev_feature"] = ops.nhwc_to_nchw(bev)
+        outs["refine_BEV_feature"] = ops.nhwc_to_nchw(s_bev.view(B * self.refine_num, H, W, 32)).view(
+            B, self.refine_num, 32, H, W)
+        fut_nchw = ops.nhwc_to_nchw(s_fut.view(B * self.refine_num * 4, H, W, 32)).view(B, self.refine_num, 4, 32, H, W)
+        # DEC:481 re-views the (B,R,4,...) stack as (B,4,R,...) and transposes (memory reinterpretation)
+        outs["refine_future_BEV_feature"] = fut_nchw.view(B, 4, self.refine_num, 32, H, W).transpose(1, 2)
+        return outs
+
+    __call__ = forward
+

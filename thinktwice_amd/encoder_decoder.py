@@ -1,0 +1,109 @@
+"""`EncoderDecoder` -- host-side mirror of the reference model root
+(open_loop_training/code/encoder_decoder_framework.py:23-250): same registry name, constructor
+arguments, state_dict keys and `forward_inference(batch) -> dict` contract, so the reference's agent
+(leaderboard/team_code/thinktwice_agent.py:168-172,457) can build and call it unchanged through this
+package's registry.  Every tensor op runs on the gfx950 kernels behind include/thinktwice_hip.h.
+"""
+import torch
+
+from . import _lib, ops
+from .fusion import BEVFusion
+from .layers import linear_from_sd, rows, unrows
+from .registry import DETECTORS, build_backbone, build_head
+
+F32 = torch.float32
+
+
+@DETECTORS.register_module()
+class EncoderDecoder:
+    def __init__(self, img_encoder, decoder, lidar_encoder=None, num_cams=4, use_depth=False, use_seg=False,
+                 downsample_factor=16, seg_downsample_factor=2, train_cfg=None, test_cfg=None,
+                 dtype=torch.float32, device="cuda", cfg=None):
+        self.config = train_cfg if train_cfg is not None else cfg
+        self.num_cams = num_cams
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.img_encoder = build_backbone(img_encoder, dtype=dtype, device=device)
+        self.lidar_encoder = build_backbone(lidar_encoder, device=device) if lidar_encoder is not None else None
+        dec = dict(decoder)
+        dec.setdefault("config", self.config)
+        self.decoder = build_head(dec, dtype=dtype, device=device)
+        self.training = False
+        self.loaded = False
+
+    # mmcv / torch.nn.Module surface used by the callers (AGENT:170-172)
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def init_weights(self):
+        pass
+
+    def load_state_dict(self, sd, strict=False):
+        """Accepts the reference's checkpoint `state_dict` (optionally with a `module.` prefix)."""
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        dev = self.device
+        self.img_encoder.load_state_dict(sd, "img_encoder")
+        if self.lidar_encoder is not None:
+            self.lidar_encoder.load_state_dict(sd, "lidar_encoder")
+        self.fusion = BEVFusion(sd, dev)
+        self.meas0 = linear_from_sd(sd, "measurements_encoder.0", dev, act="relu", in_pad=12)
+        self.meas2 = linear_from_sd(sd, "measurements_encoder.2", dev, act="relu")
+        self.decoder.load_state_dict(sd, "decoder")
+        self.loaded = True
+        return self
+
+    def flatten_tail(self, grid_feat):
+        """Shared flatten network (thinktwice_decoder.py:405-415 uses parent_module's layers)."""
+        return self.fusion.tail(grid_feat)
+
+    # ------------------------------------------------------------------ forward
+    def measurement_feat(self, batch):
+        """speed/12, cat(speed, target_point, command) -> measurements_encoder (EDF:198,242-243)."""
+        dev = self.device
+        speed = batch["speed"].to(dev, F32).view(-1, 1)
+        B = speed.shape[0]
+        state = torch.zeros(B, 12, dtype=F32, device=dev)
+        ops.affine_rows(speed, torch.full((1,), 1.0 / 12.0, device=dev), None, out=state[:, 0:1])
+        ops.ew(3, batch["target_point"].to(dev, F32), out=state, C=2, out_coff=1)
+        ops.ew(3, batch["target_command"].to(dev, F32), out=state, C=6, out_coff=3)
+        return unrows(self.meas2(self.meas0(rows(state))))
+
+    def extract_sensor_feat(self, img, img_metas, points):
+        cam = self.img_encoder(img.to(self.device), img_metas, channel_last=True)
+        B, H, W, C = cam["_bev_cl"].shape
+        cam_bev = torch.empty(B, H, W, C, dtype=F32, device=self.device)
+        ops.copy_nhwc(cam["_bev_cl"], cam_bev, rot_flip=True)          # EDF:241
+        lidar = self.lidar_encoder(points[:, -1].to(self.device), channel_last=True, rot_flip=True)  # EDF:244-246
+        return cam, cam_bev, lidar
+
+    def forward_inference(self, batch, channel_last_out=False):
+        if not self.loaded:
+            raise _lib.TTError("EncoderDecoder: load_state_dict() first")
+        self.epoch = 10000
+        meas = self.measurement_feat(batch)
+        cam, cam_bev, lidar = self.extract_sensor_feat(batch["img"], batch["img_metas"], batch.get("points"))
+        flat, bev32, mids = self.fusion(cam_bev, lidar)
+        pred = self.decoder(flat, bev32, meas, batch["target_point"], self, None,
+                            [cam["lidar2img"], cam["ida_mat"], cam["_fpn_cl"], lidar],
+                            channel_last_out=channel_last_out)
+        pred["_cam_bev_cl"], pred["_lidar_bev_cl"], pred["_flat"], pred["_meas"] = cam_bev, lidar, flat, meas
+        return pred
+
+    def forward_train(self, batch):
+        raise _lib.TTError("training forward (losses / teacher forcing) is a later scope row (SURVEY 8f-4)")
+
+    def train_step(self, data, optimizer):
+        return self.forward_train(data)
+
+    def __call__(self, **kwargs):
+        return self.forward_train(kwargs)

@@ -91,8 +91,10 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     out [N,OH,OW,Ct] written at channel offset out_coff (allocated if None)
     """
     require_cuda(x, w)
-    assert x.is_contiguous() and w.is_contiguous() and x.dim() == 4 and w.dim() == 4
+    assert w.is_contiguous() and x.dim() == 4 and w.dim() == 4
     N, H, W, Cs = x.shape
+    # inner (H, W, C) block must be dense; the image (batch) stride may be anything
+    assert x.stride(3) == 1 and (W == 1 or x.stride(2) == Cs) and (H == 1 or x.stride(1) == W * Cs), x.stride()
     Cout, KH, KW, Cin = w.shape
     if cin is None:
         cin = Cin
@@ -106,10 +108,11 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
         out = torch.empty(N, oh, ow, cr, dtype=odt, device=x.device)
     d = _ConvDesc()
     d.in_ = x.data_ptr(); d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.in_cstride = Cs; d.in_coff = in_coff
-    d.in_nstride = 0
+    d.in_nstride = x.stride(0) if N > 1 else 0
     d.weight = w.data_ptr(); d.Cout = Cout; d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad; d.dil = dil
     d.out = out.data_ptr(); d.OH = OH; d.OW = OW
-    d.out_cstride = out.shape[-1]; d.out_coff = out_coff; d.out_nstride = out_nstride
+    d.out_cstride = out.shape[-1]; d.out_coff = out_coff
+    d.out_nstride = out_nstride or (out.stride(0) if (out.dim() == 4 and N > 1) else 0)
     d.pixel_shuffle2 = 1 if pixel_shuffle2 else 0
     d.scale = _dp(scale); d.shift = _dp(shift); d.shift_n = _dp(shift_n); d.shift_n_mod = shift_n_mod
     d.res1 = _dp(res1); d.res1_cstride = 0 if res1 is None else res1.shape[-1]; d.res1_coff = res1_coff
@@ -239,6 +242,7 @@ def ew(op, a, b=None, g=None, out=None, C=None, a_coff=0, b_coff=0, g_coff=0, ou
     if out is None:
         out = torch.empty(R, C, dtype=a.dtype, device=a.device)
     o2 = out.reshape(-1, out.shape[-1])
+    assert o2.data_ptr() == out.data_ptr() and o2.stride(1) == 1, "ew: `out` must be viewable as rows"
     b2 = None if b is None else b.reshape(-1, b.shape[-1])
     g2 = None if g is None else g.reshape(-1, g.shape[-1])
     check(lib().tt_ew(ptr(a2), ptr(b2), ptr(g2), ptr(o2), _ll(R), _c(C), _c(a2.stride(0)), _c(a_coff),
@@ -257,3 +261,46 @@ def deform_im2col3x3(x, offsets, pad=1):
                                     _c(offsets.shape[-1]), _c(pad), _c(dtype_code(x)), _st(x)),
           "tt_deform_im2col3x3")
     return cols
+
+
+# ----------------------------------------------------------------------------- look module
+def look_project_pack(wp, lidar2img, ida_mat, img_hw):
+    B = wp.shape[0]
+    dev = wp.device
+    ref = torch.empty(B, 4, 120, 2, dtype=torch.float32, device=dev)
+    qos = torch.empty(B, 4, 120, dtype=torch.int32, device=dev)
+    count = torch.empty(B, 4, dtype=torch.int32, device=dev)
+    max_len = torch.empty(1, dtype=torch.int32, device=dev)
+    check(lib().tt_look_project_pack(_c(B), ptr(wp), ptr(lidar2img), ptr(ida_mat), _f(img_hw[0]), _f(img_hw[1]),
+                                     ptr(ref), ptr(qos), ptr(count), ptr(max_len), _st(wp)), "tt_look_project_pack")
+    return ref, qos, count, max_len
+
+
+def _level_args(maps):
+    arr = (ctypes.c_void_p * 4)(*[m.data_ptr() for m in maps])
+    hw = (ctypes.c_int * 8)(*[v for m in maps for v in (m.shape[1], m.shape[2])])
+    return arr, hw
+
+
+def look_gather_query(qos, ref, wp, ctrl_sp, temporal, static, meas, flat, maps, row_stride=1544):
+    B = wp.shape[0]
+    out = torch.empty(B * 4 * 120, row_stride, dtype=torch.float32, device=wp.device)
+    arr, hw = _level_args(maps)
+    check(lib().tt_look_gather_query(_c(B), ptr(qos), ptr(ref), ptr(wp), ptr(ctrl_sp), ptr(temporal), ptr(static),
+                                     ptr(meas), ptr(flat), arr, hw, _c(dtype_code(maps[0])), ptr(out),
+                                     _c(row_stride), _st(wp)), "tt_look_gather_query")
+    return out
+
+
+def msda_sample(value, offsets, logits, ref, level_hw, B):
+    out = torch.empty(B * 4 * 120, 256, dtype=torch.float32, device=value.device)
+    hw = (ctypes.c_int * 8)(*[v for pair in level_hw for v in pair])
+    check(lib().tt_msda_sample(_c(B), ptr(value), _c(dtype_code(value)), ptr(offsets), ptr(logits), ptr(ref), hw,
+                               ptr(out), _st(value)), "tt_msda_sample")
+    return out
+
+
+def sca_reduce(x, max_len, B):
+    out = torch.empty(B, 1024, dtype=torch.float32, device=x.device)
+    check(lib().tt_sca_reduce(_c(B), ptr(x), ptr(max_len), ptr(out), _st(x)), "tt_sca_reduce")
+    return out
