@@ -237,8 +237,8 @@ class ThinkTwiceDecoder:
             ops.ew(3, ctrl.view(B * 4, 4), out=cin, C=4, out_coff=0)
             ops.ew(3, h, out=cin, C=512, out_coff=4)
             d_ctrl = unrows(_run(lay.ctrl, rows(cin)))                                # (B*4,4)
-            ops.ew(0, d_wp, b=wp.view(B * 4, 2), out=wp_all[:, L + 1].view(B * 4, 2))
-            ops.ew(0, d_ctrl, b=ctrl.view(B * 4, 4), out=ctrl_all[:, L + 1].view(B * 4, 4))
+            ops.ew(0, d_wp.view(B, 8), b=wp.view(B, 8), out=wp_all[:, L + 1].view(B, 8))
+            ops.ew(0, d_ctrl.view(B, 16), b=ctrl.view(B, 16), out=ctrl_all[:, L + 1].view(B, 16))
             hb = h.view(B, 2048)
             xb = torch.empty(B, H, W, 2080, dtype=F32, device=dev)
             ops.copy_nhwc(cur_bev, xb, out_coff=0)
