@@ -188,6 +188,42 @@ int tt_msda_sample(int B, const void* value, int value_dtype, const float* offse
  * out (B, 4*256) = sum_{s=B}^{max_len-1} x[b,cam,s,:] / B. */
 int tt_sca_reduce(int B, const float* x, const int* max_len, float* out, void* stream);
 
+/* ------------------------------------------------------------------------
+ * LiDAR branch (backbones/lidarnet.py:87-96; bodies are third-party: mmcv Voxelization, mmdet3d
+ * HardSimpleVFE / SparseEncoder, spconv).  Active-row counts live in DEVICE ints; every kernel is
+ * launched over an upper bound (`max_*`) and exits early, so there is no host synchronisation
+ * (the reference syncs at lidarnet.py:90 `coors[-1,0]+1`).  coords are int32 (b,z,y,x).
+ * ---------------------------------------------------------------------- */
+long long tt_lidar_voxelize_workspace_bytes(long long num_points_total);
+/* hard voxelisation + mean VFE: points f32 [B,Np,nfeat]; pc_range_lo / voxel_size: 3 HOST floats;
+ * grid_xyz: 3 HOST ints; voxels with z index >= z_limit are dropped (sparse_shape z, CFG:170).
+ * -> voxel_feats f32 [<=B*Np, nfeat] (mean of the first <=max_points points in point order),
+ *    coords int32 [<=B*Np,4], num_voxels (device int). */
+int tt_lidar_voxelize(const float* points, int B, int Np, int nfeat, const float* pc_range_lo,
+                      const float* voxel_size, const int* grid_xyz, int z_limit, int max_points,
+                      void* workspace, long long workspace_bytes, float* voxel_feats, int* coords,
+                      int* num_voxels, void* stream);
+/* open-addressing hash (uint32 key -> row) of the active sites of one resolution level */
+int tt_sp_hash_build(const int* coords, const int* num_rows, long long max_rows, const int* dims_zyx,
+                     unsigned* hash_keys, int* hash_vals, long long hash_size, void* stream);
+/* spconv SparseConv3d output-site generation; kernel_stride_pad = {kz,ky,kx,sz,sy,sx,pz,py,px} (host) */
+int tt_sp_strided_outputs(const int* in_coords, const int* in_rows, long long max_in,
+                          const int* kernel_stride_pad, const int* out_dims_zyx, unsigned* hash_keys,
+                          int* hash_vals, long long hash_size, int* out_coords, int* out_rows,
+                          long long max_out, void* stream);
+/* nbr[o][k] = input row feeding output o through tap k, or -1 (SubM: out coords == in coords) */
+int tt_sp_rulebook(const int* out_coords, const int* out_rows, long long max_out,
+                   const int* kernel_stride_pad, const int* in_dims_zyx, const unsigned* hash_keys,
+                   const int* hash_vals, long long hash_size, int* nbr, void* stream);
+/* out[o,:] = relu?(scale * sum_k W_k f[nbr[o,k],:] + shift (+ res[o,:])); W f32 [KV][Cin][Cout] */
+int tt_sp_conv(const float* feats, const int* nbr, const int* out_rows, long long max_out, int KV, int Cin,
+               int Cout, const float* weight_k_ci_co, const float* scale, const float* shift,
+               const float* res, int relu, float* out, void* stream);
+/* SparseConvTensor.dense() + view(N, C*D, H, W) (lidarnet.py:53-56), channel-last: dense
+ * [B, H, W, C*D] with channel c*D+z; `dense` must be pre-zeroed. */
+int tt_sp_to_dense(const float* feats, const int* coords, const int* num_rows, long long max_rows, int C,
+                   const int* dims_zyx, float* dense, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

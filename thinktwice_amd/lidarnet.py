@@ -1,0 +1,230 @@
+"""`LidarNet` -- host-side mirror of the reference LiDAR backbone
+(open_loop_training/code/model_code/backbones/lidarnet.py:61-96 + `SparseEncoder_fp32` :24-58; the layer
+bodies live in mmdet3d / mmcv / spconv, config at configs/thinktwice.py:159-193).
+
+points (B,Np,5) -> hard voxelise + mean VFE -> sparse 3-D conv encoder -> dense (B,84,84,256)
+-> SECOND -> SECONDFPN -> (B,84,84,512), channel-last f32.  The sparse part keeps its active-row
+counts on the device (no `coors[-1,0]+1` host sync, lidarnet.py:90).
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from .layers import conv_from_sd, deconv2x2_from_sd
+from .ops import _c, _ll, check, lib, ptr
+from .registry import BACKBONES, MIDDLE_ENCODERS
+
+F32 = torch.float32
+
+
+def _pow2(n):
+    p = 1
+    while p < n:
+        p *= 2
+    return p
+
+
+class _Level:
+    """Active sites of one resolution level: coords, row count, hash, SubM rulebook."""
+
+    def __init__(self, coords, rows, max_rows, dims, dev):
+        self.coords, self.rows, self.max_rows, self.dims = coords, rows, max_rows, list(dims)
+        self.hsize = _pow2(2 * max_rows)
+        self.hk = torch.empty(self.hsize, dtype=torch.int32, device=dev)
+        self.hv = torch.empty(self.hsize, dtype=torch.int32, device=dev)
+        self.dims_c = (ctypes.c_int * 3)(*self.dims)
+        self._subm = None
+        self.built = False
+
+    def build_hash(self):
+        check(lib().tt_sp_hash_build(ptr(self.coords), ptr(self.rows), _ll(self.max_rows), self.dims_c, ptr(self.hk),
+                                     ptr(self.hv), _ll(self.hsize), ops.cur_stream(self.coords.device)),
+              "tt_sp_hash_build")
+        self.built = True
+
+    def subm_rulebook(self):
+        if self._subm is None:
+            if not self.built:
+                self.build_hash()
+            g = (ctypes.c_int * 9)(3, 3, 3, 1, 1, 1, 1, 1, 1)
+            nbr = torch.empty(self.max_rows, 27, dtype=torch.int32, device=self.coords.device)
+            check(lib().tt_sp_rulebook(ptr(self.coords), ptr(self.rows), _ll(self.max_rows), g, self.dims_c,
+                                       ptr(self.hk), ptr(self.hv), _ll(self.hsize), ptr(nbr),
+                                       ops.cur_stream(nbr.device)), "tt_sp_rulebook")
+            self._subm = nbr
+        return self._subm
+
+
+def _sp_weight(w, dev):
+    """spconv (Cout,kD,kH,kW,Cin) -> [KV][Cin][Cout] f32."""
+    co, kd, kh, kw, ci = w.shape
+    return w.to(dev, F32).permute(1, 2, 3, 4, 0).reshape(kd * kh * kw, ci, co).contiguous()
+
+
+def _bn1d(sd, p, dev, eps=1e-3):
+    s = sd[p + ".weight"].float() / torch.sqrt(sd[p + ".running_var"].float() + eps)
+    t = sd[p + ".bias"].float() - sd[p + ".running_mean"].float() * s
+    return s.to(dev).contiguous(), t.to(dev).contiguous()
+
+
+def _sp_conv(feats, nbr, level, w, bn, res=None, relu=True):
+    KV, Cin, Cout = w.shape
+    out = torch.empty(level.max_rows, Cout, dtype=F32, device=feats.device)
+    check(lib().tt_sp_conv(ptr(feats), ptr(nbr), ptr(level.rows), _ll(level.max_rows), _c(KV), _c(Cin), _c(Cout),
+                           ptr(w), ptr(bn[0]), ptr(bn[1]), ptr(res), _c(1 if relu else 0), ptr(out),
+                           ops.cur_stream(feats.device)), "tt_sp_conv")
+    return out
+
+
+@MIDDLE_ENCODERS.register_module()
+class SparseEncoder_fp32:
+    """mmdet3d SparseEncoder body on gfx950 (lidarnet.py:24-58)."""
+
+    def __init__(self, in_channels, sparse_shape, output_channels=128, base_channels=16,
+                 encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                 encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), device="cuda", **kw):
+        self.sparse_shape = list(sparse_shape)
+        self.encoder_channels, self.encoder_paddings = encoder_channels, encoder_paddings
+        self.device = torch.device(device)
+
+    def load_state_dict(self, sd, p):
+        dev = self.device
+        self.w_in = _sp_weight(sd[p + ".conv_input.0.weight"], dev)
+        self.bn_in = _bn1d(sd, p + ".conv_input.1", dev)
+        self.stages = []
+        n = len(self.encoder_channels)
+        for i, blocks in enumerate(self.encoder_channels):
+            st = []
+            for j in range(len(blocks)):
+                r = f"{p}.encoder_layers.encoder_layer{i + 1}.{j}"
+                if j == len(blocks) - 1 and i != n - 1:
+                    pd = self.encoder_paddings[i][j]
+                    pd = [pd] * 3 if isinstance(pd, int) else list(pd)
+                    st.append(("down", _sp_weight(sd[r + ".0.weight"], dev), _bn1d(sd, r + ".1", dev), pd))
+                else:
+                    st.append(("block", _sp_weight(sd[r + ".conv1.weight"], dev), _bn1d(sd, r + ".bn1", dev),
+                               _sp_weight(sd[r + ".conv2.weight"], dev), _bn1d(sd, r + ".bn2", dev)))
+            self.stages.append(st)
+        self.w_out = _sp_weight(sd[p + ".conv_out.0.weight"], dev)
+        self.bn_out = _bn1d(sd, p + ".conv_out.1", dev)
+        return self
+
+    def _down(self, feats, lvl, w, bn, kernel, stride, pad, batch):
+        dev = feats.device
+        od = [(lvl.dims[d] + 2 * pad[d] - kernel[d]) // stride[d] + 1 for d in range(3)]
+        cells = batch * od[0] * od[1] * od[2]
+        max_out = min(lvl.max_rows * 8, cells)
+        coords = torch.empty(max_out, 4, dtype=torch.int32, device=dev)
+        rows = torch.empty(1, dtype=torch.int32, device=dev)
+        new = _Level(coords, rows, max_out, od, dev)
+        g = (ctypes.c_int * 9)(*kernel, *stride, *pad)
+        st = ops.cur_stream(dev)
+        check(lib().tt_sp_strided_outputs(ptr(lvl.coords), ptr(lvl.rows), _ll(lvl.max_rows), g, new.dims_c,
+                                          ptr(new.hk), ptr(new.hv), _ll(new.hsize), ptr(coords), ptr(rows),
+                                          _ll(max_out), st), "tt_sp_strided_outputs")
+        new.built = True
+        if not lvl.built:
+            lvl.build_hash()
+        KV = kernel[0] * kernel[1] * kernel[2]
+        nbr = torch.empty(max_out, KV, dtype=torch.int32, device=dev)
+        check(lib().tt_sp_rulebook(ptr(coords), ptr(rows), _ll(max_out), g, lvl.dims_c, ptr(lvl.hk), ptr(lvl.hv),
+                                   _ll(lvl.hsize), ptr(nbr), st), "tt_sp_rulebook")
+        return _sp_conv(feats, nbr, new, w, bn), new
+
+    def forward(self, voxel_features, coors, num_rows, max_rows, batch_size):
+        """-> dense channel-last (B, H, W, C*D) f32 (== spatial_features.view(N, C*D, H, W))."""
+        dev = voxel_features.device
+        lvl = _Level(coors, num_rows, max_rows, self.sparse_shape, dev)
+        x = _sp_conv(voxel_features, lvl.subm_rulebook(), lvl, self.w_in, self.bn_in)
+        for st in self.stages:
+            for item in st:
+                if item[0] == "block":
+                    _, w1, b1, w2, b2 = item
+                    nbr = lvl.subm_rulebook()
+                    y = _sp_conv(x, nbr, lvl, w1, b1)
+                    x = _sp_conv(y, nbr, lvl, w2, b2, res=x)       # relu(bn2(conv2) + identity)
+                else:
+                    _, w, bn, pd = item
+                    x, lvl = self._down(x, lvl, w, bn, (3, 3, 3), (2, 2, 2), pd, batch_size)
+        x, lvl = self._down(x, lvl, self.w_out, self.bn_out, (3, 1, 1), (2, 1, 1), (0, 0, 0), batch_size)
+        D, H, W = lvl.dims
+        C = x.shape[1]
+        dense = torch.zeros(batch_size, H, W, C * D, dtype=F32, device=dev)
+        check(lib().tt_sp_to_dense(ptr(x), ptr(lvl.coords), ptr(lvl.rows), _ll(lvl.max_rows), _c(C), lvl.dims_c,
+                                   ptr(dense), ops.cur_stream(dev)), "tt_sp_to_dense")
+        return dense
+
+
+@BACKBONES.register_module()
+class LidarNet:
+    def __init__(self, bev_h=None, bev_w=None, pts_voxel_layer=None, pts_voxel_encoder=None,
+                 pts_middle_encoder=None, pts_fusion_layer=None, pts_backbone=None, pts_neck=None,
+                 pts_bbox_head=None, train_cfg=None, test_cfg=None, device="cuda", **kw):
+        self.vl, self.bb, self.nk = dict(pts_voxel_layer), dict(pts_backbone), dict(pts_neck)
+        me = dict(pts_middle_encoder)
+        me.pop("type", None)
+        self.middle = SparseEncoder_fp32(**me, device=device)
+        self.device = torch.device(device)
+        self.training = False
+
+    def load_state_dict(self, sd, prefix="lidar_encoder"):
+        dev, p = self.device, prefix
+        self.middle.load_state_dict(sd, p + ".pts_middle_encoder")
+        eps = self.bb.get("bn_eps", 1e-3)
+        self.blocks = []
+        for b, (n, s) in enumerate(zip(self.bb["layer_nums"], self.bb["layer_strides"])):
+            q = f"{p}.pts_backbone.blocks.{b}"
+            self.blocks.append([conv_from_sd(sd, f"{q}.{3 * l}", F32, dev, bn=f"{q}.{3 * l + 1}", eps=eps,
+                                             stride=s if l == 0 else 1, pad=1, act="relu") for l in range(n + 1)])
+        q = p + ".pts_neck.deblocks"
+        self.de0 = conv_from_sd(sd, q + ".0.0", F32, dev, bn=q + ".0.1", eps=eps, act="relu")
+        self.de1 = deconv2x2_from_sd(sd, q + ".1.0", F32, dev, bn=q + ".1.1", eps=eps, act="relu")
+        return self
+
+    def voxelize(self, pts):
+        """MVXTwoStageDetector.voxelize + HardSimpleVFE on the device (eval: max_voxels[1])."""
+        B, Np, nf = pts.shape
+        vl = self.vl
+        rng, vs = vl["point_cloud_range"], vl["voxel_size"]
+        grid = [int(round((rng[3 + d] - rng[d]) / vs[d])) for d in range(3)]
+        n = B * Np
+        ws_bytes = int(lib().tt_lidar_voxelize_workspace_bytes(_ll(n)))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pts.device)
+        feats = torch.empty(n, nf, dtype=F32, device=pts.device)
+        coords = torch.empty(n, 4, dtype=torch.int32, device=pts.device)
+        num = torch.empty(1, dtype=torch.int32, device=pts.device)
+        lo = (ctypes.c_float * 3)(*rng[:3])
+        vsz = (ctypes.c_float * 3)(*vs)
+        g = (ctypes.c_int * 3)(*grid)
+        check(lib().tt_lidar_voxelize(ptr(pts), _c(B), _c(Np), _c(nf), lo, vsz, g, _c(self.middle.sparse_shape[0]),
+                                      _c(vl["max_num_points"]), ptr(ws), _ll(ws_bytes), ptr(feats), ptr(coords),
+                                      ptr(num), ops.cur_stream(pts.device)), "tt_lidar_voxelize")
+        return feats, coords, num, n
+
+    def forward(self, pts, channel_last=False, rot_flip=False):
+        """pts (B,Np,5) f32 device -> [(B,512,84,84)] like the reference (NCHW f32), or the channel-last
+        map (optionally with the rot90(flip) of encoder_decoder_framework.py:245-246 applied)."""
+        _lib.require_cuda(pts)
+        pts = pts.contiguous().float()
+        feats, coords, num, max_rows = self.voxelize(pts)
+        B = pts.shape[0]
+        x = self.middle.forward(feats, coords, num, max_rows, B)          # (B,84,84,256)
+        outs = []
+        for blk in self.blocks:
+            for cv in blk:
+                x = cv(x)
+            outs.append(x)
+        H, W = outs[0].shape[1:3]
+        cat = torch.empty(B, H, W, 512, dtype=F32, device=pts.device)
+        self.de0(outs[0], out=cat, out_coff=0)
+        self.de1(outs[1], out=cat, out_coff=256)
+        if rot_flip:
+            o = torch.empty_like(cat)
+            ops.copy_nhwc(cat, o, rot_flip=True)
+            cat = o
+        if channel_last:
+            return cat
+        return [ops.nhwc_to_nchw(cat)]
+
+    __call__ = forward
