@@ -1,0 +1,85 @@
+"""End-to-end `forward_inference` (BASELINE configs 1-3): HIP model vs the oracle (reduced image size,
+seconds on CPU) and vs the committed golden vectors produced by the REFERENCE modules
+(f7: B=2 128x256; f8: B=1 full 448x896 thinktwice.py size).  f32 tolerance 1e-3 (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("pred_wp", "mu_branches", "sigma_branches", "future_mu", "future_sigma", "pred_speed", "pred_value_traj",
+        "pred_value_ctrl", "pred_features_traj", "pred_features_ctrl", "bev_feature", "refine_BEV_feature",
+        "refine_flattned_BEV_feature", "refine_future_BEV_feature")
+
+
+def _check_against_pack(pack, out, tol):
+    errs = {}
+    for k in KEYS:
+        v = out[k].detach().float().cpu()
+        if k in pack.files:
+            want = torch.from_numpy(pack[k])
+            assert v.shape == want.shape, k
+            errs[k] = float((v - want).abs().max() / want.abs().max().clamp_min(1e-6))
+        else:
+            idx = torch.from_numpy(pack[k + "__idx"])
+            want = torch.from_numpy(pack[k + "__val"])
+            errs[k] = float((v.reshape(-1)[idx] - want).abs().max() / float(pack[k + "__stats"][2]))
+    assert max(errs.values()) < tol, errs
+    return errs
+
+
+def _run_model(B, hw, npts, seed, dtype=torch.float32):
+    from thinktwice_amd import model as tm, params, synth
+    m, cfg = tm.build_thinktwice(dtype=dtype, final_dim=hw)
+    sd = params.init_params(cfg, seed=seed)
+    m.load_state_dict(sd)
+    batch = synth.make_batch(B, img_hw=hw, num_points=npts)
+    out = m.forward_inference(tm.batch_to_device(batch))
+    torch.cuda.synchronize()
+    return out, cfg, sd, batch
+
+
+def test_forward_small_matches_reference_golden_and_oracle(golden_dir):
+    from oracle import model_ref as M
+    pack = np.load(os.path.join(golden_dir, "f7_forward_small_b2.npz"))
+    B, H, W, npts, seed = (int(v) for v in pack["meta"])
+    out, cfg, sd, batch = _run_model(B, (H, W), npts, seed)
+    errs = _check_against_pack(pack, out, 1e-3)
+    print("f7 (reference golden) rel errs", errs)
+    with torch.no_grad():
+        ref = M.forward_inference(sd, cfg, batch, return_intermediates=True)
+    for k in KEYS:
+        e = float((out[k].cpu() - ref[k]).abs().max() / ref[k].abs().max().clamp_min(1e-6))
+        assert e < 1e-3, (k, e)
+    for L in range(5):
+        assert int(out["_look_info"][L][1].item()) == int(pack["look_max_len"][L])
+    # waypoint L2 vs reference (BASELINE metric "waypoint L2 vs ref")
+    l2 = float((out["pred_wp"].cpu() - torch.from_numpy(pack["pred_wp"])).norm(dim=-1).max())
+    assert l2 < 1e-3, l2
+
+
+def test_forward_full_size_matches_reference_golden(golden_dir):
+    pack = np.load(os.path.join(golden_dir, "f8_forward_full_b1.npz"))
+    B, H, W, npts, seed = (int(v) for v in pack["meta"])
+    assert (H, W) == (448, 896)
+    out, *_ = _run_model(B, (H, W), npts, seed)
+    errs = _check_against_pack(pack, out, 1e-3)
+    print("f8 (reference golden, thinktwice.py size) rel errs", errs)
+    assert out["pred_wp"].shape == (1, 6, 4, 2)
+
+
+def test_forward_bf16_reports_error(golden_dir):
+    pack = np.load(os.path.join(golden_dir, "f7_forward_small_b2.npz"))
+    B, H, W, npts, seed = (int(v) for v in pack["meta"])
+    out, *_ = _run_model(B, (H, W), npts, seed, dtype=torch.bfloat16)
+    errs = _check_against_pack(pack, out, 0.5)
+    print("bf16 trunk: rel errs vs reference golden", errs)
+
+
+def test_forward_refuses_missing_weights():
+    from thinktwice_amd import _lib, model as tm
+    m, _ = tm.build_thinktwice(final_dim=(128, 256))
+    with pytest.raises(_lib.TTError):
+        m.forward_inference({})
