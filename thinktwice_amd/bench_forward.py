@@ -1,0 +1,76 @@
+"""bench.py workload: the full `forward_inference` at the thinktwice.py configuration
+(BASELINE.json configs[2]: encoder + 5-stage decoder, batch 8 per GPU, synthetic inputs resident in
+HBM, random-init weights of the reference architecture)."""
+import os
+import time
+
+import torch
+
+from . import model as tm
+from . import ops, params, synth
+
+MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0}
+
+
+class ForwardWorkload:
+    def __init__(self, batch, device, dtype=None):
+        dtype = dtype or os.environ.get("TT_BENCH_DTYPE", "bf16")
+        self.dtype = dtype
+        tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        self.B = batch
+        self.name = (f"forward_inference thinktwice.py cfg: {batch} frames x (2 sweeps x 4 cams x 448x896 + "
+                     f"65536-pt LiDAR), ResNet50+PAFPN+DepthNet+UNet+LSS splat, LidarNet, fusion, 5-stage decoder")
+        self.model, self.cfg = tm.build_thinktwice(dtype=tdt, device=str(device))
+        sd = params.init_params(self.cfg, seed=0)
+        self.model.load_state_dict(sd)
+        del sd
+        self.batch = tm.batch_to_device(synth.make_batch(batch), device)
+        self.last = None
+
+    def step(self):
+        self.last = self.model.forward_inference(self.batch, channel_last_out=True)
+        return self.last
+
+    def frames_per_step(self):
+        return self.B
+
+    def roofline(self):
+        """Dominant kernel = conv_igemm (MFMA-bound): algorithmic FLOPs of every conv/linear launch of one
+        forward divided by the summed launch durations (HIP events on the launch stream)."""
+        torch.cuda.synchronize()
+        ops.CONV_PROFILE = []
+        self.step()
+        torch.cuda.synchronize()
+        rec = ops.CONV_PROFILE
+        ops.CONV_PROFILE = None
+        flops = sum(r[0] for r in rec)
+        ms = sum(r[1].elapsed_time(r[2]) for r in rec)
+        ach = flops / (ms * 1e-3) / 1e12
+        peak = MFMA_PEAK_TF[self.dtype]
+        top = sorted(rec, key=lambda r: -r[1].elapsed_time(r[2]))[:5]
+        return {"kernel": "conv_igemm_kernel (all conv/linear launches of one forward)", "bound": "mfma",
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": None, "launches": len(rec), "conv_ms_per_step": round(ms, 3),
+                "algorithmic_gflop_per_step": round(flops / 1e9, 1),
+                "slowest_launches": [{"gflop": round(r[0] / 1e9, 2), "ms": round(r[1].elapsed_time(r[2]), 3),
+                                      "tf": round(r[0] / (r[1].elapsed_time(r[2]) * 1e-3) / 1e12, 1),
+                                      "shape": r[3]} for r in top]}
+
+    def extra(self):
+        return {}
+
+    def cpu_baseline(self):
+        """oracle (torch-CPU restatement, validated bit-exact against the reference modules) on ONE frame of
+        the same workload, all host cores."""
+        from oracle import model_ref as M
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        sd = params.init_params(self.cfg, seed=0)
+        batch = synth.make_batch(1)
+        t0 = time.time()
+        with torch.no_grad():
+            M.forward_inference(sd, self.cfg, batch)
+        dt = time.time() - t0
+        return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+                "sample": f"1 frame (B=1) full forward, oracle/model_ref.py, torch {torch.__version__} CPU f32, "
+                          f"{dt:.1f} s"}

@@ -60,6 +60,8 @@ def lift_splat(depth_logits, context, geom_xyz, voxel_num, batch_size, num_cams,
 
 
 # ----------------------------------------------------------------------------- conv / linear
+CONV_PROFILE = None   # bench.py sets this to a list to collect (flops, start, end, shape) per launch
+
 class _ConvDesc(ctypes.Structure):
     _fields_ = [
         ("in_", ctypes.c_void_p), ("N", _c), ("H", _c), ("W", _c), ("Cin", _c), ("in_cstride", _c),
@@ -118,8 +120,15 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     d.res1 = _dp(res1); d.res1_cstride = 0 if res1 is None else res1.shape[-1]; d.res1_coff = res1_coff
     d.res2 = _dp(res2); d.res2_cstride = 0 if res2 is None else res2.shape[-1]; d.res2_coff = res2_coff
     d.act = act; d.dtype = dtype_code(x); d.out_dtype = dtype_code(out)
+    if CONV_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = lib().tt_conv2d_fwd(ctypes.byref(d), cur_stream(x.device))
     check(rc, "tt_conv2d_fwd")
+    if CONV_PROFILE is not None:
+        e1.record()
+        CONV_PROFILE.append((2.0 * N * OH * OW * Cout * KH * KW * Cin, e0, e1,
+                             f"M={N * OH * OW} N={Cout} K={KH * KW * Cin} k{KH}x{KW}s{stride}"))
     return out
 
 
