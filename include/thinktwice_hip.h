@@ -110,6 +110,11 @@ typedef struct tt_conv_desc {
     int act;
     int dtype;       /* TT_F32 / TT_BF16: input, weight, residual storage type */
     int out_dtype;   /* storage type of out */
+    /* sparse (spconv) mode: in = feature rows [*, in_cstride]; N = upper bound of output rows,
+     * H=W=OH=OW=KH=1, KW = taps; gather_idx int32 [N][KW] = input row per (output row, tap) or -1
+     * (the rulebook of tt_sp_rulebook); m_dev (nullable) = device int with the live row count. */
+    const int* gather_idx;
+    const int* m_dev;
 } tt_conv_desc;
 
 int tt_conv2d_fwd(const tt_conv_desc* d, void* stream);
@@ -215,14 +220,11 @@ int tt_sp_strided_outputs(const int* in_coords, const int* in_rows, long long ma
 int tt_sp_rulebook(const int* out_coords, const int* out_rows, long long max_out,
                    const int* kernel_stride_pad, const int* in_dims_zyx, const unsigned* hash_keys,
                    const int* hash_vals, long long hash_size, int* nbr, void* stream);
-/* out[o,:] = relu?(scale * sum_k W_k f[nbr[o,k],:] + shift (+ res[o,:])); W f32 [KV][Cin][Cout] */
-int tt_sp_conv(const float* feats, const int* nbr, const int* out_rows, long long max_out, int KV, int Cin,
-               int Cout, const float* weight_k_ci_co, const float* scale, const float* shift,
-               const float* res, int relu, float* out, void* stream);
+/* the sparse convolution itself = tt_conv2d_fwd with gather_idx = this rulebook (MFMA gathered GEMM) */
 /* SparseConvTensor.dense() + view(N, C*D, H, W) (lidarnet.py:53-56), channel-last: dense
  * [B, H, W, C*D] with channel c*D+z; `dense` must be pre-zeroed. */
-int tt_sp_to_dense(const float* feats, const int* coords, const int* num_rows, long long max_rows, int C,
-                   const int* dims_zyx, float* dense, void* stream);
+int tt_sp_to_dense(const void* feats, const int* coords, const int* num_rows, long long max_rows, int C,
+                   const int* dims_zyx, void* dense, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -41,7 +41,12 @@ class ForwardWorkload:
         ops.CONV_PROFILE = []
         self.step()
         torch.cuda.synchronize()
-        rec = ops.CONV_PROFILE
+        rec = []
+        for r in ops.CONV_PROFILE:
+            if len(r) > 4:      # sparse launch: FLOPs of the LIVE rows only
+                rows_live = min(int(r[5]), int(r[4].item())) if r[4] is not None else int(r[5])
+                r = (r[0] * rows_live, r[1], r[2], r[3].replace("M<=", f"M={rows_live} of <="))
+            rec.append(r)
         ops.CONV_PROFILE = None
         flops = sum(r[0] for r in rec)
         ms = sum(r[1].elapsed_time(r[2]) for r in rec)

@@ -35,6 +35,8 @@ struct ConvArgs {
     const float* shift_n;
     const void* res1;
     const void* res2;
+    const int* gather;   // GATHER mode: [M][KH*KW] input row per (output row, tap), -1 = none
+    const int* m_dev;    // optional device-side row count (rows >= *m_dev are skipped)
     long long in_nstride, out_nstride;
     int N, H, W, Cin, in_cstride, in_coff;
     int Cout, KH, KW, stride, pad, dil;
@@ -66,7 +68,7 @@ template <> struct Mfma<uint16_t> {
     }
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GATHER>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int VEC = Elem<T>::kVec;               // elements per 16 B
     constexpr int BKB = (sizeof(T) == 4) ? 64 : 128; // K bytes per row per tile
@@ -91,6 +93,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int tile_n = blockIdx.x % p.tiles_n;
     const int tile_m = blockIdx.x / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    int Mlim = p.M;
+    if (p.m_dev) {
+        const int md = *p.m_dev;
+        Mlim = md < Mlim ? md : Mlim;
+    }
+    if (m0 >= Mlim) return;   // block-uniform: before any barrier
 
     const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
     const T* __restrict__ wgt = reinterpret_cast<const T*>(p.weight);
@@ -105,14 +113,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         a_row[i] = idx / VPR;
         a_vc[i] = idx % VPR;
         const int m = m0 + a_row[i];
-        a_ok[i] = (m < p.M) && (idx < BM * VPR);
+        a_ok[i] = (m < Mlim) && (idx < BM * VPR);
         const int mm = a_ok[i] ? m : 0;
-        const int n = mm / (p.OH * p.OW);
-        const int r = mm - n * (p.OH * p.OW);
-        const int oh = r / p.OW, ow = r - oh * p.OW;
-        a_h0[i] = oh * p.stride - p.pad;
-        a_w0[i] = ow * p.stride - p.pad;
-        a_base[i] = (long long)n * p.in_nstride + p.in_coff;
+        if (GATHER) {
+            a_h0[i] = 0;
+            a_w0[i] = 0;
+            a_base[i] = (long long)mm * (p.KH * p.KW);      // row of the gather table
+        } else {
+            const int n = mm / (p.OH * p.OW);
+            const int r = mm - n * (p.OH * p.OW);
+            const int oh = r / p.OW, ow = r - oh * p.OW;
+            a_h0[i] = oh * p.stride - p.pad;
+            a_w0[i] = ow * p.stride - p.pad;
+            a_base[i] = (long long)n * p.in_nstride + p.in_coff;
+        }
     }
     int b_row[NVB], b_vc[NVB];
     bool b_ok[NVB];
@@ -148,14 +162,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                 kh = tap / p.KW;
                 kw = tap - kh * p.KW;
             }
-            const int ih = a_h0[i] + kh * p.dil;
-            const int iw = a_w0[i] + kw * p.dil;
-            const bool ok = a_ok[i] && (k < p.K) && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            if (ok) {
-                const T* src = in + a_base[i] + ((long long)ih * p.W + iw) * p.in_cstride + ci;
-                ra[i] = *reinterpret_cast<const uint4*>(src);
+            if (GATHER) {
+                int j = -1;
+                if (a_ok[i] && (k < p.K)) j = p.gather[a_base[i] + kh * p.KW + kw];
+                if (j >= 0) {
+                    const T* src = in + (long long)j * p.in_cstride + p.in_coff + ci;
+                    ra[i] = *reinterpret_cast<const uint4*>(src);
+                } else {
+                    ra[i] = make_uint4(0, 0, 0, 0);
+                }
             } else {
-                ra[i] = make_uint4(0, 0, 0, 0);
+                const int ih = a_h0[i] + kh * p.dil;
+                const int iw = a_w0[i] + kw * p.dil;
+                const bool ok = a_ok[i] && (k < p.K) && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                if (ok) {
+                    const T* src = in + a_base[i] + ((long long)ih * p.W + iw) * p.in_cstride + ci;
+                    ra[i] = *reinterpret_cast<const uint4*>(src);
+                } else {
+                    ra[i] = make_uint4(0, 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -234,7 +259,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= p.M) continue;
+                if (m >= Mlim) continue;
                 float v = acc[i][j][r] * sc + sh;
                 long long o;
                 int n = 0;
@@ -273,7 +298,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GATHER>
 static int launch_conv(ConvArgs& a, hipStream_t st) {
     constexpr int BKB = (sizeof(T) == 4) ? 64 : 128;
     constexpr int BK = BKB / (int)sizeof(T);
@@ -282,7 +307,7 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
     a.tiles_n = div_up(a.Cout, BN);
     a.cin_fast = (a.Cin % BK == 0) ? 1 : 0;
     const size_t smem = (size_t)2 * (BM + BN) * ROWB;
-    auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GATHER>;
     static bool attr_set = false;
     if (!attr_set && smem > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -293,11 +318,16 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
     return check_launch("tt_conv2d_fwd");
 }
 
+template <typename T, bool GATHER>
+static int dispatch_conv2(ConvArgs& a, hipStream_t st) {
+    if (a.Cout > 64) return launch_conv<T, 128, 128, 2, 2, GATHER>(a, st);
+    if (a.Cout > 32) return launch_conv<T, 128, 64, 2, 2, GATHER>(a, st);
+    return launch_conv<T, 128, 32, 4, 1, GATHER>(a, st);
+}
+
 template <typename T>
 static int dispatch_conv(ConvArgs& a, hipStream_t st) {
-    if (a.Cout > 64) return launch_conv<T, 128, 128, 2, 2>(a, st);
-    if (a.Cout > 32) return launch_conv<T, 128, 64, 2, 2>(a, st);
-    return launch_conv<T, 128, 32, 4, 1>(a, st);
+    return a.gather ? dispatch_conv2<T, true>(a, st) : dispatch_conv2<T, false>(a, st);
 }
 
 }  // namespace tt
@@ -323,6 +353,10 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
     a.in = d->in; a.weight = d->weight; a.out = d->out;
     a.scale = d->scale; a.shift = d->shift; a.shift_n = d->shift_n;
     a.res1 = d->res1; a.res2 = d->res2;
+    a.gather = d->gather_idx; a.m_dev = d->m_dev;
+    TT_REQUIRE(!d->gather_idx || (d->H == 1 && d->W == 1 && d->OH == 1 && d->OW == 1 && d->KH == 1 &&
+                                  !d->pixel_shuffle2),
+               "tt_conv2d_fwd: gather mode wants H=W=OH=OW=KH=1, KW=taps");
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_cstride = d->in_cstride; a.in_coff = d->in_coff;
     a.in_nstride = d->in_nstride ? d->in_nstride : (long long)d->H * d->W * d->in_cstride;
     a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;

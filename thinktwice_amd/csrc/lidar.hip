@@ -5,8 +5,8 @@
 //                                               run heads by scan, first <=max_points points per voxel
 //                                               IN POINT ORDER, mean over them = HardSimpleVFE)
 //   spconv SubMConv3d / SparseConv3d          -> tt_sp_hash_build / tt_sp_strided_outputs /
-//                                               tt_sp_rulebook / tt_sp_conv (gather-FMA with fused
-//                                               BN1d + ReLU + residual)
+//                                               tt_sp_rulebook, then tt_conv2d_fwd in gather mode
+//                                               (MFMA gathered GEMM, fused BN1d + ReLU + residual)
 //   SparseConvTensor.dense() + view           -> tt_sp_to_dense (channel index c*D + z, channel-last)
 // No host synchronisation: active-row counts stay in device memory; kernels are launched over an
 // upper bound and exit early.
@@ -178,61 +178,10 @@ __global__ void rulebook_kernel(const int* __restrict__ out_coords, const int* _
     nbr[o * KV + k] = r;
 }
 
-// out[o, :] = act(scale * sum_k W_k . f[nbr[o,k], :] + shift (+ res[o, :]));  W layout [k][ci][co]
-template <int NCO>   // outputs per lane (Cout <= 64*NCO); rows per wave = max(1, 64/Cout)
-__global__ __launch_bounds__(256) void spconv_gather_kernel(const float* __restrict__ f, const int* __restrict__ nbr,
-                                                            const int* __restrict__ out_rows, long long max_out,
-                                                            int KV, int Cin, int Cout, const float* __restrict__ W,
-                                                            const float* __restrict__ scale,
-                                                            const float* __restrict__ shift,
-                                                            const float* __restrict__ res, int relu,
-                                                            float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int rpw = (Cout >= 64) ? 1 : 64 / Cout;          // rows per wave
-    const int sub = (Cout >= 64) ? 0 : lane / Cout;
-    const int co0 = (Cout >= 64) ? lane : lane % Cout;
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
-    long long M = *out_rows;
-    if (M > max_out) M = max_out;
-    for (long long base = wave * rpw; base < M; base += nw * rpw) {
-        const long long o = base + sub;
-        const bool live = (o < M) && (sub < rpw);
-        float acc[NCO];
-#pragma unroll
-        for (int u = 0; u < NCO; ++u) acc[u] = 0.f;
-        if (live) {
-            for (int k = 0; k < KV; ++k) {
-                const int j = nbr[o * KV + k];
-                if (j < 0) continue;
-                const float* fr = f + (long long)j * Cin;
-                const float* wk = W + (long long)k * Cin * Cout;
-                for (int ci = 0; ci < Cin; ++ci) {
-                    const float a = fr[ci];
-#pragma unroll
-                    for (int u = 0; u < NCO; ++u) {
-                        const int co = co0 + 64 * u;
-                        if (co < Cout) acc[u] += a * wk[ci * Cout + co];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < NCO; ++u) {
-                const int co = co0 + 64 * u;
-                if (co < Cout) {
-                    float v = acc[u] * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
-                    if (res) v += res[o * Cout + co];
-                    if (relu) v = fmaxf(v, 0.f);
-                    out[o * Cout + co] = v;
-                }
-            }
-        }
-    }
-}
-
-__global__ void sp_to_dense_kernel(const float* __restrict__ f, const int* __restrict__ coords,
+template <typename T>
+__global__ void sp_to_dense_kernel(const T* __restrict__ f, const int* __restrict__ coords,
                                    const int* __restrict__ rows_n, long long max_rows, int C, Dims3 d,
-                                   float* __restrict__ dense) {
+                                   T* __restrict__ dense) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long r = t / C;
     const int c = (int)(t % C);
@@ -355,36 +304,16 @@ extern "C" int tt_sp_rulebook(const int* out_coords, const int* out_rows, long l
     return check_launch("tt_sp_rulebook");
 }
 
-extern "C" int tt_sp_conv(const float* feats, const int* nbr, const int* out_rows, long long max_out, int KV, int Cin,
-                          int Cout, const float* weight_k_ci_co, const float* scale, const float* shift,
-                          const float* res, int relu, float* out, void* stream) {
-    TT_REQUIRE(feats && nbr && out_rows && weight_k_ci_co && out, "tt_sp_conv: null");
-    TT_REQUIRE(Cout > 0 && Cout <= 256 && (Cout >= 64 || 64 % Cout == 0), "tt_sp_conv: Cout=%d unsupported", Cout);
-    const int rpw = Cout >= 64 ? 1 : 64 / Cout;
-    long long waves = (max_out + rpw - 1) / rpw;
-    long long blocks = (waves + 3) / 4;
-    if (blocks > 256 * 64) blocks = 256 * 64;
-    if (blocks < 1) blocks = 1;
-    hipStream_t st = (hipStream_t)stream;
-    const int nco = (Cout + 63) / 64;
-#define SPL(N)                                                                                                 \
-    hipLaunchKernelGGL(spconv_gather_kernel<N>, dim3((unsigned)blocks), dim3(256), 0, st, feats, nbr, out_rows, \
-                       max_out, KV, Cin, Cout, weight_k_ci_co, scale, shift, res, relu, out)
-    switch (nco) {
-        case 1: SPL(1); break;
-        case 2: SPL(2); break;
-        case 3: SPL(3); break;
-        default: SPL(4); break;
-    }
-#undef SPL
-    return check_launch("tt_sp_conv");
-}
-
-extern "C" int tt_sp_to_dense(const float* feats, const int* coords, const int* num_rows, long long max_rows, int C,
-                              const int* dims_zyx, float* dense, void* stream) {
+extern "C" int tt_sp_to_dense(const void* feats, const int* coords, const int* num_rows, long long max_rows, int C,
+                              const int* dims_zyx, void* dense, int dtype, void* stream) {
     TT_REQUIRE(feats && coords && num_rows && dims_zyx && dense, "tt_sp_to_dense: null");
     Dims3 d{dims_zyx[0], dims_zyx[1], dims_zyx[2]};
-    hipLaunchKernelGGL(sp_to_dense_kernel, dim3((unsigned)div_up(max_rows * C, 256)), dim3(256), 0,
-                       (hipStream_t)stream, feats, coords, num_rows, max_rows, C, d, dense);
+    const dim3 grid((unsigned)div_up(max_rows * C, 256));
+    if (dtype == TT_F32)
+        hipLaunchKernelGGL(sp_to_dense_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)feats,
+                           coords, num_rows, max_rows, C, d, (float*)dense);
+    else
+        hipLaunchKernelGGL(sp_to_dense_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t*)feats, coords, num_rows, max_rows, C, d, (uint16_t*)dense);
     return check_launch("tt_sp_to_dense");
 }

@@ -24,7 +24,7 @@ class EncoderDecoder:
         self.dtype = dtype
         self.device = torch.device(device)
         self.img_encoder = build_backbone(img_encoder, dtype=dtype, device=device)
-        self.lidar_encoder = build_backbone(lidar_encoder, device=device) if lidar_encoder is not None else None
+        self.lidar_encoder = build_backbone(lidar_encoder, device=device, dtype=dtype) if lidar_encoder is not None else None
         dec = dict(decoder)
         dec.setdefault("config", self.config)
         self.decoder = build_head(dec, dtype=dtype, device=device)

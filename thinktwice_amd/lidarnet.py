@@ -56,10 +56,14 @@ class _Level:
         return self._subm
 
 
-def _sp_weight(w, dev):
-    """spconv (Cout,kD,kH,kW,Cin) -> [KV][Cin][Cout] f32."""
+def _sp_weight(w, dev, dtype):
+    """spconv (Cout,kD,kH,kW,Cin) -> [Cout][1][KV][Cin_p] (K-contiguous rows of the gathered GEMM)."""
     co, kd, kh, kw, ci = w.shape
-    return w.to(dev, F32).permute(1, 2, 3, 4, 0).reshape(kd * kh * kw, ci, co).contiguous()
+    vec = 4 if dtype == F32 else 8
+    cp = (ci + vec - 1) // vec * vec
+    out = torch.zeros(co, 1, kd * kh * kw, cp, dtype=dtype, device=dev)
+    out[..., :ci] = w.to(dev).reshape(co, 1, kd * kh * kw, ci).to(dtype)
+    return out.contiguous()
 
 
 def _bn1d(sd, p, dev, eps=1e-3):
@@ -69,12 +73,9 @@ def _bn1d(sd, p, dev, eps=1e-3):
 
 
 def _sp_conv(feats, nbr, level, w, bn, res=None, relu=True):
-    KV, Cin, Cout = w.shape
-    out = torch.empty(level.max_rows, Cout, dtype=F32, device=feats.device)
-    check(lib().tt_sp_conv(ptr(feats), ptr(nbr), ptr(level.rows), _ll(level.max_rows), _c(KV), _c(Cin), _c(Cout),
-                           ptr(w), ptr(bn[0]), ptr(bn[1]), ptr(res), _c(1 if relu else 0), ptr(out),
-                           ops.cur_stream(feats.device)), "tt_sp_conv")
-    return out
+    """SubMConv3d / SparseConv3d + BN1d (+ residual) + ReLU as ONE gathered MFMA GEMM."""
+    return ops.gather_conv(feats, nbr, level.rows, w, scale=bn[0], shift=bn[1], res=res,
+                           act=_lib.ACT_RELU if relu else _lib.ACT_NONE)
 
 
 @MIDDLE_ENCODERS.register_module()
@@ -83,14 +84,19 @@ class SparseEncoder_fp32:
 
     def __init__(self, in_channels, sparse_shape, output_channels=128, base_channels=16,
                  encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
-                 encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), device="cuda", **kw):
+                 encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), device="cuda",
+                 dtype=torch.float32, **kw):
+        self.dtype = dtype
+        self.in_channels = in_channels
         self.sparse_shape = list(sparse_shape)
         self.encoder_channels, self.encoder_paddings = encoder_channels, encoder_paddings
         self.device = torch.device(device)
 
     def load_state_dict(self, sd, p):
         dev = self.device
-        self.w_in = _sp_weight(sd[p + ".conv_input.0.weight"], dev)
+        def _sp_w(t, d):
+            return _sp_weight(t, d, self.dtype)
+        self.w_in = _sp_w(sd[p + ".conv_input.0.weight"], dev)
         self.bn_in = _bn1d(sd, p + ".conv_input.1", dev)
         self.stages = []
         n = len(self.encoder_channels)
@@ -101,12 +107,12 @@ class SparseEncoder_fp32:
                 if j == len(blocks) - 1 and i != n - 1:
                     pd = self.encoder_paddings[i][j]
                     pd = [pd] * 3 if isinstance(pd, int) else list(pd)
-                    st.append(("down", _sp_weight(sd[r + ".0.weight"], dev), _bn1d(sd, r + ".1", dev), pd))
+                    st.append(("down", _sp_w(sd[r + ".0.weight"], dev), _bn1d(sd, r + ".1", dev), pd))
                 else:
-                    st.append(("block", _sp_weight(sd[r + ".conv1.weight"], dev), _bn1d(sd, r + ".bn1", dev),
-                               _sp_weight(sd[r + ".conv2.weight"], dev), _bn1d(sd, r + ".bn2", dev)))
+                    st.append(("block", _sp_w(sd[r + ".conv1.weight"], dev), _bn1d(sd, r + ".bn1", dev),
+                               _sp_w(sd[r + ".conv2.weight"], dev), _bn1d(sd, r + ".bn2", dev)))
             self.stages.append(st)
-        self.w_out = _sp_weight(sd[p + ".conv_out.0.weight"], dev)
+        self.w_out = _sp_w(sd[p + ".conv_out.0.weight"], dev)
         self.bn_out = _bn1d(sd, p + ".conv_out.1", dev)
         return self
 
@@ -136,7 +142,11 @@ class SparseEncoder_fp32:
         """-> dense channel-last (B, H, W, C*D) f32 (== spatial_features.view(N, C*D, H, W))."""
         dev = voxel_features.device
         lvl = _Level(coors, num_rows, max_rows, self.sparse_shape, dev)
-        x = _sp_conv(voxel_features, lvl.subm_rulebook(), lvl, self.w_in, self.bn_in)
+        cp = self.w_in.shape[-1]
+        f0 = torch.zeros(max_rows, cp, dtype=self.dtype, device=dev)      # channel-padded voxel features
+        nf = voxel_features.shape[1]
+        ops.copy_nhwc(voxel_features.view(max_rows, 1, 1, nf), f0.view(max_rows, 1, 1, cp), C=nf)
+        x = _sp_conv(f0, lvl.subm_rulebook(), lvl, self.w_in, self.bn_in)
         for st in self.stages:
             for item in st:
                 if item[0] == "block":
@@ -150,9 +160,9 @@ class SparseEncoder_fp32:
         x, lvl = self._down(x, lvl, self.w_out, self.bn_out, (3, 1, 1), (2, 1, 1), (0, 0, 0), batch_size)
         D, H, W = lvl.dims
         C = x.shape[1]
-        dense = torch.zeros(batch_size, H, W, C * D, dtype=F32, device=dev)
+        dense = torch.zeros(batch_size, H, W, C * D, dtype=x.dtype, device=dev)
         check(lib().tt_sp_to_dense(ptr(x), ptr(lvl.coords), ptr(lvl.rows), _ll(lvl.max_rows), _c(C), lvl.dims_c,
-                                   ptr(dense), ops.cur_stream(dev)), "tt_sp_to_dense")
+                                   ptr(dense), _c(ops.dtype_code(x)), ops.cur_stream(dev)), "tt_sp_to_dense")
         return dense
 
 
@@ -160,11 +170,12 @@ class SparseEncoder_fp32:
 class LidarNet:
     def __init__(self, bev_h=None, bev_w=None, pts_voxel_layer=None, pts_voxel_encoder=None,
                  pts_middle_encoder=None, pts_fusion_layer=None, pts_backbone=None, pts_neck=None,
-                 pts_bbox_head=None, train_cfg=None, test_cfg=None, device="cuda", **kw):
+                 pts_bbox_head=None, train_cfg=None, test_cfg=None, device="cuda", dtype=torch.float32, **kw):
         self.vl, self.bb, self.nk = dict(pts_voxel_layer), dict(pts_backbone), dict(pts_neck)
         me = dict(pts_middle_encoder)
         me.pop("type", None)
-        self.middle = SparseEncoder_fp32(**me, device=device)
+        self.dtype = dtype
+        self.middle = SparseEncoder_fp32(**me, device=device, dtype=dtype)
         self.device = torch.device(device)
         self.training = False
 
@@ -175,11 +186,11 @@ class LidarNet:
         self.blocks = []
         for b, (n, s) in enumerate(zip(self.bb["layer_nums"], self.bb["layer_strides"])):
             q = f"{p}.pts_backbone.blocks.{b}"
-            self.blocks.append([conv_from_sd(sd, f"{q}.{3 * l}", F32, dev, bn=f"{q}.{3 * l + 1}", eps=eps,
+            self.blocks.append([conv_from_sd(sd, f"{q}.{3 * l}", self.dtype, dev, bn=f"{q}.{3 * l + 1}", eps=eps,
                                              stride=s if l == 0 else 1, pad=1, act="relu") for l in range(n + 1)])
         q = p + ".pts_neck.deblocks"
-        self.de0 = conv_from_sd(sd, q + ".0.0", F32, dev, bn=q + ".0.1", eps=eps, act="relu")
-        self.de1 = deconv2x2_from_sd(sd, q + ".1.0", F32, dev, bn=q + ".1.1", eps=eps, act="relu")
+        self.de0 = conv_from_sd(sd, q + ".0.0", self.dtype, dev, bn=q + ".0.1", eps=eps, act="relu")
+        self.de1 = deconv2x2_from_sd(sd, q + ".1.0", self.dtype, dev, bn=q + ".1.1", eps=eps, act="relu")
         return self
 
     def voxelize(self, pts):
@@ -216,11 +227,11 @@ class LidarNet:
                 x = cv(x)
             outs.append(x)
         H, W = outs[0].shape[1:3]
-        cat = torch.empty(B, H, W, 512, dtype=F32, device=pts.device)
+        cat = torch.empty(B, H, W, 512, dtype=self.dtype, device=pts.device)
         self.de0(outs[0], out=cat, out_coff=0)
         self.de1(outs[1], out=cat, out_coff=256)
         if rot_flip:
-            o = torch.empty_like(cat)
+            o = torch.empty(cat.shape, dtype=F32, device=cat.device)     # fusion neck runs in f32
             ops.copy_nhwc(cat, o, rot_flip=True)
             cat = o
         if channel_last:

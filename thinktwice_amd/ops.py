@@ -76,11 +76,39 @@ class _ConvDesc(ctypes.Structure):
         ("res1", ctypes.c_void_p), ("res1_cstride", _c), ("res1_coff", _c),
         ("res2", ctypes.c_void_p), ("res2_cstride", _c), ("res2_coff", _c),
         ("act", _c), ("dtype", _c), ("out_dtype", _c),
+        ("gather_idx", ctypes.c_void_p), ("m_dev", ctypes.c_void_p),
     ]
 
 
 def _dp(t):
     return None if t is None else t.data_ptr()
+
+
+def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None, out_dtype=None):
+    """Sparse convolution as a gathered GEMM on MFMA: feats [R_in, C] rows, nbr int32 [M, taps]
+    (rulebook, -1 = no input), m_dev device int (live output rows), w [Cout,1,taps,C] -> [M, Cout]."""
+    require_cuda(feats, nbr, w)
+    M, taps = nbr.shape
+    Cout, _, KW, Cin = w.shape
+    assert KW == taps and feats.shape[1] == Cin and feats.is_contiguous() and nbr.is_contiguous()
+    out = torch.empty(M, Cout, dtype=out_dtype or feats.dtype, device=feats.device)
+    d = _ConvDesc()
+    d.in_ = feats.data_ptr(); d.N = M; d.H = 1; d.W = 1; d.Cin = Cin; d.in_cstride = Cin; d.in_coff = 0
+    d.in_nstride = 0
+    d.weight = w.data_ptr(); d.Cout = Cout; d.KH = 1; d.KW = KW; d.stride = 1; d.pad = 0; d.dil = 1
+    d.out = out.data_ptr(); d.OH = 1; d.OW = 1; d.out_cstride = Cout; d.out_coff = 0; d.out_nstride = 0
+    d.scale = _dp(scale); d.shift = _dp(shift)
+    d.res1 = _dp(res); d.res1_cstride = 0 if res is None else res.shape[-1]
+    d.act = act; d.dtype = dtype_code(feats); d.out_dtype = dtype_code(out)
+    d.gather_idx = nbr.data_ptr(); d.m_dev = _dp(m_dev)
+    if CONV_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib().tt_conv2d_fwd(ctypes.byref(d), cur_stream(feats.device)), "tt_conv2d_fwd(gather)")
+    if CONV_PROFILE is not None:
+        e1.record()
+        CONV_PROFILE.append((2.0 * Cout * KW * Cin, e0, e1, f"sparse M<={M} N={Cout} K={KW * Cin}", m_dev, M))
+    return out
 
 
 def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=None, res1_coff=0,
