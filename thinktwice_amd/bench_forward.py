@@ -53,6 +53,20 @@ class ForwardWorkload:
         ach = flops / (ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TF[self.dtype]
         top = sorted(rec, key=lambda r: -r[1].elapsed_time(r[2]))[:5]
+        dump = os.environ.get("TT_BENCH_DUMP")
+        if dump:
+            import json
+            agg = {}
+            for r in rec:
+                a = agg.setdefault(r[3], [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += r[1].elapsed_time(r[2])
+                a[2] += r[0]
+            rows_ = sorted(({"shape": k, "calls": v[0], "ms": round(v[1], 3), "gflop": round(v[2] / 1e9, 2),
+                             "tf": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in agg.items()),
+                           key=lambda d: -d["ms"])
+            with open(dump, "w") as f:
+                json.dump(rows_, f, indent=0)
         return {"kernel": "conv_igemm_kernel (all conv/linear launches of one forward)", "bound": "mfma",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None, "launches": len(rec), "conv_ms_per_step": round(ms, 3),

@@ -47,6 +47,7 @@ struct ConvArgs {
     int M, K;            // GEMM sizes
     int cin_fast;        // 1 if Cin % BK == 0 (tap uniform per K tile)
     int out_fast;        // 1 if plain [M][out_cstride] addressing
+    int vec_epi;         // 1: LDS-staged epilogue with 16 B stores (channel counts / offsets aligned)
     int tiles_n;
 };
 
@@ -243,6 +244,96 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     // ---- epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int cout_real = p.pixel_shuffle2 ? (p.Cout >> 2) : p.Cout;
     const int ohw = p.OH * p.OW;
+    if (p.vec_epi) {
+        // Stage each wave's 32 x WTN accumulator block through LDS (the tile buffers are free after
+        // the K loop) so that every lane stores 16 contiguous bytes of one output row: full 128 B
+        // lines instead of 64 B half-lines per MFMA register, and residuals are read the same way.
+        constexpr int LDC = WTN + 4;
+        float* sC = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
+        const int CO = (p.out_dtype == TT_F32) ? 4 : 8;           // channels per lane
+        const int cpr = WTN / CO;                                  // chunks per row
+        const int rpp = 64 / cpr;                                  // rows per pass
+        const int row_in_pass = lane / cpr;
+        const int col_l = (lane % cpr) * CO;
+        const int col = n0 + wn * WTN + col_l;
+        int co = col, q = 0;
+        if (p.pixel_shuffle2) {
+            q = col / cout_real;
+            co = col - q * cout_real;
+        }
+        const bool col_ok = col < p.Cout;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = (col_ok && e < CO && p.scale) ? p.scale[co + e] : 1.f;
+            sh[e] = (col_ok && e < CO && p.shift) ? p.shift[co + e] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sC[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDC + j * 32 + (lane & 31)] = acc[i][j][r];
+            __syncthreads();
+            for (int rl = row_in_pass; rl < 32; rl += rpp) {
+                const int m = m0 + wm * WTM + i * 32 + rl;
+                if (m >= Mlim || !col_ok) continue;
+                float v[8];
+                const float4 t0 = *reinterpret_cast<const float4*>(sC + rl * LDC + col_l);
+                v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
+                if (CO == 8) {
+                    const float4 t1 = *reinterpret_cast<const float4*>(sC + rl * LDC + col_l + 4);
+                    v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+                }
+                long long o;
+                int n = 0;
+                if (p.out_fast) {
+                    o = (long long)m * p.out_cstride + p.out_coff + co;
+                } else {
+                    n = m / ohw;
+                    const int rem = m - n * ohw;
+                    int oh = rem / p.OW, ow = rem - oh * p.OW;
+                    int OWo = p.OW;
+                    if (p.pixel_shuffle2) {
+                        oh = 2 * oh + (q >> 1);
+                        ow = 2 * ow + (q & 1);
+                        OWo = 2 * p.OW;
+                    }
+                    o = (long long)n * p.out_nstride + ((long long)oh * OWo + ow) * p.out_cstride + p.out_coff + co;
+                }
+                const float* sn = nullptr;
+                if (p.shift_n) {
+                    if (p.out_fast) n = m / ohw;
+                    sn = p.shift_n + (long long)(n % p.shift_n_mod) * cout_real + co;
+                }
+                const T* r1 = p.res1 ? reinterpret_cast<const T*>(p.res1) + (long long)m * p.res1_cstride + p.res1_coff + co : nullptr;
+                const T* r2 = p.res2 ? reinterpret_cast<const T*>(p.res2) + (long long)m * p.res2_cstride + p.res2_coff + co : nullptr;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (e < CO) {
+                        float x = v[e] * sc[e] + sh[e];
+                        if (sn) x += sn[e];
+                        if (r1) x += Elem<T>::ld(r1 + e);
+                        if (r2) x += Elem<T>::ld(r2 + e);
+                        v[e] = apply_act(x, p.act);
+                    }
+                }
+                if (CO == 4) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint4 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    pk.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+                    pk.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.out) + o) = pk;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * WTN + j * 32 + (lane & 31);
@@ -374,6 +465,15 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
     TT_REQUIRE(!(d->pixel_shuffle2 && (d->res1 || d->res2)),
                "tt_conv2d_fwd: residuals are not supported with pixel_shuffle2");
     a.tiles_n = 1; a.cin_fast = 0;
+    {
+        const int co_vec = d->out_dtype == TT_F32 ? 4 : 8;
+        const int osz = d->out_dtype == TT_F32 ? 4 : 2;
+        const int cr = d->pixel_shuffle2 ? d->Cout / 4 : d->Cout;
+        bool ok = (cr % co_vec == 0) && (d->out_cstride % co_vec == 0) && (d->out_coff % co_vec == 0) &&
+                  (a.out_nstride % co_vec == 0) && ((reinterpret_cast<uintptr_t>(d->out) & 15) == 0);
+        (void)osz;
+        a.vec_epi = ok ? 1 : 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == TT_F32) return dispatch_conv<float>(a, st);
     return dispatch_conv<uint16_t>(a, st);
