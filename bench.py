@@ -44,6 +44,7 @@ class VoxelPoolWorkload:
         g = torch.Generator(device=device).manual_seed(1234)
         self.feats = [torch.randn(batch, self.Np, 256, device=device, generator=g) for _ in range(2)]
         self.kernel_ms = []
+
         # algorithmic bytes per launch: geom + feats + out, per sample
         self.alg_bytes_per_launch = batch * (self.Np * 3 * 4 + self.Np * 256 * 4 + 441 * 256 * 4)
 
@@ -64,13 +65,17 @@ class VoxelPoolWorkload:
     def frames_per_step(self):
         return self.B
 
+    def on_warm(self):
+        torch.cuda.synchronize()
+        self.kernel_ms.clear()
+
     def roofline(self):
         torch.cuda.synchronize()
         ms = [a.elapsed_time(b) for a, b in self.kernel_ms]
         ms = sorted(ms)[: max(1, len(ms) // 2)]   # launch+memset overhead sits in the upper half
         avg = sum(ms) / len(ms)
         ach = self.alg_bytes_per_launch / (avg * 1e-3) / 1e9
-        return {"kernel": "voxel_pool_rows_kernel", "bound": "hbm", "achieved": round(ach, 1),
+        return {"kernel": "voxel_pool_p1_kernel + voxel_pool_p2_kernel", "bound": "hbm", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": None, "avg_launch_ms": round(avg, 4),
                 "algorithmic_bytes_per_launch": self.alg_bytes_per_launch,
@@ -133,25 +138,9 @@ def main():
             else "voxel_pool"
     wl = make_workload(name, args.batch, device)
 
-    for _ in range(args.warmup):
-        wl.step()
-    if hasattr(wl, "kernel_ms"):
-        torch.cuda.synchronize()
-        wl.kernel_ms.clear()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from thinktwice_amd.bench_harness import run_timed
+    res = run_timed(wl, args.steps, args.warmup, dist=dist, sync=torch.cuda.synchronize, device=device)
+    dt = res["seconds"]
 
     if rank == 0:
         frames = wl.frames_per_step() * args.steps * world

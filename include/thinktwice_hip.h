@@ -51,6 +51,17 @@ int tt_voxel_pool_fwd(int batch_size, int num_points, int num_channels,
                       const int32_t* geom_xyz, const float* input_features,
                       float* output_features, int32_t* pos_memo, void* stream);
 
+/* Same operator with a caller-provided workspace: atomics-free two-phase reduce (LDS-privatised
+ * per-chunk cell sums, then an ordered per-cell gather).  Falls back to tt_voxel_pool_fwd when the
+ * workspace is missing/small or the shape is unsupported (bytes query returns 0). */
+long long tt_voxel_pool_workspace_bytes(int batch_size, int num_points, int num_channels,
+                                        int num_voxel_x, int num_voxel_y);
+int tt_voxel_pool_fwd_ws(int batch_size, int num_points, int num_channels,
+                         int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                         const int32_t* geom_xyz, const float* input_features,
+                         float* output_features, int32_t* pos_memo,
+                         void* workspace, long long workspace_bytes, void* stream);
+
 /* A9: VoxelPooling.backward (ops/voxel_pooling/voxel_pooling.py:57-69):
  * grad_in[b,p,:] = grad_out[b,:,y,x] for kept points, 0 elsewhere.
  * grad_out is the [B,Y,X,C] (channel-last) view of the reference's [B,C,Y,X]. */
@@ -115,6 +126,10 @@ typedef struct tt_conv_desc {
      * (the rulebook of tt_sp_rulebook); m_dev (nullable) = device int with the live row count. */
     const int* gather_idx;
     const int* m_dev;
+    /* optional split-K workspace: f32 [N*OH*OW][Cout], zero-filled by the caller.  When given and the
+     * launch would occupy < 128 workgroups with a long K loop, K is split across gridDim.y and a tiny
+     * finalize kernel applies the epilogue (latency-bound decoder layers with M <= a few thousand). */
+    float* splitk_ws;
 } tt_conv_desc;
 
 int tt_conv2d_fwd(const tt_conv_desc* d, void* stream);

@@ -98,7 +98,8 @@ def test_hip_voxel_pool_matches_golden(golden_dir):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,Np,C", [(1, 1, 4), (2, 63, 256), (2, 64, 256), (3, 1000, 256),
-                                    (1, 4097, 512), (2, 777, 7), (1, 300, 1024), (2, 128, 36)])
+                                    (1, 4097, 512), (2, 777, 7), (1, 300, 1024), (2, 128, 36),
+                                    (2, 20000, 256), (1, 9000, 64), (3, 8193, 1024)])
 def test_hip_voxel_pool_matches_oracle_random(B, Np, C):
     rng = np.random.default_rng(B * 1000 + Np + C)
     geom = np.stack([rng.integers(-2, 23, (B, Np)), rng.integers(-2, 23, (B, Np)),

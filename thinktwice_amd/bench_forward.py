@@ -24,7 +24,9 @@ class ForwardWorkload:
         sd = params.init_params(self.cfg, seed=0)
         self.model.load_state_dict(sd)
         del sd
-        self.batch = tm.batch_to_device(synth.make_batch(batch), device)
+        rank = int(os.environ.get("RANK", "0"))
+        # weak scaling: rank r owns global frames [r*batch, (r+1)*batch)
+        self.batch = tm.batch_to_device(synth.make_batch(batch, seed=1234 + rank * batch), device)
         self.last = None
 
     def step(self):
@@ -79,17 +81,16 @@ class ForwardWorkload:
         return {}
 
     def cpu_baseline(self):
-        """oracle (torch-CPU restatement, validated bit-exact against the reference modules) on ONE frame of
-        the same workload, all host cores."""
-        from oracle import model_ref as M
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
-        sd = params.init_params(self.cfg, seed=0)
-        batch = synth.make_batch(1)
-        t0 = time.time()
-        with torch.no_grad():
-            M.forward_inference(sd, self.cfg, batch)
-        dt = time.time() - t0
-        return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-                "sample": f"1 frame (B=1) full forward, oracle/model_ref.py, torch {torch.__version__} CPU f32, "
-                          f"{dt:.1f} s"}
+        """oracle on ONE frame in a bounded subprocess (<= 32 threads, 240 s cap)."""
+        import json
+        import subprocess
+        import sys
+        threads = min(os.cpu_count() or 1, 32)
+        root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+        try:
+            r = subprocess.run([sys.executable, "-m", "thinktwice_amd.cpu_baseline", str(threads)], cwd=root,
+                               capture_output=True, text=True, timeout=240)
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:   # timeout / failure: report, never block the bench
+            return {"value": None, "unit": "frames/s", "cores": threads, "kind": "port",
+                    "sample": f"oracle forward did not finish within 240 s ({type(e).__name__})"}

@@ -37,6 +37,7 @@ struct ConvArgs {
     const void* res2;
     const int* gather;   // GATHER mode: [M][KH*KW] input row per (output row, tap), -1 = none
     const int* m_dev;    // optional device-side row count (rows >= *m_dev are skipped)
+    float* ws;           // split-K: f32 [M][Cout] partial-sum workspace (pre-zeroed), else null
     long long in_nstride, out_nstride;
     int N, H, W, Cin, in_cstride, in_coff;
     int Cout, KH, KW, stride, pad, dil;
@@ -48,6 +49,7 @@ struct ConvArgs {
     int cin_fast;        // 1 if Cin % BK == 0 (tap uniform per K tile)
     int out_fast;        // 1 if plain [M][out_cstride] addressing
     int vec_epi;         // 1: LDS-staged epilogue with 16 B stores (channel counts / offsets aligned)
+    int splits;          // split-K factor (gridDim.y)
     int tiles_n;
 };
 
@@ -139,7 +141,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         b_ok[i] = ((n0 + b_row[i]) < p.Cout) && (idx < BN * VPR);
     }
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + BK - 1) / BK;
+    int kt0 = 0, nk = nk_all;
+    if (p.splits > 1) {       // this block owns K tiles [kt0, nk)
+        const int per = (nk_all + p.splits - 1) / p.splits;
+        kt0 = blockIdx.y * per;
+        nk = min(nk_all, kt0 + per);
+        if (kt0 >= nk) return;
+    }
     uint4 ra[NVA], rb[NVB];
 
     auto load_tile = [&](int kt) {
@@ -213,13 +222,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
 
     const int frag_off = (lane & 31) * ROWB + (lane >> 5) * 16;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int buf = (kt - kt0) & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
         const unsigned char* tA = sA + (buf * BM + wm * WTM) * ROWB + frag_off;
         const unsigned char* tB = sB + (buf * BN + wn * WTN) * ROWB + frag_off;
@@ -244,6 +253,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     // ---- epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int cout_real = p.pixel_shuffle2 ? (p.Cout >> 2) : p.Cout;
     const int ohw = p.OH * p.OW;
+    if (p.ws) {   // split-K: raw partial sums; scale/shift/residual/activation run in splitk_finalize_kernel
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WTN + j * 32 + (lane & 31);
+            if (col >= p.Cout) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < Mlim) unsafeAtomicAdd(p.ws + (long long)m * p.Cout + col, acc[i][j][r]);
+                }
+        }
+        return;
+    }
     if (p.vec_epi) {
         // Stage each wave's 32 x WTN accumulator block through LDS (the tile buffers are free after
         // the K loop) so that every lane stores 16 contiguous bytes of one output row: full 128 B
@@ -389,6 +413,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     }
 }
 
+// split-K epilogue: out = act(scale * ws + shift + shift_n + res1 + res2), same addressing as the fused one
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const ConvArgs p) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)p.M * p.Cout) return;
+    const int m = (int)(t / p.Cout), col = (int)(t % p.Cout);
+    const int cout_real = p.pixel_shuffle2 ? (p.Cout >> 2) : p.Cout;
+    int co = col, q = 0;
+    if (p.pixel_shuffle2) { q = col / cout_real; co = col - q * cout_real; }
+    const int ohw = p.OH * p.OW;
+    const int n = m / ohw;
+    const int rem = m - n * ohw;
+    int oh = rem / p.OW, ow = rem - oh * p.OW, OWo = p.OW;
+    if (p.pixel_shuffle2) { oh = 2 * oh + (q >> 1); ow = 2 * ow + (q & 1); OWo = 2 * p.OW; }
+    const long long o = (long long)n * p.out_nstride + ((long long)oh * OWo + ow) * p.out_cstride + p.out_coff + co;
+    float v = p.ws[t] * (p.scale ? p.scale[co] : 1.f) + (p.shift ? p.shift[co] : 0.f);
+    if (p.shift_n) v += p.shift_n[(n % p.shift_n_mod) * cout_real + co];
+    if (p.res1) v += Elem<T>::ld(reinterpret_cast<const T*>(p.res1) + (long long)m * p.res1_cstride + p.res1_coff + co);
+    if (p.res2) v += Elem<T>::ld(reinterpret_cast<const T*>(p.res2) + (long long)m * p.res2_cstride + p.res2_coff + co);
+    v = apply_act(v, p.act);
+    if (p.out_dtype == TT_F32) reinterpret_cast<float*>(p.out)[o] = v;
+    else reinterpret_cast<uint16_t*>(p.out)[o] = f32_to_bf16(v);
+}
+
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GATHER>
 static int launch_conv(ConvArgs& a, hipStream_t st) {
     constexpr int BKB = (sizeof(T) == 4) ? 64 : 128;
@@ -405,7 +453,21 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * a.tiles_n)), dim3(256), smem, st, a);
+    const int tiles = tiles_m * a.tiles_n;
+    const int nk = div_up(a.K, BK);
+    a.splits = 1;
+    if (a.ws && !a.m_dev && tiles < 128 && nk >= 8) {
+        int sp = div_up(512, tiles);
+        if (sp > nk / 2) sp = nk / 2;
+        if (sp > 64) sp = 64;
+        a.splits = sp < 1 ? 1 : sp;
+    }
+    if (a.splits <= 1) a.ws = nullptr;
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)a.splits), dim3(256), smem, st, a);
+    if (a.ws) {
+        const long long tot = (long long)a.M * a.Cout;
+        hipLaunchKernelGGL(splitk_finalize_kernel<T>, dim3((unsigned)div_up(tot, 256)), dim3(256), 0, st, a);
+    }
     return check_launch("tt_conv2d_fwd");
 }
 
@@ -445,6 +507,7 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
     a.scale = d->scale; a.shift = d->shift; a.shift_n = d->shift_n;
     a.res1 = d->res1; a.res2 = d->res2;
     a.gather = d->gather_idx; a.m_dev = d->m_dev;
+    a.ws = d->splitk_ws;
     TT_REQUIRE(!d->gather_idx || (d->H == 1 && d->W == 1 && d->OH == 1 && d->OW == 1 && d->KH == 1 &&
                                   !d->pixel_shuffle2),
                "tt_conv2d_fwd: gather mode wants H=W=OH=OW=KH=1, KW=taps");

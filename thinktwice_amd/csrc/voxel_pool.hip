@@ -129,6 +129,183 @@ __global__ __launch_bounds__(256) void voxel_pool_rows_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// forward v2: atomics-free two-phase reduce (needs a workspace).
+//   phase 1: one workgroup per chunk of kChunk consecutive points of ONE sample.  The BEV cells the
+//            chunk touches get LDS slots (wave-ballot compaction of a presence table); every in-range
+//            point row (one coalesced 1 KiB load per wave) is accumulated into its slot with LDS
+//            float atomics; slots and the cell->slot table go to the workspace with plain stores.
+//   phase 2: one wave per (sample, cell): sums that cell's slots over the sample's chunks in chunk
+//            order and adds them to the caller's output -- no global atomics, deterministic up to the
+//            LDS accumulation order inside a chunk.
+// Cells beyond the slot budget (never the case for Lift-Splat geometry; random indices in tests do
+// hit it) fall back to global atomics inside phase 1.
+// ---------------------------------------------------------------------------
+constexpr int kChunk = 2048;
+constexpr int kMaxCells = 2048;
+
+__global__ __launch_bounds__(512) void voxel_pool_p1_kernel(
+    int num_points, int C, int X, int Y, int Z, int chunks_per_sample, int smax,
+    const int32_t* __restrict__ geom, const float* __restrict__ feats, float* __restrict__ out,
+    int32_t* __restrict__ pos_memo, float* __restrict__ partial, int* __restrict__ slot_table) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    __shared__ int table[kMaxCells];
+    __shared__ int nslots_sh;
+    float* slots = lds_f;                                   // [smax][C]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cells = X * Y;
+    const int chunk = blockIdx.x;
+    const int b = chunk / chunks_per_sample;
+    const int cis = chunk - b * chunks_per_sample;
+    const long long p0 = (long long)b * num_points + (long long)cis * kChunk;
+    const int npts = min(kChunk, num_points - cis * kChunk);
+    for (int i = tid; i < cells; i += 512) table[i] = -1;
+    for (int i = tid; i < smax * C; i += 512) slots[i] = 0.f;
+    __syncthreads();
+    // pass A: presence + pos_memo
+    for (int i = tid; i < npts; i += 512) {
+        const long long p = p0 + i;
+        const int x = geom[p * 3], y = geom[p * 3 + 1], z = geom[p * 3 + 2];
+        if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {
+            table[y * X + x] = -2;
+            if (pos_memo) {
+                pos_memo[p * 3] = b;
+                pos_memo[p * 3 + 1] = y;
+                pos_memo[p * 3 + 2] = x;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {   // slot assignment by ballot compaction
+        int base = 0;
+        for (int c0 = 0; c0 < cells; c0 += 64) {
+            const int c = c0 + lane;
+            const bool hit = (c < cells) && (table[c] == -2);
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int s = base + __popcll(m & ((1ull << lane) - 1ull));
+                table[c] = (s < smax) ? s : -3;             // -3: over budget -> global atomics
+            }
+            base += __popcll(m);
+        }
+        if (lane == 0) nslots_sh = min(base, smax);
+    }
+    __syncthreads();
+    // pass B: accumulate rows (C % 4 == 0, C <= 1024: up to 4 float4 per lane)
+    const int c4 = C >> 2;
+    for (int g0 = wave * 64; g0 < npts; g0 += 8 * 64) {
+        const int i = g0 + lane;
+        int cell = -1;
+        if (i < npts) {
+            const long long p = p0 + i;
+            const int x = geom[p * 3], y = geom[p * 3 + 1], z = geom[p * 3 + 2];
+            if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) cell = y * X + x;
+        }
+        unsigned long long mask = __ballot(cell >= 0);
+        while (mask) {
+            int idx[4], cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (mask) { idx[j] = __builtin_ctzll(mask); mask &= mask - 1; cnt = j + 1; } else idx[j] = 0;
+            }
+            float4 row[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < cnt) {
+                    const float4* src = reinterpret_cast<const float4*>(feats + (p0 + g0 + idx[j]) * (long long)C);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int ch = lane + 64 * v;
+                        row[j][v] = (ch < c4) ? src[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < cnt) {
+                    const int c = __builtin_amdgcn_readlane(cell, idx[j]);
+                    const int s = table[c];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int ch = lane + 64 * v;
+                        if (ch < c4) {
+                            if (s >= 0) {
+                                float* d = slots + s * C + ch * 4;
+                                atomicAdd(d + 0, row[j][v].x);
+                                atomicAdd(d + 1, row[j][v].y);
+                                atomicAdd(d + 2, row[j][v].z);
+                                atomicAdd(d + 3, row[j][v].w);
+                            } else {
+                                float* d = out + ((long long)b * cells + c) * C + ch * 4;
+                                unsafeAtomicAdd(d + 0, row[j][v].x);
+                                unsafeAtomicAdd(d + 1, row[j][v].y);
+                                unsafeAtomicAdd(d + 2, row[j][v].z);
+                                unsafeAtomicAdd(d + 3, row[j][v].w);
+                            }
+                        }
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    const int ns = nslots_sh;
+    float4* dst = reinterpret_cast<float4*>(partial + (long long)chunk * smax * C);
+    const float4* srcv = reinterpret_cast<const float4*>(slots);
+    for (int i = tid; i < ns * c4; i += 512) dst[i] = srcv[i];
+    // slot_table layout [b][cell][chunk_in_sample]: phase 2 reads a cell's chunks contiguously
+    for (int c = tid; c < cells; c += 512) {
+        const int s = table[c];
+        slot_table[((long long)b * cells + c) * chunks_per_sample + cis] = (s >= 0) ? s : -1;
+    }
+}
+
+__global__ __launch_bounds__(64) void voxel_pool_p2_kernel(int C, int cells, int chunks_per_sample, int smax,
+                                                           const float* __restrict__ partial,
+                                                           const int* __restrict__ slot_table,
+                                                           float* __restrict__ out) {
+    const int bc = blockIdx.x;                  // b * cells + cell
+    const int b = bc / cells;
+    const int lane = threadIdx.x;
+    const int c4 = C >> 2;
+    float4 acc[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool any = false;
+    const int* tab = slot_table + (long long)bc * chunks_per_sample;
+    for (int k0 = 0; k0 < chunks_per_sample; k0 += 64) {
+        const int k = k0 + lane;
+        const int s = (k < chunks_per_sample) ? tab[k] : -1;
+        unsigned long long m = __ballot(s >= 0);
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const int sj = __builtin_amdgcn_readlane(s, j);
+            const long long chunk = (long long)b * chunks_per_sample + k0 + j;
+            const float4* src = reinterpret_cast<const float4*>(partial + (chunk * smax + sj) * C);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ch = lane + 64 * v;
+                if (ch < c4) {
+                    const float4 t = src[ch];
+                    acc[v].x += t.x; acc[v].y += t.y; acc[v].z += t.z; acc[v].w += t.w;
+                }
+            }
+            any = true;
+        }
+    }
+    if (!any) return;
+    float4* dst = reinterpret_cast<float4*>(out + (long long)bc * C);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int ch = lane + 64 * v;
+        if (ch < c4) {
+            float4 o = dst[ch];
+            o.x += acc[v].x; o.y += acc[v].y; o.z += acc[v].z; o.w += acc[v].w;
+            dst[ch] = o;
+        }
+    }
+}
+
 // Generic fallback (any C): one thread per (point, channel).  Correctness path
 // for odd channel counts only.
 __global__ __launch_bounds__(256) void voxel_pool_scalar_kernel(
@@ -386,6 +563,63 @@ extern "C" int tt_voxel_pool_fwd(int batch_size, int num_points, int num_channel
                            geom_xyz, input_features, output_features, pos_memo);
     }
     return check_launch("tt_voxel_pool_fwd");
+}
+
+
+static int v2_smax(int C) {
+    int s = (40 * 1024) / (C * 4);   // 40 KiB of slots + 8 KiB table => 3 workgroups per CU
+    if (s > 64) s = 64;
+    return s;
+}
+
+static bool v2_ok(long long total, int C, int X, int Y) {
+    return C % 4 == 0 && C <= 1024 && (long long)X * Y <= kMaxCells && v2_smax(C) >= 8 && total >= 4 * kChunk;
+}
+
+extern "C" long long tt_voxel_pool_workspace_bytes(int batch_size, int num_points, int num_channels,
+                                                   int num_voxel_x, int num_voxel_y) {
+    const long long total = (long long)batch_size * num_points;
+    if (!v2_ok(total, num_channels, num_voxel_x, num_voxel_y)) return 0;
+    const long long cps = (num_points + kChunk - 1) / kChunk;
+    const long long nchunks = cps * batch_size;
+    const long long part = nchunks * v2_smax(num_channels) * num_channels * 4;
+    const long long tab = (long long)batch_size * num_voxel_x * num_voxel_y * cps * 4;
+    return part + tab + 256;
+}
+
+extern "C" int tt_voxel_pool_fwd_ws(int batch_size, int num_points, int num_channels, int num_voxel_x,
+                                    int num_voxel_y, int num_voxel_z, const int32_t* geom_xyz,
+                                    const float* input_features, float* output_features, int32_t* pos_memo,
+                                    void* workspace, long long workspace_bytes, void* stream) {
+    const long long total = (long long)batch_size * num_points;
+    const long long need = tt_voxel_pool_workspace_bytes(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y);
+    if (need == 0 || !workspace || workspace_bytes < need ||
+        (reinterpret_cast<uintptr_t>(input_features) & 15) || (reinterpret_cast<uintptr_t>(output_features) & 15))
+        return tt_voxel_pool_fwd(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, num_voxel_z,
+                                 geom_xyz, input_features, output_features, pos_memo, stream);
+    TT_REQUIRE(geom_xyz && input_features && output_features, "tt_voxel_pool_fwd_ws: null pointer");
+    (void)total;
+    hipStream_t st = (hipStream_t)stream;
+    const int C = num_channels, cells = num_voxel_x * num_voxel_y;
+    const int cps = (num_points + kChunk - 1) / kChunk;
+    const int nchunks = cps * batch_size;
+    const int smax = v2_smax(C);
+    float* partial = reinterpret_cast<float*>(workspace);
+    const long long part_bytes = (long long)nchunks * smax * C * 4;
+    int* slot_table = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + ((part_bytes + 255) / 256) * 256);
+    const size_t lds = (size_t)smax * C * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(voxel_pool_p1_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(voxel_pool_p1_kernel, dim3((unsigned)nchunks), dim3(512), lds, st, num_points, C,
+                       num_voxel_x, num_voxel_y, num_voxel_z, cps, smax, geom_xyz, input_features,
+                       output_features, pos_memo, partial, slot_table);
+    hipLaunchKernelGGL(voxel_pool_p2_kernel, dim3((unsigned)(batch_size * cells)), dim3(64), 0, st, C, cells, cps,
+                       smax, partial, slot_table, output_features);
+    return check_launch("tt_voxel_pool_fwd_ws");
 }
 
 extern "C" int tt_voxel_pool_bwd(int batch_size, int num_points, int num_channels,

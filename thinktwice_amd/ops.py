@@ -76,7 +76,7 @@ class _ConvDesc(ctypes.Structure):
         ("res1", ctypes.c_void_p), ("res1_cstride", _c), ("res1_coff", _c),
         ("res2", ctypes.c_void_p), ("res2_cstride", _c), ("res2_coff", _c),
         ("act", _c), ("dtype", _c), ("out_dtype", _c),
-        ("gather_idx", ctypes.c_void_p), ("m_dev", ctypes.c_void_p),
+        ("gather_idx", ctypes.c_void_p), ("m_dev", ctypes.c_void_p), ("splitk_ws", ctypes.c_void_p),
     ]
 
 
@@ -148,6 +148,10 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     d.res1 = _dp(res1); d.res1_cstride = 0 if res1 is None else res1.shape[-1]; d.res1_coff = res1_coff
     d.res2 = _dp(res2); d.res2_cstride = 0 if res2 is None else res2.shape[-1]; d.res2_coff = res2_coff
     d.act = act; d.dtype = dtype_code(x); d.out_dtype = dtype_code(out)
+    M_ = N * OH * OW
+    if M_ <= 4096 and KH * KW * Cin >= 512:      # latency-bound shape: let the library split K
+        ws = torch.zeros(M_, Cout, dtype=torch.float32, device=x.device)
+        d.splitk_ws = ws.data_ptr()
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -18,6 +18,20 @@ from torch.autograd import Function
 from . import _lib
 
 
+def _pool_launch(B, Np, C, vx, vy, vz, geom_xyz, input_features, out, pos_memo):
+    """tt_voxel_pool_fwd_ws with a torch-allocated workspace (atomics-free two-phase kernel); the
+    library itself falls back to the single-pass atomic kernel for shapes the fast path does not cover."""
+    L = _lib.lib()
+    ws_bytes = int(L.tt_voxel_pool_workspace_bytes(ctypes.c_int(B), ctypes.c_int(Np), ctypes.c_int(C),
+                                                   ctypes.c_int(vx), ctypes.c_int(vy)))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=input_features.device) if ws_bytes > 0 else None
+    rc = L.tt_voxel_pool_fwd_ws(
+        ctypes.c_int(B), ctypes.c_int(Np), ctypes.c_int(C), ctypes.c_int(vx), ctypes.c_int(vy), ctypes.c_int(vz),
+        _lib.ptr(geom_xyz), _lib.ptr(input_features), _lib.ptr(out), _lib.ptr(pos_memo), _lib.ptr(ws),
+        ctypes.c_longlong(ws_bytes), _lib.cur_stream(input_features.device))
+    _lib.check(rc, "tt_voxel_pool_fwd_ws")
+
+
 def _voxel_num_tuple(voxel_num):
     if isinstance(voxel_num, torch.Tensor):
         voxel_num = voxel_num.detach().cpu().tolist()
@@ -45,11 +59,7 @@ class VoxelPooling(Function):
         out = input_features.new_zeros(B, vy, vx, C)
         need_memo = input_features.requires_grad
         pos_memo = geom_xyz.new_full((B, Np, 3), -1) if need_memo else None
-        rc = _lib.lib().tt_voxel_pool_fwd(
-            ctypes.c_int(B), ctypes.c_int(Np), ctypes.c_int(C), ctypes.c_int(vx), ctypes.c_int(vy),
-            ctypes.c_int(vz), _lib.ptr(geom_xyz), _lib.ptr(input_features), _lib.ptr(out),
-            _lib.ptr(pos_memo), _lib.cur_stream(input_features.device))
-        _lib.check(rc, "tt_voxel_pool_fwd")
+        _pool_launch(B, Np, C, vx, vy, vz, geom_xyz, input_features, out, pos_memo)
         if need_memo:
             ctx.save_for_backward(pos_memo)
         ctx.in_shape = in_shape
@@ -83,10 +93,6 @@ def voxel_pooling_forward_wrapper(batch_size, num_points, num_channels, num_voxe
     for name, t in (("geom_xyz", geom_xyz), ("input_features", input_features)):
         if not t.is_contiguous():
             raise RuntimeError(f"{name} must be contiguous ")
-    rc = _lib.lib().tt_voxel_pool_fwd(
-        ctypes.c_int(int(batch_size)), ctypes.c_int(int(num_points)), ctypes.c_int(int(num_channels)),
-        ctypes.c_int(int(num_voxel_x)), ctypes.c_int(int(num_voxel_y)), ctypes.c_int(int(num_voxel_z)),
-        _lib.ptr(geom_xyz), _lib.ptr(input_features), _lib.ptr(output_features), _lib.ptr(pos_memo),
-        _lib.cur_stream(input_features.device))
-    _lib.check(rc, "tt_voxel_pool_fwd")
+    _pool_launch(int(batch_size), int(num_points), int(num_channels), int(num_voxel_x), int(num_voxel_y),
+                 int(num_voxel_z), geom_xyz, input_features, output_features, pos_memo)
     return 1
