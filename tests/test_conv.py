@@ -61,6 +61,13 @@ CASES = [
     (5, 1, 1, 1543, 512, 1, 1, 0, 1, 3, False, 0),    # linear 1543->512 + GELU, 5 rows
     (300, 1, 1, 256, 1024, 1, 1, 0, 1, 2, False, 0),  # linear + sigmoid
     (1, 7, 7, 128, 256, 3, 1, 0, 1, 4, False, 0),     # valid conv, softplus
+    # M >= 2048 with Cin % BK == 0: the LDS-DMA (glds) 3-stage kernel
+    (2, 40, 48, 64, 128, 3, 1, 1, 1, 1, True, 1),     # 256x128 tile, ragged M (3840), residual
+    (1, 64, 64, 128, 64, 1, 1, 0, 1, 0, False, 0),    # 256x64 tile, 1x1
+    (2, 56, 100, 256, 512, 3, 2, 1, 1, 1, True, 0),   # stride 2, many N tiles
+    (2, 40, 48, 64, 64, 3, 1, 6, 6, 1, True, 2),      # dilation 6, two residuals
+    (3, 30, 30, 192, 200, 3, 1, 1, 1, 3, False, 0),   # Cout tail (200), gelu
+    (1, 50, 60, 64, 256, 1, 1, 0, 1, 2, True, 1),     # single K tile (bf16), sigmoid
 ]
 
 

@@ -1,0 +1,258 @@
+// Implicit-GEMM convolution, LDS-DMA pipelined variant (gfx950 `global_load_lds_dwordx4`).
+//
+// Same math and epilogue as conv_igemm.hip; different data movement, built for the large dense layers
+// of the camera trunk / SECOND / decoder value projections where the register-staged 2-stage loop sits
+// at 2 workgroups per CU and ~23 % MFMA utilisation:
+//   * 512 threads = 8 waves, block tile 256 x {128, 64}; the weight tile is shared by 8 waves.
+//   * global -> LDS by DMA (no staging VGPRs), THREE stages in flight: tile k+2 is issued right after
+//     the barrier that publishes tile k, with a COUNTED `s_waitcnt vmcnt(N)` (never 0 in the main loop)
+//     and a raw `s_barrier`, so two K tiles of loads overlap the MFMA phase (cdna_hip_programming.md
+//     section 5 "glds span barrier").
+//   * LDS rows are unpadded (the DMA writes wave-uniform base + lane*16); bank conflicts are removed
+//     by an XOR swizzle applied to the SOURCE address: 16 B chunk c of row r is stored at chunk slot
+//     c ^ f(r), f(r) = (r>>1)&7 for 128 B rows (bf16), (r>>2)&3 for 64 B rows (f32) -- every 16-lane
+//     group of ds_read_b128 then touches 16 distinct slots of the 256 B bank row.
+//   * rows that are padding / beyond M / beyond K read from a 16 B zero page instead of branching.
+//   * XCD-aware tile order: workgroups that share an A row-block are consecutive on ONE XCD (its L2).
+// Requires: dense (non-gather) conv, Cin % BK == 0 (one tap per K tile), no split-K.
+#include "conv_common.h"
+
+namespace tt {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <typename T, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
+                                                              int tiles_m, int tiles_n) {
+    constexpr int BM = 256;
+    constexpr int VEC = Elem<T>::kVec;
+    constexpr int BKB = (sizeof(T) == 4) ? 64 : 128;
+    constexpr int BK = BKB / (int)sizeof(T);
+    constexpr int CPR = BKB / 16;                     // 16 B chunks per row
+    constexpr int STAGES = 3;
+    constexpr int STAGE_BYTES = (BM + BN) * BKB;
+    constexpr int NA_INSTR = BM * CPR / 64;           // 1 KiB wave-instructions in the A tile
+    constexpr int NB_INSTR = BN * CPR / 64;
+    constexpr int NIA = NA_INSTR / 8;                 // A wave-instructions per wave per tile
+    constexpr int NIB = (NB_INSTR + 7) / 8;           // B  " (when NB_INSTR < 8 some waves re-load a chunk
+                                                      //       another wave also loads: same bytes, harmless,
+                                                      //       and every wave keeps the same vmcnt arithmetic)
+    constexpr int LPT = NIA + NIB;                    // DMA loads per thread per tile
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(WAVES_M * WAVES_N == 8, "8 waves");
+    static_assert(NA_INSTR % 8 == 0 && NIA >= 1 && NIB >= 1, "tile too small for 8 waves");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    // XCD-aware remap (bijective for any grid size): hardware places block b on XCD b % 8
+    const int nblk = tiles_m * tiles_n;
+    int L;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = nblk >> 3, r = nblk & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int tile_n = L % tiles_n, tile_m = L / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int Mlim = p.M;
+
+    const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(p.weight);
+    const T* zp = reinterpret_cast<const T*>(zero_page);
+
+    auto swz = [](int row) { return (sizeof(T) == 4) ? ((row >> 2) & 3) : ((row >> 1) & 7); };
+
+    // ---- per-thread DMA slots: A slot j covers LDS chunk g = (wave + 8*j)*64 + lane of the A tile
+    int a_h0[NIA], a_w0[NIA], a_c[NIA];
+    long long a_base[NIA];
+    bool a_ok[NIA];
+#pragma unroll
+    for (int j = 0; j < NIA; ++j) {
+        const int g = (wave + 8 * j) * 64 + lane;
+        const int row = g / CPR, pos = g % CPR;
+        a_c[j] = (pos ^ swz(row)) * VEC;               // element offset of the global chunk inside the K tile
+        const int m = m0 + row;
+        a_ok[j] = m < Mlim;
+        const int mm = a_ok[j] ? m : 0;
+        const int n = mm / (p.OH * p.OW);
+        const int r = mm - n * (p.OH * p.OW);
+        const int oh = r / p.OW, ow = r - oh * p.OW;
+        a_h0[j] = oh * p.stride - p.pad;
+        a_w0[j] = ow * p.stride - p.pad;
+        a_base[j] = (long long)n * p.in_nstride + p.in_coff;
+    }
+    int b_c[NIB];
+    long long b_base[NIB];
+    bool b_ok[NIB];
+#pragma unroll
+    for (int j = 0; j < NIB; ++j) {
+        const int g = ((wave + 8 * j) % NB_INSTR) * 64 + lane;
+        const int row = g / CPR, pos = g % CPR;
+        b_c[j] = (pos ^ swz(row)) * VEC;
+        b_ok[j] = (n0 + row) < p.Cout;
+        b_base[j] = (long long)(n0 + row) * p.K;
+    }
+
+    const int nk = (p.K + BK - 1) / BK;
+
+    auto issue_tile = [&](int kt) {
+        unsigned char* st = smem + (kt % STAGES) * STAGE_BYTES;
+        const int k0 = kt * BK;
+        const int tap = k0 / p.Cin;                    // Cin % BK == 0: one tap per K tile
+        const int ci = k0 - tap * p.Cin;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) {
+            const int ih = a_h0[j] + kh * p.dil, iw = a_w0[j] + kw * p.dil;
+            const bool ok = a_ok[j] && (k0 + a_c[j] < p.K) && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const T* src = ok ? in + a_base[j] + ((long long)ih * p.W + iw) * p.in_cstride + ci + a_c[j] : zp;
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(st + (wave + 8 * j) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NIB; ++j) {
+            const bool ok = b_ok[j] && (k0 + b_c[j] < p.K);
+            const T* src = ok ? wgt + b_base[j] + k0 + b_c[j] : zp;
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(st + BM * BKB + ((wave + 8 * j) % NB_INSTR) * 1024),
+                                             16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue_tile(0);
+    if (nk > 1) issue_tile(1);
+
+    // fragment addressing: row = tile row + (lane&31); 16 B chunk c16 = 2*kc + (lane>>5), swizzled.
+    // The fragment reads are INLINE ASM: hipcc treats every ds_read of this array as aliasing the
+    // in-flight LDS-DMA and would insert `s_waitcnt vmcnt(0)` in front of it (draining the two tiles
+    // of prefetch every iteration); asm reads are invisible to that pass, ordering is by the counted
+    // vmcnt + barrier above (MI355X_MICROARCH.md "Two waves per SIMD" item 7).
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned fa_off[TM], fb_off[TN], fa_s[TM], fb_s[TN];
+    const unsigned hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 32 + (lane & 31);
+        fa_off[i] = row * BKB;
+        fa_s[i] = swz(row);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * WTN + j * 32 + (lane & 31);
+        fb_off[j] = BM * BKB + row * BKB;
+        fb_s[j] = swz(row);
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto lds_read = [](unsigned addr) {
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+        return v;
+    };
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed for THIS wave once at most one younger tile (LPT loads) is outstanding
+        if (kt + 1 < nk) {
+            if constexpr (LPT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (LPT == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if constexpr (LPT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");   // publishes tile kt; everyone is done reading tile kt-1
+        if (kt + 2 < nk) issue_tile(kt + 2);
+
+        const unsigned sbase = lds_base + (unsigned)((kt % STAGES) * STAGE_BYTES);
+        constexpr int NKC = BKB / 32;
+        u32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = lds_read(sbase + fa_off[i] + (((0u + hi) ^ fa_s[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = lds_read(sbase + fb_off[j] + (((0u + hi) ^ fb_s[j]) << 4));
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const int cur = kc & 1, nxt = cur ^ 1;
+            // wait for the fragments of step kc; tie the wait to the registers the MFMAs read
+            if constexpr (TM == 2 && TN == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0]), "+v"(fa[cur][1]), "+v"(fb[cur][0]), "+v"(fb[cur][1]) :: "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0]), "+v"(fb[cur][0]), "+v"(fb[cur][TN - 1]) :: "memory");
+            if (kc + 1 < NKC) {
+                const unsigned c16 = 2u * (kc + 1) + hi;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[nxt][i] = lds_read(sbase + fa_off[i] + ((c16 ^ fa_s[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read(sbase + fb_off[j] + ((c16 ^ fb_s[j]) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const uint4 av = __builtin_bit_cast(uint4, fa[cur][i]);
+                    const uint4 bv = __builtin_bit_cast(uint4, fb[cur][j]);
+                    Mfma<T>::run(av, bv, acc[i][j]);
+                }
+        }
+    }
+    __syncthreads();   // all waves done with the last stage before the epilogue reuses LDS
+    conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, smem, wave, lane, wm, wn, m0, n0, Mlim);
+}
+
+static const void* zero_page() {
+    static void* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+        (void)hipMemset(z, 0, 256);
+    }
+    return z;
+}
+
+template <typename T, int BN, int WAVES_M, int WAVES_N>
+static int launch_glds(ConvArgs& a, hipStream_t st) {
+    constexpr int BM = 256;
+    constexpr int BKB = (sizeof(T) == 4) ? 64 : 128;
+    constexpr int WTN = BN / WAVES_N;
+    const void* zp = zero_page();
+    if (!zp) return 0;
+    const int tiles_m = div_up(a.M, BM), tiles_n = div_up(a.Cout, BN);
+    size_t smem = (size_t)3 * (BM + BN) * BKB;
+    const size_t epi = (size_t)8 * 32 * (WTN + 4) * 4;
+    if (smem < epi) smem = epi;
+    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+        attr_set = true;
+    }
+    a.tiles_n = tiles_n;
+    a.splits = 1;
+    a.ws = nullptr;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), smem, st, a, zp, tiles_m, tiles_n);
+    return 1;
+}
+
+int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
+    const int BK = dtype == TT_F32 ? 16 : 64;
+    if (a.gather || a.m_dev || a.Cin % BK != 0 || a.M < 2048 || a.Cout < 64) return 0;
+    // LDS-staged epilogue of the shared code needs the vector path or the scalar one; both fine.
+    if (dtype == TT_F32) {
+        if (a.Cout > 64) return launch_glds<float, 128, 4, 2>(a, st);
+        return launch_glds<float, 64, 8, 1>(a, st);
+    }
+    if (a.Cout > 64) return launch_glds<uint16_t, 128, 4, 2>(a, st);
+    return launch_glds<uint16_t, 64, 8, 1>(a, st);
+}
+
+}  // namespace tt

@@ -142,6 +142,11 @@ __global__ void strided_outputs_kernel(const int* __restrict__ in_coords, const 
     const unsigned key = lin_key(b, oz, oy, ox, od);
     unsigned s = hash_u32(key) & mask;
     while (true) {
+        // ~27 candidates map to each output site: probe with a plain load first so that only the
+        // first arrival pays for an atomic (a stale miss just falls through to the CAS)
+        const unsigned cur = __hip_atomic_load(&hk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return;
+        if (cur != kEmpty) { s = (s + 1) & mask; continue; }
         const unsigned old = atomicCAS(&hk[s], kEmpty, key);
         if (old == key) return;
         if (old == kEmpty) {

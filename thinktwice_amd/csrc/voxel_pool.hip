@@ -133,9 +133,10 @@ __global__ __launch_bounds__(256) void voxel_pool_rows_kernel(
 // ---------------------------------------------------------------------------
 // forward v2: atomics-free two-phase reduce (needs a workspace).
 //   phase 1: one workgroup per chunk of kChunk consecutive points of ONE sample.  The BEV cells the
-//            chunk touches get LDS slots (wave-ballot compaction of a presence table); every in-range
-//            point row (one coalesced 1 KiB load per wave) is accumulated into its slot with LDS
-//            float atomics; slots and the cell->slot table go to the workspace with plain stores.
+//            chunk touches get slots (wave-ballot compaction of an LDS presence table); the chunk's
+//            in-range points are counting-sorted by slot in LDS; then one WAVE per slot streams its
+//            point rows (coalesced 1 KiB loads, 4 in flight) into registers and writes the partial
+//            row and the cell->slot table to the workspace with plain stores.
 //   phase 2: one wave per (sample, cell): sums that cell's slots over the sample's chunks in chunk
 //            order and adds them to the caller's output -- no global atomics, deterministic up to the
 //            LDS accumulation order inside a chunk.
@@ -149,10 +150,12 @@ __global__ __launch_bounds__(512) void voxel_pool_p1_kernel(
     int num_points, int C, int X, int Y, int Z, int chunks_per_sample, int smax,
     const int32_t* __restrict__ geom, const float* __restrict__ feats, float* __restrict__ out,
     int32_t* __restrict__ pos_memo, float* __restrict__ partial, int* __restrict__ slot_table) {
-    extern __shared__ __attribute__((aligned(16))) float lds_f[];
-    __shared__ int table[kMaxCells];
+    __shared__ int table[kMaxCells];           // cell -> slot (-1 none)
+    __shared__ short cell_of[kChunk];          // point -> cell (-1 out of range)
+    __shared__ unsigned short sorted[kChunk];  // point indices grouped by slot
+    __shared__ int cnt[kMaxCells + 1];         // per-slot count, then exclusive offsets
+    __shared__ int cursor[kMaxCells];
     __shared__ int nslots_sh;
-    float* slots = lds_f;                                   // [smax][C]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cells = X * Y;
     const int chunk = blockIdx.x;
@@ -161,59 +164,82 @@ __global__ __launch_bounds__(512) void voxel_pool_p1_kernel(
     const long long p0 = (long long)b * num_points + (long long)cis * kChunk;
     const int npts = min(kChunk, num_points - cis * kChunk);
     for (int i = tid; i < cells; i += 512) table[i] = -1;
-    for (int i = tid; i < smax * C; i += 512) slots[i] = 0.f;
     __syncthreads();
-    // pass A: presence + pos_memo
+    // pass A: cell per point, presence, pos_memo
     for (int i = tid; i < npts; i += 512) {
         const long long p = p0 + i;
         const int x = geom[p * 3], y = geom[p * 3 + 1], z = geom[p * 3 + 2];
+        int c = -1;
         if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {
-            table[y * X + x] = -2;
+            c = y * X + x;
+            table[c] = -2;
             if (pos_memo) {
                 pos_memo[p * 3] = b;
                 pos_memo[p * 3 + 1] = y;
                 pos_memo[p * 3 + 2] = x;
             }
         }
+        cell_of[i] = (short)c;
     }
     __syncthreads();
-    if (wave == 0) {   // slot assignment by ballot compaction
+    if (wave == 0) {   // slot assignment by ballot compaction (cell order)
         int base = 0;
         for (int c0 = 0; c0 < cells; c0 += 64) {
             const int c = c0 + lane;
             const bool hit = (c < cells) && (table[c] == -2);
             const unsigned long long m = __ballot(hit);
-            if (hit) {
-                const int s = base + __popcll(m & ((1ull << lane) - 1ull));
-                table[c] = (s < smax) ? s : -3;             // -3: over budget -> global atomics
-            }
+            if (hit) table[c] = base + __popcll(m & ((1ull << lane) - 1ull));
             base += __popcll(m);
         }
-        if (lane == 0) nslots_sh = min(base, smax);
+        if (lane == 0) nslots_sh = base;
     }
     __syncthreads();
-    // pass B: accumulate rows (C % 4 == 0, C <= 1024: up to 4 float4 per lane)
-    const int c4 = C >> 2;
-    for (int g0 = wave * 64; g0 < npts; g0 += 8 * 64) {
-        const int i = g0 + lane;
-        int cell = -1;
-        if (i < npts) {
-            const long long p = p0 + i;
-            const int x = geom[p * 3], y = geom[p * 3 + 1], z = geom[p * 3 + 2];
-            if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) cell = y * X + x;
-        }
-        unsigned long long mask = __ballot(cell >= 0);
-        while (mask) {
-            int idx[4], cnt = 0;
+    const int ns = nslots_sh;
+    for (int i = tid; i <= ns; i += 512) cnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < npts; i += 512) {
+        const int c = cell_of[i];
+        if (c >= 0) atomicAdd(&cnt[table[c]], 1);
+    }
+    __syncthreads();
+    if (wave == 0) {   // exclusive scan of the slot counts
+        int carry = 0;
+        for (int s0 = 0; s0 < ns; s0 += 64) {
+            const int sidx = s0 + lane;
+            const int v = (sidx < ns) ? cnt[sidx] : 0;
+            int incl = v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (mask) { idx[j] = __builtin_ctzll(mask); mask &= mask - 1; cnt = j + 1; } else idx[j] = 0;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
             }
+            if (sidx < ns) {
+                cnt[sidx] = carry + incl - v;
+                cursor[sidx] = carry + incl - v;
+            }
+            carry += __shfl(incl, 63);
+        }
+        if (lane == 0) cnt[ns] = carry;
+    }
+    __syncthreads();
+    for (int i = tid; i < npts; i += 512) {
+        const int c = cell_of[i];
+        if (c >= 0) sorted[atomicAdd(&cursor[table[c]], 1)] = (unsigned short)i;
+    }
+    __syncthreads();
+    // pass B: one wave per slot, register accumulation, no atomics for slots < smax
+    const int c4 = C >> 2;
+    for (int sl = wave; sl < ns; sl += 8) {
+        const int beg = cnt[sl], end = cnt[sl + 1];
+        float4 acc[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = beg; k < end; k += 4) {
             float4 row[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (j < cnt) {
-                    const float4* src = reinterpret_cast<const float4*>(feats + (p0 + g0 + idx[j]) * (long long)C);
+                if (k + j < end) {
+                    const float4* src = reinterpret_cast<const float4*>(feats + (p0 + sorted[k + j]) * (long long)C);
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int ch = lane + 64 * v;
@@ -222,40 +248,40 @@ __global__ __launch_bounds__(512) void voxel_pool_p1_kernel(
                 }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (j < cnt) {
-                    const int c = __builtin_amdgcn_readlane(cell, idx[j]);
-                    const int s = table[c];
+                if (k + j < end) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        const int ch = lane + 64 * v;
-                        if (ch < c4) {
-                            if (s >= 0) {
-                                float* d = slots + s * C + ch * 4;
-                                atomicAdd(d + 0, row[j][v].x);
-                                atomicAdd(d + 1, row[j][v].y);
-                                atomicAdd(d + 2, row[j][v].z);
-                                atomicAdd(d + 3, row[j][v].w);
-                            } else {
-                                float* d = out + ((long long)b * cells + c) * C + ch * 4;
-                                unsafeAtomicAdd(d + 0, row[j][v].x);
-                                unsafeAtomicAdd(d + 1, row[j][v].y);
-                                unsafeAtomicAdd(d + 2, row[j][v].z);
-                                unsafeAtomicAdd(d + 3, row[j][v].w);
-                            }
-                        }
+                        acc[v].x += row[j][v].x; acc[v].y += row[j][v].y;
+                        acc[v].z += row[j][v].z; acc[v].w += row[j][v].w;
                     }
                 }
         }
+        if (sl < smax) {
+            float4* dst = reinterpret_cast<float4*>(partial + ((long long)chunk * smax + sl) * C);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ch = lane + 64 * v;
+                if (ch < c4) dst[ch] = acc[v];
+            }
+        } else {   // over the workspace budget: one atomic row per (chunk, cell)
+            const int cell = cell_of[sorted[beg]];
+            float* d = out + ((long long)b * cells + cell) * C;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ch = lane + 64 * v;
+                if (ch < c4) {
+                    unsafeAtomicAdd(d + ch * 4 + 0, acc[v].x);
+                    unsafeAtomicAdd(d + ch * 4 + 1, acc[v].y);
+                    unsafeAtomicAdd(d + ch * 4 + 2, acc[v].z);
+                    unsafeAtomicAdd(d + ch * 4 + 3, acc[v].w);
+                }
+            }
+        }
     }
-    __syncthreads();
-    const int ns = nslots_sh;
-    float4* dst = reinterpret_cast<float4*>(partial + (long long)chunk * smax * C);
-    const float4* srcv = reinterpret_cast<const float4*>(slots);
-    for (int i = tid; i < ns * c4; i += 512) dst[i] = srcv[i];
     // slot_table layout [b][cell][chunk_in_sample]: phase 2 reads a cell's chunks contiguously
     for (int c = tid; c < cells; c += 512) {
-        const int s = table[c];
-        slot_table[((long long)b * cells + c) * chunks_per_sample + cis] = (s >= 0) ? s : -1;
+        const int sl = table[c];
+        slot_table[((long long)b * cells + c) * chunks_per_sample + cis] = (sl >= 0 && sl < smax) ? sl : -1;
     }
 }
 
@@ -567,9 +593,8 @@ extern "C" int tt_voxel_pool_fwd(int batch_size, int num_points, int num_channel
 
 
 static int v2_smax(int C) {
-    int s = (40 * 1024) / (C * 4);   // 40 KiB of slots + 8 KiB table => 3 workgroups per CU
-    if (s > 64) s = 64;
-    return s;
+    (void)C;
+    return 64;   // workspace rows per chunk (Lift-Splat chunks touch <= ~40 cells)
 }
 
 static bool v2_ok(long long total, int C, int X, int Y) {
@@ -607,14 +632,7 @@ extern "C" int tt_voxel_pool_fwd_ws(int batch_size, int num_points, int num_chan
     float* partial = reinterpret_cast<float*>(workspace);
     const long long part_bytes = (long long)nchunks * smax * C * 4;
     int* slot_table = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + ((part_bytes + 255) / 256) * 256);
-    const size_t lds = (size_t)smax * C * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(voxel_pool_p1_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(voxel_pool_p1_kernel, dim3((unsigned)nchunks), dim3(512), lds, st, num_points, C,
+    hipLaunchKernelGGL(voxel_pool_p1_kernel, dim3((unsigned)nchunks), dim3(512), 0, st, num_points, C,
                        num_voxel_x, num_voxel_y, num_voxel_z, cps, smax, geom_xyz, input_features,
                        output_features, pos_memo, partial, slot_table);
     hipLaunchKernelGGL(voxel_pool_p2_kernel, dim3((unsigned)(batch_size * cells)), dim3(64), 0, st, C, cells, cps,
