@@ -24,6 +24,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <typename T, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                                                               int tiles_m, int tiles_n) {
+#if defined(__HIP_DEVICE_COMPILE__)   // amdgcn builtins / inline asm: keep the x86 host pass away from the body
     constexpr int BM = 256;
     constexpr int VEC = Elem<T>::kVec;
     constexpr int BKB = (sizeof(T) == 4) ? 64 : 128;
@@ -156,12 +157,17 @@ __global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto lds_read = [](unsigned addr) {
         u32x4 v;
+#if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+#else
+        v = u32x4{addr, 0, 0, 0};   // host pass only parses this kernel
+#endif
         return v;
     };
 
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed for THIS wave once at most one younger tile (LPT loads) is outstanding
+#if defined(__HIP_DEVICE_COMPILE__)
         if (kt + 1 < nk) {
             if constexpr (LPT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if constexpr (LPT == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -171,6 +177,7 @@ __global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_barrier" ::: "memory");   // publishes tile kt; everyone is done reading tile kt-1
+#endif
         if (kt + 2 < nk) issue_tile(kt + 2);
 
         const unsigned sbase = lds_base + (unsigned)((kt % STAGES) * STAGE_BYTES);
@@ -184,10 +191,12 @@ __global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, 
         for (int kc = 0; kc < NKC; ++kc) {
             const int cur = kc & 1, nxt = cur ^ 1;
             // wait for the fragments of step kc; tie the wait to the registers the MFMAs read
+#if defined(__HIP_DEVICE_COMPILE__)
             if constexpr (TM == 2 && TN == 2)
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0]), "+v"(fa[cur][1]), "+v"(fb[cur][0]), "+v"(fb[cur][1]) :: "memory");
             else
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0]), "+v"(fb[cur][0]), "+v"(fb[cur][TN - 1]) :: "memory");
+#endif
             if (kc + 1 < NKC) {
                 const unsigned c16 = 2u * (kc + 1) + hi;
 #pragma unroll
@@ -207,6 +216,7 @@ __global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, 
     }
     __syncthreads();   // all waves done with the last stage before the epilogue reuses LDS
     conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, smem, wave, lane, wm, wn, m0, n0, Mlim);
+#endif
 }
 
 static const void* zero_page() {
