@@ -30,6 +30,7 @@ struct ConvArgs {
     int cin_fast;        // 1 if Cin % BK == 0 (tap uniform per K tile)
     int out_fast;        // 1 if plain [M][out_cstride] addressing
     int vec_epi;         // 1: LDS-staged epilogue with 16 B stores (channel counts / offsets aligned)
+    int res_vec;         // 1: residual chunks are 8/16 B aligned (vector loads)
     int splits;          // split-K factor (gridDim.y)
     int tiles_n;
 };
@@ -143,13 +144,50 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                 }
                 const T* r1 = p.res1 ? reinterpret_cast<const T*>(p.res1) + (long long)m * p.res1_cstride + p.res1_coff + co : nullptr;
                 const T* r2 = p.res2 ? reinterpret_cast<const T*>(p.res2) + (long long)m * p.res2_cstride + p.res2_coff + co : nullptr;
+                float rr[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rr[e] = 0.f;
+                auto add_res = [&](const T* rp) {   // 8 / 16 B vector loads of the residual chunk
+                    if (sizeof(T) == 2) {
+                        if (CO == 8) {
+                            const uint4 u = *reinterpret_cast<const uint4*>(rp);
+                            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                rr[2 * e] += __uint_as_float(w[e] << 16);
+                                rr[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+                            }
+                        } else {
+                            const uint2 u = *reinterpret_cast<const uint2*>(rp);
+                            rr[0] += __uint_as_float(u.x << 16); rr[1] += __uint_as_float(u.x & 0xffff0000u);
+                            rr[2] += __uint_as_float(u.y << 16); rr[3] += __uint_as_float(u.y & 0xffff0000u);
+                        }
+                    } else {
+                        const float4 f0 = *reinterpret_cast<const float4*>(rp);
+                        rr[0] += f0.x; rr[1] += f0.y; rr[2] += f0.z; rr[3] += f0.w;
+                        if (CO == 8) {
+                            const float4 f1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(rp) + 4);
+                            rr[4] += f1.x; rr[5] += f1.y; rr[6] += f1.z; rr[7] += f1.w;
+                        }
+                    }
+                };
+                if (p.res_vec) {
+                    if (r1) add_res(r1);
+                    if (r2) add_res(r2);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e < CO) {
+                            if (r1) rr[e] += Elem<T>::ld(r1 + e);
+                            if (r2) rr[e] += Elem<T>::ld(r2 + e);
+                        }
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (e < CO) {
                         float x = v[e] * sc[e] + sh[e];
                         if (sn) x += sn[e];
-                        if (r1) x += Elem<T>::ld(r1 + e);
-                        if (r2) x += Elem<T>::ld(r2 + e);
+                        x += rr[e];
                         v[e] = apply_act(x, p.act);
                     }
                 }

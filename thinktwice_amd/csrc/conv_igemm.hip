@@ -332,6 +332,10 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
                   (a.out_nstride % co_vec == 0) && ((reinterpret_cast<uintptr_t>(d->out) & 15) == 0);
         (void)osz;
         a.vec_epi = ok ? 1 : 0;
+        auto res_ok = [&](const void* r, int cs, int co_) {
+            return !r || ((cs % co_vec == 0) && (co_ % co_vec == 0) && ((reinterpret_cast<uintptr_t>(r) & 15) == 0));
+        };
+        a.res_vec = (res_ok(d->res1, d->res1_cstride, d->res1_coff) && res_ok(d->res2, d->res2_cstride, d->res2_coff)) ? 1 : 0;
     }
     hipStream_t st = (hipStream_t)stream;
     if (!d->splitk_ws && try_launch_conv_glds(a, d->dtype, st)) return check_launch("tt_conv2d_fwd(glds)");

@@ -15,20 +15,21 @@
 //   * rows that are padding / beyond M / beyond K read from a 16 B zero page instead of branching.
 //   * XCD-aware tile order: workgroups that share an A row-block are consecutive on ONE XCD (its L2).
 // Requires: dense (non-gather) conv, Cin % BK == 0 (one tap per K tile), no split-K.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 namespace tt {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <typename T, int BN, int WAVES_M, int WAVES_N>
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB>
 __global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                                                               int tiles_m, int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)   // amdgcn builtins / inline asm: keep the x86 host pass away from the body
     constexpr int BM = 256;
     constexpr int VEC = Elem<T>::kVec;
-    constexpr int BKB = (sizeof(T) == 4) ? 64 : 128;
-    constexpr int BK = BKB / (int)sizeof(T);
+    constexpr int BK = BKB / (int)sizeof(T);          // BKB = K bytes per row per tile (64 or 128)
     constexpr int CPR = BKB / 16;                     // 16 B chunks per row
     constexpr int STAGES = 3;
     constexpr int STAGE_BYTES = (BM + BN) * BKB;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, 
     const T* __restrict__ wgt = reinterpret_cast<const T*>(p.weight);
     const T* zp = reinterpret_cast<const T*>(zero_page);
 
-    auto swz = [](int row) { return (sizeof(T) == 4) ? ((row >> 2) & 3) : ((row >> 1) & 7); };
+    auto swz = [](int row) { return (BKB == 64) ? ((row >> 2) & 3) : ((row >> 1) & 7); };
 
     // ---- per-thread DMA slots: A slot j covers LDS chunk g = (wave + 8*j)*64 + lane of the A tile
     int a_h0[NIA], a_w0[NIA], a_c[NIA];
@@ -228,10 +229,9 @@ static const void* zero_page() {
     return z;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N>
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB>
 static int launch_glds(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 256;
-    constexpr int BKB = (sizeof(T) == 4) ? 64 : 128;
     constexpr int WTN = BN / WAVES_N;
     const void* zp = zero_page();
     if (!zp) return 0;
@@ -239,7 +239,7 @@ static int launch_glds(ConvArgs& a, hipStream_t st) {
     size_t smem = (size_t)3 * (BM + BN) * BKB;
     const size_t epi = (size_t)8 * 32 * (WTN + 4) * 4;
     if (smem < epi) smem = epi;
-    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N>;
+    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -254,15 +254,35 @@ static int launch_glds(ConvArgs& a, hipStream_t st) {
 }
 
 int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
-    const int BK = dtype == TT_F32 ? 16 : 64;
-    if (a.gather || a.m_dev || a.Cin % BK != 0 || a.M < 2048 || a.Cout < 64) return 0;
-    // LDS-staged epilogue of the shared code needs the vector path or the scalar one; both fine.
-    if (dtype == TT_F32) {
-        if (a.Cout > 64) return launch_glds<float, 128, 4, 2>(a, st);
-        return launch_glds<float, 64, 8, 1>(a, st);
+    // bf16: 128 B rows (1 workgroup / CU, 16 MFMA per barrier) for long-K compute-bound layers, 64 B rows
+    // (2 workgroups / CU: one streams while the other stores) for short-K memory-bound ones.
+    static int force_bkb = -1;
+    if (force_bkb < 0) {
+        const char* e = getenv("TT_GLDS_BKB");
+        force_bkb = e ? atoi(e) : 0;
     }
-    if (a.Cout > 64) return launch_glds<uint16_t, 128, 4, 2>(a, st);
-    return launch_glds<uint16_t, 64, 8, 1>(a, st);
+    static int min_tiles = -1;
+    if (min_tiles < 0) {
+        const char* e = getenv("TT_GLDS_MIN_KTILES");
+        min_tiles = e ? atoi(e) : 3;
+    }
+    if (a.gather || a.m_dev || a.M < 2048 || a.Cout < 64) return 0;
+    if (dtype == TT_F32) {
+        if (a.Cin % 16 != 0 || div_up(a.K, 16) < min_tiles) return 0;
+        if (a.Cout > 64) return launch_glds<float, 128, 4, 2, 64>(a, st);
+        return launch_glds<float, 64, 8, 1, 64>(a, st);
+    }
+    int bkb = (a.K >= 1024) ? 128 : 64;
+    if (force_bkb == 64 || force_bkb == 128) bkb = force_bkb;
+    if (bkb == 128 && a.Cin % 64 != 0) bkb = 64;
+    const int bk = bkb / 2;
+    if (a.Cin % bk != 0 || div_up(a.K, bk) < min_tiles) return 0;
+    if (bkb == 128) {
+        if (a.Cout > 64) return launch_glds<uint16_t, 128, 4, 2, 128>(a, st);
+        return launch_glds<uint16_t, 64, 8, 1, 128>(a, st);
+    }
+    if (a.Cout > 64) return launch_glds<uint16_t, 128, 4, 2, 64>(a, st);
+    return launch_glds<uint16_t, 64, 8, 1, 64>(a, st);
 }
 
 }  // namespace tt
