@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         b_ok[i] = ((n0 + b_row[i]) < p.Cout) && (idx < BN * VPR);
     }
 
+    int jn[NVA];   // GATHER + cin_fast: rulebook entries of the NEXT K tile, fetched one tile ahead
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) jn[i] = -1;
     const int nk_all = (p.K + BK - 1) / BK;
     int kt0 = 0, nk = nk_all;
     if (p.splits > 1) {       // this block owns K tiles [kt0, nk)
@@ -127,7 +130,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             }
             if (GATHER) {
                 int j = -1;
-                if (a_ok[i] && (k < p.K)) j = p.gather[a_base[i] + kh * p.KW + kw];
+                if (p.cin_fast) {
+                    // the entry for this tile was fetched while the previous tile was in flight, so the
+                    // feature-row load below does not sit behind a dependent index load
+                    j = jn[i];
+                    const int kn = k0 + BK;
+                    jn[i] = (a_ok[i] && kn < p.K) ? p.gather[a_base[i] + kn / p.Cin] : -1;
+                } else if (a_ok[i] && (k < p.K)) {
+                    j = p.gather[a_base[i] + kh * p.KW + kw];
+                }
                 if (j >= 0) {
                     const T* src = in + (long long)j * p.in_cstride + p.in_coff + ci;
                     ra[i] = *reinterpret_cast<const uint4*>(src);
@@ -175,6 +186,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    if (GATHER && p.cin_fast) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i)
+            jn[i] = (a_ok[i] && kt0 * BK < p.K) ? p.gather[a_base[i] + (kt0 * BK) / p.Cin] : -1;
+    }
     load_tile(kt0);
     store_tile(0);
     __syncthreads();
