@@ -223,18 +223,20 @@ int tt_lidar_voxelize(const float* points, int B, int Np, int nfeat, const float
                       const float* voxel_size, const int* grid_xyz, int z_limit, int max_points,
                       void* workspace, long long workspace_bytes, float* voxel_feats, int* coords,
                       int* num_voxels, void* stream);
-/* open-addressing hash (uint32 key -> row) of the active sites of one resolution level */
-int tt_sp_hash_build(const int* coords, const int* num_rows, long long max_rows, const int* dims_zyx,
-                     unsigned* hash_keys, int* hash_vals, long long hash_size, void* stream);
-/* spconv SparseConv3d output-site generation; kernel_stride_pad = {kz,ky,kx,sz,sy,sx,pz,py,px} (host) */
-int tt_sp_strided_outputs(const int* in_coords, const int* in_rows, long long max_in,
-                          const int* kernel_stride_pad, const int* out_dims_zyx, unsigned* hash_keys,
-                          int* hash_vals, long long hash_size, int* out_coords, int* out_rows,
+/* dense index volume of one resolution level: vol int32 [batch, D, H, W] = feature row or -1 */
+int tt_sp_volume_build(const int* coords, const int* num_rows, long long max_rows, int batch,
+                       const int* dims_zyx, int* vol, void* stream);
+/* spconv SparseConv3d output-site generation (mark + scan + compact, no atomics; rows come out in cell
+ * order); kernel_stride_pad = {kz,ky,kx,sz,sy,sx,pz,py,px} (host).  Also fills the OUTPUT level's volume. */
+long long tt_sp_strided_outputs_workspace_bytes(long long out_cells);
+int tt_sp_strided_outputs(const int* in_coords, const int* in_rows, long long max_in, int batch,
+                          const int* kernel_stride_pad, const int* out_dims_zyx, void* workspace,
+                          long long workspace_bytes, int* out_vol, int* out_coords, int* out_rows,
                           long long max_out, void* stream);
 /* nbr[o][k] = input row feeding output o through tap k, or -1 (SubM: out coords == in coords) */
 int tt_sp_rulebook(const int* out_coords, const int* out_rows, long long max_out,
-                   const int* kernel_stride_pad, const int* in_dims_zyx, const unsigned* hash_keys,
-                   const int* hash_vals, long long hash_size, int* nbr, void* stream);
+                   const int* kernel_stride_pad, const int* in_dims_zyx, const int* in_vol, int* nbr,
+                   void* stream);
 /* the sparse convolution itself = tt_conv2d_fwd with gather_idx = this rulebook (MFMA gathered GEMM) */
 /* SparseConvTensor.dense() + view(N, C*D, H, W) (lidarnet.py:53-56), channel-last: dense
  * [B, H, W, C*D] with channel c*D+z; `dense` must be pre-zeroed. */

@@ -69,6 +69,22 @@ class ForwardWorkload:
                            key=lambda d: -d["ms"])
             with open(dump, "w") as f:
                 json.dump(rows_, f, indent=0)
+        dec = [r for r in rec if " N=256 K=256 k1x1s1" in r[3] and not r[3].startswith("sparse")]
+        self._decoder_gemm = None
+        if dec:
+            mmax = max(int(r[3].split()[0][2:]) for r in dec)
+            big = [r for r in dec if int(r[3].split()[0][2:]) == mmax]
+            gf = sum(r[0] for r in big)
+            gms = sum(r[1].elapsed_time(r[2]) for r in big)
+            tf = gf / (gms * 1e-3) / 1e12
+            # HBM roofline of this GEMM: reads M*K + writes M*N elements once
+            esz = 2 if self.dtype == "bf16" else 4
+            bytes_ = sum(int(r[3].split()[0][2:]) * (256 + 256) * esz for r in big)
+            self._decoder_gemm = {"shape": big[0][3], "launches": len(big), "tflops": round(tf, 1),
+                                  "mfma_frac": round(tf / peak, 4),
+                                  "hbm_gbs": round(bytes_ / (gms * 1e-3) / 1e9, 1),
+                                  "note": "value_proj / fpn_linear GEMM (K=N=256): 128 (bf16) / 64 (f32) FLOP per HBM "
+                                          "byte, i.e. HBM-bound below ~1 PF (bf16)"}
         return {"kernel": "conv_igemm_kernel (all conv/linear launches of one forward)", "bound": "mfma",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None, "launches": len(rec), "conv_ms_per_step": round(ms, 3),
@@ -78,7 +94,7 @@ class ForwardWorkload:
                                       "shape": r[3]} for r in top]}
 
     def extra(self):
-        return {}
+        return {"decoder_gemm": self._decoder_gemm} if getattr(self, "_decoder_gemm", None) else {}
 
     def cpu_baseline(self):
         """oracle on ONE frame in a bounded subprocess (<= 32 threads, 240 s cap)."""

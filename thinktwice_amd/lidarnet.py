@@ -26,32 +26,29 @@ def _pow2(n):
 
 
 class _Level:
-    """Active sites of one resolution level: coords, row count, hash, SubM rulebook."""
+    """Active sites of one resolution level: coords, device row count, dense index volume, SubM rulebook."""
 
-    def __init__(self, coords, rows, max_rows, dims, dev):
-        self.coords, self.rows, self.max_rows, self.dims = coords, rows, max_rows, list(dims)
-        self.hsize = _pow2(2 * max_rows)
-        self.hk = torch.empty(self.hsize, dtype=torch.int32, device=dev)
-        self.hv = torch.empty(self.hsize, dtype=torch.int32, device=dev)
+    def __init__(self, coords, rows, max_rows, dims, batch, dev, vol=None):
+        self.coords, self.rows, self.max_rows, self.dims, self.batch = coords, rows, max_rows, list(dims), batch
         self.dims_c = (ctypes.c_int * 3)(*self.dims)
+        self.vol = vol
         self._subm = None
-        self.built = False
 
-    def build_hash(self):
-        check(lib().tt_sp_hash_build(ptr(self.coords), ptr(self.rows), _ll(self.max_rows), self.dims_c, ptr(self.hk),
-                                     ptr(self.hv), _ll(self.hsize), ops.cur_stream(self.coords.device)),
-              "tt_sp_hash_build")
-        self.built = True
+    def volume(self):
+        if self.vol is None:
+            D, H, W = self.dims
+            self.vol = torch.empty(self.batch * D * H * W, dtype=torch.int32, device=self.coords.device)
+            check(lib().tt_sp_volume_build(ptr(self.coords), ptr(self.rows), _ll(self.max_rows), _c(self.batch),
+                                           self.dims_c, ptr(self.vol), ops.cur_stream(self.coords.device)),
+                  "tt_sp_volume_build")
+        return self.vol
 
     def subm_rulebook(self):
         if self._subm is None:
-            if not self.built:
-                self.build_hash()
             g = (ctypes.c_int * 9)(3, 3, 3, 1, 1, 1, 1, 1, 1)
             nbr = torch.empty(self.max_rows, 27, dtype=torch.int32, device=self.coords.device)
             check(lib().tt_sp_rulebook(ptr(self.coords), ptr(self.rows), _ll(self.max_rows), g, self.dims_c,
-                                       ptr(self.hk), ptr(self.hv), _ll(self.hsize), ptr(nbr),
-                                       ops.cur_stream(nbr.device)), "tt_sp_rulebook")
+                                       ptr(self.volume()), ptr(nbr), ops.cur_stream(nbr.device)), "tt_sp_rulebook")
             self._subm = nbr
         return self._subm
 
@@ -120,28 +117,32 @@ class SparseEncoder_fp32:
         dev = feats.device
         od = [(lvl.dims[d] + 2 * pad[d] - kernel[d]) // stride[d] + 1 for d in range(3)]
         cells = batch * od[0] * od[1] * od[2]
-        max_out = min(lvl.max_rows * 8, cells)
+        fan = 1
+        for d in range(3):
+            fan *= -(-kernel[d] // stride[d])          # outputs one input can reach per dim
+        max_out = min(lvl.max_rows * fan, cells)
         coords = torch.empty(max_out, 4, dtype=torch.int32, device=dev)
         rows = torch.empty(1, dtype=torch.int32, device=dev)
-        new = _Level(coords, rows, max_out, od, dev)
+        vol = torch.empty(cells, dtype=torch.int32, device=dev)
         g = (ctypes.c_int * 9)(*kernel, *stride, *pad)
+        odc = (ctypes.c_int * 3)(*od)
         st = ops.cur_stream(dev)
-        check(lib().tt_sp_strided_outputs(ptr(lvl.coords), ptr(lvl.rows), _ll(lvl.max_rows), g, new.dims_c,
-                                          ptr(new.hk), ptr(new.hv), _ll(new.hsize), ptr(coords), ptr(rows),
-                                          _ll(max_out), st), "tt_sp_strided_outputs")
-        new.built = True
-        if not lvl.built:
-            lvl.build_hash()
+        ws_bytes = int(lib().tt_sp_strided_outputs_workspace_bytes(_ll(cells)))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(lib().tt_sp_strided_outputs(ptr(lvl.coords), ptr(lvl.rows), _ll(lvl.max_rows), _c(batch), g, odc,
+                                          ptr(ws), _ll(ws_bytes), ptr(vol), ptr(coords), ptr(rows), _ll(max_out), st),
+              "tt_sp_strided_outputs")
+        new = _Level(coords, rows, max_out, od, batch, dev, vol=vol)
         KV = kernel[0] * kernel[1] * kernel[2]
         nbr = torch.empty(max_out, KV, dtype=torch.int32, device=dev)
-        check(lib().tt_sp_rulebook(ptr(coords), ptr(rows), _ll(max_out), g, lvl.dims_c, ptr(lvl.hk), ptr(lvl.hv),
-                                   _ll(lvl.hsize), ptr(nbr), st), "tt_sp_rulebook")
+        check(lib().tt_sp_rulebook(ptr(coords), ptr(rows), _ll(max_out), g, lvl.dims_c, ptr(lvl.volume()), ptr(nbr), st),
+              "tt_sp_rulebook")
         return _sp_conv(feats, nbr, new, w, bn), new
 
     def forward(self, voxel_features, coors, num_rows, max_rows, batch_size):
         """-> dense channel-last (B, H, W, C*D) f32 (== spatial_features.view(N, C*D, H, W))."""
         dev = voxel_features.device
-        lvl = _Level(coors, num_rows, max_rows, self.sparse_shape, dev)
+        lvl = _Level(coors, num_rows, max_rows, self.sparse_shape, batch_size, dev)
         cp = self.w_in.shape[-1]
         f0 = torch.zeros(max_rows, cp, dtype=self.dtype, device=dev)      # channel-padded voxel features
         nf = voxel_features.shape[1]
