@@ -24,7 +24,8 @@ namespace tt {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB>
-__global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 16 || BKB == 64) ? 4 : 2)
+void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                                                               int tiles_m, int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)   // amdgcn builtins / inline asm: keep the x86 host pass away from the body
     constexpr int BM = 256;
@@ -35,15 +36,16 @@ __global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, 
     constexpr int STAGE_BYTES = (BM + BN) * BKB;
     constexpr int NA_INSTR = BM * CPR / 64;           // 1 KiB wave-instructions in the A tile
     constexpr int NB_INSTR = BN * CPR / 64;
-    constexpr int NIA = NA_INSTR / 8;                 // A wave-instructions per wave per tile
-    constexpr int NIB = (NB_INSTR + 7) / 8;           // B  " (when NB_INSTR < 8 some waves re-load a chunk
+    constexpr int NW = WAVES_M * WAVES_N;             // waves per workgroup (8 or 16)
+    constexpr int NIA = NA_INSTR / NW;                // A wave-instructions per wave per tile
+    constexpr int NIB = (NB_INSTR + NW - 1) / NW;     // B  " (when NB_INSTR < NW some waves re-load a chunk
                                                       //       another wave also loads: same bytes, harmless,
                                                       //       and every wave keeps the same vmcnt arithmetic)
     constexpr int LPT = NIA + NIB;                    // DMA loads per thread per tile
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    static_assert(WAVES_M * WAVES_N == 8, "8 waves");
-    static_assert(NA_INSTR % 8 == 0 && NIA >= 1 && NIB >= 1, "tile too small for 8 waves");
+    static_assert(NW == 8 || NW == 16, "8 or 16 waves");
+    static_assert(NA_INSTR % NW == 0 && NIA >= 1 && NIB >= 1, "tile too small for the wave count");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, 
     bool a_ok[NIA];
 #pragma unroll
     for (int j = 0; j < NIA; ++j) {
-        const int g = (wave + 8 * j) * 64 + lane;
+        const int g = (wave + NW * j) * 64 + lane;
         const int row = g / CPR, pos = g % CPR;
         a_c[j] = (pos ^ swz(row)) * VEC;               // element offset of the global chunk inside the K tile
         const int m = m0 + row;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, 
     bool b_ok[NIB];
 #pragma unroll
     for (int j = 0; j < NIB; ++j) {
-        const int g = ((wave + 8 * j) % NB_INSTR) * 64 + lane;
+        const int g = ((wave + NW * j) % NB_INSTR) * 64 + lane;
         const int row = g / CPR, pos = g % CPR;
         b_c[j] = (pos ^ swz(row)) * VEC;
         b_ok[j] = (n0 + row) < p.Cout;
@@ -113,13 +115,13 @@ __global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, 
             const int ih = a_h0[j] + kh * p.dil, iw = a_w0[j] + kw * p.dil;
             const bool ok = a_ok[j] && (k0 + a_c[j] < p.K) && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
             const T* src = ok ? in + a_base[j] + ((long long)ih * p.W + iw) * p.in_cstride + ci + a_c[j] : zp;
-            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(st + (wave + 8 * j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(st + (wave + NW * j) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NIB; ++j) {
             const bool ok = b_ok[j] && (k0 + b_c[j] < p.K);
             const T* src = ok ? wgt + b_base[j] + k0 + b_c[j] : zp;
-            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(st + BM * BKB + ((wave + 8 * j) % NB_INSTR) * 1024),
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(st + BM * BKB + ((wave + NW * j) % NB_INSTR) * 1024),
                                              16, 0, 0);
         }
     };
@@ -170,8 +172,11 @@ __global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, 
         // tile kt has landed for THIS wave once at most one younger tile (LPT loads) is outstanding
 #if defined(__HIP_DEVICE_COMPILE__)
         if (kt + 1 < nk) {
-            if constexpr (LPT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if constexpr (LPT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (LPT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if constexpr (LPT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if constexpr (LPT == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if constexpr (LPT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if constexpr (LPT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
@@ -193,10 +198,13 @@ __global__ __launch_bounds__(512) void conv_igemm_glds_kernel(const ConvArgs p, 
             const int cur = kc & 1, nxt = cur ^ 1;
             // wait for the fragments of step kc; tie the wait to the registers the MFMAs read
 #if defined(__HIP_DEVICE_COMPILE__)
-            if constexpr (TM == 2 && TN == 2)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0]), "+v"(fa[cur][1]), "+v"(fb[cur][0]), "+v"(fb[cur][1]) :: "memory");
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur][0]), "+v"(fb[cur][0]), "+v"(fb[cur][TN - 1]) :: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // volatile asms stay in order: these empty ones come after the wait, and the MFMAs below
+            // consume their outputs, so no MFMA can be scheduled above the wait
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[cur][i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[cur][j]));
 #endif
             if (kc + 1 < NKC) {
                 const unsigned c16 = 2u * (kc + 1) + hi;
@@ -237,7 +245,7 @@ static int launch_glds(ConvArgs& a, hipStream_t st) {
     if (!zp) return 0;
     const int tiles_m = div_up(a.M, BM), tiles_n = div_up(a.Cout, BN);
     size_t smem = (size_t)3 * (BM + BN) * BKB;
-    const size_t epi = (size_t)8 * 32 * (WTN + 4) * 4;
+    const size_t epi = (size_t)(WAVES_M * WAVES_N) * 32 * (WTN + 4) * 4;
     if (smem < epi) smem = epi;
     auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB>;
     static bool attr_set = false;
@@ -249,7 +257,8 @@ static int launch_glds(ConvArgs& a, hipStream_t st) {
     a.tiles_n = tiles_n;
     a.splits = 1;
     a.ws = nullptr;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), smem, st, a, zp, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(WAVES_M * WAVES_N * 64), smem, st, a, zp,
+                       tiles_m, tiles_n);
     return 1;
 }
 
@@ -277,6 +286,15 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
     if (bkb == 128 && a.Cin % 64 != 0) bkb = 64;
     const int bk = bkb / 2;
     if (a.Cin % bk != 0 || div_up(a.K, bk) < min_tiles) return 0;
+    static int big_n = -1;
+    if (big_n < 0) {
+        const char* e = getenv("TT_GLDS_BN256");
+        big_n = e ? atoi(e) : 1;
+    }
+    // 256x256 tile (64 B rows, 3 stages = 96 KiB): halves the LDS-fill bytes per FLOP of the 256x128 tile
+    if (big_n && a.Cout >= 256 && a.Cout % 256 == 0 && a.K >= 512 && a.Cin % 32 == 0 &&
+        div_up(a.M, 256) * (a.Cout / 256) >= 200)
+        return launch_glds<uint16_t, 256, 4, 4, 64>(a, st);
     if (bkb == 128) {
         if (a.Cout > 64) return launch_glds<uint16_t, 128, 4, 2, 128>(a, st);
         return launch_glds<uint16_t, 64, 8, 1, 128>(a, st);
