@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Time one conv shape through tt_conv2d_fwd:  tools/conv_microbench.py N H W Cin Cout k [stride] [dtype] [iters]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from thinktwice_amd import ops, weights  # noqa: E402
+
+
+def main():
+    a = sys.argv[1:]
+    N, H, W, Cin, Cout, k = (int(v) for v in a[:6])
+    stride = int(a[6]) if len(a) > 6 else 1
+    dt = torch.bfloat16 if (len(a) <= 7 or a[7] == "bf16") else torch.float32
+    iters = int(a[8]) if len(a) > 8 else 20
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(N, H, W, Cin, device="cuda", generator=g).to(dt)
+    w = (torch.randn(Cout, k, k, Cin, device="cuda", generator=g) * (Cin * k * k) ** -0.5).to(dt)
+    pad = k // 2
+    for _ in range(3):
+        y = ops.conv2d(x, w, stride=stride, pad=pad)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        y = ops.conv2d(x, w, stride=stride, pad=pad)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    M = y.shape[0] * y.shape[1] * y.shape[2]
+    fl = 2.0 * M * Cout * k * k * Cin
+    print(f"M={M} N={Cout} K={k*k*Cin} {dt}: {ms:.3f} ms  {fl/ms/1e9:.1f} TF/s  env BKB={os.environ.get('TT_GLDS_BKB')} BN256={os.environ.get('TT_GLDS_BN256')} MINK={os.environ.get('TT_GLDS_MIN_KTILES')}")
+
+
+if __name__ == "__main__":
+    main()
