@@ -263,8 +263,9 @@ static int launch_glds(ConvArgs& a, hipStream_t st) {
 }
 
 int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
-    // bf16: 128 B rows (1 workgroup / CU, 16 MFMA per barrier) for long-K compute-bound layers, 64 B rows
-    // (2 workgroups / CU: one streams while the other stores) for short-K memory-bound ones.
+    // bf16 variants: 64 B rows (3 stages = 72 KiB, 2 workgroups / CU: one streams while the other stores),
+    // 128 B rows (144 KiB, 1 workgroup / CU, 16 MFMA per barrier) and a 16-wave 256x256 tile; selectable
+    // by TT_GLDS_BKB / TT_GLDS_BN256 for experiments, default = the fastest measured on the bench.
     static int force_bkb = -1;
     if (force_bkb < 0) {
         const char* e = getenv("TT_GLDS_BKB");
@@ -281,7 +282,7 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
         if (a.Cout > 64) return launch_glds<float, 128, 4, 2, 64>(a, st);
         return launch_glds<float, 64, 8, 1, 64>(a, st);
     }
-    int bkb = (a.K >= 1024) ? 128 : 64;
+    int bkb = 64;   // measured (profiles/r01 sweep): 64 B rows + 2 workgroups/CU >= 128 B rows + 1 on every layer
     if (force_bkb == 64 || force_bkb == 128) bkb = force_bkb;
     if (bkb == 128 && a.Cin % 64 != 0) bkb = 64;
     const int bk = bkb / 2;
@@ -289,7 +290,7 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
     static int big_n = -1;
     if (big_n < 0) {
         const char* e = getenv("TT_GLDS_BN256");
-        big_n = e ? atoi(e) : 1;
+        big_n = e ? atoi(e) : 0;
     }
     // 256x256 tile (64 B rows, 3 stages = 96 KiB): halves the LDS-fill bytes per FLOP of the 256x128 tile
     if (big_n && a.Cout >= 256 && a.Cout % 256 == 0 && a.K >= 512 && a.Cin % 32 == 0 &&
