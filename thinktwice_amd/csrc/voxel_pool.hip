@@ -546,6 +546,163 @@ __global__ __launch_bounds__(256) void lift_splat_kernel(
     if (cur >= 0) flush(cur, w);
 }
 
+
+// ---------------------------------------------------------------------------
+// fused lift-splat v2: workgroup-level pre-reduction.  One workgroup owns a full-height strip of
+// kStripW image columns of one camera: all its rays share (almost) the same azimuth, so the strip's
+// 28 x kStripW x 80 frustum points fall into only ~10-30 BEV cells.  The block
+//   1. softmaxes every pixel's depth logits into LDS and tags each (pixel, depth) with its cell,
+//   2. gives the touched cells LDS slots (ballot compaction) and builds W[slot][pixel] = sum of the
+//      depth probabilities that pixel sends to that cell,
+//   3. forms sum_pixel W[slot][pixel] * context[pixel, :] with one wave per slot (context rows are
+//      coalesced 1 KiB loads, L2 resident) and issues ONE atomic row per (strip, cell)
+// -- ~13x fewer global atomics than the one-wave-per-pixel kernel above.
+// ---------------------------------------------------------------------------
+constexpr int kStripW = 2;
+constexpr int kMaxStripPix = 64;     // fH * kStripW <= 64
+constexpr int kMaxSlots = 64;
+constexpr int kMaxD = 128;
+
+template <typename T>
+__global__ __launch_bounds__(256) void lift_splat_strip_kernel(
+    int B, int ncam, int D, int fH, int fW, int C, int X, int Y, int Z, const T* __restrict__ depth_logits,
+    const T* __restrict__ ctx, const int32_t* __restrict__ geom, float* __restrict__ out, int out_cstride,
+    int out_coff, int rot_flip) {
+    __shared__ float prob[kMaxStripPix][kMaxD];
+    __shared__ short cellid[kMaxStripPix][kMaxD];
+    __shared__ int table[kMaxCells];
+    __shared__ float Wt[kMaxSlots][kMaxStripPix];
+    __shared__ int slot_cell[kMaxSlots];
+    __shared__ int nslots_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int strips = (fW + kStripW - 1) / kStripW;
+    const int bc = blockIdx.x / strips;            // b * ncam + cam
+    const int strip = blockIdx.x % strips;
+    const int b = bc / ncam, cam = bc % ncam;
+    const int w0 = strip * kStripW;
+    const int sw = min(kStripW, fW - w0);
+    const int npx = fH * sw;                        // pixels in this strip: p -> (h = p / sw, w = w0 + p % sw)
+    const int cells = X * Y;
+    for (int i = tid; i < cells; i += 256) table[i] = -1;
+    for (int i = tid; i < kMaxSlots * kMaxStripPix; i += 256) (&Wt[0][0])[i] = 0.f;
+    __syncthreads();
+    const long long per_cam = (long long)D * fH * fW;
+    const int32_t* g = geom + ((long long)b * ncam + cam) * per_cam * 3;
+    // 1. softmax + cell tags, one wave per pixel in turn
+    for (int p = wave; p < npx; p += 4) {
+        const int h = p / sw, w = w0 + p % sw;
+        const long long pix = ((long long)bc * fH + h) * fW + w;
+        const T* lg = depth_logits + pix * D;
+        const float l0 = (lane < D) ? Elem<T>::ld(lg + lane) : -INFINITY;
+        const float l1 = (lane + 64 < D) ? Elem<T>::ld(lg + lane + 64) : -INFINITY;
+        float m = fmaxf(l0, l1);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const float e0 = (lane < D) ? expf(l0 - m) : 0.f;
+        const float e1 = (lane + 64 < D) ? expf(l1 - m) : 0.f;
+        float ssum = e0 + e1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
+        const float inv = 1.f / ssum;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int d = lane + 64 * half;
+            if (d < D) {
+                const int32_t* q = g + ((long long)d * fH * fW + (long long)h * fW + w) * 3;
+                const int x = q[0], y = q[1], z = q[2];
+                int c = -1;
+                if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {
+                    c = y * X + x;
+                    table[c] = -2;
+                }
+                cellid[p][d] = (short)c;
+                prob[p][d] = (half ? e1 : e0) * inv;
+            }
+        }
+    }
+    __syncthreads();
+    // 2. slots
+    if (wave == 0) {
+        int base = 0;
+        for (int c0 = 0; c0 < cells; c0 += 64) {
+            const int c = c0 + lane;
+            const bool hit = (c < cells) && (table[c] == -2);
+            const unsigned long long mk = __ballot(hit);
+            if (hit) {
+                const int sidx = base + __popcll(mk & ((1ull << lane) - 1ull));
+                table[c] = sidx;
+                if (sidx < kMaxSlots) slot_cell[sidx] = c;
+            }
+            base += __popcll(mk);
+        }
+        if (lane == 0) nslots_sh = base;
+    }
+    __syncthreads();
+    const int ns = nslots_sh;
+    const int c4 = C >> 2;
+    auto out_row = [&](int cell) {
+        const int y = cell / X, x = cell % X;
+        int oi = y, oj = x;
+        if (rot_flip) { oi = X - 1 - x; oj = Y - 1 - y; }
+        const int OW = rot_flip ? Y : X, OH = rot_flip ? X : Y;
+        return out + (((long long)b * OH + oi) * OW + oj) * out_cstride + out_coff;
+    };
+    // W[slot][pixel]; (pixel, depth) pairs whose slot is over budget go straight to global atomics
+    for (int i = tid; i < npx * D; i += 256) {
+        const int p = i / D, d = i % D;
+        const int c = cellid[p][d];
+        if (c < 0) continue;
+        const int sidx = table[c];
+        if (sidx < kMaxSlots) atomicAdd(&Wt[sidx][p], prob[p][d]);
+    }
+    __syncthreads();
+    // 3. one wave per slot
+    for (int sidx = wave; sidx < min(ns, kMaxSlots); sidx += 4) {
+        float4 acc[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < npx; ++p) {
+            const float wgt = Wt[sidx][p];
+            if (wgt == 0.f) continue;
+            const int h = p / sw, w = w0 + p % sw;
+            const T* crow = ctx + (((long long)bc * fH + h) * fW + w) * C;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ch = lane + 64 * v;
+                if (ch < c4) {
+                    acc[v].x += wgt * Elem<T>::ld(crow + ch * 4 + 0);
+                    acc[v].y += wgt * Elem<T>::ld(crow + ch * 4 + 1);
+                    acc[v].z += wgt * Elem<T>::ld(crow + ch * 4 + 2);
+                    acc[v].w += wgt * Elem<T>::ld(crow + ch * 4 + 3);
+                }
+            }
+        }
+        float* dst = out_row(slot_cell[sidx]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int ch = lane + 64 * v;
+            if (ch < c4) {
+                unsafeAtomicAdd(dst + ch * 4 + 0, acc[v].x);
+                unsafeAtomicAdd(dst + ch * 4 + 1, acc[v].y);
+                unsafeAtomicAdd(dst + ch * 4 + 2, acc[v].z);
+                unsafeAtomicAdd(dst + ch * 4 + 3, acc[v].w);
+            }
+        }
+    }
+    if (ns > kMaxSlots) {   // rare (never with Lift-Splat geometry): per-(pixel,depth) atomics for the excess cells
+        for (int i = wave; i < npx * D; i += 4) {
+            const int p = i / D, d = i % D;
+            const int c = cellid[p][d];
+            if (c < 0 || table[c] < kMaxSlots) continue;
+            const float wgt = prob[p][d];
+            const int h = p / sw, w = w0 + p % sw;
+            const T* crow = ctx + (((long long)bc * fH + h) * fW + w) * C;
+            float* dst = out_row(c);
+            for (int ch = lane; ch < C; ch += 64) unsafeAtomicAdd(dst + ch, wgt * Elem<T>::ld(crow + ch));
+        }
+    }
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -688,6 +845,21 @@ extern "C" int tt_lift_splat_fwd(int batch_size, int num_cams, int D, int fH, in
     const long long npix = (long long)batch_size * num_cams * fH * fW;
     if (npix == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    const bool strip_ok = fH * kStripW <= kMaxStripPix && D <= kMaxD && num_voxel_x * num_voxel_y <= kMaxCells;
+    if (strip_ok) {
+        const unsigned sblocks = (unsigned)(batch_size * num_cams * div_up(fW, kStripW));
+        if (dtype == TT_F32)
+            hipLaunchKernelGGL(lift_splat_strip_kernel<float>, dim3(sblocks), dim3(256), 0, st, batch_size, num_cams, D,
+                               fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z, (const float*)depth_logits,
+                               (const float*)context, geom_xyz, out, out_cstride, out_coff, rot_flip);
+        else if (dtype == TT_BF16)
+            hipLaunchKernelGGL(lift_splat_strip_kernel<uint16_t>, dim3(sblocks), dim3(256), 0, st, batch_size, num_cams,
+                               D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z, (const uint16_t*)depth_logits,
+                               (const uint16_t*)context, geom_xyz, out, out_cstride, out_coff, rot_flip);
+        else
+            TT_REQUIRE(false, "tt_lift_splat_fwd: bad dtype %d", dtype);
+        return check_launch("tt_lift_splat_fwd");
+    }
     const unsigned blocks = (unsigned)div_up(npix, 4);
     if (dtype == TT_F32) {
         hipLaunchKernelGGL(lift_splat_kernel<float>, dim3(blocks), dim3(256), 0, st, batch_size,
