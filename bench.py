@@ -157,7 +157,8 @@ def main():
             "vs_baseline": None,
             "dtype": wl.dtype,
             "data": "synthetic (seeded N(0,1) images / uniform LiDAR / CARLA calibration constants), random-init weights",
-            "config": {"workload": wl.name, "frames_per_gpu_per_step": args.batch,
+            "config": {"workload": wl.name, "precision": getattr(wl, "precision_note", wl.dtype),
+                       "frames_per_gpu_per_step": args.batch,
                        "global_frames_per_step": args.batch * world,
                        "parallelism": f"replicas x{world} (no data-path collective)"},
             "roofline": wl.roofline(),
