@@ -314,7 +314,39 @@ def gen_f8():
     _gen_forward("f8_forward_full_b1.npz", 1, (448, 896), 65536)
 
 
-FIXTURES = {"F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8}
+# ---------------------------------------------------------------------------
+# F9: closed-loop post-processing (EDF:268-390, code/utils.py:7-29) -- a 16-tick sequence through the
+#     reference model's process_action / control_pid (stateful PID windows)
+# ---------------------------------------------------------------------------
+def gen_f9():
+    from thinktwice_amd import config, params
+    cfg = config.model_config(final_dim=(128, 256))
+    sd = params.init_params(cfg, seed=0, parts=("fusion", "decoder", "img_encoder"))
+    model = build_reference_model(cfg, sd)
+    g = torch.Generator().manual_seed(9)
+    rec = {k: [] for k in ("mu", "sigma", "wp", "speed", "target", "pa", "pid")}
+    for t in range(16):
+        mu = torch.rand(1, 6, 2, generator=g) * 3.0
+        sigma = torch.rand(1, 6, 2, generator=g) * 3.0
+        if t % 4 == 1:
+            mu[:, -1] = mu[:, -1] * 0.2           # alpha <= 1 branches
+        if t % 4 == 2:
+            sigma[:, -1] = sigma[:, -1] * 0.2
+        wp = torch.cumsum(torch.rand(1, 4, 2, generator=g) * torch.tensor([0.6, 1.5]) + torch.tensor([-0.3, 0.1]), 1)
+        speed = torch.rand(1, generator=g) * (0.005 if t == 5 else 8.0)
+        target = (torch.randn(2, generator=g) * torch.tensor([3.0, 10.0]) + torch.tensor([0.0, 12.0])).numpy()
+        pred = {"mu_branches": mu, "sigma_branches": sigma}
+        s1, th1, b1, _ = model.process_action(pred, 3, speed, target)
+        s2, th2, b2, m2 = model.control_pid(wp, speed, target.copy())
+        rec["mu"].append(mu.numpy()); rec["sigma"].append(sigma.numpy()); rec["wp"].append(wp.numpy())
+        rec["speed"].append(speed.numpy()); rec["target"].append(target)
+        rec["pa"].append([s1, th1, b1])
+        rec["pid"].append([s2, th2, float(b2), m2["desired_speed"], m2["angle"], m2["angle_last"], m2["angle_target"],
+                           m2["angle_final"], m2["delta"]])
+    _save("f9_control.npz", **{k: np.asarray(v, dtype=np.float64) for k, v in rec.items()})
+
+
+FIXTURES = {"F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8, "F9": gen_f9}
 
 
 def main():

@@ -6,7 +6,7 @@ package's registry.  Every tensor op runs on the gfx950 kernels behind include/t
 """
 import torch
 
-from . import _lib, ops
+from . import _lib, control, ops
 from .fusion import BEVFusion
 from .layers import linear_from_sd, rows, unrows
 from .registry import DETECTORS, build_backbone, build_head
@@ -30,6 +30,18 @@ class EncoderDecoder:
         self.decoder = build_head(dec, dtype=dtype, device=device)
         self.training = False
         self.loaded = False
+        c = self.config or {}
+        if "turn_KP" in c:   # EDF:47-48
+            self.turn_controller = control.PIDController(c["turn_KP"], c["turn_KI"], c["turn_KD"], c["turn_n"])
+            self.speed_controller = control.PIDController(c["speed_KP"], c["speed_KI"], c["speed_KD"], c["speed_n"])
+
+    # closed-loop post-processing (host scalar math, thinktwice_agent.py:458-461)
+    def process_action(self, pred, command, speed, target_point):
+        return control.process_action(pred, command, speed, target_point)
+
+    def control_pid(self, waypoints, velocity, target, stuck_desired_speed=-1):
+        return control.control_pid(self.config, self.turn_controller, self.speed_controller, waypoints, velocity,
+                                   target, stuck_desired_speed)
 
     # mmcv / torch.nn.Module surface used by the callers (AGENT:170-172)
     def eval(self):
