@@ -243,6 +243,17 @@ int tt_sp_rulebook(const int* out_coords, const int* out_rows, long long max_out
 int tt_sp_to_dense(const void* feats, const int* coords, const int* num_rows, long long max_rows, int C,
                    const int* dims_zyx, void* dense, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------
+ * fused camera preprocessing (undistort grid_sample + bilinear resize + crop + /255 +
+ * ImageNet normalise; datasets/pipelines/transform.py:283-286,346-356,144,163) in one gather kernel.
+ * raw uint8 [NI,H,W,3]; mapx/mapy f32 [H,W] = cv2.initUndistortRectifyMap output (pixel units);
+ * mean3/std3: HOST floats.  Writes channel-last out_nhwc [NI,out_h,out_w,Cp] (dtype) and/or NCHW f32.
+ * ---------------------------------------------------------------------- */
+int tt_preprocess_images(const uint8_t* raw_hwc, int num_images, int H, int W, const float* mapx,
+                         const float* mapy, int resized_h, int resized_w, int crop_y, int crop_x,
+                         int out_h, int out_w, const float* mean3, const float* std3, void* out_nhwc,
+                         int out_channels_padded, int out_dtype, float* out_nchw_or_null, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

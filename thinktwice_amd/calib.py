@@ -54,3 +54,30 @@ def camera_tables():
     l2c = np.stack([np.array(LIDAR2CAM[n]) for n in CAMERA_NAMES]).astype(np.float32)
     l2i = np.stack([np.array(UNDISTORT_LIDAR2IMG[n]) for n in CAMERA_NAMES]).astype(np.float32)
     return intr, l2c, l2i
+
+
+# raw (distorted) pinhole + distortion coefficients [k1, k2, p1, p2, k3] (transform.py:47-48)
+RAW_INTRINSIC = np.array([[214.35935394, 0.0, 800.0], [0.0, 214.35935394, 450.0], [0.0, 0.0, 1.0]], dtype=np.float64)
+DIST_COEFFS = np.array([0.00888296, -0.00130899, 0.00012061, -0.00338673, 0.00028834], dtype=np.float64)
+IMAGENET_MEAN = (0.485, 0.456, 0.406)     # transform.py:144
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def undistort_rectify_map(width=IMG_W, height=IMG_H):
+    """(mapx, mapy) float32 [H, W]: restatement of cv2.initUndistortRectifyMap(mtx, dist, None, newcameramtx,
+    (1600, 900), CV_32FC1) as called at transform.py:235 (OpenCV is not installed here: the published pinhole +
+    Brown-Conrady model; "parity unpinned" for this table)."""
+    fx, fy, cx, cy = RAW_INTRINSIC[0, 0], RAW_INTRINSIC[1, 1], RAW_INTRINSIC[0, 2], RAW_INTRINSIC[1, 2]
+    nfx, nfy, ncx, ncy = CAM_INTRINSIC[0, 0], CAM_INTRINSIC[1, 1], CAM_INTRINSIC[0, 2], CAM_INTRINSIC[1, 2]
+    k1, k2, p1, p2, k3 = DIST_COEFFS
+    u = np.arange(width, dtype=np.float64)[None, :]
+    v = np.arange(height, dtype=np.float64)[:, None]
+    x = (u - ncx) / nfx + 0 * v
+    y = (v - ncy) / nfy + 0 * u
+    x2, y2 = x * x, y * y
+    r2 = x2 + y2
+    two_xy = 2 * x * y
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = x * kr + p1 * two_xy + p2 * (r2 + 2 * x2)
+    yd = y * kr + p1 * (r2 + 2 * y2) + p2 * two_xy
+    return (fx * xd + cx).astype(np.float32), (fy * yd + cy).astype(np.float32)
