@@ -30,6 +30,7 @@ class EncoderDecoder:
         self.decoder = build_head(dec, dtype=dtype, device=device)
         self.training = False
         self.loaded = False
+        self._side = None
         c = self.config or {}
         if "turn_KP" in c:   # EDF:47-48
             self.turn_controller = control.PIDController(c["turn_KP"], c["turn_KI"], c["turn_KD"], c["turn_n"])
@@ -91,11 +92,21 @@ class EncoderDecoder:
         return unrows(self.meas2(self.meas0(rows(state))))
 
     def extract_sensor_feat(self, img, img_metas, points):
+        # The LiDAR branch is independent of the camera trunk until the BEV fusion: run it on its own HIP
+        # stream so its many small launches fill the tail of the big camera convolutions.
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        pts = points[:, -1].to(self.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            lidar = self.lidar_encoder(pts, channel_last=True, rot_flip=True)          # EDF:244-246
         cam = self.img_encoder(img.to(self.device), img_metas, channel_last=True)
         B, H, W, C = cam["_bev_cl"].shape
         cam_bev = torch.empty(B, H, W, C, dtype=F32, device=self.device)
         ops.copy_nhwc(cam["_bev_cl"], cam_bev, rot_flip=True)          # EDF:241
-        lidar = self.lidar_encoder(points[:, -1].to(self.device), channel_last=True, rot_flip=True)  # EDF:244-246
+        main.wait_stream(self._side)
+        lidar.record_stream(main)
         return cam, cam_bev, lidar
 
     def forward_inference(self, batch, channel_last_out=False):
