@@ -44,8 +44,10 @@ class ForwardWorkload:
         forward divided by the summed launch durations (HIP events on the launch stream)."""
         torch.cuda.synchronize()
         ops.CONV_PROFILE = []
+        self.model.use_side_stream = False     # per-launch timing needs the launches serialised on one stream
         self.step()
         torch.cuda.synchronize()
+        self.model.use_side_stream = True
         rec = []
         for r in ops.CONV_PROFILE:
             if len(r) > 4:      # sparse launch: FLOPs of the LIVE rows only

@@ -31,6 +31,7 @@ class EncoderDecoder:
         self.training = False
         self.loaded = False
         self._side = None
+        self.use_side_stream = True
         c = self.config or {}
         if "turn_KP" in c:   # EDF:47-48
             self.turn_controller = control.PIDController(c["turn_KP"], c["turn_KI"], c["turn_KD"], c["turn_n"])
@@ -95,12 +96,19 @@ class EncoderDecoder:
         # The LiDAR branch is independent of the camera trunk until the BEV fusion: run it on its own HIP
         # stream so its many small launches fill the tail of the big camera convolutions.
         main = torch.cuda.current_stream(self.device)
+        pts = points[:, -1].to(self.device)
+        if not self.use_side_stream:
+            lidar = self.lidar_encoder(pts, channel_last=True, rot_flip=True)          # EDF:244-246
+            cam = self.img_encoder(img.to(self.device), img_metas, channel_last=True)
+            B, H, W, C = cam["_bev_cl"].shape
+            cam_bev = torch.empty(B, H, W, C, dtype=F32, device=self.device)
+            ops.copy_nhwc(cam["_bev_cl"], cam_bev, rot_flip=True)      # EDF:241
+            return cam, cam_bev, lidar
         if self._side is None:
             self._side = torch.cuda.Stream(self.device)
-        pts = points[:, -1].to(self.device)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            lidar = self.lidar_encoder(pts, channel_last=True, rot_flip=True)          # EDF:244-246
+            lidar = self.lidar_encoder(pts, channel_last=True, rot_flip=True)
         cam = self.img_encoder(img.to(self.device), img_metas, channel_last=True)
         B, H, W, C = cam["_bev_cl"].shape
         cam_bev = torch.empty(B, H, W, C, dtype=F32, device=self.device)
