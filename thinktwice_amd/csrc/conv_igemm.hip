@@ -23,10 +23,12 @@
 
 namespace tt {
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GATHER>
+// KX = K-tile widening factor: 1 => 64 B (f32) / 128 B (bf16) of K per row per tile; 4 => 256 / 512 B, used for
+// latency-bound small-M layers (GRU / decoder convs, M ~ 3.5k) where the K loop length is what costs.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GATHER, int KX = 1>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int VEC = Elem<T>::kVec;               // elements per 16 B
-    constexpr int BKB = (sizeof(T) == 4) ? 64 : 128; // K bytes per row per tile
+    constexpr int BKB = ((sizeof(T) == 4) ? 64 : 128) * KX; // K bytes per row per tile
     constexpr int BK = BKB / (int)sizeof(T);
     constexpr int VPR = BKB / 16;                    // 16 B vectors per row
     constexpr int ROWB = BKB + 16;                   // padded LDS row stride (bytes)
@@ -246,9 +248,9 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const ConvArgs p) 
     else reinterpret_cast<uint16_t*>(p.out)[o] = f32_to_bf16(v);
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GATHER>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GATHER, int KX = 1>
 static int launch_conv(ConvArgs& a, hipStream_t st) {
-    constexpr int BKB = (sizeof(T) == 4) ? 64 : 128;
+    constexpr int BKB = ((sizeof(T) == 4) ? 64 : 128) * KX;
     constexpr int BK = BKB / (int)sizeof(T);
     constexpr int ROWB = BKB + 16;
     const int tiles_m = div_up(a.M, BM);
@@ -258,11 +260,14 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
     size_t smem = (size_t)((a.K > BK) ? 2 : 1) * (BM + BN) * ROWB;
     const size_t epi = (size_t)4 * 32 * (WTN_ + 4) * 4;            // LDS-staged epilogue
     if (smem < epi) smem = epi;
-    auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GATHER>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GATHER, KX>;
     static bool attr_set = false;
-    if (!attr_set && smem > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (!attr_set) {   // once per instantiation, sized for the largest (double-buffered) request
+        size_t mx = (size_t)2 * (BM + BN) * ROWB;
+        if (mx < epi) mx = epi;
+        if (mx > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
         attr_set = true;
     }
     const int tiles = tiles_m * a.tiles_n;
@@ -285,6 +290,14 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
 
 template <typename T, bool GATHER>
 static int dispatch_conv2(ConvArgs& a, hipStream_t st) {
+    if constexpr (!GATHER && sizeof(T) == 4) {
+        // small-M f32 layers that are NOT split-K: 4x wider K tiles => 4x fewer barrier/latency rounds
+        if (a.M <= 8192 && !a.ws && a.K >= 128) {
+            if (a.Cout > 64) return launch_conv<T, 128, 128, 2, 2, false, 4>(a, st);
+            if (a.Cout > 32) return launch_conv<T, 128, 64, 2, 2, false, 4>(a, st);
+            return launch_conv<T, 128, 32, 4, 1, false, 4>(a, st);
+        }
+    }
     if (a.Cout > 64) return launch_conv<T, 128, 128, 2, 2, GATHER>(a, st);
     if (a.Cout > 32) return launch_conv<T, 128, 64, 2, 2, GATHER>(a, st);
     return launch_conv<T, 128, 32, 4, 1, GATHER>(a, st);
