@@ -23,8 +23,9 @@
 
 namespace tt {
 
-// KX = K-tile widening factor: 1 => 64 B (f32) / 128 B (bf16) of K per row per tile; 4 => 256 / 512 B, used for
-// latency-bound small-M layers (GRU / decoder convs, M ~ 3.5k) where the K loop length is what costs.
+// KX = K-tile widening factor (1 => 64 B (f32) / 128 B (bf16) of K per row per tile).  A 4x variant was measured
+// on the M ~ 3.5k GRU / decoder layers and did not help: those layers are bound by the f32 MFMA issue rate of a
+// single 32x32 tile per wave (profiles/README.md), not by the K-loop round trips.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GATHER, int KX = 1>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int VEC = Elem<T>::kVec;               // elements per 16 B
@@ -290,14 +291,6 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
 
 template <typename T, bool GATHER>
 static int dispatch_conv2(ConvArgs& a, hipStream_t st) {
-    if constexpr (!GATHER && sizeof(T) == 4) {
-        // small-M f32 layers that are NOT split-K: 4x wider K tiles => 4x fewer barrier/latency rounds
-        if (a.M <= 8192 && !a.ws && a.K >= 128) {
-            if (a.Cout > 64) return launch_conv<T, 128, 128, 2, 2, false, 4>(a, st);
-            if (a.Cout > 32) return launch_conv<T, 128, 64, 2, 2, false, 4>(a, st);
-            return launch_conv<T, 128, 32, 4, 1, false, 4>(a, st);
-        }
-    }
     if (a.Cout > 64) return launch_conv<T, 128, 128, 2, 2, GATHER>(a, st);
     if (a.Cout > 32) return launch_conv<T, 128, 64, 2, 2, GATHER>(a, st);
     return launch_conv<T, 128, 32, 4, 1, GATHER>(a, st);
