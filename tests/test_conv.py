@@ -134,3 +134,19 @@ def test_conv_rejects_unpadded_channels():
     w = torch.zeros(8, 1, 1, 6).cuda()
     with pytest.raises(_lib.TTError):
         ops.conv2d(x, w)
+
+
+def test_splitk_workspace_path_matches_torch():
+    """tt_conv_desc.splitk_ws: K split over gridDim.y + finalize kernel (kept for callers that want it)."""
+    from thinktwice_amd import ops, weights
+    g = torch.Generator().manual_seed(11)
+    x = _mk((2, 64, 21, 21), g)
+    w = _mk((128, 64, 3, 3), g, (64 * 9) ** -0.5)
+    b = _mk((128,), g, 0.1)
+    xq = weights.to_channel_last(x).cuda()
+    wq = weights.prep_conv_weight(w, torch.float32).cuda()
+    ws = torch.zeros(2 * 21 * 21, 128, device="cuda")
+    out = ops.conv2d(xq, wq, pad=1, shift=b.cuda(), act=1, splitk_ws=ws)
+    ref = F.relu(F.conv2d(x, w, b, padding=1))
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-4

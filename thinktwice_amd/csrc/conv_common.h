@@ -262,5 +262,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 
 // glds (LDS-DMA, 3-stage) variant: returns 1 if it took the launch, 0 if the shape is not covered.
 int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st);
+// latency-bound small-M variant (32x32 tile, intra-block split-K): same contract.
+int try_launch_conv_small(ConvArgs& a, int dtype, hipStream_t st);
 
 }  // namespace tt

@@ -360,6 +360,7 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
         a.res_vec = (res_ok(d->res1, d->res1_cstride, d->res1_coff) && res_ok(d->res2, d->res2_cstride, d->res2_coff)) ? 1 : 0;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (!d->splitk_ws && try_launch_conv_small(a, d->dtype, st)) return check_launch("tt_conv2d_fwd(small)");
     if (!d->splitk_ws && try_launch_conv_glds(a, d->dtype, st)) return check_launch("tt_conv2d_fwd(glds)");
     if (d->dtype == TT_F32) return dispatch_conv<float>(a, st);
     return dispatch_conv<uint16_t>(a, st);

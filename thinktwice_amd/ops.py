@@ -113,7 +113,7 @@ def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None
 
 def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=None, res1_coff=0,
            res2=None, res2_coff=0, out=None, out_coff=0, in_coff=0, cin=None, pixel_shuffle2=False,
-           shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None):
+           shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None, splitk_ws=None):
     """Channel-last implicit-GEMM convolution on MFMA (tt_conv2d_fwd).
 
     x   [N,H,W,Cs]  (f32 or bf16); channels [in_coff, in_coff+cin) are convolved
@@ -148,10 +148,8 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     d.res1 = _dp(res1); d.res1_cstride = 0 if res1 is None else res1.shape[-1]; d.res1_coff = res1_coff
     d.res2 = _dp(res2); d.res2_cstride = 0 if res2 is None else res2.shape[-1]; d.res2_coff = res2_coff
     d.act = act; d.dtype = dtype_code(x); d.out_dtype = dtype_code(out)
-    M_ = N * OH * OW
-    if M_ <= 4096 and KH * KW * Cin >= 512:      # latency-bound shape: let the library split K
-        ws = torch.zeros(M_, Cout, dtype=torch.float32, device=x.device)
-        d.splitk_ws = ws.data_ptr()
+    if splitk_ws is not None:                    # optional: force the two-launch split-K path (tests)
+        d.splitk_ws = splitk_ws.data_ptr()
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
