@@ -148,7 +148,10 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     d.res1 = _dp(res1); d.res1_cstride = 0 if res1 is None else res1.shape[-1]; d.res1_coff = res1_coff
     d.res2 = _dp(res2); d.res2_cstride = 0 if res2 is None else res2.shape[-1]; d.res2_coff = res2_coff
     d.act = act; d.dtype = dtype_code(x); d.out_dtype = dtype_code(out)
-    if splitk_ws is not None:                    # optional: force the two-launch split-K path (tests)
+    if splitk_ws is None and N * OH * OW <= 4096 and KH * KW * Cin >= 2048:
+        # few rows, very long K (BEV-update conv, flatten MLPs): split K over workgroups (library decides how)
+        splitk_ws = torch.zeros(N * OH * OW, Cout, dtype=torch.float32, device=x.device)
+    if splitk_ws is not None:
         d.splitk_ws = splitk_ws.data_ptr()
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
