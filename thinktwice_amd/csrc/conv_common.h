@@ -63,6 +63,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
     // ---- epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int cout_real = p.pixel_shuffle2 ? (p.Cout >> 2) : p.Cout;
     const int ohw = p.OH * p.OW;
+    if (p.act == 99) return;   // profiling aid (tools/conv_microbench.py): main loop only, no epilogue
     if (p.ws) {   // split-K: raw partial sums; scale/shift/residual/activation run in splitk_finalize_kernel
 #pragma unroll
         for (int j = 0; j < TN; ++j) {

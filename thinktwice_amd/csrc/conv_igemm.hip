@@ -19,6 +19,8 @@
 //     along Cin) while tile k is on the matrix pipe; one barrier per K-tile.
 //   * fused epilogue: BN/bias scale+shift, per-image shift, up to two residuals, activation,
 //     channel-offset / strided output (concat-free), ConvTranspose k2s2 pixel shuffle.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 namespace tt {
@@ -354,6 +356,7 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
                   (a.out_nstride % co_vec == 0) && ((reinterpret_cast<uintptr_t>(d->out) & 15) == 0);
         (void)osz;
         a.vec_epi = ok ? 1 : 0;
+        if (getenv("TT_CONV_SCALAR_EPI")) a.vec_epi = 0;   // experiment knob
         auto res_ok = [&](const void* r, int cs, int co_) {
             return !r || ((cs % co_vec == 0) && (co_ % co_vec == 0) && ((reinterpret_cast<uintptr_t>(r) & 15) == 0));
         };

@@ -20,19 +20,34 @@ def main():
     x = torch.randn(N, H, W, Cin, device="cuda", generator=g).to(dt)
     w = (torch.randn(Cout, k, k, Cin, device="cuda", generator=g) * (Cin * k * k) ** -0.5).to(dt)
     pad = k // 2
+    act = int(os.environ.get("TT_MB_ACT", "0"))
+    res = torch.randn(N, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, Cout, device="cuda").to(dt) \
+        if os.environ.get("TT_MB_RES") else None
     for _ in range(3):
-        y = ops.conv2d(x, w, stride=stride, pad=pad)
+        y = ops.conv2d(x, w, stride=stride, pad=pad, act=act, res1=res)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        y = ops.conv2d(x, w, stride=stride, pad=pad)
+        y = ops.conv2d(x, w, stride=stride, pad=pad, act=act, res1=res)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     M = y.shape[0] * y.shape[1] * y.shape[2]
     fl = 2.0 * M * Cout * k * k * Cin
-    print(f"M={M} N={Cout} K={k*k*Cin} {dt}: {ms:.3f} ms  {fl/ms/1e9:.1f} TF/s  env BKB={os.environ.get('TT_GLDS_BKB')} BN256={os.environ.get('TT_GLDS_BN256')} MINK={os.environ.get('TT_GLDS_MIN_KTILES')}")
+    print(f"M={M} N={Cout} K={k*k*Cin} {dt}: {ms:.3f} ms  {fl/ms/1e9:.1f} TF/s  env BKB={os.environ.get('TT_GLDS_BKB')} BN256={os.environ.get('TT_GLDS_BN256')} MINK={os.environ.get('TT_GLDS_MIN_KTILES')} ACT={act} RES={res is not None} SCALAR_EPI={os.environ.get('TT_CONV_SCALAR_EPI')}")
+    # reference point: a plain device copy of the output-sized tensor (read + write M*N elements)
+    src = torch.empty_like(y)
+    for _ in range(3):
+        src.copy_(y)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        src.copy_(y)
+    e1.record()
+    torch.cuda.synchronize()
+    cms = e0.elapsed_time(e1) / iters
+    print(f"   copy of the output tensor ({y.numel() * y.element_size() / 1e6:.0f} MB): {cms:.3f} ms = {2 * y.numel() * y.element_size() / cms / 1e9:.2f} TB/s")
 
 
 if __name__ == "__main__":
