@@ -104,14 +104,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
             sh[e] = (col_ok && e < CO && p.shift) ? p.shift[co + e] : 0.f;
         }
 #pragma unroll
+        __syncthreads();   // every wave is done with the K-loop tiles before LDS is reused
         for (int i = 0; i < TM; ++i) {
-            __syncthreads();
+            // Each wave stages through its PRIVATE region, and a wave's LDS operations execute in program
+            // order, so wave-level ordering is enough.  A workgroup barrier here would also wait for the
+            // previous block-row's GLOBAL STORES (vmcnt counts stores on gfx950) and serialise the epilogue
+            // on store latency.
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     sC[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDC + j * 32 + (lane & 31)] = acc[i][j][r];
-            __syncthreads();
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
             for (int rl = row_in_pass; rl < 32; rl += rpp) {
                 const int m = m0 + wm * WTM + i * 32 + rl;
                 if (m >= Mlim || !col_ok) continue;
