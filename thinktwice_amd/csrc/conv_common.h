@@ -103,8 +103,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
             sc[e] = (col_ok && e < CO && p.scale) ? p.scale[co + e] : 1.f;
             sh[e] = (col_ok && e < CO && p.shift) ? p.shift[co + e] : 0.f;
         }
-#pragma unroll
         __syncthreads();   // every wave is done with the K-loop tiles before LDS is reused
+#pragma unroll
         for (int i = 0; i < TM; ++i) {
             // Each wave stages through its PRIVATE region, and a wave's LDS operations execute in program
             // order, so wave-level ordering is enough.  A workgroup barrier here would also wait for the
