@@ -300,6 +300,13 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
         if (a.Cout > 64) return launch_glds<uint16_t, 128, 4, 2, 128>(a, st);
         return launch_glds<uint16_t, 64, 8, 1, 128>(a, st);
     }
+    static int wide = -1;
+    if (wide < 0) {
+        const char* e = getenv("TT_GLDS_WIDE_WAVE");
+        wide = e ? atoi(e) : 0;
+    }
+    // experiment: 8x1 wave grid => every wave owns 32 rows x 128 cols (256 B row segments in the epilogue)
+    if (wide && a.Cout > 64) return launch_glds<uint16_t, 128, 8, 1, 64>(a, st);
     if (a.Cout > 64) return launch_glds<uint16_t, 128, 4, 2, 64>(a, st);
     return launch_glds<uint16_t, 64, 8, 1, 64>(a, st);
 }
