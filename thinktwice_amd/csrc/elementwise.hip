@@ -33,7 +33,7 @@ template <> struct Vec<uint16_t> {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+            w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };

@@ -37,11 +37,15 @@ static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) {
     return __uint_as_float(((uint32_t)v) << 16);
 }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+// f32 -> bf16 (round to nearest even) on the gfx950 converter: one v_cvt_pk_bf16_f32 instead of the ~6-op integer
+// sequence.  The software form made every bf16 epilogue VALU-bound (measured: 1.37 TB/s of output regardless of
+// the write pattern, profiles/README.md).
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+typedef __bf16 tt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float tt_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    tt_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, tt_bf16x2));
 }
 
 template <typename T> struct Elem;
