@@ -1,5 +1,6 @@
 // Shared definitions of the implicit-GEMM convolution kernels (conv_igemm.hip, conv_igemm_glds.hip).
 #pragma once
+#include <type_traits>
 #include "tt_common.h"
 
 namespace tt {
@@ -55,6 +56,203 @@ template <> struct Mfma<uint16_t> {
 
 
 
+// Stage one 32 x WTN block of a wave's accumulators into its private LDS region with the folded-BN scale/shift
+// already applied.  In the MFMA C/D layout a lane owns ONE output channel per 32-wide column block, so the affine
+// costs 2*TN registers here instead of 2*CO per lane after the transposition.
+template <int TN, int WTN>
+__device__ __forceinline__ void stage_scaled(float* sC, const f32x16 (&acc)[TN], const float (&sc)[TN],
+                                             const float (&sh)[TN], int lane) {
+    constexpr int LDC = WTN + 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's reads of the previous block are done
+#endif
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            sC[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDC + j * 32 + (lane & 31)] = acc[j][r] * sc[j] + sh[j];
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+}
+
+template <int TN, int WTN>
+__device__ __forceinline__ void load_scale_shift(const ConvArgs& p, float (&sc)[TN], float (&sh)[TN], int lane, int wn,
+                                                 int n0) {
+    const int cout_real = p.pixel_shuffle2 ? (p.Cout >> 2) : p.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WTN + j * 32 + (lane & 31);
+        const int co = (col < p.Cout) ? col % cout_real : 0;
+        sc[j] = p.scale ? p.scale[co] : 1.f;
+        sh[j] = p.shift ? p.shift[co] : 0.f;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): settle these loads before the store-heavy passes
+#endif
+}
+
+// Vector epilogue: each wave stages a 32 x WTN block of its accumulators through its PRIVATE LDS region so that
+// every lane ends up with CO (4 f32 / 8 bf16) consecutive channels of one output row = one 16-byte store (full
+// 128 B lines).  Everything is compile-time indexed so it stays in registers: an earlier version with runtime CO and
+// by-reference lambdas put its small arrays in scratch, and every scratch reload carried an `s_waitcnt vmcnt(0)` that
+// also waited for the in-flight global stores (1.4 TB/s ceiling on every memory-bound layer).
+template <typename T, int CO, int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&acc)[TM][TN], float* sC, int lane, int wm,
+                                                  int wn, int m0, int n0, int Mlim) {
+    constexpr int LDC = WTN + 4;
+    constexpr int cpr = WTN / CO;          // 16 B chunks per row of the wave's block
+    constexpr int rpp = 64 / cpr;          // rows per pass
+    constexpr int NPASS = 32 / rpp;
+    const int cout_real = p.pixel_shuffle2 ? (p.Cout >> 2) : p.Cout;
+    const int ohw = p.OH * p.OW;
+    const int row_in_pass = lane / cpr;
+    const int col_l = (lane % cpr) * CO;
+    const int col = n0 + wn * WTN + col_l;
+    int co = col, q = 0;
+    if (p.pixel_shuffle2) {
+        q = col / cout_real;
+        co = col - q * cout_real;
+    }
+    const bool col_ok = col < p.Cout;
+    const int act = p.act;
+    float sc[TN], sh[TN];
+    load_scale_shift<TN, WTN>(p, sc, sh, lane, wn, n0);
+    const bool has_sn = p.shift_n != nullptr;
+    const bool has_r1 = p.res1 != nullptr, has_r2 = p.res2 != nullptr;
+    const bool rvec = p.res_vec != 0;
+    using RV = typename std::conditional<sizeof(T) == 2 && CO == 8, uint4,
+                                         typename std::conditional<sizeof(T) == 2, uint2, float4>::type>::type;
+    auto add_rv = [](float (&v)[CO], const RV& u) {
+        if constexpr (sizeof(T) == 2 && CO == 8) {
+            v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+            v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+            v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
+            v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+        } else if constexpr (sizeof(T) == 2) {
+            v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+            v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+        } else {
+            v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w;
+        }
+    };
+    const bool fast_act = (act == TT_ACT_NONE || act == TT_ACT_RELU);
+    auto out_offset = [&](int m, int cc, int& n) -> long long {
+        if (p.out_fast) {
+            if (has_sn) n = m / ohw;
+            return (long long)m * p.out_cstride + p.out_coff + cc;
+        }
+        n = m / ohw;
+        const int rem = m - n * ohw;
+        int oh = rem / p.OW, ow = rem - oh * p.OW;
+        int OWo = p.OW;
+        if (p.pixel_shuffle2) {
+            oh = 2 * oh + (q >> 1);
+            ow = 2 * ow + (q & 1);
+            OWo = 2 * p.OW;
+        }
+        return (long long)n * p.out_nstride + ((long long)oh * OWo + ow) * p.out_cstride + p.out_coff + cc;
+    };
+    auto store_row = [&](long long o, const float (&v)[CO]) {
+        if constexpr (CO == 4) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            uint4 pk;
+            pk.x = pack_bf16x2(v[0], v[1]);
+            pk.y = pack_bf16x2(v[2], v[3]);
+            pk.z = pack_bf16x2(v[4], v[5]);
+            pk.w = pack_bf16x2(v[6], v[7]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.out) + o) = pk;
+        }
+    };
+    const int cc = col_ok ? co : 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * WTM + i * 32;
+        // a wave's LDS operations execute in program order and the region is private: wave-level ordering suffices
+        stage_scaled<TN, WTN>(sC, acc[i], sc, sh, lane);
+        const bool full_block = (mb + 32 <= Mlim) && (n0 + wn * WTN + WTN <= p.Cout);   // wave-uniform
+        if (fast_act && rvec && p.out_fast && !has_sn && !has_r2 && full_block) {
+            // Hot path (every large conv of the camera/BEV trunks: row-linear output, at most one residual, ReLU or
+            // identity, whole 32 x WTN block in range).  The residual reads of ALL passes are issued up front and the
+            // passes are branch-free LDS read -> math -> 16 B store, so the stores of consecutive passes stay in flight
+            // together.  vmcnt counts stores on gfx950 and is in-order: a load issued between two stores -- or a
+            // predicated store, which makes the compiler's count conservative -- serialises the passes on the store
+            // latency, which capped these layers at 1.4 TB/s of output.
+            auto hot = [&](auto with_r1) {
+                constexpr bool R1 = decltype(with_r1)::value;
+                RV r1[R1 ? NPASS : 1];
+                if constexpr (R1) {
+#pragma unroll
+                    for (int pass = 0; pass < NPASS; ++pass) {
+                        const int m = mb + pass * rpp + row_in_pass;
+                        r1[pass] = *reinterpret_cast<const RV*>(reinterpret_cast<const T*>(p.res1) +
+                                                               (long long)m * p.res1_cstride + p.res1_coff + co);
+                    }
+                }
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    const int rl = pass * rpp + row_in_pass;
+                    const int mr = mb + rl;
+                    float v[CO];
+#pragma unroll
+                    for (int e = 0; e < CO; e += 4) {
+                        const float4 t0 = *reinterpret_cast<const float4*>(sC + rl * LDC + col_l + e);
+                        v[e] = t0.x; v[e + 1] = t0.y; v[e + 2] = t0.z; v[e + 3] = t0.w;
+                    }
+                    if constexpr (R1) add_rv(v, r1[pass]);
+                    if (act == TT_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < CO; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    }
+                    store_row((long long)mr * p.out_cstride + p.out_coff + co, v);
+                }
+            };
+            if (has_r1) hot(std::true_type{});
+            else hot(std::false_type{});
+        } else {
+            // Everything else (sigmoid/GELU/softplus, strided or pixel-shuffled outputs, per-image shifts, two
+            // residuals: the small and mid-size layers): one pass at a time, rolled
+#pragma unroll 1
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int rl = pass * rpp + row_in_pass;
+                const int m = mb + rl;
+                if (m >= Mlim || !col_ok) continue;
+                float v[CO];
+#pragma unroll
+                for (int e = 0; e < CO; e += 4) {
+                    const float4 t0 = *reinterpret_cast<const float4*>(sC + rl * LDC + col_l + e);
+                    v[e] = t0.x; v[e + 1] = t0.y; v[e + 2] = t0.z; v[e + 3] = t0.w;
+                }
+                int n = 0;
+                const long long o = out_offset(m, co, n);
+                if (has_sn) {
+                    const float* sn = p.shift_n + (long long)(n % p.shift_n_mod) * cout_real + co;
+#pragma unroll
+                    for (int e = 0; e < CO; ++e) v[e] += sn[e];
+                }
+#pragma unroll
+                for (int which = 0; which < 2; ++which) {
+                    const void* rb = which ? p.res2 : p.res1;
+                    if (!rb) continue;
+                    const T* rp = reinterpret_cast<const T*>(rb) +
+                                  (long long)m * (which ? p.res2_cstride : p.res1_cstride) +
+                                  (which ? p.res2_coff : p.res1_coff) + co;
+                    if (rvec) {
+                        add_rv(v, *reinterpret_cast<const RV*>(rp));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < CO; ++e) v[e] += Elem<T>::ld(rp + e);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < CO; ++e) v[e] = apply_act(v[e], act);
+                store_row(o, v);
+            }
+        }
+    }
+}
+
 // Fused epilogue shared by both kernels.  C/D map of the 32x32 MFMA: col = lane&31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 template <typename T, int TM, int TN, int WTM, int WTN>
@@ -79,193 +277,61 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
         }
         return;
     }
+    float* sC = reinterpret_cast<float*>(smem) + wave * (32 * (WTN + 4));
+    __syncthreads();   // every wave is done with the K-loop tiles before LDS is reused
     if (p.vec_epi) {
-        // Stage each wave's 32 x WTN accumulator block through LDS (the tile buffers are free after
-        // the K loop) so that every lane stores 16 contiguous bytes of one output row: full 128 B
-        // lines instead of 64 B half-lines per MFMA register, and residuals are read the same way.
-        constexpr int LDC = WTN + 4;
-        float* sC = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
-        const int CO = (p.out_dtype == TT_F32) ? 4 : 8;           // channels per lane
-        const int cpr = WTN / CO;                                  // chunks per row
-        const int rpp = 64 / cpr;                                  // rows per pass
-        const int row_in_pass = lane / cpr;
-        const int col_l = (lane % cpr) * CO;
-        const int col = n0 + wn * WTN + col_l;
-        int co = col, q = 0;
-        if (p.pixel_shuffle2) {
-            q = col / cout_real;
-            co = col - q * cout_real;
-        }
-        const bool col_ok = col < p.Cout;
-        float sc[8], sh[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sc[e] = (col_ok && e < CO && p.scale) ? p.scale[co + e] : 1.f;
-            sh[e] = (col_ok && e < CO && p.shift) ? p.shift[co + e] : 0.f;
-        }
-        __syncthreads();   // every wave is done with the K-loop tiles before LDS is reused
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            // Each wave stages through its PRIVATE region, and a wave's LDS operations execute in program
-            // order, so wave-level ordering is enough.  A workgroup barrier here would also wait for the
-            // previous block-row's GLOBAL STORES (vmcnt counts stores on gfx950) and serialise the epilogue
-            // on store latency.
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    sC[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDC + j * 32 + (lane & 31)] = acc[i][j][r];
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-            for (int rl = row_in_pass; rl < 32; rl += rpp) {
-                const int m = m0 + wm * WTM + i * 32 + rl;
-                if (m >= Mlim || !col_ok) continue;
-                float v[8];
-                const float4 t0 = *reinterpret_cast<const float4*>(sC + rl * LDC + col_l);
-                v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
-                if (CO == 8) {
-                    const float4 t1 = *reinterpret_cast<const float4*>(sC + rl * LDC + col_l + 4);
-                    v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
-                }
-                long long o;
-                int n = 0;
-                if (p.out_fast) {
-                    o = (long long)m * p.out_cstride + p.out_coff + co;
-                } else {
-                    n = m / ohw;
-                    const int rem = m - n * ohw;
-                    int oh = rem / p.OW, ow = rem - oh * p.OW;
-                    int OWo = p.OW;
-                    if (p.pixel_shuffle2) {
-                        oh = 2 * oh + (q >> 1);
-                        ow = 2 * ow + (q & 1);
-                        OWo = 2 * p.OW;
-                    }
-                    o = (long long)n * p.out_nstride + ((long long)oh * OWo + ow) * p.out_cstride + p.out_coff + co;
-                }
-                const float* sn = nullptr;
-                if (p.shift_n) {
-                    if (p.out_fast) n = m / ohw;
-                    sn = p.shift_n + (long long)(n % p.shift_n_mod) * cout_real + co;
-                }
-                const T* r1 = p.res1 ? reinterpret_cast<const T*>(p.res1) + (long long)m * p.res1_cstride + p.res1_coff + co : nullptr;
-                const T* r2 = p.res2 ? reinterpret_cast<const T*>(p.res2) + (long long)m * p.res2_cstride + p.res2_coff + co : nullptr;
-                float rr[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) rr[e] = 0.f;
-                auto add_res = [&](const T* rp) {   // 8 / 16 B vector loads of the residual chunk
-                    if (sizeof(T) == 2) {
-                        if (CO == 8) {
-                            const uint4 u = *reinterpret_cast<const uint4*>(rp);
-                            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                rr[2 * e] += __uint_as_float(w[e] << 16);
-                                rr[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
-                            }
-                        } else {
-                            const uint2 u = *reinterpret_cast<const uint2*>(rp);
-                            rr[0] += __uint_as_float(u.x << 16); rr[1] += __uint_as_float(u.x & 0xffff0000u);
-                            rr[2] += __uint_as_float(u.y << 16); rr[3] += __uint_as_float(u.y & 0xffff0000u);
-                        }
-                    } else {
-                        const float4 f0 = *reinterpret_cast<const float4*>(rp);
-                        rr[0] += f0.x; rr[1] += f0.y; rr[2] += f0.z; rr[3] += f0.w;
-                        if (CO == 8) {
-                            const float4 f1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(rp) + 4);
-                            rr[4] += f1.x; rr[5] += f1.y; rr[6] += f1.z; rr[7] += f1.w;
-                        }
-                    }
-                };
-                if (p.res_vec) {
-                    if (r1) add_res(r1);
-                    if (r2) add_res(r2);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (e < CO) {
-                            if (r1) rr[e] += Elem<T>::ld(r1 + e);
-                            if (r2) rr[e] += Elem<T>::ld(r2 + e);
-                        }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (e < CO) {
-                        float x = v[e] * sc[e] + sh[e];
-                        if (sn) x += sn[e];
-                        x += rr[e];
-                        v[e] = apply_act(x, p.act);
-                    }
-                }
-                if (CO == 4) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    uint4 pk;
-                    pk.x = pack_bf16x2(v[0], v[1]);
-                    pk.y = pack_bf16x2(v[2], v[3]);
-                    pk.z = pack_bf16x2(v[4], v[5]);
-                    pk.w = pack_bf16x2(v[6], v[7]);
-                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.out) + o) = pk;
-                }
-            }
-        }
+        if (p.out_dtype == TT_F32)
+            conv_epilogue_vec<T, 4, TM, TN, WTM, WTN>(p, acc, sC, lane, wm, wn, m0, n0, Mlim);
+        else
+            conv_epilogue_vec<T, 8, TM, TN, WTM, WTN>(p, acc, sC, lane, wm, wn, m0, n0, Mlim);
         return;
     }
+    // Scalar path (channel counts / offsets that are not 16 B friendly: the 3-channel stem input side, heads with
+    // odd widths): same LDS staging, then a ROLLED loop over the wave's 32 x WTN block, lanes along channels.
+    constexpr int LDC = WTN + 4;
+    const int act = p.act;
+    float sc[TN], sh[TN];
+    load_scale_shift<TN, WTN>(p, sc, sh, lane, wn, n0);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * WTN + j * 32 + (lane & 31);
-        if (col >= p.Cout) continue;
-        int co = col, q = 0;
-        if (p.pixel_shuffle2) {
-            q = col / cout_real;
-            co = col - q * cout_real;
-        }
-        const float sc = p.scale ? p.scale[co] : 1.f;
-        const float sh = p.shift ? p.shift[co] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= Mlim) continue;
-                float v = acc[i][j][r] * sc + sh;
-                long long o;
-                int n = 0;
-                if (p.out_fast) {
-                    o = (long long)m * p.out_cstride + p.out_coff + co;
-                } else {
-                    n = m / ohw;
-                    const int rem = m - n * ohw;
-                    int oh = rem / p.OW, ow = rem - oh * p.OW;
-                    int OWo = p.OW;
-                    if (p.pixel_shuffle2) {
-                        oh = 2 * oh + (q >> 1);
-                        ow = 2 * ow + (q & 1);
-                        OWo = 2 * p.OW;
-                    }
-                    o = (long long)n * p.out_nstride + ((long long)oh * OWo + ow) * p.out_cstride +
-                        p.out_coff + co;
-                }
-                if (p.shift_n) {
-                    if (p.out_fast) n = m / ohw;
-                    v += p.shift_n[(n % p.shift_n_mod) * cout_real + co];
-                }
-                if (p.res1)
-                    v += Elem<T>::ld(reinterpret_cast<const T*>(p.res1) +
-                                     (long long)m * p.res1_cstride + p.res1_coff + co);
-                if (p.res2)
-                    v += Elem<T>::ld(reinterpret_cast<const T*>(p.res2) +
-                                     (long long)m * p.res2_cstride + p.res2_coff + co);
-                v = apply_act(v, p.act);
-                if (p.out_dtype == TT_F32)
-                    reinterpret_cast<float*>(p.out)[o] = v;
-                else
-                    reinterpret_cast<uint16_t*>(p.out)[o] = f32_to_bf16(v);
+    for (int i = 0; i < TM; ++i) {
+        stage_scaled<TN, WTN>(sC, acc[i], sc, sh, lane);
+#pragma unroll 1
+        for (int idx = lane; idx < 32 * WTN; idx += 64) {
+            const int rl = idx / WTN, cl = idx - rl * WTN;
+            const int m = m0 + wm * WTM + i * 32 + rl;
+            const int col = n0 + wn * WTN + cl;
+            if (m >= Mlim || col >= p.Cout) continue;
+            int co = col, q = 0;
+            if (p.pixel_shuffle2) {
+                q = col / cout_real;
+                co = col - q * cout_real;
             }
+            float v = sC[rl * LDC + cl];
+            const int n = m / ohw;
+            long long o;
+            if (p.out_fast) {
+                o = (long long)m * p.out_cstride + p.out_coff + co;
+            } else {
+                const int rem = m - n * ohw;
+                int oh = rem / p.OW, ow = rem - oh * p.OW;
+                int OWo = p.OW;
+                if (p.pixel_shuffle2) {
+                    oh = 2 * oh + (q >> 1);
+                    ow = 2 * ow + (q & 1);
+                    OWo = 2 * p.OW;
+                }
+                o = (long long)n * p.out_nstride + ((long long)oh * OWo + ow) * p.out_cstride + p.out_coff + co;
+            }
+            if (p.shift_n) v += p.shift_n[(n % p.shift_n_mod) * cout_real + co];
+            if (p.res1)
+                v += Elem<T>::ld(reinterpret_cast<const T*>(p.res1) + (long long)m * p.res1_cstride + p.res1_coff + co);
+            if (p.res2)
+                v += Elem<T>::ld(reinterpret_cast<const T*>(p.res2) + (long long)m * p.res2_cstride + p.res2_coff + co);
+            v = apply_act(v, act);
+            if (p.out_dtype == TT_F32)
+                reinterpret_cast<float*>(p.out)[o] = v;
+            else
+                reinterpret_cast<uint16_t*>(p.out)[o] = f32_to_bf16(v);
         }
     }
 }

@@ -60,22 +60,19 @@ template <> struct Elem<uint16_t> {  // bf16 storage
     __device__ static __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
-// Rare activations live out of line: inlining erff / expf / log1pf into every unrolled epilogue element blew the
-// conv kernels up to ~50k ISA lines with scratch spills; ReLU / identity (99 % of the launches) stay inline.
-__device__ __noinline__ float apply_act_slow(float v, int act) {
+// Inline everywhere.  The conv epilogues only reach the transcendental cases from ROLLED loops (an unrolled use
+// per accumulator element once blew the kernels up to ~50k ISA lines; an out-of-line call instead pinned the hot
+// path's registers to the call ABI and spilled them).
+__device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
+        case TT_ACT_NONE: return v;
+        case TT_ACT_RELU: return v > 0.f ? v : 0.f;
         case TT_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         case TT_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
         case TT_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
         case TT_ACT_SOFTPLUS_CLAMP: return fmaxf(v > 20.f ? v : log1pf(expf(v)), 1e-3f);
         default: return v;
     }
-}
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == TT_ACT_NONE) return v;
-    if (act == TT_ACT_RELU) return v > 0.f ? v : 0.f;
-    return apply_act_slow(v, act);
 }
 
 }  // namespace tt
