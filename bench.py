@@ -160,7 +160,8 @@ def main():
             "config": {"workload": wl.name, "precision": getattr(wl, "precision_note", wl.dtype),
                        "frames_per_gpu_per_step": args.batch,
                        "global_frames_per_step": args.batch * world,
-                       "parallelism": f"replicas x{world} (no data-path collective)"},
+                       "parallelism": f"replicas x{world} (no data-path collective)",
+                       "launch": getattr(wl, "launch_note", "eager launches")},
             "roofline": wl.roofline(),
         }
         extra = getattr(wl, "extra", None)

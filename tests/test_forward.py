@@ -83,3 +83,33 @@ def test_forward_refuses_missing_weights():
     m, _ = tm.build_thinktwice(final_dim=(128, 256))
     with pytest.raises(_lib.TTError):
         m.forward_inference({})
+
+
+def test_inference_graph_replay_matches_eager_and_golden(golden_dir):
+    """The captured HIP graph (bench.py's launch mode) runs the same kernels as the eager forward: its outputs match
+    the eager ones to f32 rounding (split-K atomics reorder sums), still match the reference golden, and a replay
+    after `update()` with different inputs tracks the eager result for those inputs."""
+    from thinktwice_amd import model as tm, params, synth
+    from thinktwice_amd.encoder_decoder import InferenceGraph
+    pack = np.load(os.path.join(golden_dir, "f7_forward_small_b2.npz"))
+    B, H, W, npts, seed = (int(v) for v in pack["meta"])
+    m, cfg = tm.build_thinktwice(dtype=torch.float32, final_dim=(H, W))
+    m.load_state_dict(params.init_params(cfg, seed=seed))
+    batch = tm.batch_to_device(synth.make_batch(B, img_hw=(H, W), num_points=npts))
+    eager = {k: v.clone() for k, v in m.forward_inference(batch).items() if k in KEYS}
+    g = InferenceGraph(m, batch, channel_last_out=False)
+    out = g.replay()
+    torch.cuda.synchronize()
+    _check_against_pack(pack, out, 1e-3)
+    for k in KEYS:
+        e = float((out[k] - eager[k]).abs().max() / eager[k].abs().max().clamp_min(1e-6))
+        assert e < 1e-5, (k, e)
+    # new inputs through the static buffers
+    batch2 = tm.batch_to_device(synth.make_batch(B, img_hw=(H, W), num_points=npts, seed=77))
+    eager2 = {k: v.clone() for k, v in m.forward_inference(batch2).items() if k in KEYS}
+    out2 = g(batch2)
+    torch.cuda.synchronize()
+    for k in KEYS:
+        e = float((out2[k] - eager2[k]).abs().max() / eager2[k].abs().max().clamp_min(1e-6))
+        assert e < 1e-5, (k, e)
+    assert float((out2["pred_wp"] - eager["pred_wp"]).abs().max()) > 0   # the replay really saw the new inputs

@@ -23,8 +23,12 @@ namespace tt {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 16 || BKB == 64) ? 4 : 2)
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64,
+                             ((256 / WAVES_M / 32) * (BN / WAVES_N / 32) >= 16)  ? 1      // 128x128 per wave: 512 regs
+                             : ((256 / WAVES_M / 32) * (BN / WAVES_N / 32) >= 8) ? 2      // 128x64 per wave: 256 regs
+                             : (WAVES_M * WAVES_N == 16 || BKB == 64)            ? 4
+                                                                                 : 2)
 void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                                                               int tiles_m, int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)   // amdgcn builtins / inline asm: keep the x86 host pass away from the body
@@ -32,7 +36,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     constexpr int VEC = Elem<T>::kVec;
     constexpr int BK = BKB / (int)sizeof(T);          // BKB = K bytes per row per tile (64 or 128)
     constexpr int CPR = BKB / 16;                     // 16 B chunks per row
-    constexpr int STAGES = 3;
+    static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
     constexpr int STAGE_BYTES = (BM + BN) * BKB;
     constexpr int NA_INSTR = BM * CPR / 64;           // 1 KiB wave-instructions in the A tile
     constexpr int NB_INSTR = BN * CPR / 64;
@@ -44,7 +48,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     constexpr int LPT = NIA + NIB;                    // DMA loads per thread per tile
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    static_assert(NW == 8 || NW == 16, "8 or 16 waves");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
     static_assert(NA_INSTR % NW == 0 && NIA >= 1 && NIB >= 1, "tile too small for the wave count");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -104,12 +108,23 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
 
     const int nk = (p.K + BK - 1) / BK;
 
+    // K order: channel chunk OUTER, filter tap INNER (Cin % BK == 0: one tap per K tile).  The KH*KW taps of one
+    // BK-channel chunk re-read the same (tile + halo) pixels back to back, so the re-reads hit the XCD's 4 MiB L2
+    // (64 resident tiles x ~700 px x 128 B lines = ~2 MiB with the XCD-contiguous tile order).  With taps outer the
+    // reuse distance was the whole channel extent (~8 MiB per XCD for Cin = 256) and 8 of 9 reads fell through to
+    // the Infinity Cache.  Summation order differs from (tap, channel) only in f32 rounding.
+    int it_kh = 0, it_kw = 0, it_ci = 0;               // running (kh, kw, ci) of the next tile to issue
     auto issue_tile = [&](int kt) {
         unsigned char* st = smem + (kt % STAGES) * STAGE_BYTES;
-        const int k0 = kt * BK;
-        const int tap = k0 / p.Cin;                    // Cin % BK == 0: one tap per K tile
-        const int ci = k0 - tap * p.Cin;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int kh = it_kh, kw = it_kw, ci = it_ci;
+        const int k0 = (kh * p.KW + kw) * p.Cin + ci;  // position of this tile in the [KH][KW][Cin] weight row
+        if (++it_kw == p.KW) {
+            it_kw = 0;
+            if (++it_kh == p.KH) {
+                it_kh = 0;
+                it_ci += BK;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NIA; ++j) {
             const int ih = a_h0[j] + kh * p.dil, iw = a_w0[j] + kw * p.dil;
@@ -135,7 +150,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     issue_tile(0);
-    if (nk > 1) issue_tile(1);
+    if (STAGES == 3 && nk > 1) issue_tile(1);
 
     // fragment addressing: row = tile row + (lane&31); 16 B chunk c16 = 2*kc + (lane>>5), swizzled.
     // The fragment reads are INLINE ASM: hipcc treats every ds_read of this array as aliasing the
@@ -171,7 +186,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed for THIS wave once at most one younger tile (LPT loads) is outstanding
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (kt + 1 < nk) {
+        if (STAGES == 3 && kt + 1 < nk) {
             if constexpr (LPT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (LPT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if constexpr (LPT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -184,7 +199,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         }
         asm volatile("s_barrier" ::: "memory");   // publishes tile kt; everyone is done reading tile kt-1
 #endif
-        if (kt + 2 < nk) issue_tile(kt + 2);
+        if (kt + STAGES - 1 < nk) issue_tile(kt + STAGES - 1);
 
         const unsigned sbase = lds_base + (unsigned)((kt % STAGES) * STAGE_BYTES);
         constexpr int NKC = BKB / 32;
@@ -237,17 +252,17 @@ static const void* zero_page() {
     return z;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB>
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3>
 static int launch_glds(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 256;
     constexpr int WTN = BN / WAVES_N;
     const void* zp = zero_page();
     if (!zp) return 0;
     const int tiles_m = div_up(a.M, BM), tiles_n = div_up(a.Cout, BN);
-    size_t smem = (size_t)3 * (BM + BN) * BKB;
+    size_t smem = (size_t)STAGES * (BM + BN) * BKB;
     const size_t epi = (size_t)(WAVES_M * WAVES_N) * 32 * (WTN + 4) * 4;
     if (smem < epi) smem = epi;
-    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB>;
+    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB, STAGES>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -274,7 +289,7 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
     static int min_tiles = -1;
     if (min_tiles < 0) {
         const char* e = getenv("TT_GLDS_MIN_KTILES");
-        min_tiles = e ? atoi(e) : 3;
+        min_tiles = e ? atoi(e) : 2;
     }
     if (a.gather || a.m_dev || a.M < 2048 || a.Cout < 64) return 0;
     if (dtype == TT_F32) {
@@ -299,6 +314,37 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
     if (bkb == 128) {
         if (a.Cout > 64) return launch_glds<uint16_t, 128, 4, 2, 128>(a, st);
         return launch_glds<uint16_t, 64, 8, 1, 128>(a, st);
+    }
+    // Tile selection (profiles/r01_conv_microbench_tiles.txt).  Three things set the rate of these kernels:
+    //  * L2->LDS bytes per FLOP = workgroup tile: 256x128 -> 85 FLOP/B, 256x256 -> 128 FLOP/B;
+    //  * whether a DMA lane group consumes WHOLE 128 B cache lines: with 64 B rows every activation line is
+    //    fetched twice from L2 (the other half is needed one K tile later and the 32 KiB L1 cannot hold a tile);
+    //    128 B rows in 2 stages beat 64 B rows in 3 stages by 10-17 % on every layer whose LDS budget allows it;
+    //  * LDS fragment bytes per MFMA = per-wave register tile (64x64: 1 KiB, 128x64: 0.75 KiB) -- second order.
+    // Auto: Cout % 256 == 0 -> 256x256 tile of eight 128x64 waves (128 B rows if Cin % 64 == 0); short K -> four
+    // 128x64 waves on 256x128; Cout <= 64 -> 256x64 tile with 128 B rows; else eight 64x64 waves on 256x128.
+    // TT_GLDS_VARIANT forces one (0 = the 256x128 / 64 B-row base kernel).
+    static int variant = -2;
+    if (variant == -2) {
+        const char* e = getenv("TT_GLDS_VARIANT");
+        variant = e ? atoi(e) : -1;
+    }
+    if (a.Cout > 64) {
+        int v = variant;
+        if (v < 0) {
+            const long long tiles256 = (long long)div_up(a.M, 256) * (a.Cout / 256);
+            if (a.Cout % 256 == 0 && tiles256 >= 200) v = (a.Cin % 64 == 0) ? 6 : 2;
+            else if (a.K <= 512) v = 1;
+            else v = 0;
+        }
+        // 128 B rows (whole cache lines per DMA lane group), 2 stages = 128 KiB
+        if (v == 6 && a.Cout % 256 == 0 && a.Cin % 64 == 0) return launch_glds<uint16_t, 256, 2, 4, 128, 2>(a, st);
+        if (v == 1) return launch_glds<uint16_t, 128, 2, 2, 64>(a, st);                         // 4 waves x 128x64
+        if (v == 2 && a.Cout % 256 == 0) return launch_glds<uint16_t, 256, 2, 4, 64>(a, st);    // 8 waves x 128x64
+    } else {
+        // Cout <= 64 (the 224x448 UNet / stem-level layers): 128 B rows in 2 stages (80 KiB, 2 workgroups / CU)
+        // measured +17 % over 64 B rows x 3 stages (1.61 vs 1.89 ms on M=6.4M K=1152)
+        if (a.Cin % 64 == 0 && (variant < 0 || variant == 11)) return launch_glds<uint16_t, 64, 8, 1, 128, 2>(a, st);
     }
     static int wide = -1;
     if (wide < 0) {

@@ -1,28 +1,28 @@
 // Implicit-GEMM convolution / linear for LATENCY-BOUND shapes (M <= a few thousand rows): the conv-GRU cell,
 // the BEV-update convs and every row-batched decoder MLP (M = B or 4B).  With so few rows the large-tile
-// kernels occupy a handful of CUs and each wave walks the whole K loop alone -- on the f32 MFMA pipe
-// (64 cycles per 32x32x2 instruction) that chain, not bandwidth, sets the time (23-30 us per GRU conv).
-// Here a workgroup owns ONE 32x32 output tile and its 4 waves split the K tiles between them (intra-block
-// split-K), each wave staging its own A/B slices through a private LDS region; the four partial accumulators
-// are reduced through LDS and wave 0 runs the fused epilogue.  ~4x shorter dependent chain, ~4x more
-// workgroups than the 128-row tiles, no atomics, no second launch.
+// kernels occupy a handful of CUs and each wave walks the whole K loop alone; what sets the time is the
+// dependent chain global load -> LDS -> barrier -> MFMA per K tile, not bandwidth or FLOPs.
+//
+// Here a workgroup owns ONE 32x32 output tile and its 4 waves split K between them (intra-block split-K).
+// The MFMA operand layout needs no transposition for this tile shape: lane l supplies row (l & 31) and the
+// 16-byte K chunk (l >> 5) of a 32-byte K step for BOTH operands (A = im2col row of the activation, B = weight
+// row, each [row][K] with K contiguous), so every lane loads its operands straight from global memory into the
+// registers the MFMA reads -- no LDS staging, no barrier in the K loop, and all loads of a step group are
+// independent: a wave issues GROUP steps of loads back to back (the next group before the current group's
+// MFMAs), so a whole GRU conv (K = 288..360) is one or two memory round trips.  The four partial accumulators
+// are reduced through LDS and all 256 threads run the fused epilogue.  No atomics, no second launch.
 #include "conv_common.h"
 
 namespace tt {
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs p, int tiles_n) {
-    constexpr int VEC = Elem<T>::kVec;
-    constexpr int BKB = (sizeof(T) == 4) ? 64 : 128;
-    constexpr int BK = BKB / (int)sizeof(T);
-    constexpr int VPR = BKB / 16;
-    constexpr int ROWB = BKB + 16;
-    constexpr int NV = 32 * VPR / 64;                 // 16 B vectors per lane per operand per tile (2 or 4)
-    constexpr int WAVE_LDS = 2 * 64 * ROWB;           // [2 buffers][A 32 rows | B 32 rows]
+    constexpr int VEC = Elem<T>::kVec;                // elements per 16 B chunk (4 f32 / 8 bf16)
+    constexpr int STEP = 2 * VEC;                     // K elements per step (32 B per row)
+    constexpr int GROUP = 6;                          // steps in flight per wave (x2 with the prefetched group)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned char* my = smem + wave * WAVE_LDS;
 
     const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
     const int m0 = tile_m * 32, n0 = tile_n * 32;
@@ -30,52 +30,42 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs p, int t
     const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
     const T* __restrict__ wgt = reinterpret_cast<const T*>(p.weight);
 
-    int a_row[NV], a_vc[NV], a_h0[NV], a_w0[NV];
-    long long a_base[NV];
-    bool a_ok[NV], b_ok[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int idx = lane + 64 * i;
-        a_row[i] = idx / VPR;
-        a_vc[i] = idx % VPR;
-        const int m = m0 + a_row[i];
-        a_ok[i] = m < Mlim;
-        const int mm = a_ok[i] ? m : 0;
-        const int n = mm / (p.OH * p.OW);
-        const int r = mm - n * (p.OH * p.OW);
-        const int oh = r / p.OW, ow = r - oh * p.OW;
-        a_h0[i] = oh * p.stride - p.pad;
-        a_w0[i] = ow * p.stride - p.pad;
-        a_base[i] = (long long)n * p.in_nstride + p.in_coff;
-        b_ok[i] = (n0 + a_row[i]) < p.Cout;
-    }
-    const int nk = (p.K + BK - 1) / BK;
-    const int my_tiles = (nk - wave + 3) / 4;          // this wave owns K tiles wave, wave+4, ...
-    const int max_tiles = (nk + 3) / 4;                // uniform trip count (barriers)
-    uint4 ra[NV], rb[NV];
+    // this lane's output row (A operand) and output channel (B operand)
+    const int row = lane & 31;
+    const int m = m0 + row;
+    const bool a_ok = m < Mlim;
+    const int mm = a_ok ? m : 0;
+    const int n_img = mm / (p.OH * p.OW);
+    const int r_img = mm - n_img * (p.OH * p.OW);
+    const int oh = r_img / p.OW, ow = r_img - oh * p.OW;
+    const int h0 = oh * p.stride - p.pad, w0 = ow * p.stride - p.pad;
+    const T* a_base = in + (long long)n_img * p.in_nstride + p.in_coff;
+    const bool b_ok = (n0 + row) < p.Cout;
+    const T* b_base = wgt + (long long)(b_ok ? n0 + row : 0) * p.K;
 
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int k = k0 + a_vc[i] * VEC;
-            const int tap = k / p.Cin;
-            const int ci = k - tap * p.Cin;
-            const int kh = tap / p.KW, kw = tap - kh * p.KW;
-            const int ih = a_h0[i] + kh * p.dil, iw = a_w0[i] + kw * p.dil;
-            const bool ok = a_ok[i] && (k < p.K) && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            ra[i] = ok ? *reinterpret_cast<const uint4*>(in + a_base[i] + ((long long)ih * p.W + iw) * p.in_cstride + ci)
-                       : make_uint4(0, 0, 0, 0);
-            rb[i] = (b_ok[i] && k < p.K)
-                        ? *reinterpret_cast<const uint4*>(wgt + (long long)(n0 + a_row[i]) * p.K + k)
-                        : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            *reinterpret_cast<uint4*>(my + buf * 64 * ROWB + a_row[i] * ROWB + a_vc[i] * 16) = ra[i];
-            *reinterpret_cast<uint4*>(my + buf * 64 * ROWB + (32 + a_row[i]) * ROWB + a_vc[i] * 16) = rb[i];
+    // K position of this lane's chunk in the wave's current step, kept as (kh, kw, ci) incrementally:
+    // wave w owns steps w, w+4, w+8, ...; consecutive owned steps are 4*STEP elements apart
+    const int nsteps = (p.K + STEP - 1) / STEP;
+    int k = wave * STEP + (lane >> 5) * VEC;
+    int tap = k / p.Cin;
+    int ci = k - tap * p.Cin;
+    int kh = tap / p.KW, kw = tap - kh * p.KW;
+
+    auto load_step = [&](uint4& ra, uint4& rb, bool live) {
+        const int ih = h0 + kh * p.dil, iw = w0 + kw * p.dil;
+        const bool ok = live && a_ok && (k < p.K) && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        const T* src = a_base + ((long long)ih * p.W + iw) * p.in_cstride + ci;
+        ra = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+        rb = (live && b_ok && k < p.K) ? *reinterpret_cast<const uint4*>(b_base + k) : make_uint4(0, 0, 0, 0);
+        // advance to this wave's next step
+        k += 4 * STEP;
+        ci += 4 * STEP;
+        while (ci >= p.Cin) {
+            ci -= p.Cin;
+            if (++kw == p.KW) {
+                kw = 0;
+                ++kh;
+            }
         }
     };
 
@@ -83,30 +73,28 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs p, int t
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    if (my_tiles > 0) {
-        load_tile(wave);
-        store_tile(0);
-    }
-    __syncthreads();
-    const int frag = (lane & 31) * ROWB + (lane >> 5) * 16;
-    for (int t = 0; t < max_tiles; ++t) {
-        const bool live = t < my_tiles;
-        const bool more = (t + 1) < my_tiles;
-        if (more) load_tile(wave + 4 * (t + 1));
-        if (live) {
-            const unsigned char* tA = my + (t & 1) * 64 * ROWB + frag;
-            const unsigned char* tB = tA + 32 * ROWB;
+    const int my_steps = (nsteps - wave + 3) / 4;
+    uint4 ra[2][GROUP], rb[2][GROUP];
 #pragma unroll
-            for (int kc = 0; kc < BKB / 32; ++kc) {
-                const uint4 fa = *reinterpret_cast<const uint4*>(tA + kc * 32);
-                const uint4 fb = *reinterpret_cast<const uint4*>(tB + kc * 32);
-                Mfma<T>::run(fa, fb, acc);
+    for (int g = 0; g < GROUP; ++g) load_step(ra[0][g], rb[0][g], g < my_steps);
+    for (int s0 = 0; s0 < my_steps; s0 += 2 * GROUP) {
+        // two groups per trip so the register double buffer is statically indexed
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int base = s0 + half * GROUP;
+            if (base < my_steps) {
+                if (base + GROUP < my_steps) {
+#pragma unroll
+                    for (int g = 0; g < GROUP; ++g)
+                        load_step(ra[half ^ 1][g], rb[half ^ 1][g], base + GROUP + g < my_steps);
+                }
+#pragma unroll
+                for (int g = 0; g < GROUP; ++g) Mfma<T>::run(ra[half][g], rb[half][g], acc);   // dead steps add zeros
             }
         }
-        if (more) store_tile((t + 1) & 1);
-        __syncthreads();
     }
-    // reduce the 4 partial accumulators through LDS (reuse the staging area: 4 x 32 x 33 floats)
+
+    // reduce the 4 partial accumulators through LDS (4 x 32 x 33 floats)
     float* red = reinterpret_cast<float*>(smem);
     constexpr int LDR = 33;
 #pragma unroll
@@ -120,21 +108,21 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs p, int t
     for (int e = 0; e < 4; ++e) {
         const int idx = tid + 256 * e;
         const int rl = idx >> 5, cl = idx & 31;
-        const int m = m0 + rl, col = n0 + cl;
-        if (m >= Mlim || col >= p.Cout) continue;
+        const int mo = m0 + rl, col = n0 + cl;
+        if (mo >= Mlim || col >= p.Cout) continue;
         float v = red[rl * LDR + cl] + red[32 * LDR + rl * LDR + cl] + red[2 * 32 * LDR + rl * LDR + cl] +
                   red[3 * 32 * LDR + rl * LDR + cl];
         int co = col, q = 0;
         if (p.pixel_shuffle2) { q = col / cout_real; co = col - q * cout_real; }
-        const int n = m / ohw;
-        const int rem = m - n * ohw;
-        int oh = rem / p.OW, ow = rem - oh * p.OW, OWo = p.OW;
-        if (p.pixel_shuffle2) { oh = 2 * oh + (q >> 1); ow = 2 * ow + (q & 1); OWo = 2 * p.OW; }
-        const long long o = (long long)n * p.out_nstride + ((long long)oh * OWo + ow) * p.out_cstride + p.out_coff + co;
+        const int n = mo / ohw;
+        const int rem = mo - n * ohw;
+        int oho = rem / p.OW, owo = rem - oho * p.OW, OWo = p.OW;
+        if (p.pixel_shuffle2) { oho = 2 * oho + (q >> 1); owo = 2 * owo + (q & 1); OWo = 2 * p.OW; }
+        const long long o = (long long)n * p.out_nstride + ((long long)oho * OWo + owo) * p.out_cstride + p.out_coff + co;
         v = v * (p.scale ? p.scale[co] : 1.f) + (p.shift ? p.shift[co] : 0.f);
         if (p.shift_n) v += p.shift_n[(n % p.shift_n_mod) * cout_real + co];
-        if (p.res1) v += Elem<T>::ld(reinterpret_cast<const T*>(p.res1) + (long long)m * p.res1_cstride + p.res1_coff + co);
-        if (p.res2) v += Elem<T>::ld(reinterpret_cast<const T*>(p.res2) + (long long)m * p.res2_cstride + p.res2_coff + co);
+        if (p.res1) v += Elem<T>::ld(reinterpret_cast<const T*>(p.res1) + (long long)mo * p.res1_cstride + p.res1_coff + co);
+        if (p.res2) v += Elem<T>::ld(reinterpret_cast<const T*>(p.res2) + (long long)mo * p.res2_cstride + p.res2_coff + co);
         v = apply_act(v, p.act);
         if (p.out_dtype == TT_F32) reinterpret_cast<float*>(p.out)[o] = v;
         else reinterpret_cast<uint16_t*>(p.out)[o] = f32_to_bf16(v);
@@ -147,22 +135,12 @@ int try_launch_conv_small(ConvArgs& a, int dtype, hipStream_t st) {
     if ((long long)tiles_m * tiles_n > 4096) return 0;
     a.ws = nullptr;
     a.splits = 1;
-    const int rowb = (dtype == TT_F32 ? 64 : 128) + 16;
-    size_t smem = (size_t)4 * 2 * 64 * rowb;
-    const size_t red = (size_t)4 * 32 * 33 * 4;
-    if (smem < red) smem = red;
+    const size_t smem = (size_t)4 * 32 * 33 * 4;
     if (dtype == TT_F32)
         hipLaunchKernelGGL(conv_small_kernel<float>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), smem, st, a, tiles_n);
-    else {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_small_kernel<uint16_t>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            attr = true;
-        }
+    else
         hipLaunchKernelGGL(conv_small_kernel<uint16_t>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), smem, st, a,
                            tiles_n);
-    }
     return 1;
 }
 

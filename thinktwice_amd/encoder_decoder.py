@@ -92,14 +92,14 @@ class EncoderDecoder:
         ops.ew(3, batch["target_command"].to(dev, F32), out=state, C=6, out_coff=3)
         return unrows(self.meas2(self.meas0(rows(state))))
 
-    def extract_sensor_feat(self, img, img_metas, points):
+    def extract_sensor_feat(self, img, img_metas, points, consts=None):
         # The LiDAR branch is independent of the camera trunk until the BEV fusion: run it on its own HIP
         # stream so its many small launches fill the tail of the big camera convolutions.
         main = torch.cuda.current_stream(self.device)
         pts = points[:, -1].to(self.device)
         if not self.use_side_stream:
             lidar = self.lidar_encoder(pts, channel_last=True, rot_flip=True)          # EDF:244-246
-            cam = self.img_encoder(img.to(self.device), img_metas, channel_last=True)
+            cam = self.img_encoder(img.to(self.device), img_metas, channel_last=True, consts=consts)
             B, H, W, C = cam["_bev_cl"].shape
             cam_bev = torch.empty(B, H, W, C, dtype=F32, device=self.device)
             ops.copy_nhwc(cam["_bev_cl"], cam_bev, rot_flip=True)      # EDF:241
@@ -109,20 +109,23 @@ class EncoderDecoder:
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             lidar = self.lidar_encoder(pts, channel_last=True, rot_flip=True)
-        cam = self.img_encoder(img.to(self.device), img_metas, channel_last=True)
+        cam = self.img_encoder(img.to(self.device), img_metas, channel_last=True, consts=consts)
         B, H, W, C = cam["_bev_cl"].shape
         cam_bev = torch.empty(B, H, W, C, dtype=F32, device=self.device)
         ops.copy_nhwc(cam["_bev_cl"], cam_bev, rot_flip=True)          # EDF:241
         main.wait_stream(self._side)
-        lidar.record_stream(main)
+        if not torch.cuda.is_current_stream_capturing():
+            lidar.record_stream(main)
         return cam, cam_bev, lidar
 
-    def forward_inference(self, batch, channel_last_out=False):
+    def forward_inference(self, batch, channel_last_out=False, consts=None):
+        """`consts`: optional device copies of `LSS.host_constants(batch["img_metas"])` (see InferenceGraph)."""
         if not self.loaded:
             raise _lib.TTError("EncoderDecoder: load_state_dict() first")
         self.epoch = 10000
         meas = self.measurement_feat(batch)
-        cam, cam_bev, lidar = self.extract_sensor_feat(batch["img"], batch["img_metas"], batch.get("points"))
+        cam, cam_bev, lidar = self.extract_sensor_feat(batch["img"], batch["img_metas"], batch.get("points"),
+                                                       consts=consts)
         flat, bev32, mids = self.fusion(cam_bev, lidar)
         pred = self.decoder(flat, bev32, meas, batch["target_point"], self, None,
                             [cam["lidar2img"], cam["ida_mat"], cam["_fpn_cl"], lidar],
@@ -138,3 +141,64 @@ class EncoderDecoder:
 
     def __call__(self, **kwargs):
         return self.forward_train(kwargs)
+
+
+class InferenceGraph:
+    """One HIP graph for the whole `forward_inference` of a fixed batch shape.
+
+    The forward is ~1150 kernel launches per batch, ~900 of them in the 5-stage decoder where every launch is
+    microseconds of GPU work: issued one by one from the host that phase is launch-bound (rocprofv3 shows 8 us
+    kernels 25-30 us apart).  Capturing the launches once and replaying the graph removes the host from the loop;
+    the LiDAR side stream is captured as a fork/join inside the same graph.
+
+    Inputs live in STATIC device buffers (the tensors of the batch given at construction): `update(batch)` copies a
+    new batch into them (and re-derives the img_metas constants on the host), `replay()` runs the graph and returns
+    the output dict, whose tensors are overwritten by the next replay.  Everything inside the graph is the same
+    eager code path; there is no host sync, allocation or img_metas-dependent host arithmetic in it.
+    """
+
+    _KEYS = ("img", "points", "speed", "target_point", "target_command")
+
+    def __init__(self, model, batch, channel_last_out=True, warmup=2):
+        self.model = model
+        dev = model.device
+        self.batch = dict(batch)
+        for k in self._KEYS:
+            if k in batch and torch.is_tensor(batch[k]):
+                self.batch[k] = batch[k].to(dev)
+        ncam = self.batch["img"].shape[-4]
+        self.consts = {k: v.to(dev) for k, v in LSS_host_constants(batch["img_metas"], ncam).items()}
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):            # warm-up off the default stream: lazy allocations, attributes
+            for _ in range(warmup):
+                model.forward_inference(self.batch, channel_last_out=channel_last_out, consts=self.consts)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = model.forward_inference(self.batch, channel_last_out=channel_last_out, consts=self.consts)
+
+    def update(self, batch):
+        for k in self._KEYS:
+            if k in batch and torch.is_tensor(batch[k]) and batch[k] is not self.batch[k]:
+                self.batch[k].copy_(batch[k], non_blocking=True)
+        if batch.get("img_metas") is not None and batch["img_metas"] is not self.batch.get("img_metas"):
+            ncam = self.batch["img"].shape[-4]
+            for k, v in LSS_host_constants(batch["img_metas"], ncam).items():
+                self.consts[k].copy_(v, non_blocking=True)
+            self.batch["img_metas"] = batch["img_metas"]
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+    def __call__(self, batch=None):
+        if batch is not None:
+            self.update(batch)
+        return self.replay()
+
+
+def LSS_host_constants(img_metas, num_cams):
+    from .lss import LSS
+    return LSS.host_constants(img_metas, num_cams)

@@ -224,14 +224,23 @@ class LSS:
         self.conv_last(d0, out=seg)
         return seg
 
-    def geometry(self, mats, batch_size, num_cams):
-        gm = camera.geometry_matrices(mats, -1).to(self.device)
+    def geometry(self, gm, batch_size, num_cams):
         return ops.frustum_voxel_index(self._frustum_dev, gm, self.grid.lower, self.grid.voxel_size.tolist(),
                                        batch_size, num_cams)
 
+    @staticmethod
+    def host_constants(img_metas, num_cams=4):
+        """Everything the forward derives from `img_metas` on the HOST (small CPU tensors): geometry matrix pairs
+        (LSS:502-512 inputs), the camera-aware DepthNet vector (LSS:206-231) and the key frame's lidar2img / ida
+        for the look module.  Split out so a captured HIP graph can take them as device-resident inputs."""
+        mats = camera.stack_img_metas(img_metas, num_cams)
+        return {"gm": camera.geometry_matrices(mats, -1), "mlp_in": camera.depth_mlp_input(mats),
+                "lidar2img": mats["lidar2img"], "ida_mat": mats["ida_mat"]}
+
     # ------------------------------------------------------------------ forward
-    def forward(self, img, img_metas, timestamps=None, is_return_depth=False, channel_last=False):
-        """img (B,T,N,3,H,W) f32 on device (key frame = last T index) -> dict like LSS.forward."""
+    def forward(self, img, img_metas, timestamps=None, is_return_depth=False, channel_last=False, consts=None):
+        """img (B,T,N,3,H,W) f32 on device (key frame = last T index) -> dict like LSS.forward.
+        `consts`: device copies of `host_constants(img_metas)` (graph replay); derived and uploaded here if None."""
         if not self.loaded:
             raise _lib.TTError("LSS: load_state_dict() first")
         _lib.require_cuda(img)
@@ -240,7 +249,8 @@ class LSS:
         B, T, N, C, H, W = img.shape
         assert T == self.queue_len, "LSS.queue_len must be set correctly in config!"
         assert (H, W) == self.final_dim
-        mats = camera.stack_img_metas(img_metas, N)
+        if consts is None:
+            consts = {k: v.to(img.device) for k, v in self.host_constants(img_metas, N).items()}
         NI = T * B * N
         # sweep-major image order: key sweep first (index 0 == reference sweep index -1)
         x = torch.empty(NI, H, W, self.backbone.cin_pad, dtype=self.dtype, device=img.device)
@@ -254,7 +264,7 @@ class LSS:
         bufs = self._trunk(x)
         fpn2_buf, fpn2_off, _ = self._fpn_views(bufs)[2]
         src = self.neck_conv(fpn2_buf, in_coff=fpn2_off, cin=256)
-        mlp_in = camera.depth_mlp_input(mats).to(img.device)
+        mlp_in = consts["mlp_in"]
         depth, merge_in = self._depth_net(src, mlp_in, T)
         # keep FPN maps of the key sweep before the UNet overwrites nothing of them (offset slices)
         seg = self._seg_net(bufs)
@@ -263,7 +273,7 @@ class LSS:
             f = cv(f)
         self.seg2feat[-1](f, out=merge_in, out_coff=256)
         ctx = self.merge(merge_in, out_dtype=torch.float32)
-        geom = self.geometry(mats, B, N)
+        geom = self.geometry(consts["gm"], B, N)
         vx, vy, vz = (int(v) for v in self.voxel_num)
         bev_cat = torch.zeros(B, vy, vx, self.output_channels * T, dtype=torch.float32, device=img.device)
         BN = B * N
@@ -272,7 +282,7 @@ class LSS:
                            out=bev_cat, out_coff=s * self.output_channels)
         bev = self.bev_merge(bev_cat) if T > 1 else bev_cat
         fpn = [(t[:BN], off, c) for (t, off, c) in self._fpn_views(bufs)]
-        outs = {"lidar2img": mats["lidar2img"], "ida_mat": mats["ida_mat"], "_fpn_cl": fpn, "_bev_cl": bev,
+        outs = {"lidar2img": consts["lidar2img"], "ida_mat": consts["ida_mat"], "_fpn_cl": fpn, "_bev_cl": bev,
                 "_geom": geom}
         if channel_last:
             return outs

@@ -4,6 +4,7 @@ All functions take device tensors and launch on torch's current stream.  No func
 computes anything in PyTorch: allocation and stream handling only.
 """
 import ctypes
+import os
 
 import torch
 
@@ -60,6 +61,7 @@ def lift_splat(depth_logits, context, geom_xyz, voxel_num, batch_size, num_cams,
 
 
 # ----------------------------------------------------------------------------- conv / linear
+_AUTO_SPLITK = os.environ.get("TT_CONV_AUTO_SPLITK", "1") == "1"
 CONV_PROFILE = None   # bench.py sets this to a list to collect (flops, start, end, shape) per launch
 
 class _ConvDesc(ctypes.Structure):
@@ -148,8 +150,10 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     d.res1 = _dp(res1); d.res1_cstride = 0 if res1 is None else res1.shape[-1]; d.res1_coff = res1_coff
     d.res2 = _dp(res2); d.res2_cstride = 0 if res2 is None else res2.shape[-1]; d.res2_coff = res2_coff
     d.act = act; d.dtype = dtype_code(x); d.out_dtype = dtype_code(out)
-    if splitk_ws is None and N * OH * OW <= 4096 and KH * KW * Cin >= 2048:
-        # few rows, very long K (BEV-update conv, flatten MLPs): split K over workgroups (library decides how)
+    if _AUTO_SPLITK and splitk_ws is None and N * OH * OW <= 4096 and KH * KW * Cin >= 2048:
+        # few rows, very long K (BEV-update conv K=18720, flatten MLPs): cross-workgroup split-K with an f32 workspace
+        # beats conv_small.hip's in-workgroup split there (277 vs 416 us on the BEV-update conv: the direct 32 B/row
+        # operand loads of the small kernel waste L2 sectors on a 10 MB weight matrix).  TT_CONV_AUTO_SPLITK=0 disables.
         splitk_ws = torch.zeros(N * OH * OW, Cout, dtype=torch.float32, device=x.device)
     if splitk_ws is not None:
         d.splitk_ws = splitk_ws.data_ptr()
