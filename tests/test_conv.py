@@ -150,3 +150,37 @@ def test_splitk_workspace_path_matches_torch():
     ref = F.relu(F.conv2d(x, w, b, padding=1))
     got = out.cpu().permute(0, 3, 1, 2)
     assert float((got - ref).abs().max() / ref.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("dt,Cin,Cout,rows_in,M,live", [
+    (torch.bfloat16, 64, 64, 5000, 6000, 5300),      # LDS-DMA gather kernel, 256x64 tile
+    (torch.bfloat16, 128, 128, 3000, 4096, 4096),    # LDS-DMA gather kernel, 256x128 tile, 2 K tiles per tap
+    (torch.bfloat16, 32, 32, 3000, 4000, 3500),      # LDS-DMA gather kernel, 2 taps per 128 B row, 256x32 tile
+    (torch.bfloat16, 16, 16, 3000, 2500, 2400),      # 4 taps per 128 B row, last K tile ragged (27 taps)
+    (torch.bfloat16, 32, 64, 1000, 1500, 1400),      # M < 2048: register-staged gather kernel
+    (torch.float32, 16, 32, 2000, 3000, 2999),
+])
+def test_gathered_sparse_conv_matches_torch(dt, Cin, Cout, rows_in, M, live):
+    """Sparse conv as a gathered GEMM (tt_conv2d_fwd gather mode): rulebook [M, 27] with -1 holes, device-side live
+    row count; rows >= live are not written.  Reference: explicit gather + matmul in f32 on the rounded inputs."""
+    from thinktwice_amd import ops
+    g = torch.Generator().manual_seed(3)
+    taps = 27
+    feats = (torch.randn(rows_in, Cin, generator=g)).to(dt)
+    w = (torch.randn(Cout, 1, taps, Cin, generator=g) * (taps * Cin) ** -0.5).to(dt)
+    nbr = torch.randint(0, rows_in, (M, taps), generator=g, dtype=torch.int32)
+    nbr[torch.rand(M, taps, generator=g) < 0.4] = -1
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.3
+    res = torch.randn(M, Cout, generator=g).to(dt)
+    m_dev = torch.tensor([live], dtype=torch.int32)
+    out = ops.gather_conv(feats.cuda(), nbr.cuda(), m_dev.cuda(), w.cuda(), scale=scale.cuda(), shift=shift.cuda(),
+                          act=1, res=res.cuda())
+    torch.cuda.synchronize()
+    f32 = feats.float()
+    gathered = torch.where((nbr >= 0).unsqueeze(-1), f32[nbr.clamp_min(0).long()], torch.zeros(()))   # [M, taps, Cin]
+    ref = torch.relu(gathered.reshape(M, -1) @ w.float().reshape(Cout, -1).t() * scale + shift + res.float())
+    got = out.float().cpu()
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    err = float((got[:live] - ref[:live]).abs().max() / ref[:live].abs().max())
+    assert err < tol, err

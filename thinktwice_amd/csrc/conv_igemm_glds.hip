@@ -23,7 +23,7 @@ namespace tt {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3>
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64,
                              ((256 / WAVES_M / 32) * (BN / WAVES_N / 32) >= 16)  ? 1      // 128x128 per wave: 512 regs
                              : ((256 / WAVES_M / 32) * (BN / WAVES_N / 32) >= 8) ? 2      // 128x64 per wave: 256 regs
@@ -37,6 +37,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     constexpr int BK = BKB / (int)sizeof(T);          // BKB = K bytes per row per tile (64 or 128)
     constexpr int CPR = BKB / 16;                     // 16 B chunks per row
     static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
+    static_assert(!GATHER || STAGES == 2, "gather mode is written for the 2-stage pipeline");
     constexpr int STAGE_BYTES = (BM + BN) * BKB;
     constexpr int NA_INSTR = BM * CPR / 64;           // 1 KiB wave-instructions in the A tile
     constexpr int NB_INSTR = BN * CPR / 64;
@@ -67,7 +68,12 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     }
     const int tile_n = L % tiles_n, tile_m = L / tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int Mlim = p.M;
+    int Mlim = p.M;
+    if (GATHER && p.m_dev) {           // sparse conv: live output rows are only known on the device
+        const int md = *p.m_dev;
+        Mlim = md < Mlim ? md : Mlim;
+    }
+    if (m0 >= Mlim) return;            // block-uniform, before any barrier
 
     const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
     const T* __restrict__ wgt = reinterpret_cast<const T*>(p.weight);
@@ -92,7 +98,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         const int oh = r / p.OW, ow = r - oh * p.OW;
         a_h0[j] = oh * p.stride - p.pad;
         a_w0[j] = ow * p.stride - p.pad;
-        a_base[j] = (long long)n * p.in_nstride + p.in_coff;
+        a_base[j] = GATHER ? (long long)mm * p.KW : (long long)n * p.in_nstride + p.in_coff;   // GATHER: rulebook row
     }
     int b_c[NIB];
     long long b_base[NIB];
@@ -114,10 +120,25 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     // reuse distance was the whole channel extent (~8 MiB per XCD for Cin = 256) and 8 of 9 reads fell through to
     // the Infinity Cache.  Summation order differs from (tap, channel) only in f32 rounding.
     int it_kh = 0, it_kw = 0, it_ci = 0;               // running (kh, kw, ci) of the next tile to issue
+    // GATHER (sparse conv) walks K in natural [tap][channel] order; a K tile covers BK/Cin taps when Cin < BK
+    // (each 16 B chunk of a row then comes from its own tap's input row) or a BK-channel slice of one tap.
+    // Cin is a power of two there (dispatcher): tap / channel by shift and mask, not integer division.
+    int g_cur[NIA];                                    // rulebook entries of the next tile to issue
+    int g_t = 0;                                       // K tile of the next rulebook fetch
+    const int cin_shift = 31 - __clz(p.Cin), cin_mask = p.Cin - 1;
+    auto fetch_rulebook = [&]() {
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) {
+            const int k = g_t * BK + a_c[j];
+            g_cur[j] = (a_ok[j] && k < p.K) ? p.gather[a_base[j] + (k >> cin_shift)] : -1;
+        }
+        ++g_t;
+    };
     auto issue_tile = [&](int kt) {
         unsigned char* st = smem + (kt % STAGES) * STAGE_BYTES;
         const int kh = it_kh, kw = it_kw, ci = it_ci;
-        const int k0 = (kh * p.KW + kw) * p.Cin + ci;  // position of this tile in the [KH][KW][Cin] weight row
+        const int k0 = GATHER ? kt * BK                // position of this tile in the [KH][KW][Cin] weight row
+                              : (kh * p.KW + kw) * p.Cin + ci;
         if (++it_kw == p.KW) {
             it_kw = 0;
             if (++it_kh == p.KH) {
@@ -127,9 +148,18 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         }
 #pragma unroll
         for (int j = 0; j < NIA; ++j) {
-            const int ih = a_h0[j] + kh * p.dil, iw = a_w0[j] + kw * p.dil;
-            const bool ok = a_ok[j] && (k0 + a_c[j] < p.K) && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            const T* src = ok ? in + a_base[j] + ((long long)ih * p.W + iw) * p.in_cstride + ci + a_c[j] : zp;
+            const T* src;
+            if (GATHER) {
+                // sparse conv: the activation row of (output row, tap) comes from the rulebook entry that was
+                // fetched one iteration ago (g_cur), so the DMA does not sit behind a dependent index load
+                const int gi = g_cur[j];
+                const int kl = k0 + a_c[j];
+                src = gi >= 0 ? in + (long long)gi * p.in_cstride + p.in_coff + (kl & cin_mask) : zp;
+            } else {
+                const int ih = a_h0[j] + kh * p.dil, iw = a_w0[j] + kw * p.dil;
+                const bool ok = a_ok[j] && (k0 + a_c[j] < p.K) && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                src = ok ? in + a_base[j] + ((long long)ih * p.W + iw) * p.in_cstride + ci + a_c[j] : zp;
+            }
             __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(st + (wave + NW * j) * 1024), 16, 0, 0);
         }
 #pragma unroll
@@ -149,7 +179,9 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    if (GATHER) fetch_rulebook();
     issue_tile(0);
+    if (GATHER && nk > 1) fetch_rulebook();            // for tile 1; lands while tile 0 streams in
     if (STAGES == 3 && nk > 1) issue_tile(1);
 
     // fragment addressing: row = tile row + (lane&31); 16 B chunk c16 = 2*kc + (lane>>5), swizzled.
@@ -200,6 +232,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         asm volatile("s_barrier" ::: "memory");   // publishes tile kt; everyone is done reading tile kt-1
 #endif
         if (kt + STAGES - 1 < nk) issue_tile(kt + STAGES - 1);
+        if (GATHER && kt + 2 < nk) fetch_rulebook();   // for tile kt+2, consumed at the top of the next iteration
 
         const unsigned sbase = lds_base + (unsigned)((kt % STAGES) * STAGE_BYTES);
         constexpr int NKC = BKB / 32;
@@ -252,7 +285,7 @@ static const void* zero_page() {
     return z;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3>
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false>
 static int launch_glds(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 256;
     constexpr int WTN = BN / WAVES_N;
@@ -262,7 +295,7 @@ static int launch_glds(ConvArgs& a, hipStream_t st) {
     size_t smem = (size_t)STAGES * (BM + BN) * BKB;
     const size_t epi = (size_t)(WAVES_M * WAVES_N) * 32 * (WTN + 4) * 4;
     if (smem < epi) smem = epi;
-    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB, STAGES>;
+    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -291,7 +324,20 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
         const char* e = getenv("TT_GLDS_MIN_KTILES");
         min_tiles = e ? atoi(e) : 2;
     }
-    if (a.gather || a.m_dev || a.M < 2048 || a.Cout < 64) return 0;
+    if (a.gather) {
+        // sparse 3D conv as a gathered GEMM (rulebook rows): whole 128 B+ activation rows per DMA lane group
+        static int sp = -1;
+        if (sp < 0) {
+            const char* e = getenv("TT_GLDS_GATHER");
+            sp = e ? atoi(e) : 1;
+        }
+        const bool cin_ok = a.Cin >= 16 && (a.Cin & (a.Cin - 1)) == 0;   // power of two: taps tile the 128 B rows
+        if (!sp || dtype != TT_BF16 || !cin_ok || a.M < 2048 || a.Cout < 16 || a.Cout > 128) return 0;
+        if (a.Cout <= 32 && sp != 2) return launch_glds<uint16_t, 32, 8, 1, 128, 2, true>(a, st);
+        if (a.Cout <= 64) return launch_glds<uint16_t, 64, 8, 1, 128, 2, true>(a, st);
+        return launch_glds<uint16_t, 128, 4, 2, 128, 2, true>(a, st);
+    }
+    if (a.m_dev || a.M < 2048 || a.Cout < 64) return 0;
     if (dtype == TT_F32) {
         if (a.Cin % 16 != 0 || div_up(a.K, 16) < min_tiles) return 0;
         if (a.Cout > 64) return launch_glds<float, 128, 4, 2, 64>(a, st);
