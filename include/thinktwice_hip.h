@@ -141,6 +141,11 @@ int tt_conv2d_fwd(const tt_conv_desc* d, void* stream);
 /* img (B*T*N,3,H,W) f32 NCHW -> channel-last with zero-padded channels (lss.py:517-519) */
 int tt_nchw_to_nhwc_pad(const float* in, void* out, int N, int C, int H, int W, int Cp,
                         int out_dtype, void* stream);
+/* Same conversion into the interior of a spatially padded buffer out[N][Hp][Wp][Cp] at pixel offset (top, left);
+ * the border is NOT written (allocate it zeroed once).  Feeds the row-run form of the 7x7/2 ResNet stem, whose 8-pixel
+ * input runs overhang the image (reference: mmdet ResNet.conv1 via backbones/lss.py:517-519 get_cam_feats). */
+int tt_nchw_to_nhwc_border(const float* in, void* out, int N, int C, int H, int W, int Cp, int Hp, int Wp,
+                           int top, int left, int out_dtype, void* stream);
 /* channel-last -> NCHW f32 (outputs returned in the reference layout) */
 int tt_nhwc_to_nchw(const void* in, float* out, int N, int C, int H, int W, int cstride, int coff,
                     int in_dtype, void* stream);

@@ -184,3 +184,29 @@ def test_gathered_sparse_conv_matches_torch(dt, Cin, Cout, rows_in, M, live):
     tol = 1e-4 if dt == torch.float32 else 2e-2
     err = float((got[:live] - ref[:live]).abs().max() / ref[:live].abs().max())
     assert err < tol, err
+
+
+def test_row_run_stem_matches_conv7x7s2():
+    """bf16 7x7/2 stem as a KH=7, KW=1, Cin=64 'row-run' convolution over a zero-bordered 8-channel image
+    (lss.py _ResNet50.stem_rr) == F.conv2d(x, w, stride=2, padding=3) on the same rounded operands."""
+    from thinktwice_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 6, 64, 96
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * (3 * 49) ** -0.5
+    shift = torch.randn(64, generator=g) * 0.1
+    dt = torch.bfloat16
+    xp = torch.zeros(N, H + 6, W + 8, 8, dtype=dt, device="cuda")
+    ops.nchw_to_nhwc_border(x.cuda(), xp, 3, 3)
+    wr = torch.zeros(64, 7, 1, 64, dtype=dt)
+    wr[:, :, 0, :56] = F.pad(w.permute(0, 2, 3, 1), (0, 5)).reshape(64, 7, 56).to(dt)
+    out = ops.conv2d(xp, wr.cuda(), stride=2, pad=0, shift=shift.cuda(), act=1, in_cstride=8,
+                     out_hw=(H // 2, W // 2))
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv2d(x.to(dt).float(), w.to(dt).float(), None, 2, 3) + shift.view(1, -1, 1, 1))
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 2e-2, err
+    # the border must still be zero (the conversion writes the interior only)
+    assert float(xp[:, :3].abs().max()) == 0 and float(xp[:, :, :3].abs().max()) == 0 and float(xp[:, :, W + 3:].abs().max()) == 0

@@ -62,6 +62,21 @@ __global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ in, T* __restr
     }
 }
 
+// ---- same, into the interior of a spatially padded channel-last buffer [N][Hp][Wp][Cp] at (top, left): the
+// row-run stem conv (lss.py) reads 8-pixel runs that overhang the image, so the zero border is physical
+template <typename T>
+__global__ void nchw_to_nhwc_border_kernel(const float* __restrict__ in, T* __restrict__ out, long long NHW,
+                                           int H, int W, int C, int Cp, int Hp, int Wp, int top, int left) {
+    const int HW = H * W;
+    TT_GRID_STRIDE(i, NHW) {
+        const long long n = i / HW;
+        const int p = (int)(i - n * HW);
+        const int h = p / W, w = p - h * W;
+        T* o = out + (((long long)n * Hp + h + top) * Wp + w + left) * Cp;
+        for (int c = 0; c < Cp; ++c) Elem<T>::st(o + c, (c < C) ? in[(n * C + c) * HW + p] : 0.f);
+    }
+}
+
 // ---- channel-last -> NCHW f32 (outputs handed back in the reference's layout)
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, long long total,
@@ -345,6 +360,16 @@ extern "C" int tt_nchw_to_nhwc_pad(const float* in, void* out, int N, int C, int
     TT_DISPATCH(out_dtype, hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<T>, dim3(grid_for(NHW)), dim3(256), 0,
                                               (hipStream_t)stream, in, (T*)out, NHW, H * W, C, Cp));
     return check_launch("tt_nchw_to_nhwc_pad");
+}
+
+extern "C" int tt_nchw_to_nhwc_border(const float* in, void* out, int N, int C, int H, int W, int Cp, int Hp, int Wp,
+                                      int top, int left, int out_dtype, void* stream) {
+    TT_REQUIRE(in && out && Cp >= C && top >= 0 && left >= 0 && Hp >= H + top && Wp >= W + left,
+               "tt_nchw_to_nhwc_border: bad args");
+    const long long NHW = (long long)N * H * W;
+    TT_DISPATCH(out_dtype, hipLaunchKernelGGL(nchw_to_nhwc_border_kernel<T>, dim3(grid_for(NHW)), dim3(256), 0,
+                                              (hipStream_t)stream, in, (T*)out, NHW, H, W, C, Cp, Hp, Wp, top, left));
+    return check_launch("tt_nchw_to_nhwc_border");
 }
 
 extern "C" int tt_nhwc_to_nchw(const void* in, float* out, int N, int C, int H, int W, int cstride, int coff,

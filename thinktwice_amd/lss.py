@@ -24,6 +24,17 @@ class _ResNet50:
         self.cin_pad = vec
         self.stem = conv_from_sd(sd, p + ".conv1", dtype, device, bn=p + ".bn1", stride=2, pad=3, act="relu",
                                  cin_pad=vec)
+        # bf16: "row-run" form of the 7x7/2 stem.  With channel-last pixels of 8 bf16 (16 B), the 7 taps of one filter
+        # row are 112 contiguous bytes: read them as ONE 128 B run of 8 pixels (the 8th meets zero weights) from a
+        # zero-bordered image, i.e. a KH=7, KW=1, Cin=64 convolution over a tensor whose "pixels" overlap (pixel
+        # stride 8 elements).  K tiles become whole cache lines and the layer runs on the LDS-DMA kernel instead of
+        # the 3-channel im2col path (Cin=8 is below every DMA tile).  Same products, different summation order.
+        self.stem_rr = None
+        if dtype == torch.bfloat16:
+            w = sd[p + ".conv1.weight"].to(device)                      # (64, 3, 7, 7)
+            wr = torch.zeros(w.shape[0], 7, 1, 64, dtype=dtype, device=device)
+            wr[:, :, 0, :56] = torch.nn.functional.pad(w.permute(0, 2, 3, 1), (0, 5)).reshape(w.shape[0], 7, 56).to(dtype)
+            self.stem_rr = wr.contiguous()
         self.blocks = []
         for li, nb in enumerate((3, 4, 6, 3), start=1):
             stage = []
@@ -40,8 +51,18 @@ class _ResNet50:
                 stage.append(blk)
             self.blocks.append(stage)
 
-    def __call__(self, x):
-        x = ops.maxpool3x3s2(self.stem(x))
+    def stem_border(self):
+        """(top, left, bottom, right) zero border the row-run stem needs around the image, or None."""
+        return (3, 3, 3, 5) if self.stem_rr is not None else None
+
+    def __call__(self, x, bordered=False):
+        if bordered:      # x: (NI, H+6, W+8, 8) with the image at (3, 3)
+            NI, Hp, Wp, _ = x.shape
+            y = ops.conv2d(x, self.stem_rr, stride=2, pad=0, scale=self.stem.scale, shift=self.stem.shift,
+                           act=self.stem.act, in_cstride=8, out_hw=((Hp - 6) // 2, (Wp - 8) // 2))
+        else:
+            y = self.stem(x)
+        x = ops.maxpool3x3s2(y)
         outs = []
         for stage in self.blocks:
             for blk in stage:
@@ -70,6 +91,7 @@ class LSS:
         self.voxel_num = self.grid.voxel_num
         self._frustum_dev = None
         self.loaded = False
+        self._xpad = {}
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd, prefix="img_encoder"):
@@ -144,11 +166,11 @@ class LSS:
         return self
 
     # ------------------------------------------------------------------ forward pieces
-    def _trunk(self, x):
+    def _trunk(self, x, bordered=False):
         """ResNet-50 + PAFPN + neck_conv on NI channel-last images.  FPN maps are produced directly
         inside the UNet concat buffers (torch.cat of lss.py:256 becomes a channel offset)."""
         NI = x.shape[0]
-        c = self.backbone(x)
+        c = self.backbone(x, bordered=bordered)
         lat = [self.lat[i](c[i]) for i in range(4)]
         for i in range(3, 0, -1):
             ops.upsample_nearest_add_(lat[i - 1], lat[i])
@@ -253,15 +275,28 @@ class LSS:
             consts = {k: v.to(img.device) for k, v in self.host_constants(img_metas, N).items()}
         NI = T * B * N
         # sweep-major image order: key sweep first (index 0 == reference sweep index -1)
-        x = torch.empty(NI, H, W, self.backbone.cin_pad, dtype=self.dtype, device=img.device)
+        border = self.backbone.stem_border() if (H % 2 == 0 and W % 2 == 0) else None
+        if border is not None:
+            # zero-bordered image buffer for the row-run stem; the border is written once, the interior every call
+            key = (NI, H, W, str(img.device))
+            x = self._xpad.get(key)
+            if x is None:
+                x = torch.zeros(NI, H + border[0] + border[2], W + border[1] + border[3], self.backbone.cin_pad,
+                                dtype=self.dtype, device=img.device)
+                self._xpad = {key: x}
+        else:
+            x = torch.empty(NI, H, W, self.backbone.cin_pad, dtype=self.dtype, device=img.device)
         for s in range(T):
             for b in range(B):
                 src = img[b, T - 1 - s].contiguous()
                 o = (s * B + b) * N
-                ops.check(ops.lib().tt_nchw_to_nhwc_pad(ops.ptr(src), ops.ptr(x[o:o + N]), N, C, H, W,
-                                                        x.shape[-1], ops.dtype_code(x),
-                                                        ops.cur_stream(img.device)), "tt_nchw_to_nhwc_pad")
-        bufs = self._trunk(x)
+                if border is not None:
+                    ops.nchw_to_nhwc_border(src, x[o:o + N], border[0], border[1])
+                else:
+                    ops.check(ops.lib().tt_nchw_to_nhwc_pad(ops.ptr(src), ops.ptr(x[o:o + N]), N, C, H, W,
+                                                            x.shape[-1], ops.dtype_code(x),
+                                                            ops.cur_stream(img.device)), "tt_nchw_to_nhwc_pad")
+        bufs = self._trunk(x, bordered=border is not None)
         fpn2_buf, fpn2_off, _ = self._fpn_views(bufs)[2]
         src = self.neck_conv(fpn2_buf, in_coff=fpn2_off, cin=256)
         mlp_in = consts["mlp_in"]

@@ -115,12 +115,16 @@ def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None
 
 def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=None, res1_coff=0,
            res2=None, res2_coff=0, out=None, out_coff=0, in_coff=0, cin=None, pixel_shuffle2=False,
-           shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None, splitk_ws=None):
+           shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None, splitk_ws=None,
+           in_cstride=None):
     """Channel-last implicit-GEMM convolution on MFMA (tt_conv2d_fwd).
 
     x   [N,H,W,Cs]  (f32 or bf16); channels [in_coff, in_coff+cin) are convolved
     w   [Cout,KH,KW,cin] same dtype (for pixel_shuffle2: [4*Cout_real,1,1,cin])
     out [N,OH,OW,Ct] written at channel offset out_coff (allocated if None)
+    in_cstride / out_hw: "row-run" form -- the kernel reads `cin` CONTIGUOUS elements starting at pixel (ih, iw) of a
+    tensor whose pixels are only Cs < cin elements apart (a run of cin/Cs pixels along W), with the output size given
+    explicitly; used for the 7x7/2 stem (lss.py).
     """
     require_cuda(x, w)
     assert w.is_contiguous() and x.dim() == 4 and w.dim() == 4
@@ -133,13 +137,15 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     assert cin == Cin, (cin, Cin)
     OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
     OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    if out_hw is not None:
+        OH, OW = out_hw
     cr = Cout // 4 if pixel_shuffle2 else Cout
     if out is None:
         odt = out_dtype or x.dtype
         oh, ow = (2 * OH, 2 * OW) if pixel_shuffle2 else (OH, OW)
         out = torch.empty(N, oh, ow, cr, dtype=odt, device=x.device)
     d = _ConvDesc()
-    d.in_ = x.data_ptr(); d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.in_cstride = Cs; d.in_coff = in_coff
+    d.in_ = x.data_ptr(); d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.in_cstride = in_cstride or Cs; d.in_coff = in_coff
     d.in_nstride = x.stride(0) if N > 1 else 0
     d.weight = w.data_ptr(); d.Cout = Cout; d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad; d.dil = dil
     d.out = out.data_ptr(); d.OH = OH; d.OW = OW
@@ -176,6 +182,17 @@ _f = ctypes.c_float
 
 def _st(t):
     return cur_stream(t.device)
+
+
+def nchw_to_nhwc_border(x, out, top, left):
+    """(N,C,H,W) f32 -> interior of out (N,Hp,Wp,Cp) at pixel offset (top, left); border untouched."""
+    require_cuda(x, out)
+    assert x.is_contiguous() and x.dtype == torch.float32 and out.is_contiguous()
+    N, C, H, W = x.shape
+    _, Hp, Wp, Cp = out.shape
+    check(lib().tt_nchw_to_nhwc_border(ptr(x), ptr(out), _c(N), _c(C), _c(H), _c(W), _c(Cp), _c(Hp), _c(Wp),
+                                       _c(top), _c(left), _c(dtype_code(out)), _st(x)), "tt_nchw_to_nhwc_border")
+    return out
 
 
 def nchw_to_nhwc_pad(x, dtype, c_pad):
