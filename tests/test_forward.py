@@ -113,3 +113,38 @@ def test_inference_graph_replay_matches_eager_and_golden(golden_dir):
         e = float((out2[k] - eager2[k]).abs().max() / eager2[k].abs().max().clamp_min(1e-6))
         assert e < 1e-5, (k, e)
     assert float((out2["pred_wp"] - eager["pred_wp"]).abs().max()) > 0   # the replay really saw the new inputs
+
+
+def test_prev_sweep_cache_matches_two_sweep_forward():
+    """the older sweep is encoded and splatted with the key frame's matrices, so its BEV equals the
+    key-sweep BEV of the tick where that image was the key frame.  Feeding the cached BEV (camera trunk on the key
+    sweep only) must reproduce the full two-sweep forward; f32 tolerance 1e-4 (the half-size conv batch may take a
+    different tile / K order), and the PrevSweepCache tick driver must do the same on its own."""
+    from thinktwice_amd import model as tm, params, synth
+    from thinktwice_amd.encoder_decoder import PrevSweepCache
+    B, hw, npts = 2, (128, 256), 4000
+    m, cfg = tm.build_thinktwice(dtype=torch.float32, final_dim=hw)
+    m.load_state_dict(params.init_params(cfg, seed=3))
+    a = synth.make_batch(B, img_hw=hw, num_points=npts, seed=11)
+    b = synth.make_batch(B, img_hw=hw, num_points=npts, seed=29)
+    a["img"][:, 1] = b["img"][:, 0]            # tick t-lag: the key frame (last T index) is b's older sweep
+    a, b = tm.batch_to_device(a), tm.batch_to_device(b)
+    key_a = m.forward_inference(a)["_key_bev_cl"].contiguous().clone()
+    full = {k: v.clone() for k, v in m.forward_inference(b).items() if k in KEYS + ("_cam_bev_cl",)}
+    cached = m.forward_inference(b, prev_bev=key_a)
+    torch.cuda.synchronize()
+    for k in KEYS + ("_cam_bev_cl",):
+        e = float((cached[k] - full[k]).abs().max() / full[k].abs().max().clamp_min(1e-6))
+        assert e < 1e-4, (k, e)
+    drv = PrevSweepCache(m, lag=1)
+    drv.tick(a)
+    t2 = drv.tick(b)
+    torch.cuda.synchronize()
+    for k in KEYS:
+        e = float((t2[k] - full[k]).abs().max() / full[k].abs().max().clamp_min(1e-6))
+        assert e < 1e-4, (k, e)
+    # and the cache really removes work: a one-sweep image tensor is accepted
+    b1 = dict(b)
+    b1["img"] = b["img"][:, 1:].contiguous()
+    one = m.forward_inference(b1, prev_bev=key_a)
+    assert float((one["pred_wp"] - cached["pred_wp"]).abs().max()) < 1e-5      # split-K atomics reorder sums

@@ -260,17 +260,26 @@ class LSS:
                 "lidar2img": mats["lidar2img"], "ida_mat": mats["ida_mat"]}
 
     # ------------------------------------------------------------------ forward
-    def forward(self, img, img_metas, timestamps=None, is_return_depth=False, channel_last=False, consts=None):
+    def forward(self, img, img_metas, timestamps=None, is_return_depth=False, channel_last=False, consts=None,
+                prev_bev=None):
         """img (B,T,N,3,H,W) f32 on device (key frame = last T index) -> dict like LSS.forward.
-        `consts`: device copies of `host_constants(img_metas)` (graph replay); derived and uploaded here if None."""
+        `consts`: device copies of `host_constants(img_metas)` (graph replay); derived and uploaded here if None.
+        `prev_bev`: (B,vy,vx,C) f32 channel-last splat of the previous sweep taken from an earlier call's
+        `outs["_key_bev_cl"]` (closed-loop cache): the reference encodes AND splats the older sweep with
+        the key frame's matrices (lss.py:206-210, 606-611, 710-717), so with a fixed rig its BEV equals the key-sweep
+        BEV of the tick that image was the key frame; only the key sweep is then run through the camera trunk."""
         if not self.loaded:
             raise _lib.TTError("LSS: load_state_dict() first")
         _lib.require_cuda(img)
         if img.dim() == 5:
             img = img.unsqueeze(1)
         B, T, N, C, H, W = img.shape
-        assert T == self.queue_len, "LSS.queue_len must be set correctly in config!"
+        assert T == self.queue_len or (prev_bev is not None and T >= 1), "LSS.queue_len must be set correctly in config!"
         assert (H, W) == self.final_dim
+        T_all = self.queue_len
+        if prev_bev is not None:
+            img = img[:, T - 1:]            # key frame only
+            T = 1
         if consts is None:
             consts = {k: v.to(img.device) for k, v in self.host_constants(img_metas, N).items()}
         NI = T * B * N
@@ -310,15 +319,19 @@ class LSS:
         ctx = self.merge(merge_in, out_dtype=torch.float32)
         geom = self.geometry(consts["gm"], B, N)
         vx, vy, vz = (int(v) for v in self.voxel_num)
-        bev_cat = torch.zeros(B, vy, vx, self.output_channels * T, dtype=torch.float32, device=img.device)
+        OC = self.output_channels
+        bev_cat = torch.zeros(B, vy, vx, OC * T_all, dtype=torch.float32, device=img.device)
         BN = B * N
         for s in range(T):
             ops.lift_splat(depth[s * BN:(s + 1) * BN], ctx[s * BN:(s + 1) * BN], geom, (vx, vy, vz), B, N,
-                           out=bev_cat, out_coff=s * self.output_channels)
-        bev = self.bev_merge(bev_cat) if T > 1 else bev_cat
+                           out=bev_cat, out_coff=s * OC)
+        if prev_bev is not None:
+            assert T_all == 2 and tuple(prev_bev.shape) == (B, vy, vx, OC), prev_bev.shape
+            bev_cat[..., OC:2 * OC].copy_(prev_bev)
+        bev = self.bev_merge(bev_cat) if T_all > 1 else bev_cat
         fpn = [(t[:BN], off, c) for (t, off, c) in self._fpn_views(bufs)]
         outs = {"lidar2img": consts["lidar2img"], "ida_mat": consts["ida_mat"], "_fpn_cl": fpn, "_bev_cl": bev,
-                "_geom": geom}
+                "_geom": geom, "_key_bev_cl": bev_cat[..., :OC]}
         if channel_last:
             return outs
         outs["bev"] = ops.nhwc_to_nchw(bev)
