@@ -170,11 +170,35 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
     for (int i = 0; i < TM; ++i) {
         const int mb = m0 + wm * WTM + i * 32;
         // a wave's LDS operations execute in program order and the region is private: wave-level ordering suffices
-        stage_scaled<TN, WTN>(sC, acc[i], sc, sh, lane);
+        // per-image shift (ASPP global branch, value_proj camera/level embeddings): when the 32 rows of this block
+        // belong to one image -- the rule for every map wider than a few pixels -- it is just another per-column
+        // constant and folds into the staging affine; otherwise the rolled path adds it row by row
+        const int last_row = (mb + 31 < Mlim ? mb + 31 : Mlim - 1);
+        const int img = mb / ohw;
+        const bool one_image = (img == last_row / ohw);                  // wave-uniform
+        const bool sn_folded = has_sn && one_image;
+        const bool sn_loop = has_sn && !sn_folded;
+        float shb[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) shb[j] = sh[j];
+        if (sn_folded) {
+            const int nimg = img % p.shift_n_mod;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cj = n0 + wn * WTN + j * 32 + (lane & 31);
+                if (cj < p.Cout) shb[j] += p.shift_n[(long long)nimg * cout_real + cj % cout_real];
+            }
+        }
+        stage_scaled<TN, WTN>(sC, acc[i], sc, shb, lane);
         const bool full_block = (mb + 32 <= Mlim) && (n0 + wn * WTN + WTN <= p.Cout);   // wave-uniform
-        if (fast_act && rvec && p.out_fast && !has_sn && !has_r2 && full_block) {
-            // Hot path (every large conv of the camera/BEV trunks: row-linear output, at most one residual, ReLU or
-            // identity, whole 32 x WTN block in range).  The residual reads of ALL passes are issued up front and the
+        // row-linear output addressing: contiguous NHWC, or any image stride as long as the block stays in one image
+        // (the decoder's value_proj writes each FPN level into its slice of the concatenated value tensor)
+        const bool out_linear = p.out_fast || (one_image && !p.pixel_shuffle2);
+        const long long obase = (p.out_fast ? 0 : (long long)img * (p.out_nstride - (long long)ohw * p.out_cstride)) +
+                                p.out_coff + co;
+        if (fast_act && rvec && out_linear && !sn_loop && !has_r2 && full_block) {
+            // Hot path (every large conv of the camera/BEV trunks and the value projections: row-linear output, at most
+            // one residual, ReLU or identity, whole 32 x WTN block in range).  The residual reads of ALL passes are issued up front and the
             // passes are branch-free LDS read -> math -> 16 B store, so the stores of consecutive passes stay in flight
             // together.  vmcnt counts stores on gfx950 and is in-order: a load issued between two stores -- or a
             // predicated store, which makes the compiler's count conservative -- serialises the passes on the store
@@ -205,7 +229,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
 #pragma unroll
                         for (int e = 0; e < CO; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     }
-                    store_row((long long)mr * p.out_cstride + p.out_coff + co, v);
+                    store_row((long long)mr * p.out_cstride + obase, v);
                 }
             };
             if (has_r1) hot(std::true_type{});
@@ -226,7 +250,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                 }
                 int n = 0;
                 const long long o = out_offset(m, co, n);
-                if (has_sn) {
+                if (sn_loop) {
                     const float* sn = p.shift_n + (long long)(n % p.shift_n_mod) * cout_real + co;
 #pragma unroll
                     for (int e = 0; e < CO; ++e) v[e] += sn[e];

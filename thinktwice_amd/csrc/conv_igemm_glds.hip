@@ -100,9 +100,35 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         a_w0[j] = ow * p.stride - p.pad;
         a_base[j] = GATHER ? (long long)mm * p.KW : (long long)n * p.in_nstride + p.in_coff;   // GATHER: rulebook row
     }
+    // Dense path: everything about a slot that does not change over the K loop is folded into ONE pointer (the
+    // chunk's address for tap (0,0), possibly outside the image) and ONE bitmask (bit t = tap t of this row is
+    // inside the image; KH*KW <= 32, dispatcher).  Per K tile a slot then costs a 64-bit add of a wave-uniform
+    // tap offset, a bit test and a select -- the per-tile im2col arithmetic was ~2/3 of the kernel's VALU issue
+    // (SQ_INSTS_VALU 5.6 per MFMA, profiles/r01_conv_sq_counters.txt).
+    const T* a_ptr[NIA];
+    unsigned a_mask[NIA];
+    if (!GATHER) {
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) {
+            a_ptr[j] = in + a_base[j] + ((long long)a_h0[j] * p.W + a_w0[j]) * p.in_cstride + a_c[j];
+            unsigned mk = 0;
+            if (a_ok[j]) {
+                int tbit = 0;
+                for (int kh = 0; kh < p.KH; ++kh) {
+                    const int ih = a_h0[j] + kh * p.dil;
+                    for (int kw = 0; kw < p.KW; ++kw, ++tbit) {
+                        const int iw = a_w0[j] + kw * p.dil;
+                        if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) mk |= 1u << tbit;
+                    }
+                }
+            }
+            a_mask[j] = mk;
+        }
+    }
     int b_c[NIB];
     long long b_base[NIB];
     bool b_ok[NIB];
+    const T* b_ptr[NIB];
 #pragma unroll
     for (int j = 0; j < NIB; ++j) {
         const int g = ((wave + NW * j) % NB_INSTR) * 64 + lane;
@@ -110,6 +136,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         b_c[j] = (pos ^ swz(row)) * VEC;
         b_ok[j] = (n0 + row) < p.Cout;
         b_base[j] = (long long)(n0 + row) * p.K;
+        b_ptr[j] = wgt + b_base[j] + b_c[j];
     }
 
     const int nk = (p.K + BK - 1) / BK;
@@ -139,6 +166,9 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         const int kh = it_kh, kw = it_kw, ci = it_ci;
         const int k0 = GATHER ? kt * BK                // position of this tile in the [KH][KW][Cin] weight row
                               : (kh * p.KW + kw) * p.Cin + ci;
+        // wave-uniform (SALU): tap index and the element offset of tap (kh, kw), channel ci from tap (0, 0), channel 0
+        const int tap = kh * p.KW + kw;
+        const long long tap_off = ((long long)(kh * p.dil) * p.W + kw * p.dil) * p.in_cstride + ci;
         if (++it_kw == p.KW) {
             it_kw = 0;
             if (++it_kh == p.KH) {
@@ -156,16 +186,15 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                 const int kl = k0 + a_c[j];
                 src = gi >= 0 ? in + (long long)gi * p.in_cstride + p.in_coff + (kl & cin_mask) : zp;
             } else {
-                const int ih = a_h0[j] + kh * p.dil, iw = a_w0[j] + kw * p.dil;
-                const bool ok = a_ok[j] && (k0 + a_c[j] < p.K) && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-                src = ok ? in + a_base[j] + ((long long)ih * p.W + iw) * p.in_cstride + ci + a_c[j] : zp;
+                src = ((a_mask[j] >> tap) & 1u) ? a_ptr[j] + tap_off : zp;
             }
             __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(st + (wave + NW * j) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NIB; ++j) {
-            const bool ok = b_ok[j] && (k0 + b_c[j] < p.K);
-            const T* src = ok ? wgt + b_base[j] + k0 + b_c[j] : zp;
+            // dense: K % BK == 0 (Cin % BK == 0); gather: the last K tile may be ragged (27 taps of 16/32 channels)
+            const bool ok = b_ok[j] && (!GATHER || (k0 + b_c[j] < p.K));
+            const T* src = ok ? b_ptr[j] + k0 : zp;
             __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(st + BM * BKB + ((wave + NW * j) % NB_INSTR) * 1024),
                                              16, 0, 0);
         }
@@ -204,6 +233,17 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         fb_off[j] = BM * BKB + row * BKB;
         fb_s[j] = swz(row);
     }
+    // swizzled fragment offsets inside a stage for every k-step: registers instead of 3 VALU per read per step
+    constexpr int NKC_ = BKB / 32;
+    unsigned fa_pre[NKC_][TM], fb_pre[NKC_][TN];
+#pragma unroll
+    for (int kc = 0; kc < NKC_; ++kc) {
+        const unsigned c16 = 2u * kc + hi;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa_pre[kc][i] = fa_off[i] + ((c16 ^ fa_s[i]) << 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb_pre[kc][j] = fb_off[j] + ((c16 ^ fb_s[j]) << 4);
+    }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto lds_read = [](unsigned addr) {
         u32x4 v;
@@ -231,16 +271,19 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         }
         asm volatile("s_barrier" ::: "memory");   // publishes tile kt; everyone is done reading tile kt-1
 #endif
-        if (kt + STAGES - 1 < nk) issue_tile(kt + STAGES - 1);
-        if (GATHER && kt + 2 < nk) fetch_rulebook();   // for tile kt+2, consumed at the top of the next iteration
 
         const unsigned sbase = lds_base + (unsigned)((kt % STAGES) * STAGE_BYTES);
         constexpr int NKC = BKB / 32;
         u32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[0][i] = lds_read(sbase + fa_off[i] + (((0u + hi) ^ fa_s[i]) << 4));
+        for (int i = 0; i < TM; ++i) fa[0][i] = lds_read(sbase + fa_pre[0][i]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[0][j] = lds_read(sbase + fb_off[j] + (((0u + hi) ^ fb_s[j]) << 4));
+        for (int j = 0; j < TN; ++j) fb[0][j] = lds_read(sbase + fb_pre[0][j]);
+        // the next tile's DMA goes out AFTER the first fragment reads: its address arithmetic (~90 VALU/SALU) then
+        // runs under the LDS latency instead of in front of it (every wave of the block is in this phase together,
+        // so nothing else would cover that latency)
+        if (kt + STAGES - 1 < nk) issue_tile(kt + STAGES - 1);
+        if (GATHER && kt + 2 < nk) fetch_rulebook();   // for tile kt+2, consumed at the top of the next iteration
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) {
             const int cur = kc & 1, nxt = cur ^ 1;
@@ -255,11 +298,10 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
             for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[cur][j]));
 #endif
             if (kc + 1 < NKC) {
-                const unsigned c16 = 2u * (kc + 1) + hi;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[nxt][i] = lds_read(sbase + fa_off[i] + ((c16 ^ fa_s[i]) << 4));
+                for (int i = 0; i < TM; ++i) fa[nxt][i] = lds_read(sbase + fa_pre[kc + 1][i]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read(sbase + fb_off[j] + ((c16 ^ fb_s[j]) << 4));
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read(sbase + fb_pre[kc + 1][j]);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -337,7 +379,7 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
         if (a.Cout <= 64) return launch_glds<uint16_t, 64, 8, 1, 128, 2, true>(a, st);
         return launch_glds<uint16_t, 128, 4, 2, 128, 2, true>(a, st);
     }
-    if (a.m_dev || a.M < 2048 || a.Cout < 64) return 0;
+    if (a.m_dev || a.M < 2048 || a.Cout < 64 || a.KH * a.KW > 32) return 0;
     if (dtype == TT_F32) {
         if (a.Cin % 16 != 0 || div_up(a.K, 16) < min_tiles) return 0;
         if (a.Cout > 64) return launch_glds<float, 128, 4, 2, 64>(a, st);
