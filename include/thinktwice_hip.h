@@ -209,6 +209,13 @@ int tt_look_gather_query(int B, const int* query_of_slot, const float* ref_packe
  * value [B*4, sum(HW), 256] (8 heads x 32), offsets f32 [R,512], logits f32 [R,256], R = B*4*120. */
 int tt_msda_sample(int B, const void* value, int value_dtype, const float* offsets, const float* logits,
                    const float* ref_packed, const int* level_hw, float* out, void* stream);
+/* Same core over a value tensor whose rows hold `value_cstride` >= 256 channels, sampling the 256-channel window at
+ * `value_coff`: lets ONE value-projection GEMM (Cout = layers x 256) serve all five refinement layers, each layer's
+ * attention reading its own window (the reference projects per layer, thinktwice_decoder.py:392-398 inside the loop
+ * of 428-447; the projections only depend on the FPN maps). */
+int tt_msda_sample_strided(int B, const void* value, int value_dtype, int value_cstride, int value_coff,
+                           const float* offsets, const float* logits, const float* ref_packed, const int* level_hw,
+                           float* out, void* stream);
 /* SpatialCrossAttention "mask & average" incl. its batch-coupling bug (MSDA:338-342):
  * out (B, 4*256) = sum_{s=B}^{max_len-1} x[b,cam,s,:] / B. */
 int tt_sca_reduce(int B, const float* x, const int* max_len, float* out, void* stream);

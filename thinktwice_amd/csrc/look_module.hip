@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(const T* __restrict__ 
                                                           const float* __restrict__ offsets,
                                                           const float* __restrict__ logits,
                                                           const float* __restrict__ ref, LevelMaps lv,
-                                                          int S, float* __restrict__ out) {
+                                                          int S, int vcs, int vco, float* __restrict__ out) {
     const long long row = blockIdx.x;
     const int bc = (int)(row / kQ);
     const int t = threadIdx.x, head = t >> 5;
@@ -185,13 +185,13 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(const T* __restrict__ 
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
         const int H = lv.H[l], W = lv.W[l];
-        const T* map = value + ((long long)bc * S + start) * 256;
+        const T* map = value + ((long long)bc * S + start) * vcs + vco;   // 256 of vcs channels per position
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const float w = expf(lg[l * 8 + p] - mx) / den;
             const float nx = rx + of[(l * 8 + p) * 2 + 0] / (float)W;
             const float ny = ry + of[(l * 8 + p) * 2 + 1] / (float)H;
-            acc += w * bilinear_cl<T>(map, H, W, 256, t, nx, ny);
+            acc += w * bilinear_cl<T>(map, H, W, vcs, t, nx, ny);
         }
         start += (long long)H * W;
     }
@@ -259,9 +259,13 @@ extern "C" int tt_look_gather_query(int B, const int* query_of_slot, const float
     return check_launch("tt_look_gather_query");
 }
 
-extern "C" int tt_msda_sample(int B, const void* value, int value_dtype, const float* offsets, const float* logits,
-                              const float* ref_packed, const int* level_hw, float* out, void* stream) {
+extern "C" int tt_msda_sample_strided(int B, const void* value, int value_dtype, int value_cstride, int value_coff,
+                                      const float* offsets, const float* logits, const float* ref_packed,
+                                      const int* level_hw, float* out, void* stream) {
     TT_REQUIRE(value && offsets && logits && ref_packed && level_hw && out, "tt_msda_sample: null");
+    TT_REQUIRE(value_cstride >= 256 && value_coff >= 0 && value_coff + 256 <= value_cstride,
+               "tt_msda_sample: channel window [%d, %d) outside a %d-channel row", value_coff, value_coff + 256,
+               value_cstride);
     LevelMaps m;
     fill_levels(m, nullptr, level_hw);
     int S = 0;
@@ -270,11 +274,16 @@ extern "C" int tt_msda_sample(int B, const void* value, int value_dtype, const f
     hipStream_t st = (hipStream_t)stream;
     if (value_dtype == TT_F32)
         hipLaunchKernelGGL(msda_sample_kernel<float>, dim3(rows_n), dim3(256), 0, st, (const float*)value, offsets,
-                           logits, ref_packed, m, S, out);
+                           logits, ref_packed, m, S, value_cstride, value_coff, out);
     else
         hipLaunchKernelGGL(msda_sample_kernel<uint16_t>, dim3(rows_n), dim3(256), 0, st, (const uint16_t*)value,
-                           offsets, logits, ref_packed, m, S, out);
+                           offsets, logits, ref_packed, m, S, value_cstride, value_coff, out);
     return check_launch("tt_msda_sample");
+}
+
+extern "C" int tt_msda_sample(int B, const void* value, int value_dtype, const float* offsets, const float* logits,
+                              const float* ref_packed, const int* level_hw, float* out, void* stream) {
+    return tt_msda_sample_strided(B, value, value_dtype, 256, 0, offsets, logits, ref_packed, level_hw, out, stream);
 }
 
 extern "C" int tt_sca_reduce(int B, const float* x, const int* max_len, float* out, void* stream) {

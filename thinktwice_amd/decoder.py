@@ -108,6 +108,8 @@ class ThinkTwiceDecoder:
         self.device = torch.device(device)
         self.refine_num = config["refine_num"]
         self.loaded = False
+        self._branch = None          # second stream for the prediction branch of each refinement layer
+        self._vstream = None         # third stream for the layer-independent value projections
 
     def load_state_dict(self, sd, prefix="decoder"):
         p, dev = prefix, self.device
@@ -131,11 +133,29 @@ class ThinkTwiceDecoder:
             emb = cams.view(1, 4, 256) + lvls.view(4, 1, 256)                       # (lvl, cam, 256)
             lay.vshift = [torch.addmm(lay.vproj_b.new_zeros(256), emb[l], lay.vproj_w.t()).contiguous()
                           for l in range(4)]                                         # W e (bias added by shift)
+        self.vproj_all_w = torch.cat([lay.vproj.w for lay in self.layers], 0).contiguous()          # (L*256,1,1,256)
+        self.vproj_all_shift = torch.cat([lay.vproj.shift for lay in self.layers], 0).contiguous()  # (L*256,)
+        self.vshift_all = [torch.cat([lay.vshift[l] for lay in self.layers], 1).contiguous() for l in range(4)]
         self.loaded = True
         return self
 
     # ------------------------------------------------------------------ look module
-    def _look(self, lay, B, wp, ctrl_sp, meas, flat, lidar2img, ida_mat, mlvl, level_hw, S):
+    def _project_values(self, mlvl, B, S):
+        """value_proj of ALL refinement layers as one GEMM per FPN level (Cout = layers x 256): the projections depend
+        only on the FPN maps, so the activation is read once instead of once per layer (these GEMMs are HBM-bound,
+        K = N = 256) and the whole thing leaves the serial layer loop.  Layer L's attention samples the channel
+        window [256 L, 256 L + 256) (tt_msda_sample_strided)."""
+        C = 256 * len(self.layers)
+        value = torch.empty(B * 4, S, C, dtype=self.dtype, device=mlvl[0].device)
+        start = 0
+        for l, m in enumerate(mlvl):
+            hw = m.shape[1] * m.shape[2]
+            ops.conv2d(m, self.vproj_all_w, shift=self.vproj_all_shift, shift_n=self.vshift_all[l], shift_n_mod=4,
+                       out=value[:, start:start + hw].unflatten(1, (m.shape[1], m.shape[2])), out_nstride=S * C)
+            start += hw
+        return value
+
+    def _look(self, lay, B, wp, ctrl_sp, meas, flat, lidar2img, ida_mat, mlvl, level_hw, S, values):
         ref, qos, count, max_len = ops.look_project_pack(wp, lidar2img, ida_mat, self.config["img_size"])
         qrows = ops.look_gather_query(qos, ref, wp, ctrl_sp, self.temporal, self.static, meas, flat, mlvl)
         R = qrows.shape[0]
@@ -144,14 +164,10 @@ class ThinkTwiceDecoder:
         q = lay.q3(lay.q1(rows(qn)))                                                # (R,1,1,256)
         off = unrows(lay.off(q))
         aw = unrows(lay.aw(q))
-        value = torch.empty(B * 4, S, 256, dtype=self.dtype, device=wp.device)
-        start = 0
-        for l, m in enumerate(mlvl):
-            hw = m.shape[1] * m.shape[2]
-            ops.conv2d(m, lay.vproj.w, shift=lay.vproj.shift, shift_n=lay.vshift[l], shift_n_mod=4,
-                       out=value[:, start:start + hw].unflatten(1, (m.shape[1], m.shape[2])), out_nstride=S * 256)
-            start += hw
-        att = ops.msda_sample(value, off, aw, ref, level_hw, B)                      # (R,256)
+        value_all, L, ready = values
+        if ready is not None:            # the projections were issued on their own stream (forward())
+            torch.cuda.current_stream(wp.device).wait_stream(ready)
+        att = ops.msda_sample(value_all, off, aw, ref, level_hw, B, coff=L * 256)    # (R,256)
         an = ops.layernorm_rows(att, lay.ffn_ln[0], lay.ffn_ln[1])
         y = unrows(lay.ffn2(lay.ffn1(rows(an)), res1=att.view(R, 1, 1, 256)))
         red = ops.sca_reduce(y, max_len, B)                                          # (B,1024)
@@ -201,6 +217,22 @@ class ThinkTwiceDecoder:
         level_hw = [(m.shape[1], m.shape[2]) for m in mlvl]
         S = sum(h * w for h, w in level_hw)
 
+        # all layers' value projections, on their own stream under the coarse heads / first GRU
+        fork = getattr(parent_module, "use_side_stream", True)
+        vready = None
+        if fork:
+            main = torch.cuda.current_stream(dev)
+            if self._vstream is None:
+                self._vstream = torch.cuda.Stream(dev)
+            self._vstream.wait_stream(main)
+            with torch.cuda.stream(self._vstream):
+                value_all = self._project_values(mlvl, B, S)
+            if not torch.cuda.is_current_stream_capturing():
+                value_all.record_stream(main)
+            vready = self._vstream
+        else:
+            value_all = self._project_values(mlvl, B, S)
+
         H, W = bev.shape[1:3]
         s_bev = torch.empty(B, self.refine_num, H, W, 32, dtype=F32, device=dev)
         s_flat = torch.empty(B, self.refine_num, 256, dtype=F32, device=dev)
@@ -215,9 +247,28 @@ class ThinkTwiceDecoder:
             ops.ew(3, wp.view(B * 4, 2), out=inp6.view(B * 4, 6), C=2, out_coff=0)
             ops.ew(3, sp.view(B * 4, 4), out=inp6.view(B * 4, 6), C=4, out_coff=2)
             fut = torch.empty(B, 4, H, W, 32, dtype=F32, device=dev)
-            lay.gru(inp6, cur_bev, fut)
-            fflat = parent_module.flatten_tail(fut.view(B * 4, H, W, 32))            # (B*4,256)
-            look, info = self._look(lay, B, wp, sp, meas, cur_flat, lidar2img, ida_mat, mlvl, level_hw, S)
+            # The prediction branch (conv-GRU, 4 steps x 8 small convs, + the shared flatten network) and the look
+            # branch (value projections, MSDA sampling, attention MLPs) only meet at the concat below: run the
+            # former on a second HIP stream.  Both are chains of microsecond-scale launches on a few CUs each, so
+            # they overlap almost perfectly (DEC:428-447 runs them back to back).
+            fork = getattr(parent_module, "use_side_stream", True)
+            if fork:
+                main = torch.cuda.current_stream(dev)
+                if self._branch is None:
+                    self._branch = torch.cuda.Stream(dev)
+                self._branch.wait_stream(main)
+                with torch.cuda.stream(self._branch):
+                    lay.gru(inp6, cur_bev, fut)
+                    fflat = parent_module.flatten_tail(fut.view(B * 4, H, W, 32))    # (B*4,256)
+            else:
+                lay.gru(inp6, cur_bev, fut)
+                fflat = parent_module.flatten_tail(fut.view(B * 4, H, W, 32))        # (B*4,256)
+            look, info = self._look(lay, B, wp, sp, meas, cur_flat, lidar2img, ida_mat, mlvl, level_hw, S,
+                                    (value_all, L, vready if L == 0 else None))
+            if fork:
+                main.wait_stream(self._branch)
+                if not torch.cuda.is_current_stream_capturing():
+                    fflat.record_stream(main)
             look_info.append(info)
             # [future flat 256 | look 256 | zeros 256 (LiDAR look) | temporal 128 | meas 128]
             hin = torch.zeros(B * 4, 1024, dtype=F32, device=dev)

@@ -355,11 +355,13 @@ def look_gather_query(qos, ref, wp, ctrl_sp, temporal, static, meas, flat, maps,
     return out
 
 
-def msda_sample(value, offsets, logits, ref, level_hw, B):
+def msda_sample(value, offsets, logits, ref, level_hw, B, coff=0):
+    """value (B*4, S, Cv) with Cv >= 256: samples channels [coff, coff+256)."""
     out = torch.empty(B * 4 * 120, 256, dtype=torch.float32, device=value.device)
     hw = (ctypes.c_int * 8)(*[v for pair in level_hw for v in pair])
-    check(lib().tt_msda_sample(_c(B), ptr(value), _c(dtype_code(value)), ptr(offsets), ptr(logits), ptr(ref), hw,
-                               ptr(out), _st(value)), "tt_msda_sample")
+    check(lib().tt_msda_sample_strided(_c(B), ptr(value), _c(dtype_code(value)), _c(value.shape[-1]), _c(coff),
+                                       ptr(offsets), ptr(logits), ptr(ref), hw, ptr(out), _st(value)),
+          "tt_msda_sample")
     return out
 
 
