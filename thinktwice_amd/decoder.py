@@ -227,8 +227,7 @@ class ThinkTwiceDecoder:
             self._vstream.wait_stream(main)
             with torch.cuda.stream(self._vstream):
                 value_all = self._project_values(mlvl, B, S)
-            if not torch.cuda.is_current_stream_capturing():
-                value_all.record_stream(main)
+            value_all.record_stream(main)
             vready = self._vstream
         else:
             value_all = self._project_values(mlvl, B, S)
@@ -257,6 +256,8 @@ class ThinkTwiceDecoder:
                 if self._branch is None:
                     self._branch = torch.cuda.Stream(dev)
                 self._branch.wait_stream(main)
+                fut.record_stream(self._branch)           # written by the GRU and re-read by bev_update() there
+                inp6.record_stream(self._branch)
                 with torch.cuda.stream(self._branch):
                     lay.gru(inp6, cur_bev, fut)
                     fflat = parent_module.flatten_tail(fut.view(B * 4, H, W, 32))    # (B*4,256)
@@ -267,8 +268,7 @@ class ThinkTwiceDecoder:
                                     (value_all, L, vready if L == 0 else None))
             if fork:
                 main.wait_stream(self._branch)
-                if not torch.cuda.is_current_stream_capturing():
-                    fflat.record_stream(main)
+                fflat.record_stream(main)
             look_info.append(info)
             # [future flat 256 | look 256 | zeros 256 (LiDAR look) | temporal 128 | meas 128]
             hin = torch.zeros(B * 4, 1024, dtype=F32, device=dev)
@@ -291,18 +291,34 @@ class ThinkTwiceDecoder:
             ops.ew(0, d_wp.view(B, 8), b=wp.view(B, 8), out=wp_all[:, L + 1].view(B, 8))
             ops.ew(0, d_ctrl.view(B, 16), b=ctrl.view(B, 16), out=ctrl_all[:, L + 1].view(B, 16))
             hb = h.view(B, 2048)
-            xb = torch.empty(B, H, W, 2080, dtype=F32, device=dev)
-            ops.copy_nhwc(cur_bev, xb, out_coff=0)
-            ops.broadcast_rows(hb, xb, out_coff=32)
-            new_bev = lay.bev2(lay.bev0(xb), res1=cur_bev)
-            ops.ew(3, new_bev.view(B, -1), out=s_bev[:, L].view(B, -1))
+
+            def bev_update():
+                xb = torch.empty(B, H, W, 2080, dtype=F32, device=dev)
+                ops.copy_nhwc(cur_bev, xb, out_coff=0)
+                ops.broadcast_rows(hb, xb, out_coff=32)
+                nb = lay.bev2(lay.bev0(xb), res1=cur_bev)
+                ops.ew(3, nb.view(B, -1), out=s_bev[:, L].view(B, -1))
+                ops.ew(3, fut.view(B, -1), out=s_fut[:, L].view(B, -1))
+                return nb
+
+            # the BEV-map update (K = 18,720 conv) only feeds the NEXT layer's GRU: it stays on the prediction
+            # stream, beside this layer's offset heads and flattened-feature update on the main stream
+            if fork:
+                self._branch.wait_stream(main)                # h is ready
+                h.record_stream(self._branch)
+                with torch.cuda.stream(self._branch):
+                    new_bev = bev_update()
+            else:
+                new_bev = bev_update()
             fin = torch.empty(B, 2304, dtype=F32, device=dev)
             ops.ew(3, cur_flat, out=fin, C=256, out_coff=0)
             ops.ew(3, hb, out=fin, C=2048, out_coff=256)
             new_flat = unrows(lay.flat2(lay.flat0(rows(fin)), res1=rows(cur_flat)))
             ops.ew(3, new_flat, out=s_flat[:, L])
-            ops.ew(3, fut.view(B, -1), out=s_fut[:, L].view(B, -1))
             cur_bev, cur_flat = new_bev, new_flat
+        if fork:
+            main.wait_stream(self._branch)                    # last BEV update, s_bev / s_fut
+            cur_bev.record_stream(main)
         ct = ops.ew(3, ctrl_all.view(B * R1 * 4, 4), act=_lib.ACT_SOFTPLUS_CLAMP).view(B, R1, 4, 4)
         outs["pred_wp"] = wp_all
         outs["mu_branches"], outs["sigma_branches"] = ct[:, :, 0, :2], ct[:, :, 0, 2:]

@@ -116,8 +116,7 @@ class EncoderDecoder:
         cam_bev = torch.empty(B, H, W, C, dtype=F32, device=self.device)
         ops.copy_nhwc(cam["_bev_cl"], cam_bev, rot_flip=True)          # EDF:241
         main.wait_stream(self._side)
-        if not torch.cuda.is_current_stream_capturing():
-            lidar.record_stream(main)
+        lidar.record_stream(main)
         return cam, cam_bev, lidar
 
     def forward_inference(self, batch, channel_last_out=False, consts=None, prev_bev=None):
