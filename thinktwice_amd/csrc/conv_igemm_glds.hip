@@ -1,20 +1,25 @@
-// Implicit-GEMM convolution, LDS-DMA pipelined variant (gfx950 `global_load_lds_dwordx4`).
+// Implicit-GEMM convolution, LDS-DMA pipelined kernel (gfx950 `global_load_lds_dwordx4`).
 //
-// Same math and epilogue as conv_igemm.hip; different data movement, built for the large dense layers
-// of the camera trunk / SECOND / decoder value projections where the register-staged 2-stage loop sits
-// at 2 workgroups per CU and ~23 % MFMA utilisation:
-//   * 512 threads = 8 waves, block tile 256 x {128, 64}; the weight tile is shared by 8 waves.
-//   * global -> LDS by DMA (no staging VGPRs), THREE stages in flight: tile k+2 is issued right after
-//     the barrier that publishes tile k, with a COUNTED `s_waitcnt vmcnt(N)` (never 0 in the main loop)
-//     and a raw `s_barrier`, so two K tiles of loads overlap the MFMA phase (cdna_hip_programming.md
-//     section 5 "glds span barrier").
+// Same math and epilogue as conv_igemm.hip; different data movement.  Carries every large dense layer of the
+// camera trunk / SECOND / decoder value projections, the 7x7/2 stem in row-run form, and (GATHER) the sparse 3D
+// convolutions of the LiDAR encoder:
+//   * block tile 256 x {256, 128, 64, 32}, 4 or 8 waves with 64x64 or 128x64 register tiles (template parameters;
+//     the dispatcher at the bottom of this file states which shape gets which and why).
+//   * global -> LDS by DMA (no staging VGPRs).  STAGES = 3: tile k+2 is issued right after the barrier that
+//     publishes tile k, with a COUNTED `s_waitcnt vmcnt(N)` (never 0 in the main loop) and a raw `s_barrier`, so
+//     two K tiles of loads overlap the MFMA phase (64 B rows).  STAGES = 2: one tile in flight, 128 B rows =
+//     whole cache lines per DMA lane group (the faster choice wherever 2 x tile fits the LDS budget).
+//   * K order: channel chunk outer, filter tap inner (dense); natural [tap][channel] order, 1-4 taps per 128 B
+//     row, rulebook entries fetched one tile ahead (gather).
+//   * per DMA slot ONE precomputed pointer (tap (0,0)) and ONE tap-validity bitmask; per K tile a slot costs a
+//     64-bit add of a wave-uniform offset, a bit test and a select.
 //   * LDS rows are unpadded (the DMA writes wave-uniform base + lane*16); bank conflicts are removed
 //     by an XOR swizzle applied to the SOURCE address: 16 B chunk c of row r is stored at chunk slot
-//     c ^ f(r), f(r) = (r>>1)&7 for 128 B rows (bf16), (r>>2)&3 for 64 B rows (f32) -- every 16-lane
+//     c ^ f(r), f(r) = (r>>1)&7 for 128 B rows, (r>>2)&3 for 64 B rows -- every 16-lane
 //     group of ds_read_b128 then touches 16 distinct slots of the 256 B bank row.
 //   * rows that are padding / beyond M / beyond K read from a 16 B zero page instead of branching.
 //   * XCD-aware tile order: workgroups that share an A row-block are consecutive on ONE XCD (its L2).
-// Requires: dense (non-gather) conv, Cin % BK == 0 (one tap per K tile), no split-K.
+// Requires: Cin % BK == 0 (dense: one tap per K tile) or power-of-two Cin >= 16 (gather); KH*KW <= 32; no split-K.
 #include <stdlib.h>
 
 #include "conv_common.h"
@@ -353,29 +358,21 @@ static int launch_glds(ConvArgs& a, hipStream_t st) {
 }
 
 int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
-    // bf16 variants: 64 B rows (3 stages = 72 KiB, 2 workgroups / CU: one streams while the other stores),
-    // 128 B rows (144 KiB, 1 workgroup / CU, 16 MFMA per barrier) and a 16-wave 256x256 tile; selectable
-    // by TT_GLDS_BKB / TT_GLDS_BN256 for experiments, default = the fastest measured on the bench.
-    static int force_bkb = -1;
-    if (force_bkb < 0) {
-        const char* e = getenv("TT_GLDS_BKB");
-        force_bkb = e ? atoi(e) : 0;
-    }
     static int min_tiles = -1;
     if (min_tiles < 0) {
         const char* e = getenv("TT_GLDS_MIN_KTILES");
-        min_tiles = e ? atoi(e) : 2;
+        min_tiles = e ? atoi(e) : 2;   // K = 64 1x1 layers: 0.43 -> 0.27 ms against the register-staged kernel
     }
     if (a.gather) {
         // sparse 3D conv as a gathered GEMM (rulebook rows): whole 128 B+ activation rows per DMA lane group
         static int sp = -1;
         if (sp < 0) {
-            const char* e = getenv("TT_GLDS_GATHER");
+            const char* e = getenv("TT_GLDS_GATHER");   // 0: register-staged gather kernel (A/B knob)
             sp = e ? atoi(e) : 1;
         }
         const bool cin_ok = a.Cin >= 16 && (a.Cin & (a.Cin - 1)) == 0;   // power of two: taps tile the 128 B rows
         if (!sp || dtype != TT_BF16 || !cin_ok || a.M < 2048 || a.Cout < 16 || a.Cout > 128) return 0;
-        if (a.Cout <= 32 && sp != 2) return launch_glds<uint16_t, 32, 8, 1, 128, 2, true>(a, st);
+        if (a.Cout <= 32) return launch_glds<uint16_t, 32, 8, 1, 128, 2, true>(a, st);
         if (a.Cout <= 64) return launch_glds<uint16_t, 64, 8, 1, 128, 2, true>(a, st);
         return launch_glds<uint16_t, 128, 4, 2, 128, 2, true>(a, st);
     }
@@ -385,24 +382,7 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
         if (a.Cout > 64) return launch_glds<float, 128, 4, 2, 64>(a, st);
         return launch_glds<float, 64, 8, 1, 64>(a, st);
     }
-    int bkb = 64;   // measured (profiles/r01 sweep): 64 B rows + 2 workgroups/CU >= 128 B rows + 1 on every layer
-    if (force_bkb == 64 || force_bkb == 128) bkb = force_bkb;
-    if (bkb == 128 && a.Cin % 64 != 0) bkb = 64;
-    const int bk = bkb / 2;
-    if (a.Cin % bk != 0 || div_up(a.K, bk) < min_tiles) return 0;
-    static int big_n = -1;
-    if (big_n < 0) {
-        const char* e = getenv("TT_GLDS_BN256");
-        big_n = e ? atoi(e) : 0;
-    }
-    // 256x256 tile (64 B rows, 3 stages = 96 KiB): halves the LDS-fill bytes per FLOP of the 256x128 tile
-    if (big_n && a.Cout >= 256 && a.Cout % 256 == 0 && a.K >= 512 && a.Cin % 32 == 0 &&
-        div_up(a.M, 256) * (a.Cout / 256) >= 200)
-        return launch_glds<uint16_t, 256, 4, 4, 64>(a, st);
-    if (bkb == 128) {
-        if (a.Cout > 64) return launch_glds<uint16_t, 128, 4, 2, 128>(a, st);
-        return launch_glds<uint16_t, 64, 8, 1, 128>(a, st);
-    }
+    if (a.Cin % 32 != 0 || div_up(a.K, 32) < min_tiles) return 0;
     // Tile selection (profiles/r01_conv_microbench_tiles.txt).  Three things set the rate of these kernels:
     //  * L2->LDS bytes per FLOP = workgroup tile: 256x128 -> 85 FLOP/B, 256x256 -> 128 FLOP/B;
     //  * whether a DMA lane group consumes WHOLE 128 B cache lines: with 64 B rows every activation line is
@@ -411,7 +391,8 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
     //  * LDS fragment bytes per MFMA = per-wave register tile (64x64: 1 KiB, 128x64: 0.75 KiB) -- second order.
     // Auto: Cout % 256 == 0 -> 256x256 tile of eight 128x64 waves (128 B rows if Cin % 64 == 0); short K -> four
     // 128x64 waves on 256x128; Cout <= 64 -> 256x64 tile with 128 B rows; else eight 64x64 waves on 256x128.
-    // TT_GLDS_VARIANT forces one (0 = the 256x128 / 64 B-row base kernel).
+    // Retired after measurement (same file): 16-wave 256x256, 8x1 wave grid, 128 B rows x 3 stages (1 workgroup/CU),
+    // 128 B x 2 stages on the 256x128 tile.  TT_GLDS_VARIANT forces 0 / 1 / 2 / 6 (Cout > 64) for A/B runs.
     static int variant = -2;
     if (variant == -2) {
         const char* e = getenv("TT_GLDS_VARIANT");
@@ -425,23 +406,14 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
             else if (a.K <= 512) v = 1;
             else v = 0;
         }
-        // 128 B rows (whole cache lines per DMA lane group), 2 stages = 128 KiB
         if (v == 6 && a.Cout % 256 == 0 && a.Cin % 64 == 0) return launch_glds<uint16_t, 256, 2, 4, 128, 2>(a, st);
         if (v == 1) return launch_glds<uint16_t, 128, 2, 2, 64>(a, st);                         // 4 waves x 128x64
         if (v == 2 && a.Cout % 256 == 0) return launch_glds<uint16_t, 256, 2, 4, 64>(a, st);    // 8 waves x 128x64
-    } else {
-        // Cout <= 64 (the 224x448 UNet / stem-level layers): 128 B rows in 2 stages (80 KiB, 2 workgroups / CU)
-        // measured +17 % over 64 B rows x 3 stages (1.61 vs 1.89 ms on M=6.4M K=1152)
-        if (a.Cin % 64 == 0 && (variant < 0 || variant == 11)) return launch_glds<uint16_t, 64, 8, 1, 128, 2>(a, st);
+        return launch_glds<uint16_t, 128, 4, 2, 64>(a, st);                                     // 8 waves x 64x64
     }
-    static int wide = -1;
-    if (wide < 0) {
-        const char* e = getenv("TT_GLDS_WIDE_WAVE");
-        wide = e ? atoi(e) : 0;
-    }
-    // experiment: 8x1 wave grid => every wave owns 32 rows x 128 cols (256 B row segments in the epilogue)
-    if (wide && a.Cout > 64) return launch_glds<uint16_t, 128, 8, 1, 64>(a, st);
-    if (a.Cout > 64) return launch_glds<uint16_t, 128, 4, 2, 64>(a, st);
+    // Cout <= 64 (the 224x448 UNet / stem-level layers): 128 B rows in 2 stages (80 KiB, 2 workgroups / CU)
+    // measured +17 % over 64 B rows x 3 stages (1.61 vs 1.89 ms on M=6.4M K=1152)
+    if (a.Cin % 64 == 0 && variant != 0) return launch_glds<uint16_t, 64, 8, 1, 128, 2>(a, st);
     return launch_glds<uint16_t, 64, 8, 1, 64>(a, st);
 }
 

@@ -35,7 +35,7 @@ def main():
     ms = e0.elapsed_time(e1) / iters
     M = y.shape[0] * y.shape[1] * y.shape[2]
     fl = 2.0 * M * Cout * k * k * Cin
-    print(f"M={M} N={Cout} K={k*k*Cin} {dt}: {ms:.3f} ms  {fl/ms/1e9:.1f} TF/s  env BKB={os.environ.get('TT_GLDS_BKB')} BN256={os.environ.get('TT_GLDS_BN256')} MINK={os.environ.get('TT_GLDS_MIN_KTILES')} ACT={act} RES={res is not None} SCALAR_EPI={os.environ.get('TT_CONV_SCALAR_EPI')}")
+    print(f"M={M} N={Cout} K={k*k*Cin} {dt}: {ms:.3f} ms  {fl/ms/1e9:.1f} TF/s  env VARIANT={os.environ.get('TT_GLDS_VARIANT')} MINK={os.environ.get('TT_GLDS_MIN_KTILES')} ACT={act} RES={res is not None} SCALAR_EPI={os.environ.get('TT_CONV_SCALAR_EPI')}")
     # reference point: a plain device copy of the output-sized tensor (read + write M*N elements)
     src = torch.empty_like(y)
     for _ in range(3):
