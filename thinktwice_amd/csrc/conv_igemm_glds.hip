@@ -28,6 +28,12 @@ namespace tt {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// Timing experiments only (tools/conv_microbench.py, TT_MB_ACT=97/98 on the 2-stage variants): skip the weight /
+// activation DMA after the first K tile to see how much of the loop time is the L2->LDS stream.  0 in the product.
+#ifndef TT_GLDS_DEBUG
+#define TT_GLDS_DEBUG 0
+#endif
+
 template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64,
                              ((256 / WAVES_M / 32) * (BN / WAVES_N / 32) >= 16)  ? 1      // 128x128 per wave: 512 regs
@@ -181,8 +187,10 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                 it_ci += BK;
             }
         }
+        const bool dbg_skip_a = TT_GLDS_DEBUG && p.act == 98 && kt > 0, dbg_skip_b = TT_GLDS_DEBUG && p.act == 97 && kt > 0;
 #pragma unroll
         for (int j = 0; j < NIA; ++j) {
+            if (dbg_skip_a) break;
             const T* src;
             if (GATHER) {
                 // sparse conv: the activation row of (output row, tap) comes from the rulebook entry that was
@@ -197,6 +205,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         }
 #pragma unroll
         for (int j = 0; j < NIB; ++j) {
+            if (dbg_skip_b) break;
             // dense: K % BK == 0 (Cin % BK == 0); gather: the last K tile may be ragged (27 taps of 16/32 channels)
             const bool ok = b_ok[j] && (!GATHER || (k0 + b_c[j] < p.K));
             const T* src = ok ? b_ptr[j] + k0 : zp;
@@ -318,6 +327,9 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                 }
         }
     }
+    // Measured and NOT kept (profiles/r01_conv_microbench_tiles.txt): deferring each tile's last k-step past the next
+    // barrier (to cover the prologue bubble) changed nothing, and skipping either DMA stream after the first tile
+    // (TT_GLDS_DEBUG) did not shorten the loop either: at ~1.0 PF the loop is neither L2->LDS- nor bubble-bound.
     __syncthreads();   // all waves done with the last stage before the epilogue reuses LDS
     conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, smem, wave, lane, wm, wn, m0, n0, Mlim);
 #endif
