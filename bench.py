@@ -30,6 +30,7 @@ class VoxelPoolWorkload:
     per (sample, sweep) 501,760 points x 256 ch -> 21x21 BEV; B samples x 2 sweeps per step."""
     name = "voxel_pool_op_boundary"
     dtype = "f32"
+    metric = "frames/sec through the voxel_pooling op alone (2 sweeps per frame; NOT the headline forward metric)"
 
     def __init__(self, batch, device):
         from thinktwice_amd import camera, ops, synth
@@ -145,7 +146,7 @@ def main():
     if rank == 0:
         frames = wl.frames_per_step() * args.steps * world
         line = {
-            "metric": "frames/sec forward (4-cam+LiDAR, thinktwice.py cfg)",
+            "metric": getattr(wl, "metric", "frames/sec forward (4-cam+LiDAR, thinktwice.py cfg)"),
             "value": round(frames / dt, 3),
             "unit": "frames/s",
             "n_gpus": world,
