@@ -80,6 +80,9 @@ class ForwardWorkload:
         peak = MFMA_PEAK_TF[self.dtype]
         top = sorted(rec, key=lambda r: -r[1].elapsed_time(r[2]))[:5]
         dump = os.environ.get("TT_BENCH_DUMP")
+        if dump and self.dtype != "bf16":      # the f32 parity leg of the default run must not overwrite the bf16 table
+            root, ext = os.path.splitext(dump)
+            dump = f"{root}.{self.dtype}{ext}"
         if dump:
             import json
             agg = {}
