@@ -23,8 +23,12 @@ def _inputs(B, hw=(128, 256), seed=0):
     return cam_bev, lidar, fpn, batch, l2i, ida
 
 
-@pytest.mark.parametrize("B", [1, 2, 3])
+@pytest.mark.parametrize("B", [1, 2, 3, -2])
 def test_fusion_and_decoder_match_oracle(B):
+    """B < 0: |B| samples with a degenerate lidar2img (all zeros) -> no look point projects into any camera, every
+    (sample, cam) hit count and max_len are 0 and the look feature is the pure-bias path."""
+    no_hits = B < 0
+    B = abs(B)
     from oracle import model_ref as M
     from thinktwice_amd import config, params, weights
     from thinktwice_amd.encoder_decoder import EncoderDecoder
@@ -35,6 +39,8 @@ def test_fusion_and_decoder_match_oracle(B):
     cfg = config.model_config(final_dim=hw)
     sd = params.init_params(cfg, seed=0, parts=("fusion", "decoder"))
     cam_bev, lidar, fpn, batch, l2i, ida = _inputs(B, hw)
+    if no_hits:
+        l2i = torch.zeros_like(l2i)
     with torch.no_grad():
         meas_r = M.measurement_feat(sd, batch)
         flat_r, bev_r, _ = M.fusion(sd, cam_bev, lidar)

@@ -74,3 +74,29 @@ def test_voxelize_matches_oracle_exactly():
     mean_o = (v.sum(1) / n[:, None].float())[so]
     np.testing.assert_allclose(feats[:M_].cpu()[sg].numpy(), mean_o.numpy(), rtol=1e-5, atol=1e-6)
     assert int(n.max()) == 10      # the cluster exercises the max_num_points cut
+
+
+def test_lidar_empty_sample_and_collate_padding():
+    """Edge cases of the sparse path: one sample of the batch has NO voxel at all (every point above the grid) and
+    the other is mostly collate-style zero padding (2,900 identical points at the origin -> one voxel at the
+    max_num_points cut).  The dense BEV must still match the oracle (BN shifts make the empty sample a constant map)."""
+    from oracle import model_ref as M
+    from thinktwice_amd import config, params
+    from thinktwice_amd.lidarnet import LidarNet
+    cfg = config.model_config()
+    sd = params.init_params(cfg, seed=0, parts=("lidar_encoder",))
+    pts = _pts(2, 3000, seed=5, dup=False)
+    pts[0, :, 2] = 50.0
+    pts[1, 100:, :] = 0.0
+    with torch.no_grad():
+        ref = M.lidar_net(sd, "lidar_encoder", cfg, pts)[0]
+    le = dict(cfg["lidar_encoder"])
+    le.pop("type")
+    net = LidarNet(**le).load_state_dict(sd)
+    out = net(pts.cuda())[0]
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    err = float((out.cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-4, err
+    feats, coords, num, _ = net.voxelize(pts.cuda())
+    assert int((coords[:int(num.item()), 0] == 0).sum()) == 0          # nothing from the empty sample
