@@ -112,13 +112,34 @@ class ForwardWorkload:
                                   "hbm_gbs": round(bytes_ / (gms * 1e-3) / 1e9, 1),
                                   "note": "value_proj / fpn_linear GEMM (K=N=256): 128 (bf16) / 64 (f32) FLOP per HBM "
                                           "byte, i.e. HBM-bound below ~1 PF (bf16)"}
+        traffic, traffic_note = self._pmc_traffic()
         return {"kernel": "conv_igemm_kernel (all conv/linear launches of one forward)", "bound": "mfma",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": None, "launches": len(rec), "conv_ms_per_step": round(ms, 3),
+                "traffic": traffic, "traffic_note": traffic_note, "launches": len(rec),
+                "conv_ms_per_step": round(ms, 3),
                 "algorithmic_gflop_per_step": round(flops / 1e9, 1),
                 "slowest_launches": [{"gflop": round(r[0] / 1e9, 2), "ms": round(r[1].elapsed_time(r[2]), 3),
                                       "tf": round(r[0] / (r[1].elapsed_time(r[2]) * 1e-3) / 1e12, 1),
                                       "shape": r[3]} for r in top]}
+
+    def _pmc_traffic(self):
+        """HBM bytes per step of the same kernel set (every conv/linear launch of one forward), from the committed
+        rocprofv3 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command (counters cannot be read from inside
+        the process): FETCH_SIZE x 2 (gfx950 16 B/lane correction, MI355X_MICROARCH.md) + WRITE_SIZE, in KB."""
+        import json
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles",
+                            "r01_forward_bf16_v11_pmc.json")
+        if self.dtype != "bf16" or self.B != 8 or not os.path.exists(path):
+            return None, "no PMC summary for this dtype / batch"
+        forwards = 4     # the profiled command: bench.py --steps 2 --warmup 1 (+1 roofline pass)
+        rd = wr = 0.0
+        for name, c in json.load(open(path)).items():
+            if "conv_" in name or "igemm" in name or "splitk" in name:
+                rd += c.get("FETCH_SIZE", {}).get("sum", 0.0)
+                wr += c.get("WRITE_SIZE", {}).get("sum", 0.0)
+        return int((2.0 * rd + wr) * 1024 / forwards), ("bytes per step over the same launches, from profiles/"
+                                                         "r01_forward_bf16_v11_pmc.json (separate --pmc passes, "
+                                                         "FETCH_SIZE x2 corrected)")
 
     def extra(self):
         out = {}
