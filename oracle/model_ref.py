@@ -13,7 +13,6 @@ semantics, SURVEY.md Appendix C -- "parity unpinned"): mmdet ResNet/BasicBlock/P
 multi_scale_deformable_attn_pytorch / Voxelization, mmdet3d HardSimpleVFE / SparseEncoder /
 SECOND / SECONDFPN, spconv.
 """
-import math
 
 import numpy as np
 import torch

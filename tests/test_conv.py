@@ -1,7 +1,6 @@
 """Implicit-GEMM conv / linear kernel (tt_conv2d_fwd) vs a plain PyTorch fp32 reference of the
 same op on CPU.  Tolerances: f32 mode 1e-4 relative-to-max (exact-f32 MFMA, different sum order);
 bf16 mode 2e-2 (inputs rounded to bf16; reference evaluated on the same rounded inputs)."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

@@ -4,7 +4,6 @@ import json
 import os
 
 import numpy as np
-import pytest
 import torch
 
 from oracle import model_ref as M

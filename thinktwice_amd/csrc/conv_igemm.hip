@@ -356,7 +356,8 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
                   (a.out_nstride % co_vec == 0) && ((reinterpret_cast<uintptr_t>(d->out) & 15) == 0);
         (void)osz;
         a.vec_epi = ok ? 1 : 0;
-        if (getenv("TT_CONV_SCALAR_EPI")) a.vec_epi = 0;   // experiment knob
+        static const bool scalar_epi = getenv("TT_CONV_SCALAR_EPI") != nullptr;   // A/B knob
+        if (scalar_epi) a.vec_epi = 0;
         auto res_ok = [&](const void* r, int cs, int co_) {
             return !r || ((cs % co_vec == 0) && (co_ % co_vec == 0) && ((reinterpret_cast<uintptr_t>(r) & 15) == 0));
         };

@@ -195,7 +195,7 @@ class InferenceGraph:
             if k in batch and torch.is_tensor(batch[k]):
                 self.batch[k] = batch[k].to(dev)
         ncam = self.batch["img"].shape[-4]
-        self.consts = {k: v.to(dev) for k, v in LSS_host_constants(batch["img_metas"], ncam).items()}
+        self.consts = {k: v.to(dev) for k, v in _lss_host_constants(batch["img_metas"], ncam).items()}
         self.prev_bev = None if prev_bev is None else prev_bev.to(dev).contiguous().clone()
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -220,7 +220,7 @@ class InferenceGraph:
                 self.batch[k].copy_(batch[k], non_blocking=True)
         if batch.get("img_metas") is not None and batch["img_metas"] is not self.batch.get("img_metas"):
             ncam = self.batch["img"].shape[-4]
-            for k, v in LSS_host_constants(batch["img_metas"], ncam).items():
+            for k, v in _lss_host_constants(batch["img_metas"], ncam).items():
                 self.consts[k].copy_(v, non_blocking=True)
             self.batch["img_metas"] = batch["img_metas"]
 
@@ -234,6 +234,6 @@ class InferenceGraph:
         return self.replay()
 
 
-def LSS_host_constants(img_metas, num_cams):
+def _lss_host_constants(img_metas, num_cams):
     from .lss import LSS
     return LSS.host_constants(img_metas, num_cams)

@@ -2,12 +2,11 @@
 """Time one conv shape through tt_conv2d_fwd:  tools/conv_microbench.py N H W Cin Cout k [stride] [dtype] [iters]"""
 import os
 import sys
-import time
 
 import torch
 
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
-from thinktwice_amd import ops, weights  # noqa: E402
+from thinktwice_amd import ops  # noqa: E402
 
 
 def main():
