@@ -570,8 +570,10 @@ def decoder_layer(sd, p, cfg, bev, wp, ctrl, meas, flat, look_args):
     return d_wp, d_ctrl, fut, nb, nf, info
 
 
-def decoder_forward(sd, cfg, flat, bev, meas, lidar2img, ida_mat, fpn_feats):
-    """ThinkTwiceDecoder.forward (inference path) DEC:419-489."""
+def decoder_forward(sd, cfg, flat, bev, meas, lidar2img, ida_mat, fpn_feats, teacher=None):
+    """ThinkTwiceDecoder.forward DEC:419-489; with `teacher` (dict of expert waypoints / Beta parameters) also the
+    teacher-forcing pass DEC:491-533: the same five layers run a second time from the encoder's BEV state with the
+    EXPERT waypoints and inv_softplus(expert control) as constant inputs of every layer."""
     p = "decoder"
     out = {"bev_feature": bev}
     out["pred_speed"] = mlp_seq(sd, p + ".speed_branch", flat, (0, 2, 4))
@@ -621,6 +623,28 @@ def decoder_forward(sd, cfg, flat, bev, meas, lidar2img, ida_mat, fpn_feats):
     out["mu_branches"], out["sigma_branches"] = ct[:, :, 0, :2], ct[:, :, 0, 2:]
     out["future_mu"], out["future_sigma"] = ct[:, :, 1:, :2], ct[:, :, 1:, 2:]
     out["_look_info"] = infos
+    if teacher is not None:
+        t_wp = teacher["waypoints"].float()
+        cur = torch.cat([teacher["action_mu"], teacher["action_sigma"]], -1).unsqueeze(1)
+        fut = torch.cat([torch.stack(teacher["future_action_mu"][:-1], 1),
+                         torch.stack(teacher["future_action_sigma"][:-1], 1)], -1)
+        sp = torch.cat([cur, fut], 1).float()
+        t_ctrl = sp + torch.log(-torch.expm1(-sp))                       # inv_softplus, DEC:22-23
+        cur_bev, cur_flat = bev.clone(), flat.clone()
+        t_dwp, t_dctrl, t_bev, t_flat, t_fut = [], [], [], [], []
+        for L in range(cfg["cfg"]["refine_num"]):
+            d_wp, d_ctrl, futL, cur_bev, cur_flat, _ = decoder_layer(
+                sd, f"{p}.decoder_layers.{L}", cfg, cur_bev, t_wp, t_ctrl, meas, cur_flat, look_args)
+            t_dwp.append(d_wp)
+            t_dctrl.append(d_ctrl)
+            t_bev.append(cur_bev)
+            t_flat.append(cur_flat)
+            t_fut.append(futL)
+        out["teacher_pred_wp_offset"] = torch.stack(t_dwp, 1)
+        out["teacher_pred_ctrl_offset_lis"] = torch.stack(t_dctrl, 1)
+        out["teacher_future_BEV_feature"] = torch.stack(t_fut, 1)
+        out["teacher_refine_flattned_BEV_feature"] = torch.stack(t_flat, 1)
+        out["teacher_refine_BEV_feature"] = torch.stack(t_bev, 1)
     return out
 
 

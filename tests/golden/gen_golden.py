@@ -346,7 +346,36 @@ def gen_f9():
     _save("f9_control.npz", **{k: np.asarray(v, dtype=np.float64) for k, v in rec.items()})
 
 
-FIXTURES = {"F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8, "F9": gen_f9}
+def gen_f10():
+    """F10: the reference's TRAINING forward (`EncoderDecoder.forward_train`: teacher-forcing pass + every loss term)
+    under model.eval() (running-statistics BN), B=2 128x256, synthetic supervision; oracle/train_ref.py must
+    reproduce every loss."""
+    from oracle import train_ref as TR
+    from thinktwice_amd import config, params, synth
+    B, hw, npts, seed = 2, (128, 256), 20000, 0
+    cfg = config.model_config(final_dim=hw)
+    sd = params.init_params(cfg, seed=seed)
+    model = build_reference_model(cfg, sd)
+    batch = synth.make_batch(B, img_hw=hw, num_points=npts)
+    batch.update(synth.make_train_targets(B, img_hw=hw))
+    with torch.no_grad():
+        ref = model.forward_train(batch)
+        ora, _ = TR.forward_train(sd, cfg, batch)
+    pack, worst = {}, 0.0
+    assert set(ref) == set(ora), (sorted(set(ref) ^ set(ora)))
+    for k, v in ref.items():
+        v = v.detach().float()
+        e = float((v - ora[k]).abs().max() / v.abs().max().clamp_min(1e-12))
+        worst = max(worst, e)
+        print(f"  {k:40s} {tuple(v.shape)} ref {float(v.mean()):+.6e}  oracle rel err {e:.2e}")
+        pack[k] = v.numpy()
+    assert worst < 1e-5, worst
+    pack["meta"] = np.array([B, hw[0], hw[1], npts, seed])
+    pack["oracle_vs_reference_worst_rel_err"] = np.array([worst])
+    _save("f10_train_losses_b2.npz", **pack)
+
+
+FIXTURES = {"F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8, "F9": gen_f9, "F10": gen_f10}
 
 
 def main():

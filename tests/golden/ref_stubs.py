@@ -203,7 +203,20 @@ def install(third_party=None):
     _mod("mmdet3d")
     _mod("mmdet3d.models", builder=builder, build_neck=lambda cfg: tp("build_neck")(cfg))
     _mod("torchvision")
-    _mod("torchvision.transforms")
+
+    class _InterpolationMode:          # [3P] torchvision.transforms.InterpolationMode
+        NEAREST = "nearest"
+
+    class _Resize:                     # [3P] torchvision.transforms.Resize on tensors = F.interpolate
+        def __init__(self, size, interpolation="nearest"):
+            assert interpolation == "nearest"
+            self.size = tuple(size)
+
+        def __call__(self, x):
+            import torch.nn.functional as F
+            return F.interpolate(x[None].float(), size=self.size, mode="nearest")[0].to(x.dtype)
+
+    _mod("torchvision.transforms", Resize=_Resize, InterpolationMode=_InterpolationMode)
 
     # the reference's python wrapper imports `voxel_pooling_ext` relative to ops.voxel_pooling
     ext = types.ModuleType("ops.voxel_pooling.voxel_pooling_ext")

@@ -73,6 +73,38 @@ def test_oracle_forward_matches_reference_golden_small(golden_dir):
     assert out["refine_future_BEV_feature"].shape == (B, 5, 4, 32, 21, 21)
 
 
+def test_oracle_train_losses_match_reference_golden(golden_dir):
+    """SURVEY 8f-4 groundwork: the training forward (teacher-forcing pass + all 23 loss terms + seg focal loss + depth
+    BCE) of oracle/train_ref.py against the reference's own `forward_train` (model.eval(), F10)."""
+    from oracle import train_ref as TR
+    pack = np.load(os.path.join(golden_dir, "f10_train_losses_b2.npz"))
+    B, H, W, npts, seed = (int(v) for v in pack["meta"])
+    cfg = config.model_config(final_dim=(H, W))
+    sd = params.init_params(cfg, seed=seed)
+    batch = synth.make_batch(B, img_hw=(H, W), num_points=npts)
+    batch.update(synth.make_train_targets(B, img_hw=(H, W)))
+    with torch.no_grad():
+        losses, pred = TR.forward_train(sd, cfg, batch)
+    names = [k for k in pack.files if k not in ("meta", "oracle_vs_reference_worst_rel_err")]
+    assert len(names) == 23 and set(names) == set(losses)
+    for k in names:
+        got, want = losses[k].detach().float().numpy(), pack[k]
+        assert got.shape == want.shape, k                      # value_loss keeps the reference's (B,1) shape
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7, err_msg=k)
+    assert float(pack["oracle_vs_reference_worst_rel_err"][0]) == 0.0
+    # teacher-forcing outputs (DEC:525-532)
+    assert pred["teacher_pred_wp_offset"].shape == (B, 5, 4, 2)
+    assert pred["teacher_pred_ctrl_offset_lis"].shape == (B, 5, 4, 4)
+    assert pred["teacher_future_BEV_feature"].shape == (B, 5, 4, 32, 21, 21)
+    # the supervised parts respond to the supervision: perfect expert waypoints zero the wp-offset statistic
+    b2 = dict(batch)
+    b2["waypoints"] = pred["pred_wp"][:, -1].clone()
+    with torch.no_grad():
+        l2 = TR.decoder_loss(cfg, b2, pred, [None, None, pred["bev_feature"], *[torch.zeros(1)] * 3][:3] +
+                             [batch["grid_feature"][i] for i in (3, 4, 5)])
+    assert float(l2["longitudinal_offset"]) == 0.0 and float(l2["lateral_offset"]) == 0.0
+
+
 def test_sca_batch_coupling_quirk():
     """MSDA:338-341: outputs depend on the local batch size (first B slots zeroed, / B)."""
     cfg = config.model_config(final_dim=(128, 256), refine_num=1)

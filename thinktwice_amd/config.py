@@ -16,6 +16,8 @@ CFG = dict(
     img_size=(448, 896),                                         # CFG:113,120
     num_cams=4, queue_length=2,                                  # CFG:99-104
     num_seg_type=11,                                             # CFG:108-109: 9 labels + 2
+    value_weight=0.001, features_weight=0.05,                    # CFG:59-60 (training losses)
+    use_depth=True, use_seg=True,                                # CFG:106-107 (training supervision)
 )
 
 MODEL = dict(

@@ -65,3 +65,27 @@ def make_batch(batch_size, seed=1234, num_points=65536, img_hw=(calib.FINAL_H, c
     if with_img:
         batch["img"] = torch.stack(imgs).to(device)
     return batch
+
+
+def make_train_targets(batch_size, img_hw=(calib.FINAL_H, calib.FINAL_W), seed=4321, num_cams=4):
+    """Synthetic supervision for `forward_train` with the shapes the reference dataset collates
+    (carla_dataset.py / thinktwice_decoder.py:536-619, encoder_decoder_framework.py:148-191):
+    expert waypoints and Beta action parameters (current + 4 future steps), expert value / flattened feature /
+    BEV grid features (Roach maps: 32x21x21, 64x10x10, 128x4x4, 256x2x2 at list indices 2..5), future grid
+    features, sparse per-camera depth maps in metres (0 = no return) and 12-class segmentation labels."""
+    g = torch.Generator().manual_seed(seed)
+    B, (H, W) = batch_size, img_hw
+    r = lambda *s: torch.randn(*s, generator=g)                       # noqa: E731
+    pos = lambda *s: torch.rand(*s, generator=g) * 4.0 + 0.2          # noqa: E731  Beta parameters > 0
+    grid = lambda: [r(B, 1), r(B, 1), r(B, 32, 21, 21), r(B, 64, 10, 10), r(B, 128, 4, 4), r(B, 256, 2, 2)]   # noqa: E731
+    depth = torch.rand(B, num_cams, H, W, generator=g) * 45.0
+    depth[torch.rand(B, num_cams, H, W, generator=g) < 0.9] = 0.0     # LiDAR-projected depth is sparse
+    return {
+        "waypoints": r(B, 4, 2) * 3.0,
+        "action_mu": pos(B, 2), "action_sigma": pos(B, 2),
+        "future_action_mu": [pos(B, 2) for _ in range(4)], "future_action_sigma": [pos(B, 2) for _ in range(4)],
+        "value": r(B), "feature": r(B, 256),
+        "grid_feature": grid(), "future_grid_feature": [grid() for _ in range(4)],
+        "depth": depth,
+        "seg": torch.randint(0, 12, (B, num_cams, H, W), generator=g).float(),
+    }
