@@ -75,3 +75,45 @@ def test_fusion_and_decoder_match_oracle(B):
         errs[k] = _rel(out[k].cpu(), ref[k])
     print(B, errs)
     assert max(errs.values()) < 1e-3, errs
+
+
+def test_decoder_teacher_forcing_pass_matches_oracle():
+    """SURVEY 8f-4 (forward half): the teacher-forcing pass (DEC:491-533) -- five layers fed the expert waypoints and
+    inv_softplus(expert Beta parameters) -- against the oracle, which reproduces the reference's training forward
+    bit-exactly (golden F10).  The ordinary outputs must be unaffected by the extra pass."""
+    from oracle import model_ref as M
+    from thinktwice_amd import config, params, synth, weights
+    from thinktwice_amd.encoder_decoder import EncoderDecoder
+    from thinktwice_amd.fusion import BEVFusion
+    from thinktwice_amd.decoder import ThinkTwiceDecoder
+    from thinktwice_amd.layers import linear_from_sd
+    B, hw = 2, (128, 256)
+    cfg = config.model_config(final_dim=hw)
+    sd = params.init_params(cfg, seed=0, parts=("fusion", "decoder"))
+    cam_bev, lidar, fpn, batch, l2i, ida = _inputs(B, hw)
+    tgt = synth.make_train_targets(B, img_hw=hw)
+    teacher = {k: tgt[k] for k in ("waypoints", "action_mu", "action_sigma", "future_action_mu", "future_action_sigma")}
+    with torch.no_grad():
+        meas_r = M.measurement_feat(sd, batch)
+        flat_r, bev_r, _ = M.fusion(sd, cam_bev, lidar)
+        ref = M.decoder_forward(sd, cfg, flat_r, bev_r, meas_r, l2i, ida, fpn, teacher=teacher)
+    dev = torch.device("cuda")
+    par = EncoderDecoder.__new__(EncoderDecoder)
+    par.device = dev
+    par.fusion = BEVFusion(sd, dev)
+    par.meas0 = linear_from_sd(sd, "measurements_encoder.0", dev, act="relu", in_pad=12)
+    par.meas2 = linear_from_sd(sd, "measurements_encoder.2", dev, act="relu")
+    meas = par.measurement_feat(batch)
+    flat, bev32, _ = par.fusion(weights.to_channel_last(cam_bev).cuda(), weights.to_channel_last(lidar).cuda())
+    dec = ThinkTwiceDecoder(config=cfg["cfg"], bev_h=21, bev_w=21).load_state_dict(sd)
+    fpn_cl = [(weights.to_channel_last(f).cuda(), 0, 256) for f in fpn]
+    t_dev = {k: ([t.cuda() for t in v] if isinstance(v, list) else v.cuda()) for k, v in teacher.items()}
+    out = dec(flat, bev32, meas, batch["target_point"], par, t_dev, [l2i, ida, fpn_cl, None])
+    torch.cuda.synchronize()
+    errs = {}
+    for k in ("teacher_pred_wp_offset", "teacher_pred_ctrl_offset_lis", "teacher_future_BEV_feature",
+              "teacher_refine_flattned_BEV_feature", "teacher_refine_BEV_feature", "pred_wp", "refine_BEV_feature"):
+        assert out[k].shape == ref[k].shape, (k, out[k].shape, ref[k].shape)
+        errs[k] = _rel(out[k].cpu(), ref[k])
+    print(errs)
+    assert max(errs.values()) < 1e-3, errs

@@ -6,7 +6,8 @@ with its LookModule / SpatialCrossAttention / MSDeformableAttention3D / SpatialG
 Same state_dict keys and the same output dict (keys/shapes of SURVEY 8a A22).  All query packing is
 done on the device (no host sync inside the 5-layer loop); dead branches of the reference
 (LiDAR look features zeroed at DEC:186, PredictionModule.ffn discarded at DEC:44-46) are not
-computed -- their parameters are accepted and ignored.
+computed -- their parameters are accepted and ignored.  With `teacher_forcing_data` the decoder also runs the
+teacher-forcing pass of the training step (DEC:491-533); losses and backward are not part of this build.
 """
 import torch
 
@@ -180,8 +181,6 @@ class ThinkTwiceDecoder:
         """flattend_BEV_feat (B,256), BEV_feat channel-last (B,21,21,32), measurement_feat (B,128) f32 on
         device; look_feature_metadata = [lidar2img (B,4,4,4), ida_mat (B,4,4,4), fpn (4 x (tensor, coff, C))
         channel-last, lidar feature (unused: the LiDAR look branch is zeroed, DEC:186)]."""
-        if teacher_forcing_data is not None:
-            raise _lib.TTError("teacher forcing (training path) is not part of this build")
         flat, bev, meas = flattend_BEV_feat, BEV_feat, measurement_feat
         B = flat.shape[0]
         dev = flat.device
@@ -236,89 +235,132 @@ class ThinkTwiceDecoder:
         s_bev = torch.empty(B, self.refine_num, H, W, 32, dtype=F32, device=dev)
         s_flat = torch.empty(B, self.refine_num, 256, dtype=F32, device=dev)
         s_fut = torch.empty(B, self.refine_num, 4, H, W, 32, dtype=F32, device=dev)
-        cur_bev, cur_flat = bev, flat
-        look_info = []
-        for L, lay in enumerate(self.layers):
-            wp = wp_all[:, L].contiguous()
-            ctrl = ctrl_all[:, L].contiguous()
-            sp = ops.ew(3, ctrl.view(B * 4, 4), act=_lib.ACT_SOFTPLUS).view(B, 4, 4)
-            inp6 = torch.empty(B, 4, 6, dtype=F32, device=dev)
-            ops.ew(3, wp.view(B * 4, 2), out=inp6.view(B * 4, 6), C=2, out_coff=0)
-            ops.ew(3, sp.view(B * 4, 4), out=inp6.view(B * 4, 6), C=4, out_coff=2)
-            fut = torch.empty(B, 4, H, W, 32, dtype=F32, device=dev)
-            # The prediction branch (conv-GRU, 4 steps x 8 small convs, + the shared flatten network) and the look
-            # branch (value projections, MSDA sampling, attention MLPs) only meet at the concat below: run the
-            # former on a second HIP stream.  Both are chains of microsecond-scale launches on a few CUs each, so
-            # they overlap almost perfectly (DEC:428-447 runs them back to back).
-            fork = getattr(parent_module, "use_side_stream", True)
-            if fork:
-                main = torch.cuda.current_stream(dev)
-                if self._branch is None:
-                    self._branch = torch.cuda.Stream(dev)
-                self._branch.wait_stream(main)
-                fut.record_stream(self._branch)           # written by the GRU and re-read by bev_update() there
-                inp6.record_stream(self._branch)
-                with torch.cuda.stream(self._branch):
+        def run_pass(inputs_of, emit, s_bev, s_flat, s_fut, wait_values):
+            """The five refinement layers (DEC:428-447).  `inputs_of(L)` -> (wp, ctrl) fed to layer L, `emit(L, d_wp,
+            d_ctrl, wp, ctrl)` consumes its offsets; the main pass chains them, the teacher-forcing pass feeds the
+            expert's values to every layer."""
+            cur_bev, cur_flat = bev, flat
+            look_info = []
+            for L, lay in enumerate(self.layers):
+                wp, ctrl = inputs_of(L)
+                sp = ops.ew(3, ctrl.view(B * 4, 4), act=_lib.ACT_SOFTPLUS).view(B, 4, 4)
+                inp6 = torch.empty(B, 4, 6, dtype=F32, device=dev)
+                ops.ew(3, wp.view(B * 4, 2), out=inp6.view(B * 4, 6), C=2, out_coff=0)
+                ops.ew(3, sp.view(B * 4, 4), out=inp6.view(B * 4, 6), C=4, out_coff=2)
+                fut = torch.empty(B, 4, H, W, 32, dtype=F32, device=dev)
+                # The prediction branch (conv-GRU, 4 steps x 8 small convs, + the shared flatten network) and the look
+                # branch (value projections, MSDA sampling, attention MLPs) only meet at the concat below: run the
+                # former on a second HIP stream.  Both are chains of microsecond-scale launches on a few CUs each, so
+                # they overlap almost perfectly (DEC:428-447 runs them back to back).
+                fork = getattr(parent_module, "use_side_stream", True)
+                if fork:
+                    main = torch.cuda.current_stream(dev)
+                    if self._branch is None:
+                        self._branch = torch.cuda.Stream(dev)
+                    self._branch.wait_stream(main)
+                    fut.record_stream(self._branch)           # written by the GRU and re-read by bev_update() there
+                    inp6.record_stream(self._branch)
+                    with torch.cuda.stream(self._branch):
+                        lay.gru(inp6, cur_bev, fut)
+                        fflat = parent_module.flatten_tail(fut.view(B * 4, H, W, 32))    # (B*4,256)
+                else:
                     lay.gru(inp6, cur_bev, fut)
-                    fflat = parent_module.flatten_tail(fut.view(B * 4, H, W, 32))    # (B*4,256)
-            else:
-                lay.gru(inp6, cur_bev, fut)
-                fflat = parent_module.flatten_tail(fut.view(B * 4, H, W, 32))        # (B*4,256)
-            look, info = self._look(lay, B, wp, sp, meas, cur_flat, lidar2img, ida_mat, mlvl, level_hw, S,
-                                    (value_all, L, vready if L == 0 else None))
+                    fflat = parent_module.flatten_tail(fut.view(B * 4, H, W, 32))        # (B*4,256)
+                look, info = self._look(lay, B, wp, sp, meas, cur_flat, lidar2img, ida_mat, mlvl, level_hw, S,
+                                        (value_all, L, vready if (L == 0 and wait_values) else None))
+                if fork:
+                    main.wait_stream(self._branch)
+                    fflat.record_stream(main)
+                look_info.append(info)
+                # [future flat 256 | look 256 | zeros 256 (LiDAR look) | temporal 128 | meas 128]
+                hin = torch.zeros(B * 4, 1024, dtype=F32, device=dev)
+                ops.ew(3, fflat, out=hin, C=256, out_coff=0)
+                hv = hin.view(B, 4, 1024)
+                for t in range(4):
+                    ops.ew(3, look, out=hv[:, t], C=256, out_coff=256)
+                    ops.ew(3, meas, out=hv[:, t], C=128, out_coff=896)
+                    ops.ew(3, self.temporal[t:t + 1].expand(B, 128), out=hv[:, t], C=128, out_coff=768)
+                hn = ops.layernorm_rows(hin, lay.mlp_ln[0], lay.mlp_ln[1])
+                h = unrows(lay.mlp4(lay.mlp1(rows(hn))))                                 # (B*4,512)
+                tin = torch.zeros(B * 4, 516, dtype=F32, device=dev)
+                ops.ew(3, wp.view(B * 4, 2), out=tin, C=2, out_coff=0)
+                ops.ew(3, h, out=tin, C=512, out_coff=2)
+                d_wp = unrows(_run(lay.traj, rows(tin)))                                  # (B*4,2)
+                cin = torch.empty(B * 4, 516, dtype=F32, device=dev)
+                ops.ew(3, ctrl.view(B * 4, 4), out=cin, C=4, out_coff=0)
+                ops.ew(3, h, out=cin, C=512, out_coff=4)
+                d_ctrl = unrows(_run(lay.ctrl, rows(cin)))                                # (B*4,4)
+                emit(L, d_wp, d_ctrl, wp, ctrl)
+                hb = h.view(B, 2048)
+
+                def bev_update():
+                    xb = torch.empty(B, H, W, 2080, dtype=F32, device=dev)
+                    ops.copy_nhwc(cur_bev, xb, out_coff=0)
+                    ops.broadcast_rows(hb, xb, out_coff=32)
+                    nb = lay.bev2(lay.bev0(xb), res1=cur_bev)
+                    ops.ew(3, nb.view(B, -1), out=s_bev[:, L].view(B, -1))
+                    ops.ew(3, fut.view(B, -1), out=s_fut[:, L].view(B, -1))
+                    return nb
+
+                # the BEV-map update (K = 18,720 conv) only feeds the NEXT layer's GRU: it stays on the prediction
+                # stream, beside this layer's offset heads and flattened-feature update on the main stream
+                if fork:
+                    self._branch.wait_stream(main)                # h is ready
+                    h.record_stream(self._branch)
+                    with torch.cuda.stream(self._branch):
+                        new_bev = bev_update()
+                else:
+                    new_bev = bev_update()
+                fin = torch.empty(B, 2304, dtype=F32, device=dev)
+                ops.ew(3, cur_flat, out=fin, C=256, out_coff=0)
+                ops.ew(3, hb, out=fin, C=2048, out_coff=256)
+                new_flat = unrows(lay.flat2(lay.flat0(rows(fin)), res1=rows(cur_flat)))
+                ops.ew(3, new_flat, out=s_flat[:, L])
+                cur_bev, cur_flat = new_bev, new_flat
             if fork:
-                main.wait_stream(self._branch)
-                fflat.record_stream(main)
-            look_info.append(info)
-            # [future flat 256 | look 256 | zeros 256 (LiDAR look) | temporal 128 | meas 128]
-            hin = torch.zeros(B * 4, 1024, dtype=F32, device=dev)
-            ops.ew(3, fflat, out=hin, C=256, out_coff=0)
-            hv = hin.view(B, 4, 1024)
-            for t in range(4):
-                ops.ew(3, look, out=hv[:, t], C=256, out_coff=256)
-                ops.ew(3, meas, out=hv[:, t], C=128, out_coff=896)
-                ops.ew(3, self.temporal[t:t + 1].expand(B, 128), out=hv[:, t], C=128, out_coff=768)
-            hn = ops.layernorm_rows(hin, lay.mlp_ln[0], lay.mlp_ln[1])
-            h = unrows(lay.mlp4(lay.mlp1(rows(hn))))                                 # (B*4,512)
-            tin = torch.zeros(B * 4, 516, dtype=F32, device=dev)
-            ops.ew(3, wp.view(B * 4, 2), out=tin, C=2, out_coff=0)
-            ops.ew(3, h, out=tin, C=512, out_coff=2)
-            d_wp = unrows(_run(lay.traj, rows(tin)))                                  # (B*4,2)
-            cin = torch.empty(B * 4, 516, dtype=F32, device=dev)
-            ops.ew(3, ctrl.view(B * 4, 4), out=cin, C=4, out_coff=0)
-            ops.ew(3, h, out=cin, C=512, out_coff=4)
-            d_ctrl = unrows(_run(lay.ctrl, rows(cin)))                                # (B*4,4)
+                main.wait_stream(self._branch)                    # last BEV update, s_bev / s_fut
+                cur_bev.record_stream(main)
+            return look_info
+
+        def chained_inputs(L):
+            return wp_all[:, L].contiguous(), ctrl_all[:, L].contiguous()
+
+        def chained_emit(L, d_wp, d_ctrl, wp, ctrl):
             ops.ew(0, d_wp.view(B, 8), b=wp.view(B, 8), out=wp_all[:, L + 1].view(B, 8))
             ops.ew(0, d_ctrl.view(B, 16), b=ctrl.view(B, 16), out=ctrl_all[:, L + 1].view(B, 16))
-            hb = h.view(B, 2048)
 
-            def bev_update():
-                xb = torch.empty(B, H, W, 2080, dtype=F32, device=dev)
-                ops.copy_nhwc(cur_bev, xb, out_coff=0)
-                ops.broadcast_rows(hb, xb, out_coff=32)
-                nb = lay.bev2(lay.bev0(xb), res1=cur_bev)
-                ops.ew(3, nb.view(B, -1), out=s_bev[:, L].view(B, -1))
-                ops.ew(3, fut.view(B, -1), out=s_fut[:, L].view(B, -1))
-                return nb
+        look_info = run_pass(chained_inputs, chained_emit, s_bev, s_flat, s_fut, True)
 
-            # the BEV-map update (K = 18,720 conv) only feeds the NEXT layer's GRU: it stays on the prediction
-            # stream, beside this layer's offset heads and flattened-feature update on the main stream
-            if fork:
-                self._branch.wait_stream(main)                # h is ready
-                h.record_stream(self._branch)
-                with torch.cuda.stream(self._branch):
-                    new_bev = bev_update()
+        if teacher_forcing_data is not None:
+            # Teacher-forcing pass (DEC:491-533, the forward half of the training step): the same five layers from the
+            # encoder's BEV state again, every layer fed the EXPERT waypoints and inv_softplus(expert Beta parameters);
+            # its offsets are regressed to zero by the training losses.
+            tf = teacher_forcing_data
+            t_wp = tf["waypoints"].to(dev, F32).contiguous()
+            spx = torch.cat([torch.cat([tf["action_mu"], tf["action_sigma"]], -1).unsqueeze(1),
+                             torch.cat([torch.stack(list(tf["future_action_mu"][:-1]), 1),
+                                        torch.stack(list(tf["future_action_sigma"][:-1]), 1)], -1)], 1).to(dev, F32)
+            t_ctrl = (spx + torch.log(-torch.expm1(-spx))).contiguous()      # inv_softplus of B x 16 inputs (DEC:22-23)
+            R = self.refine_num
+            t_dwp = torch.empty(B, R, 4, 2, dtype=F32, device=dev)
+            t_dctrl = torch.empty(B, R, 4, 4, dtype=F32, device=dev)
+            t_bev = torch.empty(B, R, H, W, 32, dtype=F32, device=dev)
+            t_flat = torch.empty(B, R, 256, dtype=F32, device=dev)
+            t_fut = torch.empty(B, R, 4, H, W, 32, dtype=F32, device=dev)
+
+            def teacher_emit(L, d_wp, d_ctrl, wp, ctrl):
+                ops.ew(3, d_wp.view(B, 8), out=t_dwp[:, L].view(B, 8))
+                ops.ew(3, d_ctrl.view(B, 16), out=t_dctrl[:, L].view(B, 16))
+
+            run_pass(lambda L: (t_wp, t_ctrl), teacher_emit, t_bev, t_flat, t_fut, False)
+            outs["teacher_pred_wp_offset"], outs["teacher_pred_ctrl_offset_lis"] = t_dwp, t_dctrl
+            outs["teacher_refine_flattned_BEV_feature"] = t_flat
+            if channel_last_out:
+                outs["_teacher_refine_bev_cl"], outs["_teacher_fut_cl"] = t_bev, t_fut
             else:
-                new_bev = bev_update()
-            fin = torch.empty(B, 2304, dtype=F32, device=dev)
-            ops.ew(3, cur_flat, out=fin, C=256, out_coff=0)
-            ops.ew(3, hb, out=fin, C=2048, out_coff=256)
-            new_flat = unrows(lay.flat2(lay.flat0(rows(fin)), res1=rows(cur_flat)))
-            ops.ew(3, new_flat, out=s_flat[:, L])
-            cur_bev, cur_flat = new_bev, new_flat
-        if fork:
-            main.wait_stream(self._branch)                    # last BEV update, s_bev / s_fut
-            cur_bev.record_stream(main)
+                outs["teacher_refine_BEV_feature"] = ops.nhwc_to_nchw(t_bev.view(B * R, H, W, 32)).view(B, R, 32, H, W)
+                outs["teacher_future_BEV_feature"] = ops.nhwc_to_nchw(t_fut.view(B * R * 4, H, W, 32)).view(
+                    B, R, 4, 32, H, W)                              # plain stack (DEC:523), not the DEC:481 re-view
         ct = ops.ew(3, ctrl_all.view(B * R1 * 4, 4), act=_lib.ACT_SOFTPLUS_CLAMP).view(B, R1, 4, 4)
         outs["pred_wp"] = wp_all
         outs["mu_branches"], outs["sigma_branches"] = ct[:, :, 0, :2], ct[:, :, 0, 2:]

@@ -119,8 +119,10 @@ class EncoderDecoder:
         lidar.record_stream(main)
         return cam, cam_bev, lidar
 
-    def forward_inference(self, batch, channel_last_out=False, consts=None, prev_bev=None):
+    def forward_inference(self, batch, channel_last_out=False, consts=None, prev_bev=None, teacher=None):
         """`consts`: optional device copies of `LSS.host_constants(batch["img_metas"])` (see InferenceGraph).
+        `teacher`: expert waypoints / Beta parameters (`waypoints`, `action_mu/sigma`, `future_action_mu/sigma`): also
+        run the decoder's teacher-forcing pass and return its `teacher_*` outputs (forward half of `forward_train`).
         `prev_bev`: cached previous-sweep BEV (see LSS.forward / PrevSweepCache); the camera trunk then runs on the
         key sweep only.  `pred["_key_bev_cl"]` is this call's key-sweep BEV for the cache."""
         if not self.loaded:
@@ -130,7 +132,7 @@ class EncoderDecoder:
         cam, cam_bev, lidar = self.extract_sensor_feat(batch["img"], batch["img_metas"], batch.get("points"),
                                                        consts=consts, prev_bev=prev_bev)
         flat, bev32, mids = self.fusion(cam_bev, lidar)
-        pred = self.decoder(flat, bev32, meas, batch["target_point"], self, None,
+        pred = self.decoder(flat, bev32, meas, batch["target_point"], self, teacher,
                             [cam["lidar2img"], cam["ida_mat"], cam["_fpn_cl"], lidar],
                             channel_last_out=channel_last_out)
         pred["_cam_bev_cl"], pred["_lidar_bev_cl"], pred["_flat"], pred["_meas"] = cam_bev, lidar, flat, meas
@@ -138,7 +140,8 @@ class EncoderDecoder:
         return pred
 
     def forward_train(self, batch):
-        raise _lib.TTError("training forward (losses / teacher forcing) is a later scope row (SURVEY 8f-4)")
+        raise _lib.TTError("training step (losses, backward, optimizer) is a later scope row (SURVEY 8f-4); the forward "
+                           "half incl. the teacher-forcing pass is forward_inference(batch, teacher=...)")
 
     def train_step(self, data, optimizer):
         return self.forward_train(data)
