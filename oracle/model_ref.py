@@ -31,7 +31,15 @@ def linear(sd, p, x):
     return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
 
 
+# Training-mode switch (oracle/train_ref.py `train_mode()`): BatchNorm normalises with the statistics of the batch
+# in front of it (running statistics are NOT updated here: the loss does not depend on them) and the one Dropout with
+# p > 0 on the path (ASPP, LSS:91) draws its mask from torch's global RNG.  False = inference semantics.
+TRAIN_MODE = False
+
+
 def bn(sd, p, x, eps=1e-5):
+    if TRAIN_MODE:
+        return F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.0, eps)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"],
                         sd[p + ".bias"], False, 0.0, eps)
 
@@ -120,7 +128,7 @@ def dcn(sd, p, x, groups=4):
 
 # ----------------------------------------------------------------------------- LSS-owned blocks
 def aspp(sd, p, x):
-    """ASPP, LSS:49-118 (dilations 1/6/12/18; Dropout identity in eval)."""
+    """ASPP, LSS:49-118 (dilations 1/6/12/18; Dropout(0.5) LSS:91,110: identity in eval)."""
     def branch(name, padding, dilation):
         return F.relu(bn(sd, f"{p}.{name}.bn", conv(sd, f"{p}.{name}.atrous_conv", x, 1, padding, dilation)))
     x1 = branch("aspp1", 0, 1)
@@ -131,7 +139,8 @@ def aspp(sd, p, x):
     x5 = F.relu(bn(sd, p + ".global_avg_pool.2", conv(sd, p + ".global_avg_pool.1", x5)))
     x5 = F.interpolate(x5, size=x4.shape[2:], mode="bilinear", align_corners=True)
     y = torch.cat((x1, x2, x3, x4, x5), 1)
-    return F.relu(bn(sd, p + ".bn1", conv(sd, p + ".conv1", y)))
+    y = F.relu(bn(sd, p + ".bn1", conv(sd, p + ".conv1", y)))
+    return F.dropout(y, 0.5, True) if TRAIN_MODE else y
 
 
 def depth_mlp_input(intrin, ida, sensor2ego):
@@ -341,8 +350,11 @@ def sparse_conv3d(st, w, stride, pad):
 
 
 def _sp_bn_relu(sd, p, st, relu=True):
-    f = F.batch_norm(st.feats, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"],
-                     sd[p + ".bias"], False, 0.0, 1e-3)
+    if TRAIN_MODE:
+        f = F.batch_norm(st.feats, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.0, 1e-3)
+    else:
+        f = F.batch_norm(st.feats, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"],
+                         sd[p + ".bias"], False, 0.0, 1e-3)
     return SparseT(F.relu(f) if relu else f, st.coords, st.shape, st.batch)
 
 

@@ -5,12 +5,14 @@ the inference forward (oracle/model_ref.py), the decoder's teacher-forcing pass 
 `ThinkTwiceDecoder.loss` (thinktwice_decoder.py:536-619), the focal segmentation loss (utils.py:31-47,
 encoder_decoder_framework.py:172-176) and the depth BCE (encoder_decoder_framework.py:179-190, 441-481).
 
-Scope note: BatchNorm layers use their RUNNING statistics here (the in-repo reference code has no `self.training`
-branch, so this is exactly what the reference computes under `model.eval()`, and what a frozen-BN fine-tune runs).
-Batch-statistics BN of a from-scratch training run is third-party torch behaviour layered on the same graph and is not
-restated yet.  Pinned against the reference's own `forward_train` under `model.eval()`:
-tests/golden/f10_train_losses_b2.npz (tests/golden/gen_golden.py F10).
+Two modes.  Default: BatchNorm layers use their RUNNING statistics (the in-repo reference code has no `self.training`
+branch, so this is exactly what the reference computes under `model.eval()`, and what a frozen-BN fine-tune runs);
+pinned by tests/golden/f10_train_losses_b2.npz (gen_golden.py F10).  Inside `with train_mode():` every BatchNorm
+normalises with batch statistics (per sweep: the reference runs each sweep through the camera trunk separately,
+lss.py:690-717) and the ASPP Dropout(0.5) (lss.py:91) is live, drawing from torch's global RNG -- what `model.train()`
+computes; pinned by f11_train_losses_trainmode_b2.npz (F11, same seed before both forwards).
 """
+import contextlib
 import torch
 import torch.nn.functional as F
 from torch.distributions import Beta, kl_divergence
@@ -20,6 +22,17 @@ from . import model_ref as M
 DISTIL_INDEX = (2, 3, 4, 5)                                   # DEC:284
 DISTIL_W = {2: 0.25, 3: 1.0 / 3.0, 4: 1.0 / 4.0, 5: 1.0 / 11.0}   # DEC:285
 WP_W = ACTION_W = 15.0                                        # DEC:286-287
+
+
+@contextlib.contextmanager
+def train_mode():
+    """model.train() semantics for the oracle (batch-statistics BN, live ASPP dropout)."""
+    old = M.TRAIN_MODE
+    M.TRAIN_MODE = True
+    try:
+        yield
+    finally:
+        M.TRAIN_MODE = old
 
 
 def action_beta(alpha, beta):

@@ -375,7 +375,40 @@ def gen_f10():
     _save("f10_train_losses_b2.npz", **pack)
 
 
-FIXTURES = {"F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8, "F9": gen_f9, "F10": gen_f10}
+def gen_f11():
+    """F11: as F10 but under model.train(): batch-statistics BatchNorm everywhere (each sweep through the camera trunk
+    on its own) and the live ASPP Dropout(0.5); the same torch seed is set before the reference and the oracle
+    forward so both draw the same dropout masks."""
+    from oracle import train_ref as TR
+    from thinktwice_amd import config, params, synth
+    B, hw, npts, seed, rng = 2, (128, 256), 20000, 0, 20240607
+    cfg = config.model_config(final_dim=hw)
+    sd = params.init_params(cfg, seed=seed)
+    model = build_reference_model(cfg, sd)
+    batch = synth.make_batch(B, img_hw=hw, num_points=npts)
+    batch.update(synth.make_train_targets(B, img_hw=hw))
+    model.train()
+    with torch.no_grad(), TR.train_mode():            # the third-party stand-ins call the oracle blocks: same switch
+        torch.manual_seed(rng)
+        ref = model.forward_train(batch)
+        torch.manual_seed(rng)
+        ora, _ = TR.forward_train(sd, cfg, batch)
+    model.eval()
+    pack, worst = {}, 0.0
+    assert set(ref) == set(ora), (sorted(set(ref) ^ set(ora)))
+    for k, v in ref.items():
+        v = v.detach().float()
+        e = float((v - ora[k]).abs().max() / v.abs().max().clamp_min(1e-12))
+        worst = max(worst, e)
+        print(f"  {k:40s} {tuple(v.shape)} ref {float(v.mean()):+.6e}  oracle rel err {e:.2e}")
+        pack[k] = v.numpy()
+    assert worst < 1e-5, worst
+    pack["meta"] = np.array([B, hw[0], hw[1], npts, seed, rng])
+    pack["oracle_vs_reference_worst_rel_err"] = np.array([worst])
+    _save("f11_train_losses_trainmode_b2.npz", **pack)
+
+
+FIXTURES = {"F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8, "F9": gen_f9, "F10": gen_f10, "F11": gen_f11}
 
 
 def main():

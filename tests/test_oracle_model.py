@@ -105,6 +105,29 @@ def test_oracle_train_losses_match_reference_golden(golden_dir):
     assert float(l2["longitudinal_offset"]) == 0.0 and float(l2["lateral_offset"]) == 0.0
 
 
+def test_oracle_train_mode_losses_match_reference_golden(golden_dir):
+    """As above under model.train(): batch-statistics BatchNorm (per sweep) and the live ASPP Dropout(0.5), same torch
+    seed as the generator (F11)."""
+    from oracle import train_ref as TR
+    pack = np.load(os.path.join(golden_dir, "f11_train_losses_trainmode_b2.npz"))
+    B, H, W, npts, seed, rng = (int(v) for v in pack["meta"])
+    cfg = config.model_config(final_dim=(H, W))
+    sd = params.init_params(cfg, seed=seed)
+    batch = synth.make_batch(B, img_hw=(H, W), num_points=npts)
+    batch.update(synth.make_train_targets(B, img_hw=(H, W)))
+    with torch.no_grad(), TR.train_mode():
+        torch.manual_seed(rng)
+        losses, _ = TR.forward_train(sd, cfg, batch)
+    assert M.TRAIN_MODE is False                                   # the switch is scoped
+    names = [k for k in pack.files if k not in ("meta", "oracle_vs_reference_worst_rel_err")]
+    assert len(names) == 23
+    for k in names:
+        np.testing.assert_allclose(losses[k].detach().float().numpy(), pack[k], rtol=1e-5, atol=1e-7, err_msg=k)
+    # and it is a different computation from the running-statistics one
+    eval_pack = np.load(os.path.join(golden_dir, "f10_train_losses_b2.npz"))
+    assert abs(float(pack["speed_loss"]) - float(eval_pack["speed_loss"])) > 0.1
+
+
 def test_sca_batch_coupling_quirk():
     """MSDA:338-341: outputs depend on the local batch size (first B slots zeroed, / B)."""
     cfg = config.model_config(final_dim=(128, 256), refine_num=1)
