@@ -211,6 +211,15 @@ def lift_splat(depth_logits, context, geom_idx, voxel_num, num_cams):
     B = BN // num_cams
     vol = depth_logits.softmax(1).unsqueeze(1) * context.unsqueeze(2)          # (BN,C,D,H,W)
     vol = vol.reshape(B, num_cams, C, D, H, W).permute(0, 1, 3, 4, 5, 2).contiguous()
+    if torch.is_grad_enabled() and vol.requires_grad:
+        # differentiable form for gradient checks: index_add over the in-range points == the reference's autograd
+        # Function (forward VP.cu:9-36, backward = gather of grad_out by pos_memo, voxel_pooling.py:57-69)
+        vx, vy, vz = (int(v) for v in voxel_num)
+        g = geom_idx.reshape(B, -1, 3).long()
+        ok = (g[..., 0] >= 0) & (g[..., 0] < vx) & (g[..., 1] >= 0) & (g[..., 1] < vy) & (g[..., 2] >= 0) & (g[..., 2] < vz)
+        lin = (torch.arange(B).view(B, 1) * vy + g[..., 1]) * vx + g[..., 0]
+        flat = torch.zeros(B * vy * vx, C).index_add(0, lin[ok], vol.reshape(B, -1, C)[ok])
+        return flat.view(B, vy, vx, C).permute(0, 3, 1, 2).contiguous()
     out, _ = c_ref.voxel_pool_fwd(geom_idx.reshape(B, -1, 3).numpy(), vol.reshape(B, -1, C).numpy(),
                                   [int(v) for v in voxel_num], acc64=False, want_pos_memo=False)
     return torch.from_numpy(out).permute(0, 3, 1, 2).contiguous()               # (B,C,Y,X)
@@ -226,7 +235,7 @@ def lss_single_sweep(sd, p, cfg, imgs, mats, geom_idx):
     df = depth_net(sd, p + ".depth_net", src, depth_mlp_input(*mats))
     depth, ctx = df[:, :D], df[:, D:D + 256]
     seg = unet(sd, p + ".seg_net", fpn)
-    segf = seg_to_feature(sd, p + ".seg_res_to_image_feature", seg)
+    segf = seg_to_feature(sd, p + ".seg_res_to_image_feature", seg.detach())       # LSS:589 seg_output.detach()
     ctx = conv(sd, p + ".merge_seg_and_image", torch.cat((ctx, segf), 1), 1, 1)
     bev = lift_splat(depth, ctx, geom_idx, sd[p + ".voxel_num"], N)
     return {"bev": bev, "fpn_feats": fpn, "seg": seg, "depth": depth, "context": ctx}
@@ -243,7 +252,8 @@ def lss_forward(sd, p, cfg, img, img_metas):
     bevs = [key["bev"]]
     T = img.shape[1]
     for s in range(1, T):
-        bevs.append(lss_single_sweep(sd, p, cfg, img[:, T - 1 - s], mats, idx)["bev"])
+        with torch.no_grad():                                                       # LSS:711 older sweeps carry no grad
+            bevs.append(lss_single_sweep(sd, p, cfg, img[:, T - 1 - s], mats, idx)["bev"])
     bev = torch.cat(bevs, 1)
     if T > 1:
         bev = F.conv2d(bev, sd[p + ".bev_multiframe_merge.weight"], None, 1, 1)
@@ -615,10 +625,11 @@ def decoder_forward(sd, cfg, flat, bev, meas, lidar2img, ida_mat, fpn_feats, tea
     cur_bev, cur_flat = bev.clone(), flat.clone()
     s_bev, s_flat, s_fut, infos = [], [], [], []
     for L in range(cfg["cfg"]["refine_num"]):
+        wp_in, ctrl_in = wps[-1].detach(), ctrls[-1].detach()                      # DEC:429-430
         d_wp, d_ctrl, fut, cur_bev, cur_flat, info = decoder_layer(
-            sd, f"{p}.decoder_layers.{L}", cfg, cur_bev, wps[-1], ctrls[-1], meas, cur_flat, look_args)
-        wps.append(d_wp + wps[-1])
-        ctrls.append(d_ctrl + ctrls[-1])
+            sd, f"{p}.decoder_layers.{L}", cfg, cur_bev, wp_in, ctrl_in, meas, cur_flat, look_args)
+        wps.append(d_wp + wp_in)
+        ctrls.append(d_ctrl + ctrl_in)
         s_bev.append(cur_bev)
         s_flat.append(cur_flat)
         s_fut.append(fut)

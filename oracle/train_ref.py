@@ -134,6 +134,11 @@ def depth_loss(depth_logits, gt_depth, d_bound, factor=16):
     return F.binary_cross_entropy_with_logits(pred[fg], onehot[fg], reduction="none").sum() / max(1.0, fg.sum())
 
 
+def total_loss(losses):
+    """EncoderDecoder._parse_losses EDF:409-439: mean of every entry, sum of those whose name contains 'loss'."""
+    return sum(v.mean() for k, v in losses.items() if "loss" in k)
+
+
 def forward_train(sd, cfg, batch):
     """EncoderDecoder.forward_train EDF:147-191 with running-statistics BN (see module docstring)."""
     cam = M.lss_forward(sd, "img_encoder", cfg, batch["img"], batch["img_metas"])

@@ -177,7 +177,7 @@ def build_reference_model(cfg, sd):
             self.bn2 = nn.BatchNorm2d(planes)
 
         def forward(self, x):
-            return M.basic_block({"b." + k: v for k, v in self.state_dict().items()}, "b", x)
+            return M.basic_block({"b." + k: v for k, v in self.state_dict(keep_vars=True).items()}, "b", x)
 
     class DCN(nn.Module):                 # [3P] mmcv DeformConv2dPack
         def __init__(self, in_channels, out_channels, kernel_size, padding, groups, im2col_step=128):
@@ -187,12 +187,14 @@ def build_reference_model(cfg, sd):
             self.groups = groups
 
         def forward(self, x):
-            return M.dcn({"d." + k: v for k, v in self.state_dict().items()}, "d", x, self.groups)
+            return M.dcn({"d." + k: v for k, v in self.state_dict(keep_vars=True).items()}, "d", x, self.groups)
 
     def ext_fwd(batch_size, num_points, num_channels, vx, vy, vz, geom, feats, out, memo):
         o, m = c_ref.voxel_pool_fwd(geom.numpy(), feats.detach().numpy(), (int(vx), int(vy), int(vz)),
                                     acc64=False)
         out += torch.from_numpy(o)
+        sel = torch.from_numpy(m[..., 0] != -1)        # pos_memo drives the reference's backward (VP.py:57-69)
+        memo[sel] = torch.from_numpy(m)[sel]
         return 1
 
     def msda_core(value, spatial_shapes, loc, attw):
@@ -408,7 +410,65 @@ def gen_f11():
     _save("f11_train_losses_trainmode_b2.npz", **pack)
 
 
-FIXTURES = {"F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8, "F9": gen_f9, "F10": gen_f10, "F11": gen_f11}
+def _grad_leaves(sd):
+    skip = ("running_mean", "running_var", "num_batches_tracked", "voxel_size", "voxel_coord", "voxel_num", "frustum")
+    return {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith(skip) else v)
+            for k, v in sd.items()}
+
+
+def gen_f13():
+    """F13: BACKWARD of the training step.  The reference's own autograd graph (its custom VoxelPooling Function,
+    the detach() / no_grad placements of lss.py:589,711 and thinktwice_decoder.py:429-430, `_parse_losses`) against
+    autograd through the oracle restatement, model.eval(), B=2 128x256: gradient of the total loss w.r.t. every
+    parameter.  Stored: per-parameter gradient norm, 8 sampled entries each, and the set of parameters that receive
+    no gradient (the dead branches: they need find_unused_parameters in the reference's DDP, mmdet_train.py:72)."""
+    from oracle import train_ref as TR
+    from thinktwice_amd import config, params, synth
+    B, hw, npts, seed = 2, (128, 256), 20000, 0
+    cfg = config.model_config(final_dim=hw)
+    sd = params.init_params(cfg, seed=seed)
+    batch = synth.make_batch(B, img_hw=hw, num_points=npts)
+    batch.update(synth.make_train_targets(B, img_hw=hw))
+    sd_ref = _grad_leaves(sd)                      # leaves for the third-party stand-ins (they read `sd` directly)
+    model = build_reference_model(cfg, sd_ref)
+    losses = model.forward_train(batch)
+    loss_ref, _ = model._parse_losses(losses)
+    loss_ref.backward()
+    own = dict(model.named_parameters())
+    sd_ora = _grad_leaves(sd)
+    lo, _ = TR.forward_train(sd_ora, cfg, batch)
+    loss_ora = TR.total_loss(lo)
+    loss_ora.backward()
+    print(f"total loss reference {float(loss_ref):.6f} oracle {float(loss_ora):.6f}")
+    g = torch.Generator().manual_seed(5)
+    names, norms, samples, idxs, dead, worst = [], [], [], [], [], 0.0
+    for k, v in sd_ora.items():
+        if not (torch.is_tensor(v) and v.requires_grad):
+            continue
+        gr = own[k].grad if k in own else sd_ref[k].grad
+        go = v.grad
+        assert (gr is None) == (go is None), k
+        if gr is None:
+            dead.append(k)
+            continue
+        e = float((gr - go).norm() / gr.norm().clamp_min(1e-20))
+        worst = max(worst, e)
+        if e > 1e-4:
+            print(f"  {k:70s} |g| {float(gr.norm()):.3e} rel err {e:.2e}")
+        idx = torch.randint(0, gr.numel(), (8,), generator=g)
+        names.append(k)
+        norms.append(float(gr.norm()))
+        idxs.append(idx.numpy())
+        samples.append(gr.reshape(-1)[idx].numpy())
+    print(f"{len(names)} parameters with gradient, {len(dead)} without, worst relative gradient error {worst:.2e}")
+    assert worst < 1e-3, worst
+    _save("f13_train_gradients_b2.npz", names=np.array(names), norms=np.array(norms), idx=np.stack(idxs),
+          samples=np.stack(samples), dead=np.array(dead), total_loss=np.array([float(loss_ref)]),
+          meta=np.array([B, hw[0], hw[1], npts, seed]), oracle_vs_reference_worst_rel_err=np.array([worst]))
+
+
+FIXTURES = {"F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8, "F9": gen_f9, "F10": gen_f10, "F11": gen_f11,
+            "F13": gen_f13}
 
 
 def main():

@@ -128,6 +128,39 @@ def test_oracle_train_mode_losses_match_reference_golden(golden_dir):
     assert abs(float(pack["speed_loss"]) - float(eval_pack["speed_loss"])) > 0.1
 
 
+def test_oracle_backward_matches_reference_gradients(golden_dir):
+    """F13: autograd through the oracle restatement == the reference's own backward (custom VoxelPooling Function,
+    detach / no_grad placements, `_parse_losses`): gradient norm + 8 sampled entries of all 878 live parameters, and
+    the same 90 dead parameters.  This is the gradient oracle the backward kernels of SURVEY 8f-4 will be checked
+    against."""
+    from oracle import train_ref as TR
+    pack = np.load(os.path.join(golden_dir, "f13_train_gradients_b2.npz"))
+    B, H, W, npts, seed = (int(v) for v in pack["meta"])
+    cfg = config.model_config(final_dim=(H, W))
+    sd = params.init_params(cfg, seed=seed)
+    batch = synth.make_batch(B, img_hw=(H, W), num_points=npts)
+    batch.update(synth.make_train_targets(B, img_hw=(H, W)))
+    skip = ("running_mean", "running_var", "num_batches_tracked", "voxel_size", "voxel_coord", "voxel_num", "frustum")
+    leaves = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith(skip) else v)
+              for k, v in sd.items()}
+    losses, _ = TR.forward_train(leaves, cfg, batch)
+    loss = TR.total_loss(losses)
+    assert abs(float(loss.detach()) - float(pack["total_loss"][0])) < 1e-3 * abs(float(pack["total_loss"][0]))
+    loss.backward()
+    dead = sorted(k for k, v in leaves.items() if torch.is_tensor(v) and v.requires_grad and v.grad is None)
+    assert dead == sorted(str(k) for k in pack["dead"]) and len(dead) == 90
+    assert all(".prediction_module.ffn." in k or "lidar_look_module" in k or "look_feature_MLP" in k for k in dead)
+    worst = 0.0
+    for name, norm, idx, smp in zip(pack["names"], pack["norms"], pack["idx"], pack["samples"]):
+        g = leaves[str(name)].grad
+        assert g is not None, name
+        worst = max(worst, abs(float(g.norm()) - float(norm)) / max(float(norm), 1e-12))
+        got = g.reshape(-1)[torch.from_numpy(idx)].numpy()
+        assert np.allclose(got, smp, rtol=2e-3, atol=1e-4 * float(norm) + 1e-9), (name, got, smp)
+    assert worst < 1e-3, worst
+    assert float(pack["oracle_vs_reference_worst_rel_err"][0]) < 1e-4
+
+
 def test_sca_batch_coupling_quirk():
     """MSDA:338-341: outputs depend on the local batch size (first B slots zeroed, / B)."""
     cfg = config.model_config(final_dim=(128, 256), refine_num=1)
