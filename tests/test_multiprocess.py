@@ -61,3 +61,45 @@ def test_frame_sharding_is_a_partition():
                 assert a1 == b0
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from thinktwice_amd.grad_sync import FlatGradBuffer
+    g = torch.Generator().manual_seed(0)                        # same parameters on every rank
+    params = [torch.randn(s, generator=g).requires_grad_() for s in ((5, 3), (7,), (2, 2, 2))]
+    dead = torch.randn(4, generator=g).requires_grad_()         # never reached by the loss (reference: 90 such)
+    buf = FlatGradBuffer(params + [dead])
+    buf.zero_()
+    x = torch.full((3,), float(rank + 1))                       # rank-dependent data
+    loss = (params[0] @ x).sum() * (rank + 1) + (params[1] ** 2).sum() + params[2].sum() * rank
+    loss.backward()
+    assert all(p.grad.data_ptr() == buf.flat[o:o + p.numel()].data_ptr() for p, o in zip(buf.params, buf.offsets))
+    local = buf.flat.clone()
+    buf.all_reduce_mean()
+    norm = buf.clip_grad_norm_(1e9)
+    q.put((rank, local.numpy(), buf.flat.clone().numpy(), float(norm)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_all_reduce_two_ranks_gloo():
+    """SURVEY 8e training collective: one all-reduce (mean) over the flat gradient buffer; autograd accumulates
+    straight into the buffer's views, dead parameters stay zero, both ranks end with the average of the local grads."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, a0, n0), (_, l1, a1, n1) = out
+    import numpy as np
+    np.testing.assert_allclose(a0, (l0 + l1) / 2, rtol=1e-6)
+    np.testing.assert_array_equal(a0, a1)
+    assert np.all(a0[-4:] == 0.0) and not np.allclose(l0, l1)   # dead parameter: zeros; the ranks really differed
+    assert abs(n0 - float(np.linalg.norm(a0))) < 1e-4 and n0 == n1

@@ -1,0 +1,61 @@
+"""Gradient synchronisation for the data-parallel training step (reference: mmcv's
+MMDistributedDataParallel with find_unused_parameters=True, `apis/mmdet_train.py:67-74`).
+
+One process per GPU; the whole model's gradient lives in ONE flat f32 buffer (≈ 513 MB for ThinkTwice, every
+parameter's `.grad` is a view into it) and a step issues a SINGLE all-reduce over it -- on MI355X xGMI is
+point-to-point (7 links x ~153 GB/s per GPU), so one large ring collective amortises the per-collective latency that
+DDP's 25 MB buckets would pay ~20 times, and there is no bucket-ready bookkeeping: parameters the loss never reaches
+(the 90 dead ones of the reference, golden F13) simply keep their zeros.  Backend-agnostic (`torch.distributed`:
+"nccl" = RCCL on ROCm, "gloo" in the CPU tests); plumbing only, no arithmetic beyond the collective and the 1/world
+scale folded into it.
+"""
+import torch
+
+
+class FlatGradBuffer:
+    def __init__(self, params, dtype=torch.float32):
+        """`params`: iterable of leaf tensors (requires_grad).  Allocates the flat buffer on their device and points
+        every `.grad` at its slice."""
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev = self.params[0].device
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, dtype=dtype, device=dev)
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            assert p.device == dev, "all parameters on one device (one process per GPU)"
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            self.offsets.append(off)
+            off += n
+
+    def zero_(self):
+        self.flat.zero_()          # dead parameters therefore contribute zeros, as DDP's unused-parameter path does
+
+    def check_views(self):
+        """autograd replaces `.grad` if someone sets it to None; re-attach (and copy) such gradients."""
+        for p, off in zip(self.params, self.offsets):
+            view = self.flat[off:off + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = view
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+                p.grad = view
+
+    def all_reduce_mean(self, group=None, async_op=False):
+        """SUM over ranks then / world, in place on the flat buffer: the one collective of the training step."""
+        import torch.distributed as dist
+        self.check_views()
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return None
+        world = dist.get_world_size(group)
+        self.flat.div_(world)      # pre-scale: the sum of pre-scaled f32 terms equals the mean without a second pass
+        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+    def clip_grad_norm_(self, max_norm):
+        """Global L2 clip over the flat buffer (reference: OptimizerHook grad_clip max_norm, configs/thinktwice.py:290)."""
+        norm = torch.linalg.vector_norm(self.flat)
+        scale = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+        self.flat.mul_(scale)
+        return norm
