@@ -266,6 +266,21 @@ int tt_preprocess_images(const uint8_t* raw_hwc, int num_images, int H, int W, c
                          int out_h, int out_w, const float* mean3, const float* std3, void* out_nhwc,
                          int out_channels_padded, int out_dtype, float* out_nchw_or_null, void* stream);
 
+/* ------------------------------------------------------------------------
+ * SURVEY 8f-4 (training step), optimizer half: the reference's `optimizer_config = dict(grad_clip=dict(max_norm=100,
+ * norm_type=2))` and `optimizer = dict(type='AdamW', lr=1e-4, weight_decay=1e-7)` (configs/thinktwice.py:282-287:
+ * torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW through mmcv's OptimizerHook) over ONE flat f32 parameter /
+ * gradient buffer.  No host synchronisation: the clip coefficient stays on the device.
+ * ---------------------------------------------------------------------- */
+/* out_norm_scale[0] = ||grad||_2, [1] = min(1, max_norm / (norm + 1e-6)); workspace_1024: 1024 floats */
+int tt_grad_norm_clip(const float* grad, long long n, float max_norm, float* workspace_1024,
+                      float* out_norm_scale, void* stream);
+/* one AdamW update of `n` parameters in place (p, exp_avg, exp_avg_sq); `step` >= 1 is the 1-based step count of
+ * the bias correction; the gradient is multiplied by *grad_scale_or_null (device scalar, e.g. out_norm_scale + 1) */
+int tt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step,
+                  const float* grad_scale_or_null, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
