@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 # Status at the end of round 1: the kernels ran on an MI355X and matched torch to 1 ulp through the first two steps
 # (max |p - p_ref| = 3.7e-9, 2.4e-7), then the round's GPU budget ran out before the remaining assertions (third step,
-# moment buffers) could be re-checked after a tolerance fix.  Until that re-run the test only runs on request, so an
+# moment buffers) could be re-checked after a tolerance fix (the clip-factor bound of step 3 was tighter than torch's
+# own f32 norm error; an exact CPU emulation of the kernel's op order passes every assertion below).  Until that re-run the test only runs on request, so an
 # unverified threshold cannot turn the GPU tier red:  TT_RUN_UNVALIDATED=1 python -m pytest tests/test_optim.py -m gpu
 unvalidated = pytest.mark.skipif(os.environ.get("TT_RUN_UNVALIDATED") != "1",
                                  reason="thresholds of the last assertions not yet re-validated on hardware")
@@ -35,7 +36,10 @@ def test_flat_adamw_matches_torch_adamw_with_grad_clip():
         dev_g.copy_(gr)
         ns = mine.step().cpu()
         assert abs(float(ns[0]) - float(ref_norm)) < 1e-4 * float(ref_norm)
-        assert abs(float(ns[1]) - min(1.0, 100.0 / (float(ref_norm) + 1e-6))) < 1e-6
+        # torch's f32 vector_norm is itself ~1e-5 off the exact norm at n = 1e6 (300.0512 vs 300.0546 on step 3), so the
+        # clip factor can only be compared at that level (an absolute 1e-6 bound was what failed on the hardware run)
+        want = min(1.0, 100.0 / (float(ref_norm) + 1e-6))
+        assert abs(float(ns[1]) - want) < 1e-4 * want
         err = float((dev_p.cpu() - ref_p.detach()).abs().max())
         assert err < 2e-6, (i, err)            # a few f32 ulps at |p| ~ 4 (different op fusion than torch)
     # the update actually moved the parameters by about lr per step
