@@ -42,3 +42,44 @@ def test_host_constants_shapes_and_key_frame_selection():
     ida_key = torch.as_tensor(metas[0][-1]["ida_mats"], dtype=torch.float32)
     assert torch.allclose(c["gm"][:4, 0], ida_key.inverse(), atol=1e-6)
     assert torch.equal(c["ida_mat"][0], ida_key)
+
+
+def test_adamw_kernel_op_order_emulation_meets_the_gpu_test_thresholds():
+    """The GPU test of tt_adamw_step (tests/test_optim.py) compares against torch.optim.AdamW with thresholds of a few
+    f32 ulps.  This CPU test replays the kernel's exact f32 operation order (csrc/optim.hip: no FMA contraction, f32
+    hyper-parameters, bias corrections in double) and checks that those thresholds hold for it, so that a failure on
+    hardware means a kernel bug rather than a tolerance chosen blind."""
+    import math
+    n = 200_003
+    g = torch.Generator().manual_seed(11)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * s for s in (1.0, 0.01, 0.3)]
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7)
+    f32 = lambda x: torch.tensor(x, dtype=torch.float32)          # noqa: E731
+    lr, b1, b2, eps, wd, one = f32(1e-4), f32(0.9), f32(0.999), f32(1e-8), f32(1e-7), f32(1.0)
+    max_norm = 100.0 * (n / 1_000_003) ** 0.5                      # same clip pattern as the 1M-element GPU test
+    p, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
+    for i, gr in enumerate(grads):
+        ref_p.grad = gr.clone()
+        ref_norm = torch.nn.utils.clip_grad_norm_([ref_p], max_norm)
+        opt.step()
+        norm = torch.sqrt((gr.double() ** 2).sum()).float()        # the kernel sums f32 partials in double
+        coef = f32(max_norm) / (norm + f32(1e-6))
+        gs = torch.minimum(coef, one)
+        want = min(1.0, max_norm / (float(ref_norm) + 1e-6))
+        assert abs(float(gs) - want) < 1e-4 * want
+        step = i + 1
+        bc1 = f32(1.0 - float(b1) ** step)
+        bc2s = f32(math.sqrt(1.0 - float(b2) ** step))
+        gi = gr * gs
+        pi = p * (one - lr * wd)
+        mi = m + (gi - m) * (one - b1)
+        vi = v * b2 + gi * gi * (one - b2)
+        pi = pi - (lr / bc1) * (mi / (torch.sqrt(vi) / bc2s + eps))
+        p, m, v = pi, mi, vi
+        assert float((p - ref_p.detach()).abs().max()) < 2e-6
+    st = opt.state[ref_p]
+    assert float((m - st["exp_avg"]).abs().max()) < 2e-6
+    assert float((v - st["exp_avg_sq"]).abs().max()) < 1e-4 * float(st["exp_avg_sq"].max())
+    assert 1e-4 < float((p - p0).abs().max()) < 1e-3
