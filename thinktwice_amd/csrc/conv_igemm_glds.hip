@@ -404,7 +404,7 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
     // Auto: Cout % 256 == 0 -> 256x256 tile of eight 128x64 waves (128 B rows if Cin % 64 == 0); short K -> four
     // 128x64 waves on 256x128; Cout <= 64 -> 256x64 tile with 128 B rows; else eight 64x64 waves on 256x128.
     // Retired after measurement (same file): 16-wave 256x256, 8x1 wave grid, 128 B rows x 3 stages (1 workgroup/CU),
-    // 128 B x 2 stages on the 256x128 tile.  TT_GLDS_VARIANT forces 0 / 1 / 2 / 6 (Cout > 64) for A/B runs.
+    // 128 B x 2 stages on the 256x128 tile.  TT_GLDS_VARIANT forces 0 / 1 / 2 / 6 / 7 (Cout > 64) for A/B runs.
     static int variant = -2;
     if (variant == -2) {
         const char* e = getenv("TT_GLDS_VARIANT");
@@ -419,6 +419,10 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
             else v = 0;
         }
         if (v == 6 && a.Cout % 256 == 0 && a.Cin % 64 == 0) return launch_glds<uint16_t, 256, 2, 4, 128, 2>(a, st);
+        // not measured yet (added after the round's GPU budget was spent): the same 256x256 / 128 B-row / 2-stage tile
+        // as sixteen 64x64 waves = 4 waves per SIMD at a 128-register budget, to test whether the loop is issue-bound
+        // with 2 lock-stepped waves per SIMD
+        if (v == 7 && a.Cout % 256 == 0 && a.Cin % 64 == 0) return launch_glds<uint16_t, 256, 4, 4, 128, 2>(a, st);
         if (v == 1) return launch_glds<uint16_t, 128, 2, 2, 64>(a, st);                         // 4 waves x 128x64
         if (v == 2 && a.Cout % 256 == 0) return launch_glds<uint16_t, 256, 2, 4, 64>(a, st);    // 8 waves x 128x64
         return launch_glds<uint16_t, 128, 4, 2, 64>(a, st);                                     // 8 waves x 64x64
