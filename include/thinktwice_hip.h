@@ -179,6 +179,11 @@ int tt_broadcast_rows(const void* v, void* out, int N, int HW, int C, int v_stri
 int tt_ew(const void* a, const void* b, const void* g, void* out, long long R, int C, int a_stride,
           int a_coff, int b_stride, int b_coff, int g_stride, int g_coff, int o_stride, int o_coff,
           int op, int act, int dtype, void* stream);
+/* torch.cat([...], -1) of up to 8 row-batched f32 pieces in one launch (decoder MLP inputs, thinktwice_decoder.py:
+ * 236-260): piece s writes out[r, coffs[s] : coffs[s]+widths[s]] = srcs[s][((r / divs[s]) % mods[s]) * strides[s] + c]
+ * (mods[s] = 0: no modulo; srcs[s] = NULL: zeros).  Pieces are contiguous in output-column order.  All arrays HOST. */
+int tt_concat_rows(float* out, long long R, int out_stride, int nseg, const float* const* srcs, const int* strides,
+                   const int* widths, const int* coffs, const int* divs, const int* mods, void* stream);
 
 /* mmcv DeformConv2dPack (DCN v1, 3x3, stride 1, deform_groups 1) column builder (lss.py:189-197):
  * cols [N*H*W, 9, C] = bilinear samples of x [N,H,W,C] at the offset taps; offsets f32

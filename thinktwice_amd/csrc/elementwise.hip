@@ -342,6 +342,42 @@ __global__ void ew_kernel(const T* __restrict__ a, const T* __restrict__ b, cons
     }
 }
 
+// ---- torch.cat([...], -1) of row-batched f32 pieces with per-piece row mapping, in ONE launch.
+// Piece s fills out[r, coff_s : coff_s + C_s] from src_s[((r / div_s) % mod_s), :C_s] (mod_s = 0: no modulo;
+// src_s = null: zeros): a plain copy (div 1), a per-sample vector broadcast over the 4 time steps (div 4) or a
+// per-time-step embedding (mod 4).  The decoder assembles its MLP inputs from 2-14 such pieces per layer
+// (thinktwice_decoder.py:236-260); one launch each instead of one per piece.
+struct CatSeg {
+    const float* src;
+    int stride, C, coff, div, mod;
+};
+struct CatArgs {
+    CatSeg seg[8];
+    int nseg;
+};
+
+__global__ void concat_rows_kernel(CatArgs a, float* __restrict__ out, long long R, int out_stride, int total_c) {
+    const long long total = R * total_c;
+    TT_GRID_STRIDE(i, total) {
+        const long long r = i / total_c;
+        int c = (int)(i - r * total_c);
+        // pieces are given in output-column order and tile [first coff, first coff + total_c)
+        int s = 0;
+        while (s + 1 < a.nseg && c >= a.seg[s].C) {
+            c -= a.seg[s].C;
+            ++s;
+        }
+        const CatSeg sg = a.seg[s];
+        float v = 0.f;
+        if (sg.src) {
+            long long sr = r / sg.div;
+            if (sg.mod > 0) sr %= sg.mod;
+            v = sg.src[sr * sg.stride + c];
+        }
+        out[r * out_stride + sg.coff + c] = v;
+    }
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -482,4 +518,25 @@ extern "C" int tt_ew(const void* a, const void* b, const void* g, void* out, lon
                                           (const T*)a, (const T*)b, (const T*)g, (T*)out, R, C, a_stride, a_coff,
                                           b_stride, b_coff, g_stride, g_coff, o_stride, o_coff, op, act));
     return check_launch("tt_ew");
+}
+
+extern "C" int tt_concat_rows(float* out, long long R, int out_stride, int nseg, const float* const* srcs,
+                              const int* strides, const int* widths, const int* coffs, const int* divs,
+                              const int* mods, void* stream) {
+    TT_REQUIRE(out && R > 0 && nseg >= 1 && nseg <= 8 && strides && widths && coffs && divs && mods && srcs,
+               "tt_concat_rows: bad args (1..8 pieces)");
+    CatArgs a;
+    a.nseg = nseg;
+    int total_c = 0;
+    for (int s = 0; s < nseg; ++s) {
+        TT_REQUIRE(widths[s] > 0 && divs[s] >= 1 && mods[s] >= 0 && coffs[s] >= 0, "tt_concat_rows: piece %d", s);
+        TT_REQUIRE(s == 0 || coffs[s] == coffs[s - 1] + widths[s - 1],
+                   "tt_concat_rows: pieces must be contiguous in output-column order (piece %d)", s);
+        a.seg[s] = CatSeg{srcs[s], strides[s], widths[s], coffs[s], divs[s], mods[s]};
+        total_c += widths[s];
+    }
+    TT_REQUIRE(coffs[0] + total_c <= out_stride, "tt_concat_rows: pieces exceed the output row");
+    hipLaunchKernelGGL(concat_rows_kernel, dim3(grid_for(R * total_c)), dim3(256), 0, (hipStream_t)stream, a, out, R,
+                       out_stride, total_c);
+    return check_launch("tt_concat_rows");
 }

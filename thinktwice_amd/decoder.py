@@ -9,6 +9,8 @@ done on the device (no host sync inside the 5-layer loop); dead branches of the 
 computed -- their parameters are accepted and ignored.  With `teacher_forcing_data` the decoder also runs the
 teacher-forcing pass of the training step (DEC:491-533); losses and backward are not part of this build.
 """
+import os
+
 import torch
 
 from . import _lib, ops
@@ -16,6 +18,9 @@ from .layers import conv_from_sd, linear_from_sd, rows, unrows
 from .registry import HEADS
 
 F32 = torch.float32
+# A/B switch, default off (written after the round's GPU budget was spent, not yet run on hardware): assemble each
+# concatenated MLP input with ONE tt_concat_rows launch instead of one `ew` copy per piece (~25 launches per layer)
+_FUSED_CONCAT = os.environ.get("TT_DEC_FUSED_CONCAT", "0") == "1"
 
 
 def _mlp(sd, name, idx, dev, last_act=False, in_pad=None):
@@ -245,8 +250,11 @@ class ThinkTwiceDecoder:
                 wp, ctrl = inputs_of(L)
                 sp = ops.ew(3, ctrl.view(B * 4, 4), act=_lib.ACT_SOFTPLUS).view(B, 4, 4)
                 inp6 = torch.empty(B, 4, 6, dtype=F32, device=dev)
-                ops.ew(3, wp.view(B * 4, 2), out=inp6.view(B * 4, 6), C=2, out_coff=0)
-                ops.ew(3, sp.view(B * 4, 4), out=inp6.view(B * 4, 6), C=4, out_coff=2)
+                if _FUSED_CONCAT:
+                    ops.concat_rows(inp6.view(B * 4, 6), [(wp.view(B * 4, 2), 2, 1, 0), (sp.view(B * 4, 4), 4, 1, 0)])
+                else:
+                    ops.ew(3, wp.view(B * 4, 2), out=inp6.view(B * 4, 6), C=2, out_coff=0)
+                    ops.ew(3, sp.view(B * 4, 4), out=inp6.view(B * 4, 6), C=4, out_coff=2)
                 fut = torch.empty(B, 4, H, W, 32, dtype=F32, device=dev)
                 # The prediction branch (conv-GRU, 4 steps x 8 small convs, + the shared flatten network) and the look
                 # branch (value projections, MSDA sampling, attention MLPs) only meet at the concat below: run the
@@ -273,22 +281,34 @@ class ThinkTwiceDecoder:
                     fflat.record_stream(main)
                 look_info.append(info)
                 # [future flat 256 | look 256 | zeros 256 (LiDAR look) | temporal 128 | meas 128]
-                hin = torch.zeros(B * 4, 1024, dtype=F32, device=dev)
-                ops.ew(3, fflat, out=hin, C=256, out_coff=0)
-                hv = hin.view(B, 4, 1024)
-                for t in range(4):
-                    ops.ew(3, look, out=hv[:, t], C=256, out_coff=256)
-                    ops.ew(3, meas, out=hv[:, t], C=128, out_coff=896)
-                    ops.ew(3, self.temporal[t:t + 1].expand(B, 128), out=hv[:, t], C=128, out_coff=768)
+                if _FUSED_CONCAT:
+                    hin = torch.empty(B * 4, 1024, dtype=F32, device=dev)
+                    ops.concat_rows(hin, [(fflat, 256, 1, 0), (look, 256, 4, 0), (None, 256, 1, 0),
+                                          (self.temporal, 128, 1, 4), (meas, 128, 4, 0)])
+                else:
+                    hin = torch.zeros(B * 4, 1024, dtype=F32, device=dev)
+                    ops.ew(3, fflat, out=hin, C=256, out_coff=0)
+                    hv = hin.view(B, 4, 1024)
+                    for t in range(4):
+                        ops.ew(3, look, out=hv[:, t], C=256, out_coff=256)
+                        ops.ew(3, meas, out=hv[:, t], C=128, out_coff=896)
+                        ops.ew(3, self.temporal[t:t + 1].expand(B, 128), out=hv[:, t], C=128, out_coff=768)
                 hn = ops.layernorm_rows(hin, lay.mlp_ln[0], lay.mlp_ln[1])
                 h = unrows(lay.mlp4(lay.mlp1(rows(hn))))                                 # (B*4,512)
-                tin = torch.zeros(B * 4, 516, dtype=F32, device=dev)
-                ops.ew(3, wp.view(B * 4, 2), out=tin, C=2, out_coff=0)
-                ops.ew(3, h, out=tin, C=512, out_coff=2)
+                if _FUSED_CONCAT:
+                    tin = torch.empty(B * 4, 516, dtype=F32, device=dev)
+                    ops.concat_rows(tin, [(wp.view(B * 4, 2), 2, 1, 0), (h, 512, 1, 0), (None, 2, 1, 0)])
+                else:
+                    tin = torch.zeros(B * 4, 516, dtype=F32, device=dev)
+                    ops.ew(3, wp.view(B * 4, 2), out=tin, C=2, out_coff=0)
+                    ops.ew(3, h, out=tin, C=512, out_coff=2)
                 d_wp = unrows(_run(lay.traj, rows(tin)))                                  # (B*4,2)
                 cin = torch.empty(B * 4, 516, dtype=F32, device=dev)
-                ops.ew(3, ctrl.view(B * 4, 4), out=cin, C=4, out_coff=0)
-                ops.ew(3, h, out=cin, C=512, out_coff=4)
+                if _FUSED_CONCAT:
+                    ops.concat_rows(cin, [(ctrl.view(B * 4, 4), 4, 1, 0), (h, 512, 1, 0)])
+                else:
+                    ops.ew(3, ctrl.view(B * 4, 4), out=cin, C=4, out_coff=0)
+                    ops.ew(3, h, out=cin, C=512, out_coff=4)
                 d_ctrl = unrows(_run(lay.ctrl, rows(cin)))                                # (B*4,4)
                 emit(L, d_wp, d_ctrl, wp, ctrl)
                 hb = h.view(B, 2048)
@@ -312,8 +332,11 @@ class ThinkTwiceDecoder:
                 else:
                     new_bev = bev_update()
                 fin = torch.empty(B, 2304, dtype=F32, device=dev)
-                ops.ew(3, cur_flat, out=fin, C=256, out_coff=0)
-                ops.ew(3, hb, out=fin, C=2048, out_coff=256)
+                if _FUSED_CONCAT:
+                    ops.concat_rows(fin, [(cur_flat, 256, 1, 0), (hb, 2048, 1, 0)])
+                else:
+                    ops.ew(3, cur_flat, out=fin, C=256, out_coff=0)
+                    ops.ew(3, hb, out=fin, C=2048, out_coff=256)
                 new_flat = unrows(lay.flat2(lay.flat0(rows(fin)), res1=rows(cur_flat)))
                 ops.ew(3, new_flat, out=s_flat[:, L])
                 cur_bev, cur_flat = new_bev, new_flat

@@ -315,6 +315,29 @@ def ew(op, a, b=None, g=None, out=None, C=None, a_coff=0, b_coff=0, g_coff=0, ou
     return out
 
 
+def concat_rows(out, pieces, coff=0):
+    """out (R, Ct) f32; pieces = [(src or None, C, div, mod), ...] laid out left to right from column `coff`:
+    out[r, ...] = src[(r // div) % mod if mod else r // div, :C]  (None: zeros).  One launch (tt_concat_rows)."""
+    o2 = out.reshape(-1, out.shape[-1])
+    assert o2.data_ptr() == out.data_ptr() and o2.dtype == torch.float32 and 1 <= len(pieces) <= 8
+    n = len(pieces)
+    srcs = (ctypes.c_void_p * n)()
+    strides, widths, coffs, divs, mods = ((ctypes.c_int * n)() for _ in range(5))
+    c = coff
+    for i, (src, C, div, mod) in enumerate(pieces):
+        if src is not None:
+            s2 = src.reshape(-1, src.shape[-1])
+            assert s2.dtype == torch.float32 and s2.stride(1) == 1 and s2.shape[1] >= C
+            srcs[i], strides[i] = s2.data_ptr(), s2.stride(0)
+        else:
+            srcs[i], strides[i] = None, 0
+        widths[i], coffs[i], divs[i], mods[i] = C, c, div, mod
+        c += C
+    check(lib().tt_concat_rows(ptr(o2), _ll(o2.shape[0]), _c(o2.stride(0)), _c(n), srcs, strides, widths, coffs, divs,
+                               mods, _st(out)), "tt_concat_rows")
+    return out
+
+
 def deform_im2col3x3(x, offsets, pad=1):
     """x (N,H,W,C), offsets f32 (N,H,W,>=18) -> cols (N*H*W, 1, 9, C) (a [M,1,9,C] "image" for conv2d)."""
     N, H, W, C = x.shape
