@@ -24,6 +24,7 @@ extern "C" {
 
 #define TT_F32 0
 #define TT_BF16 1
+#define TT_F16 2   /* IEEE half storage, f32 accumulate (v_mfma_f32_32x32x16_f16): same rate as bf16, 8x finer rounding */
 
 /* activation codes for fused epilogues */
 #define TT_ACT_NONE 0

@@ -1,6 +1,9 @@
 """End-to-end `forward_inference` (BASELINE configs 1-3): HIP model vs the oracle (reduced image size,
 seconds on CPU) and vs the committed golden vectors produced by the REFERENCE modules
-(f7: B=2 128x256; f8: B=1 full 448x896 thinktwice.py size).  f32 tolerance 1e-3 (north_star)."""
+(f7: B=2 128x256; f8: B=1 full 448x896 thinktwice.py size; f14: B=8 full size = BASELINE configs 2 / 3).
+Tolerance 1e-3 of each tensor's max (north_star) for the f32 mode and for the 16-bit headline mode (IEEE half
+storage) on the 14 output keys; the bf16 mode and the trunk intermediates of the half mode carry their measured
+bounds."""
 import os
 
 import numpy as np
@@ -70,12 +73,58 @@ def test_forward_full_size_matches_reference_golden(golden_dir):
     assert out["pred_wp"].shape == (1, 6, 4, 2)
 
 
-def test_forward_bf16_reports_error(golden_dir):
+def _inter_errs(pack, out):
+    """Trunk intermediates of the golden packs (sampled values of the oracle, which equals the reference bit for bit
+    on every module output): segmentation logits (config 3 "waypoint/seg outputs") and the camera BEV (config 2)."""
+    seg = out["_seg_cl"][..., :12].permute(0, 3, 1, 2).float().cpu().reshape(-1)
+    bev = out["_cam_bev_cl"].permute(0, 3, 1, 2).float().cpu().reshape(-1)
+    errs = {}
+    for name, v in (("seg", seg), ("cam_bev", bev)):
+        idx = torch.from_numpy(pack[f"inter__{name}__idx"])
+        want = torch.from_numpy(pack[f"inter__{name}__val"])
+        errs[name] = float((v[idx] - want).abs().max() / float(pack[f"inter__{name}__stats"][2]))
+    return errs
+
+
+# (dtype, bound on the 14 output keys, bound on seg / camera BEV): f32 and IEEE-half storage meet the 1e-3 tolerance
+# on every output of forward_inference; half's trunk intermediates and the bf16 mode are held to their measured level
+# (bf16: 8 mantissa bits -> ~1e-2 after ~60 layers; half: 11 bits -> ~1.5e-3 on seg / BEV)
+MODES = [(torch.float32, 1e-3, 1e-3), (torch.float16, 1e-3, 3e-3), (torch.bfloat16, 1e-2, 3e-2)]
+
+
+@pytest.mark.parametrize("dt,tol,tol_inter", MODES, ids=["f32", "f16", "bf16"])
+def test_forward_batch8_full_size_matches_reference_golden(golden_dir, dt, tol, tol_inter):
+    """BASELINE configs 2 / 3: batch 8 at the thinktwice.py size against the REFERENCE's forward_inference (f14).  The
+    SCA batch coupling (multi_scale_deformable_attn_function.py:338-341: first `bs` slots zeroed, divide by `bs`)
+    makes B=8 different arithmetic from the B=1/2 goldens."""
+    pack = np.load(os.path.join(golden_dir, "f14_forward_full_b8.npz"))
+    B, H, W, npts, seed = (int(v) for v in pack["meta"])
+    assert (B, H, W) == (8, 448, 896)
+    from thinktwice_amd import model as tm, params, synth
+    m, cfg = tm.build_thinktwice(dtype=dt, final_dim=(H, W))
+    m.load_state_dict(params.init_params(cfg, seed=seed))
+    batch = synth.make_batch(B, img_hw=(H, W), num_points=npts)
+    out = m.forward_inference(tm.batch_to_device(batch))
+    torch.cuda.synchronize()
+    errs = _check_against_pack(pack, out, tol)
+    inter = _inter_errs(pack, out)
+    l2 = float((out["pred_wp"].cpu() - torch.from_numpy(pack["pred_wp"])).norm(dim=-1).max())
+    print(f"f14 B=8 {dt}: rel errs", errs, "inter", inter, "waypoint L2 max", l2)
+    assert max(inter.values()) < tol_inter, inter
+    assert l2 < (1e-3 if dt != torch.bfloat16 else 1e-2), l2
+    if dt == torch.float32:      # integer work bit-exact (a 16-bit trunk may move a projected waypoint across an image edge)
+        for L in range(5):
+            assert int(out["_look_info"][L][1].item()) == int(pack["look_max_len"][L])
+            np.testing.assert_array_equal(out["_look_info"][L][0].cpu().numpy(), pack["look_count"][L])
+
+
+@pytest.mark.parametrize("dt,tol,tol_inter", MODES[1:], ids=["f16", "bf16"])
+def test_forward_16bit_modes_small(golden_dir, dt, tol, tol_inter):
     pack = np.load(os.path.join(golden_dir, "f7_forward_small_b2.npz"))
     B, H, W, npts, seed = (int(v) for v in pack["meta"])
-    out, *_ = _run_model(B, (H, W), npts, seed, dtype=torch.bfloat16)
-    errs = _check_against_pack(pack, out, 0.5)
-    print("bf16 trunk: rel errs vs reference golden", errs)
+    out, *_ = _run_model(B, (H, W), npts, seed, dtype=dt)
+    errs = _check_against_pack(pack, out, tol)
+    print(f"{dt} trunk: rel errs vs reference golden", errs)
 
 
 def test_forward_refuses_missing_weights():

@@ -1,6 +1,6 @@
 """Camera encoder: HIP `LSS` vs the oracle restatement on the same seeded
 inputs/weights at a reduced image size (oracle runs in seconds).  f32 mode tolerance 1e-3 of the
-tensor's max (north_star), bf16 mode reported with a loose bound."""
+tensor's max (north_star); the 16-bit storage modes are held to their measured error level."""
 import numpy as np
 import pytest
 import torch
@@ -25,7 +25,9 @@ def setup():
     return cfg, sd, batch, ref
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 0.15)])
+# f32: the 1e-3 tolerance.  16-bit storage modes: measured level x ~2.5 (IEEE half 11 mantissa bits -> ~1.5e-3 after the
+# ~60-layer trunk; bf16 8 bits -> ~1.2e-2), see tools/precision_study.py and DESIGN.md section 4b
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
 def test_lss_forward_matches_oracle(setup, dt, tol):
     from thinktwice_amd.lss import LSS
     cfg, sd, batch, ref = setup

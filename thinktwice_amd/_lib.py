@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libthinktwice_hip.so")
 # experiments only (tools/): load an alternative build of the same ABI, e.g. one compiled with -DTT_GLDS_DEBUG=1
 LIB_PATH = os.environ.get("TT_LIB_PATH", LIB_PATH)
 
-TT_F32, TT_BF16 = 0, 1
+TT_F32, TT_BF16, TT_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_GELU, ACT_SOFTPLUS, ACT_SOFTPLUS_CLAMP = 0, 1, 2, 3, 4, 5
 
 _lib = None

@@ -7,6 +7,7 @@ namespace tt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvArgs {
     const void* in;
@@ -53,8 +54,12 @@ template <> struct Mfma<uint16_t> {
                                                     __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
-
-
+template <> struct Mfma<f16_t> {
+    // one 16 B vector (8 halves) per lane = 1 MFMA of K=16, same rate as bf16
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
 
 // Stage one 32 x WTN block of a wave's accumulators into its private LDS region with the folded-BN scale/shift
 // already applied.  In the MFMA C/D layout a lane owns ONE output channel per 32-wide column block, so the affine
@@ -125,13 +130,21 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                                          typename std::conditional<sizeof(T) == 2, uint2, float4>::type>::type;
     auto add_rv = [](float (&v)[CO], const RV& u) {
         if constexpr (sizeof(T) == 2 && CO == 8) {
-            v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
-            v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
-            v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
-            v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a, b;
+                Pair16<T>::unpack(w[e], a, b);
+                v[2 * e] += a; v[2 * e + 1] += b;
+            }
         } else if constexpr (sizeof(T) == 2) {
-            v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
-            v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+            const uint32_t w[2] = {u.x, u.y};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float a, b;
+                Pair16<T>::unpack(w[e], a, b);
+                v[2 * e] += a; v[2 * e + 1] += b;
+            }
         } else {
             v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w;
         }
@@ -157,11 +170,13 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
         if constexpr (CO == 4) {
             *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
+            // 16-bit output: the storage type of the operands (f32-compute layers never take the CO == 8 path)
+            using T16 = typename std::conditional<sizeof(T) == 2, T, uint16_t>::type;
             uint4 pk;
-            pk.x = pack_bf16x2(v[0], v[1]);
-            pk.y = pack_bf16x2(v[2], v[3]);
-            pk.z = pack_bf16x2(v[4], v[5]);
-            pk.w = pack_bf16x2(v[6], v[7]);
+            pk.x = Pair16<T16>::pack(v[0], v[1]);
+            pk.y = Pair16<T16>::pack(v[2], v[3]);
+            pk.z = Pair16<T16>::pack(v[4], v[5]);
+            pk.w = Pair16<T16>::pack(v[6], v[7]);
             *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.out) + o) = pk;
         }
     };
@@ -355,7 +370,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
             if (p.out_dtype == TT_F32)
                 reinterpret_cast<float*>(p.out)[o] = v;
             else
-                reinterpret_cast<uint16_t*>(p.out)[o] = f32_to_bf16(v);
+                store16(p.out, o, v, p.out_dtype);
         }
     }
 }

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const ConvArgs p) 
     if (p.res2) v += Elem<T>::ld(reinterpret_cast<const T*>(p.res2) + (long long)m * p.res2_cstride + p.res2_coff + co);
     v = apply_act(v, p.act);
     if (p.out_dtype == TT_F32) reinterpret_cast<float*>(p.out)[o] = v;
-    else reinterpret_cast<uint16_t*>(p.out)[o] = f32_to_bf16(v);
+    else store16(p.out, o, v, p.out_dtype);
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GATHER, int KX = 1>
@@ -309,8 +309,9 @@ using namespace tt;
 
 extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
     TT_REQUIRE(d && d->in && d->weight && d->out, "tt_conv2d_fwd: null pointer");
-    TT_REQUIRE(d->dtype == TT_F32 || d->dtype == TT_BF16, "tt_conv2d_fwd: bad dtype %d", d->dtype);
-    TT_REQUIRE(d->out_dtype == TT_F32 || d->out_dtype == TT_BF16, "tt_conv2d_fwd: bad out_dtype");
+    TT_REQUIRE(d->dtype == TT_F32 || d->dtype == TT_BF16 || d->dtype == TT_F16, "tt_conv2d_fwd: bad dtype %d", d->dtype);
+    TT_REQUIRE(d->out_dtype == TT_F32 || d->out_dtype == d->dtype,
+               "tt_conv2d_fwd: out_dtype must be TT_F32 or the operand dtype (got %d for dtype %d)", d->out_dtype, d->dtype);
     const int vec = d->dtype == TT_F32 ? 4 : 8;
     TT_REQUIRE(d->Cin > 0 && d->Cin % vec == 0 && d->in_cstride % vec == 0 && d->in_coff % vec == 0,
                "tt_conv2d_fwd: Cin=%d in_cstride=%d in_coff=%d must be multiples of %d (pad channels)",
@@ -367,5 +368,6 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
     if (!d->splitk_ws && try_launch_conv_small(a, d->dtype, st)) return check_launch("tt_conv2d_fwd(small)");
     if (!d->splitk_ws && try_launch_conv_glds(a, d->dtype, st)) return check_launch("tt_conv2d_fwd(glds)");
     if (d->dtype == TT_F32) return dispatch_conv<float>(a, st);
+    if (d->dtype == TT_F16) return dispatch_conv<f16_t>(a, st);
     return dispatch_conv<uint16_t>(a, st);
 }

@@ -369,6 +369,10 @@ static int launch_glds(ConvArgs& a, hipStream_t st) {
     return 1;
 }
 
+// T16 = uint16_t (bf16) or f16_t (IEEE half): same tiles, same MFMA rate.
+template <typename T16>
+static int launch_glds16(ConvArgs& a, int dtype, hipStream_t st, int min_tiles);
+
 int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
     static int min_tiles = -1;
     if (min_tiles < 0) {
@@ -383,10 +387,8 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
             sp = e ? atoi(e) : 1;
         }
         const bool cin_ok = a.Cin >= 16 && (a.Cin & (a.Cin - 1)) == 0;   // power of two: taps tile the 128 B rows
-        if (!sp || dtype != TT_BF16 || !cin_ok || a.M < 2048 || a.Cout < 16 || a.Cout > 128) return 0;
-        if (a.Cout <= 32) return launch_glds<uint16_t, 32, 8, 1, 128, 2, true>(a, st);
-        if (a.Cout <= 64) return launch_glds<uint16_t, 64, 8, 1, 128, 2, true>(a, st);
-        return launch_glds<uint16_t, 128, 4, 2, 128, 2, true>(a, st);
+        if (!sp || dtype == TT_F32 || !cin_ok || a.M < 2048 || a.Cout < 16 || a.Cout > 128) return 0;
+        return dtype == TT_F16 ? launch_glds16<f16_t>(a, dtype, st, min_tiles) : launch_glds16<uint16_t>(a, dtype, st, min_tiles);
     }
     if (a.m_dev || a.M < 2048 || a.Cout < 64 || a.KH * a.KW > 32) return 0;
     if (dtype == TT_F32) {
@@ -395,6 +397,17 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
         return launch_glds<float, 64, 8, 1, 64>(a, st);
     }
     if (a.Cin % 32 != 0 || div_up(a.K, 32) < min_tiles) return 0;
+    return dtype == TT_F16 ? launch_glds16<f16_t>(a, dtype, st, min_tiles) : launch_glds16<uint16_t>(a, dtype, st, min_tiles);
+}
+
+template <typename T16>
+static int launch_glds16(ConvArgs& a, int dtype, hipStream_t st, int min_tiles) {
+    (void)dtype; (void)min_tiles;
+    if (a.gather) {
+        if (a.Cout <= 32) return launch_glds<T16, 32, 8, 1, 128, 2, true>(a, st);
+        if (a.Cout <= 64) return launch_glds<T16, 64, 8, 1, 128, 2, true>(a, st);
+        return launch_glds<T16, 128, 4, 2, 128, 2, true>(a, st);
+    }
     // Tile selection (profiles/r01_conv_microbench_tiles.txt).  Three things set the rate of these kernels:
     //  * L2->LDS bytes per FLOP = workgroup tile: 256x128 -> 85 FLOP/B, 256x256 -> 128 FLOP/B;
     //  * whether a DMA lane group consumes WHOLE 128 B cache lines: with 64 B rows every activation line is
@@ -418,19 +431,19 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
             else if (a.K <= 512) v = 1;
             else v = 0;
         }
-        if (v == 6 && a.Cout % 256 == 0 && a.Cin % 64 == 0) return launch_glds<uint16_t, 256, 2, 4, 128, 2>(a, st);
+        if (v == 6 && a.Cout % 256 == 0 && a.Cin % 64 == 0) return launch_glds<T16, 256, 2, 4, 128, 2>(a, st);
         // not measured yet (added after the round's GPU budget was spent): the same 256x256 / 128 B-row / 2-stage tile
         // as sixteen 64x64 waves = 4 waves per SIMD at a 128-register budget, to test whether the loop is issue-bound
         // with 2 lock-stepped waves per SIMD
-        if (v == 7 && a.Cout % 256 == 0 && a.Cin % 64 == 0) return launch_glds<uint16_t, 256, 4, 4, 128, 2>(a, st);
-        if (v == 1) return launch_glds<uint16_t, 128, 2, 2, 64>(a, st);                         // 4 waves x 128x64
-        if (v == 2 && a.Cout % 256 == 0) return launch_glds<uint16_t, 256, 2, 4, 64>(a, st);    // 8 waves x 128x64
-        return launch_glds<uint16_t, 128, 4, 2, 64>(a, st);                                     // 8 waves x 64x64
+        if (v == 7 && a.Cout % 256 == 0 && a.Cin % 64 == 0) return launch_glds<T16, 256, 4, 4, 128, 2>(a, st);
+        if (v == 1) return launch_glds<T16, 128, 2, 2, 64>(a, st);                         // 4 waves x 128x64
+        if (v == 2 && a.Cout % 256 == 0) return launch_glds<T16, 256, 2, 4, 64>(a, st);    // 8 waves x 128x64
+        return launch_glds<T16, 128, 4, 2, 64>(a, st);                                     // 8 waves x 64x64
     }
     // Cout <= 64 (the 224x448 UNet / stem-level layers): 128 B rows in 2 stages (80 KiB, 2 workgroups / CU)
     // measured +17 % over 64 B rows x 3 stages (1.61 vs 1.89 ms on M=6.4M K=1152)
-    if (a.Cin % 64 == 0 && variant != 0) return launch_glds<uint16_t, 64, 8, 1, 128, 2>(a, st);
-    return launch_glds<uint16_t, 64, 8, 1, 64>(a, st);
+    if (a.Cin % 64 == 0 && variant != 0) return launch_glds<T16, 64, 8, 1, 128, 2>(a, st);
+    return launch_glds<T16, 64, 8, 1, 64>(a, st);
 }
 
 }  // namespace tt

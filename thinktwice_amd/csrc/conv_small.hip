@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs p, int t
         if (p.res2) v += Elem<T>::ld(reinterpret_cast<const T*>(p.res2) + (long long)mo * p.res2_cstride + p.res2_coff + co);
         v = apply_act(v, p.act);
         if (p.out_dtype == TT_F32) reinterpret_cast<float*>(p.out)[o] = v;
-        else reinterpret_cast<uint16_t*>(p.out)[o] = f32_to_bf16(v);
+        else store16(p.out, o, v, p.out_dtype);
     }
 }
 
@@ -138,6 +138,8 @@ int try_launch_conv_small(ConvArgs& a, int dtype, hipStream_t st) {
     const size_t smem = (size_t)4 * 32 * 33 * 4;
     if (dtype == TT_F32)
         hipLaunchKernelGGL(conv_small_kernel<float>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), smem, st, a, tiles_n);
+    else if (dtype == TT_F16)
+        hipLaunchKernelGGL(conv_small_kernel<f16_t>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), smem, st, a, tiles_n);
     else
         hipLaunchKernelGGL(conv_small_kernel<uint16_t>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), smem, st, a,
                            tiles_n);

@@ -67,6 +67,9 @@ extern "C" int tt_deform_im2col3x3(const void* x, const float* offsets, void* co
     if (dtype == TT_F32)
         hipLaunchKernelGGL(deform_im2col_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                            (const float*)x, offsets, (float*)cols, N, H, W, C, off_cstride, pad);
+    else if (dtype == TT_F16)
+        hipLaunchKernelGGL(deform_im2col_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const f16_t*)x, offsets, (f16_t*)cols, N, H, W, C, off_cstride, pad);
     else
         hipLaunchKernelGGL(deform_im2col_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                            (const uint16_t*)x, offsets, (uint16_t*)cols, N, H, W, C, off_cstride, pad);

@@ -17,26 +17,24 @@ template <> struct Vec<float> {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     }
 };
-template <> struct Vec<uint16_t> {
+template <typename T16> struct Vec16 {     // bf16 (uint16_t) or IEEE half (f16_t) storage, 8 elements per 16 B
     static constexpr int N = 8;
     float v[8];
-    __device__ __forceinline__ void load(const uint16_t* p) {
+    __device__ __forceinline__ void load(const T16* p) {
         const uint4 t = *reinterpret_cast<const uint4*>(p);
         const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[2 * i] = __uint_as_float(w[i] << 16);
-            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-        }
+        for (int i = 0; i < 4; ++i) Pair16<T16>::unpack(w[i], v[2 * i], v[2 * i + 1]);
     }
-    __device__ __forceinline__ void store(uint16_t* p) const {
+    __device__ __forceinline__ void store(T16* p) const {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+        for (int i = 0; i < 4; ++i) w[i] = Pair16<T16>::pack(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
+template <> struct Vec<uint16_t> : Vec16<uint16_t> {};
+template <> struct Vec<f16_t> : Vec16<f16_t> {};
 
 #define TT_GRID_STRIDE(i, n) \
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
@@ -386,6 +384,7 @@ using namespace tt;
     do {                                                      \
         if ((dtype) == TT_F32) { using T = float; CALL; }     \
         else if ((dtype) == TT_BF16) { using T = uint16_t; CALL; } \
+        else if ((dtype) == TT_F16) { using T = f16_t; CALL; }    \
         else { TT_REQUIRE(false, "bad dtype %d", (int)(dtype)); }  \
     } while (0)
 
@@ -493,6 +492,9 @@ extern "C" int tt_copy_nhwc(const void* in, void* out, int N, int H, int W, int 
     else if (in_dtype == TT_F32 && out_dtype == TT_BF16) CP(float, uint16_t);
     else if (in_dtype == TT_BF16 && out_dtype == TT_F32) CP(uint16_t, float);
     else if (in_dtype == TT_BF16 && out_dtype == TT_BF16) CP(uint16_t, uint16_t);
+    else if (in_dtype == TT_F32 && out_dtype == TT_F16) CP(float, f16_t);
+    else if (in_dtype == TT_F16 && out_dtype == TT_F32) CP(f16_t, float);
+    else if (in_dtype == TT_F16 && out_dtype == TT_F16) CP(f16_t, f16_t);
     else TT_REQUIRE(false, "tt_copy_nhwc: bad dtypes");
 #undef CP
     return check_launch("tt_copy_nhwc");

@@ -315,7 +315,7 @@ extern "C" int tt_sp_to_dense(const void* feats, const int* coords, const int* n
     if (dtype == TT_F32)
         hipLaunchKernelGGL(sp_to_dense_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)feats,
                            coords, num_rows, max_rows, C, d, (float*)dense);
-    else
+    else   // bf16 and IEEE half alike: a 2-byte row copy
         hipLaunchKernelGGL(sp_to_dense_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint16_t*)feats, coords, num_rows, max_rows, C, d, (uint16_t*)dense);
     return check_launch("tt_sp_to_dense");

@@ -252,6 +252,10 @@ extern "C" int tt_look_gather_query(int B, const int* query_of_slot, const float
         hipLaunchKernelGGL(look_gather_query_kernel<float>, dim3(rows_n), dim3(256), 0, st, query_of_slot, ref_packed,
                            wp, ctrl_softplus, temporal_embedding, static_embedding, measurement_feat,
                            flattened_feat, m, out, row_stride);
+    else if (maps_dtype == TT_F16)
+        hipLaunchKernelGGL(look_gather_query_kernel<f16_t>, dim3(rows_n), dim3(256), 0, st, query_of_slot,
+                           ref_packed, wp, ctrl_softplus, temporal_embedding, static_embedding, measurement_feat,
+                           flattened_feat, m, out, row_stride);
     else
         hipLaunchKernelGGL(look_gather_query_kernel<uint16_t>, dim3(rows_n), dim3(256), 0, st, query_of_slot,
                            ref_packed, wp, ctrl_softplus, temporal_embedding, static_embedding, measurement_feat,
@@ -275,6 +279,9 @@ extern "C" int tt_msda_sample_strided(int B, const void* value, int value_dtype,
     if (value_dtype == TT_F32)
         hipLaunchKernelGGL(msda_sample_kernel<float>, dim3(rows_n), dim3(256), 0, st, (const float*)value, offsets,
                            logits, ref_packed, m, S, value_cstride, value_coff, out);
+    else if (value_dtype == TT_F16)
+        hipLaunchKernelGGL(msda_sample_kernel<f16_t>, dim3(rows_n), dim3(256), 0, st, (const f16_t*)value,
+                           offsets, logits, ref_packed, m, S, value_cstride, value_coff, out);
     else
         hipLaunchKernelGGL(msda_sample_kernel<uint16_t>, dim3(rows_n), dim3(256), 0, st, (const uint16_t*)value,
                            offsets, logits, ref_packed, m, S, value_cstride, value_coff, out);

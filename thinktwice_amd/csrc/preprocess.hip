@@ -96,6 +96,9 @@ extern "C" int tt_preprocess_images(const uint8_t* raw_hwc, int num_images, int 
     else if (out_dtype == TT_BF16)
         hipLaunchKernelGGL(preprocess_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, a, raw_hwc, mapx, mapy,
                            (uint16_t*)out_nhwc, out_nchw_or_null);
+    else if (out_dtype == TT_F16)
+        hipLaunchKernelGGL(preprocess_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, a, raw_hwc, mapx, mapy,
+                           (f16_t*)out_nhwc, out_nchw_or_null);
     else
         TT_REQUIRE(false, "tt_preprocess_images: bad dtype");
     return check_launch("tt_preprocess_images");

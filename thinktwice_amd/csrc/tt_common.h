@@ -48,6 +48,20 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, tt_bf16x2));
 }
 
+// IEEE half storage (TT_F16): a distinct 2-byte type so the kernels can be instantiated for it beside bf16
+// (uint16_t).  Same MFMA rate as bf16, 3 more mantissa bits: the 16-bit mode whose outputs stay inside the 1e-3
+// tolerance of the reference.
+struct f16_t {
+    uint16_t bits;
+};
+typedef _Float16 tt_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float f16_to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }   // RNE
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    tt_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, tt_f16x2));
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int kVec = 4;  // elements per 16-byte vector
@@ -59,6 +73,35 @@ template <> struct Elem<uint16_t> {  // bf16 storage
     __device__ static __forceinline__ float ld(const uint16_t* p) { return bf16_to_f32(*p); }
     __device__ static __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
 };
+
+template <> struct Elem<f16_t> {  // IEEE half storage
+    static constexpr int kVec = 8;
+    __device__ static __forceinline__ float ld(const f16_t* p) { return f16_to_f32(p->bits); }
+    __device__ static __forceinline__ void st(f16_t* p, float v) { p->bits = f32_to_f16(v); }
+};
+
+// Two 16-bit elements packed in one dword <-> two floats (low half = element 0).
+template <typename T> struct Pair16;
+template <> struct Pair16<uint16_t> {
+    __device__ static __forceinline__ void unpack(uint32_t w, float& a, float& b) {
+        a = __uint_as_float(w << 16);
+        b = __uint_as_float(w & 0xffff0000u);
+    }
+    __device__ static __forceinline__ uint32_t pack(float a, float b) { return pack_bf16x2(a, b); }
+};
+template <> struct Pair16<f16_t> {
+    __device__ static __forceinline__ void unpack(uint32_t w, float& a, float& b) {
+        const tt_f16x2 h = __builtin_bit_cast(tt_f16x2, w);
+        a = (float)h.x;
+        b = (float)h.y;
+    }
+    __device__ static __forceinline__ uint32_t pack(float a, float b) { return pack_f16x2(a, b); }
+};
+
+// Store one value as the 16-bit type named by a runtime dtype code (TT_BF16 / TT_F16).
+__device__ __forceinline__ void store16(void* base, long long o, float v, int dtype) {
+    reinterpret_cast<uint16_t*>(base)[o] = (dtype == TT_F16) ? f32_to_f16(v) : f32_to_bf16(v);
+}
 
 // Inline everywhere.  The conv epilogues only reach the transcendental cases from ROLLED loops (an unrolled use
 // per accumulator element once blew the kernels up to ~50k ISA lines; an out-of-line call instead pinned the hot

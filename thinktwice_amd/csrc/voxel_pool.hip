@@ -856,6 +856,10 @@ extern "C" int tt_lift_splat_fwd(int batch_size, int num_cams, int D, int fH, in
             hipLaunchKernelGGL(lift_splat_strip_kernel<uint16_t>, dim3(sblocks), dim3(256), 0, st, batch_size, num_cams,
                                D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z, (const uint16_t*)depth_logits,
                                (const uint16_t*)context, geom_xyz, out, out_cstride, out_coff, rot_flip);
+        else if (dtype == TT_F16)
+            hipLaunchKernelGGL(lift_splat_strip_kernel<f16_t>, dim3(sblocks), dim3(256), 0, st, batch_size, num_cams,
+                               D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z, (const f16_t*)depth_logits,
+                               (const f16_t*)context, geom_xyz, out, out_cstride, out_coff, rot_flip);
         else
             TT_REQUIRE(false, "tt_lift_splat_fwd: bad dtype %d", dtype);
         return check_launch("tt_lift_splat_fwd");
@@ -870,6 +874,11 @@ extern "C" int tt_lift_splat_fwd(int batch_size, int num_cams, int D, int fH, in
         hipLaunchKernelGGL(lift_splat_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, batch_size,
                            num_cams, D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z,
                            (const uint16_t*)depth_logits, (const uint16_t*)context, geom_xyz, out,
+                           out_cstride, out_coff, rot_flip);
+    } else if (dtype == TT_F16) {
+        hipLaunchKernelGGL(lift_splat_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, batch_size,
+                           num_cams, D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z,
+                           (const f16_t*)depth_logits, (const f16_t*)context, geom_xyz, out,
                            out_cstride, out_coff, rot_flip);
     } else {
         TT_REQUIRE(false, "tt_lift_splat_fwd: bad dtype %d", dtype);

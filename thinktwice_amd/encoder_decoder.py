@@ -136,7 +136,7 @@ class EncoderDecoder:
                             [cam["lidar2img"], cam["ida_mat"], cam["_fpn_cl"], lidar],
                             channel_last_out=channel_last_out)
         pred["_cam_bev_cl"], pred["_lidar_bev_cl"], pred["_flat"], pred["_meas"] = cam_bev, lidar, flat, meas
-        pred["_key_bev_cl"] = cam["_key_bev_cl"]
+        pred["_key_bev_cl"], pred["_seg_cl"] = cam["_key_bev_cl"], cam["_seg_cl"]
         return pred
 
     def forward_train(self, batch):

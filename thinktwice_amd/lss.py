@@ -24,13 +24,13 @@ class _ResNet50:
         self.cin_pad = vec
         self.stem = conv_from_sd(sd, p + ".conv1", dtype, device, bn=p + ".bn1", stride=2, pad=3, act="relu",
                                  cin_pad=vec)
-        # bf16: "row-run" form of the 7x7/2 stem.  With channel-last pixels of 8 bf16 (16 B), the 7 taps of one filter
+        # 16-bit modes: "row-run" form of the 7x7/2 stem.  With channel-last pixels of 8 bf16 / f16 (16 B), the 7 taps of one filter
         # row are 112 contiguous bytes: read them as ONE 128 B run of 8 pixels (the 8th meets zero weights) from a
         # zero-bordered image, i.e. a KH=7, KW=1, Cin=64 convolution over a tensor whose "pixels" overlap (pixel
         # stride 8 elements).  K tiles become whole cache lines and the layer runs on the LDS-DMA kernel instead of
         # the 3-channel im2col path (Cin=8 is below every DMA tile).  Same products, different summation order.
         self.stem_rr = None
-        if dtype == torch.bfloat16:
+        if dtype != torch.float32:     # 16-bit storage (bf16 or IEEE half)
             w = sd[p + ".conv1.weight"].to(device)                      # (64, 3, 7, 7)
             wr = torch.zeros(w.shape[0], 7, 1, 64, dtype=dtype, device=device)
             wr[:, :, 0, :56] = torch.nn.functional.pad(w.permute(0, 2, 3, 1), (0, 5)).reshape(w.shape[0], 7, 56).to(dtype)
@@ -292,7 +292,7 @@ class LSS:
             if x is None:
                 x = torch.zeros(NI, H + border[0] + border[2], W + border[1] + border[3], self.backbone.cin_pad,
                                 dtype=self.dtype, device=img.device)
-                self._xpad = {key: x}
+                self._xpad[key] = x      # every bordered buffer stays alive: captured HIP graphs hold raw pointers
         else:
             x = torch.empty(NI, H, W, self.backbone.cin_pad, dtype=self.dtype, device=img.device)
         for s in range(T):
@@ -331,7 +331,7 @@ class LSS:
         bev = self.bev_merge(bev_cat) if T_all > 1 else bev_cat
         fpn = [(t[:BN], off, c) for (t, off, c) in self._fpn_views(bufs)]
         outs = {"lidar2img": consts["lidar2img"], "ida_mat": consts["ida_mat"], "_fpn_cl": fpn, "_bev_cl": bev,
-                "_geom": geom, "_key_bev_cl": bev_cat[..., :OC]}
+                "_geom": geom, "_key_bev_cl": bev_cat[..., :OC], "_seg_cl": seg[:BN]}
         if channel_last:
             return outs
         outs["bev"] = ops.nhwc_to_nchw(bev)

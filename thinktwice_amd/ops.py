@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import TT_BF16, TT_F32, check, cur_stream, lib, ptr, require_cuda
+from ._lib import TT_BF16, TT_F16, TT_F32, check, cur_stream, lib, ptr, require_cuda
 
 _c = ctypes.c_int
 
@@ -19,6 +19,8 @@ def dtype_code(t):
         return TT_F32
     if t.dtype == torch.bfloat16:
         return TT_BF16
+    if t.dtype == torch.float16:
+        return TT_F16
     raise _lib.TTError(f"unsupported dtype {t.dtype}")
 
 
