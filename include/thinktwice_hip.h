@@ -131,6 +131,11 @@ typedef struct tt_conv_desc {
      * launch would occupy < 128 workgroups with a long K loop, K is split across gridDim.y and a tiny
      * finalize kernel applies the epilogue (latency-bound decoder layers with M <= a few thousand). */
     float* splitk_ws;
+    /* optional (dtype == TT_F32 only): the same weights pre-split into bf16 (hi, lo) pairs, per 16 K elements
+     * 64 B = [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] (thinktwice_amd/weights.py::split_pairs_x3).  When given
+     * and the layer fits the LDS-DMA kernel it runs in "bf16x3" arithmetic -- a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on
+     * the bf16 MFMA, ~1e-5 relative error, 16/3 of the f32-MFMA rate; otherwise the exact f32 path on `weight`. */
+    const void* weight_x3;
 } tt_conv_desc;
 
 int tt_conv2d_fwd(const tt_conv_desc* d, void* stream);

@@ -119,8 +119,6 @@ def test_decoder_teacher_forcing_pass_matches_oracle():
     assert max(errs.values()) < 1e-3, errs
 
 
-@pytest.mark.skipif(__import__("os").environ.get("TT_RUN_UNVALIDATED") != "1",
-                    reason="tt_concat_rows path written after the round's GPU budget was spent: opt-in until run once")
 def test_decoder_with_fused_concat_matches_oracle(monkeypatch):
     """A/B path TT_DEC_FUSED_CONCAT=1: every concatenated MLP input assembled by one tt_concat_rows launch."""
     import thinktwice_amd.decoder as D

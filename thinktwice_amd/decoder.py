@@ -13,8 +13,8 @@ import os
 
 import torch
 
-from . import _lib, ops
-from .layers import conv_from_sd, linear_from_sd, rows, unrows
+from . import _lib, ops, weights
+from .layers import conv_from_sd, conv_from_weight, linear_from_sd, rows, unrows
 from .registry import HEADS
 
 F32 = torch.float32
@@ -110,7 +110,8 @@ class ThinkTwiceDecoder:
                  dtype=torch.float32, device="cuda", **kwargs):
         self.config = config
         self.bev_h, self.bev_w = bev_h, bev_w
-        self.dtype = dtype
+        self.wdtype = dtype                               # precision mode of the FPN-side GEMMs (may be weights.X3)
+        self.dtype = weights.storage_dtype(dtype)
         self.device = torch.device(device)
         self.refine_num = config["refine_num"]
         self.loaded = False
@@ -128,19 +129,20 @@ class ThinkTwiceDecoder:
         self.policy = _mlp(sd, p + ".policy_head", (0, 2), dev, last_act=True)
         self.dist_mu = _mlp(sd, p + ".dist_mu", (0, 2), dev)
         self.dist_sigma = _mlp(sd, p + ".dist_sigma", (0, 2), dev)
-        self.fpn_linear = [conv_from_sd(sd, f"{p}.fpn_linear{i}", self.dtype, dev) for i in range(4)]
+        self.fpn_linear = [conv_from_sd(sd, f"{p}.fpn_linear{i}", self.wdtype, dev) for i in range(4)]
         self.temporal = sd[p + ".temporal_embedding"].to(dev, F32).contiguous()
         self.static = sd[p + ".static_embedding"].to(dev, F32).contiguous()
         cams = sd[p + ".cams_embeds"].to(dev, F32)
         lvls = sd[p + ".level_embeds"].to(dev, F32)
-        self.layers = [_Layer(sd, f"{p}.decoder_layers.{L}", dev, self.dtype) for L in range(self.refine_num)]
+        self.layers = [_Layer(sd, f"{p}.decoder_layers.{L}", dev, self.wdtype) for L in range(self.refine_num)]
         # value_proj(feat + cam_embed + level_embed) = value_proj(feat) + per-(level, cam) shift  (DEC:392-393)
         for lay in self.layers:
             emb = cams.view(1, 4, 256) + lvls.view(4, 1, 256)                       # (lvl, cam, 256)
             lay.vshift = [torch.addmm(lay.vproj_b.new_zeros(256), emb[l], lay.vproj_w.t()).contiguous()
                           for l in range(4)]                                         # W e (bias added by shift)
-        self.vproj_all_w = torch.cat([lay.vproj.w for lay in self.layers], 0).contiguous()          # (L*256,1,1,256)
         self.vproj_all_shift = torch.cat([lay.vproj.shift for lay in self.layers], 0).contiguous()  # (L*256,)
+        self.vproj_all = conv_from_weight(torch.cat([lay.vproj.w for lay in self.layers], 0).contiguous(),
+                                          self.wdtype, shift=self.vproj_all_shift)                  # (L*256,1,1,256)
         self.vshift_all = [torch.cat([lay.vshift[l] for lay in self.layers], 1).contiguous() for l in range(4)]
         self.loaded = True
         return self
@@ -156,8 +158,8 @@ class ThinkTwiceDecoder:
         start = 0
         for l, m in enumerate(mlvl):
             hw = m.shape[1] * m.shape[2]
-            ops.conv2d(m, self.vproj_all_w, shift=self.vproj_all_shift, shift_n=self.vshift_all[l], shift_n_mod=4,
-                       out=value[:, start:start + hw].unflatten(1, (m.shape[1], m.shape[2])), out_nstride=S * C)
+            self.vproj_all(m, shift_n=self.vshift_all[l], shift_n_mod=4,
+                           out=value[:, start:start + hw].unflatten(1, (m.shape[1], m.shape[2])), out_nstride=S * C)
             start += hw
         return value
 

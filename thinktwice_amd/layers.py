@@ -12,8 +12,11 @@ ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "sigmoid": _lib.ACT_SIGMOID
 
 
 class Conv:
-    def __init__(self, w, scale, shift, stride=1, pad=0, dil=1, act="none", pixel_shuffle2=False):
+    def __init__(self, w, scale, shift, stride=1, pad=0, dil=1, act="none", pixel_shuffle2=False, x3=False):
         self.w, self.scale, self.shift = w, scale, shift
+        # precision mode "f32x3": the same weights pre-split into bf16 (hi, lo) pairs ride along; the C side uses them
+        # wherever the layer fits the LDS-DMA kernel and the exact f32 path on `w` elsewhere
+        self.w_x3 = weights.split_pairs_x3(w) if x3 else None
         self.stride, self.pad, self.dil = stride, pad, dil
         self.act = ACT[act]
         self.ps2 = pixel_shuffle2
@@ -21,7 +24,7 @@ class Conv:
 
     def __call__(self, x, **kw):
         return ops.conv2d(x, self.w, stride=self.stride, pad=self.pad, dil=self.dil, scale=self.scale,
-                          shift=self.shift, act=self.act, pixel_shuffle2=self.ps2, **kw)
+                          shift=self.shift, act=self.act, pixel_shuffle2=self.ps2, w_x3=self.w_x3, **kw)
 
 
 def _dev(t, device):
@@ -39,7 +42,12 @@ def conv_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, stride=1, pad=0, di
                                        sd[bn + ".running_var"], eps, bias)
     else:
         scale, shift = None, bias
-    return Conv(wq, _dev(scale, device), _dev(shift, device), stride, pad, dil, act)
+    return Conv(wq, _dev(scale, device), _dev(shift, device), stride, pad, dil, act, x3=dtype == weights.X3)
+
+
+def conv_from_weight(w, dtype, scale=None, shift=None, **kw):
+    """Kernel-layout weight tensor [Cout,KH,KW,Cin_p] (storage dtype) -> Conv in the given precision mode."""
+    return Conv(w, scale, shift, x3=dtype == weights.X3, **kw)
 
 
 def linear_from_sd(sd, name, device, act="none", in_pad=None, dtype=torch.float32, bn=None, eps=1e-5):
@@ -52,7 +60,7 @@ def linear_from_sd(sd, name, device, act="none", in_pad=None, dtype=torch.float3
                                        sd[bn + ".running_var"], eps, bias)
     else:
         scale, shift = None, bias
-    return Conv(wq, _dev(scale, device), _dev(shift, device), act=act)
+    return Conv(wq, _dev(scale, device), _dev(shift, device), act=act, x3=dtype == weights.X3)
 
 
 def deconv2x2_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, act="none"):
@@ -64,7 +72,7 @@ def deconv2x2_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, act="none"):
                                        sd[bn + ".running_var"], eps, bias)
     else:
         scale, shift = None, bias
-    return Conv(wq, _dev(scale, device), _dev(shift, device), act=act, pixel_shuffle2=True)
+    return Conv(wq, _dev(scale, device), _dev(shift, device), act=act, pixel_shuffle2=True, x3=dtype == weights.X3)
 
 
 def rows(x):

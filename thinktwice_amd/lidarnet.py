@@ -10,7 +10,7 @@ import ctypes
 
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, weights
 from .layers import conv_from_sd, deconv2x2_from_sd
 from .ops import _c, _ll, check, lib, ptr
 from .registry import BACKBONES, MIDDLE_ENCODERS
@@ -56,11 +56,14 @@ class _Level:
 def _sp_weight(w, dev, dtype):
     """spconv (Cout,kD,kH,kW,Cin) -> [Cout][1][KV][Cin_p] (K-contiguous rows of the gathered GEMM)."""
     co, kd, kh, kw, ci = w.shape
-    vec = 4 if dtype == F32 else 8
+    sdt = weights.storage_dtype(dtype)
+    vec = weights.vec_of(dtype)
     cp = (ci + vec - 1) // vec * vec
-    out = torch.zeros(co, 1, kd * kh * kw, cp, dtype=dtype, device=dev)
-    out[..., :ci] = w.to(dev).reshape(co, 1, kd * kh * kw, ci).to(dtype)
-    return out.contiguous()
+    out = torch.zeros(co, 1, kd * kh * kw, cp, dtype=sdt, device=dev)
+    out[..., :ci] = w.to(dev).reshape(co, 1, kd * kh * kw, ci).to(sdt)
+    out = out.contiguous()
+    # precision mode "f32x3": (plain f32 weights, the same pre-split into bf16 pairs)
+    return (out, weights.split_pairs_x3(out) if dtype == weights.X3 else None)
 
 
 def _bn1d(sd, p, dev, eps=1e-3):
@@ -71,8 +74,8 @@ def _bn1d(sd, p, dev, eps=1e-3):
 
 def _sp_conv(feats, nbr, level, w, bn, res=None, relu=True):
     """SubMConv3d / SparseConv3d + BN1d (+ residual) + ReLU as ONE gathered MFMA GEMM."""
-    return ops.gather_conv(feats, nbr, level.rows, w, scale=bn[0], shift=bn[1], res=res,
-                           act=_lib.ACT_RELU if relu else _lib.ACT_NONE)
+    return ops.gather_conv(feats, nbr, level.rows, w[0], scale=bn[0], shift=bn[1], res=res,
+                           act=_lib.ACT_RELU if relu else _lib.ACT_NONE, w_x3=w[1])
 
 
 @MIDDLE_ENCODERS.register_module()
@@ -83,7 +86,8 @@ class SparseEncoder_fp32:
                  encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
                  encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), device="cuda",
                  dtype=torch.float32, **kw):
-        self.dtype = dtype
+        self.wdtype = dtype
+        self.dtype = weights.storage_dtype(dtype)
         self.in_channels = in_channels
         self.sparse_shape = list(sparse_shape)
         self.encoder_channels, self.encoder_paddings = encoder_channels, encoder_paddings
@@ -92,7 +96,7 @@ class SparseEncoder_fp32:
     def load_state_dict(self, sd, p):
         dev = self.device
         def _sp_w(t, d):
-            return _sp_weight(t, d, self.dtype)
+            return _sp_weight(t, d, self.wdtype)
         self.w_in = _sp_w(sd[p + ".conv_input.0.weight"], dev)
         self.bn_in = _bn1d(sd, p + ".conv_input.1", dev)
         self.stages = []
@@ -143,7 +147,7 @@ class SparseEncoder_fp32:
         """-> dense channel-last (B, H, W, C*D) f32 (== spatial_features.view(N, C*D, H, W))."""
         dev = voxel_features.device
         lvl = _Level(coors, num_rows, max_rows, self.sparse_shape, batch_size, dev)
-        cp = self.w_in.shape[-1]
+        cp = self.w_in[0].shape[-1]
         f0 = torch.zeros(max_rows, cp, dtype=self.dtype, device=dev)      # channel-padded voxel features
         nf = voxel_features.shape[1]
         ops.copy_nhwc(voxel_features.view(max_rows, 1, 1, nf), f0.view(max_rows, 1, 1, cp), C=nf)
@@ -175,7 +179,8 @@ class LidarNet:
         self.vl, self.bb, self.nk = dict(pts_voxel_layer), dict(pts_backbone), dict(pts_neck)
         me = dict(pts_middle_encoder)
         me.pop("type", None)
-        self.dtype = dtype
+        self.wdtype = dtype
+        self.dtype = weights.storage_dtype(dtype)
         self.middle = SparseEncoder_fp32(**me, device=device, dtype=dtype)
         self.device = torch.device(device)
         self.training = False
@@ -187,11 +192,11 @@ class LidarNet:
         self.blocks = []
         for b, (n, s) in enumerate(zip(self.bb["layer_nums"], self.bb["layer_strides"])):
             q = f"{p}.pts_backbone.blocks.{b}"
-            self.blocks.append([conv_from_sd(sd, f"{q}.{3 * l}", self.dtype, dev, bn=f"{q}.{3 * l + 1}", eps=eps,
+            self.blocks.append([conv_from_sd(sd, f"{q}.{3 * l}", self.wdtype, dev, bn=f"{q}.{3 * l + 1}", eps=eps,
                                              stride=s if l == 0 else 1, pad=1, act="relu") for l in range(n + 1)])
         q = p + ".pts_neck.deblocks"
-        self.de0 = conv_from_sd(sd, q + ".0.0", self.dtype, dev, bn=q + ".0.1", eps=eps, act="relu")
-        self.de1 = deconv2x2_from_sd(sd, q + ".1.0", self.dtype, dev, bn=q + ".1.1", eps=eps, act="relu")
+        self.de0 = conv_from_sd(sd, q + ".0.0", self.wdtype, dev, bn=q + ".0.1", eps=eps, act="relu")
+        self.de1 = deconv2x2_from_sd(sd, q + ".1.0", self.wdtype, dev, bn=q + ".1.1", eps=eps, act="relu")
         return self
 
     def voxelize(self, pts):

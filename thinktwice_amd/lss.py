@@ -11,8 +11,8 @@ channel-offset writes, the depth softmax / outer product / permute / voxel pooli
 """
 import torch
 
-from . import _lib, camera, layers, ops
-from .layers import conv_from_sd, deconv2x2_from_sd, linear_from_sd, rows, unrows
+from . import _lib, camera, layers, ops, weights
+from .layers import conv_from_sd, conv_from_weight, deconv2x2_from_sd, linear_from_sd, rows, unrows
 from .registry import BACKBONES
 
 
@@ -20,7 +20,7 @@ class _ResNet50:
     """[3P] mmdet ResNet(depth=50, out_indices 0-3) with eval BN folded into the conv epilogues."""
 
     def __init__(self, sd, p, dtype, device):
-        vec = 4 if dtype == torch.float32 else 8
+        vec = weights.vec_of(dtype)
         self.cin_pad = vec
         self.stem = conv_from_sd(sd, p + ".conv1", dtype, device, bn=p + ".bn1", stride=2, pad=3, act="relu",
                                  cin_pad=vec)
@@ -30,7 +30,7 @@ class _ResNet50:
         # stride 8 elements).  K tiles become whole cache lines and the layer runs on the LDS-DMA kernel instead of
         # the 3-channel im2col path (Cin=8 is below every DMA tile).  Same products, different summation order.
         self.stem_rr = None
-        if dtype != torch.float32:     # 16-bit storage (bf16 or IEEE half)
+        if weights.storage_dtype(dtype) != torch.float32:     # 16-bit storage (bf16 or IEEE half)
             w = sd[p + ".conv1.weight"].to(device)                      # (64, 3, 7, 7)
             wr = torch.zeros(w.shape[0], 7, 1, 64, dtype=dtype, device=device)
             wr[:, :, 0, :56] = torch.nn.functional.pad(w.permute(0, 2, 3, 1), (0, 5)).reshape(w.shape[0], 7, 56).to(dtype)
@@ -84,7 +84,8 @@ class LSS:
         self.downsample_factor = downsample_factor
         self.output_channels = output_channels
         self.queue_len = queue_len
-        self.dtype = dtype
+        self.wdtype = dtype                               # precision mode of the conv weights (may be weights.X3)
+        self.dtype = weights.storage_dtype(dtype)         # storage type of the activations
         self.device = torch.device(device)
         self.frustum = camera.make_frustum(self.final_dim, downsample_factor, d_bound)
         self.depth_channels = self.frustum.shape[0]
@@ -95,7 +96,7 @@ class LSS:
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd, prefix="img_encoder"):
-        dt, dev, p = self.dtype, self.device, prefix
+        dt, dev, p = self.wdtype, self.device, prefix
         f32 = torch.float32
         self.backbone = _ResNet50(sd, p + ".img_backbone", dt, dev)
         n = p + ".img_neck"
@@ -143,7 +144,7 @@ class LSS:
         for g in range(self.dcn_groups):
             wg = wd[g * og:(g + 1) * og].to(dev)                        # (og, cg, 3, 3)
             wg = wg.permute(0, 2, 3, 1).reshape(og, 1, 9, wg.shape[1])  # [Cout][1][tap][cin]
-            self.dcn_w.append(wg.to(dt).contiguous())
+            self.dcn_w.append(conv_from_weight(wg.to(self.dtype).contiguous(), dt))
         self.depth_out = conv_from_sd(sd, d + ".depth_conv.5", dt, dev)
         s = p + ".seg_net"
         self.up = {k: deconv2x2_from_sd(sd, f"{s}.{k}.up", dt, dev) for k in ("unet_layer4", "unet_layer3", "unet_layer2")}
@@ -151,7 +152,7 @@ class LSS:
                     for k in ("unet_layer4", "unet_layer3", "unet_layer2")}
         self.u0a = conv_from_sd(sd, s + ".unet_layer0.1", dt, dev, pad=1, act="relu")
         self.u0b = conv_from_sd(sd, s + ".unet_layer0.3", dt, dev, pad=1)
-        self.seg_cp = 12 if dt == f32 else 16
+        self.seg_cp = 12 if self.dtype == f32 else 16
         self.conv_last = conv_from_sd(sd, s + ".conv_last", dt, dev)
         r = p + ".seg_res_to_image_feature"
         self.seg2feat = []
@@ -225,9 +226,9 @@ class LSS:
         cols = ops.deform_im2col3x3(d, off, pad=1)
         dd = torch.empty(NI, h, w, mid, dtype=dt, device=dev)
         cg = mid // self.dcn_groups
-        og = self.dcn_w[0].shape[0]
+        og = self.dcn_w[0].w.shape[0]
         for g, wg in enumerate(self.dcn_w):
-            ops.conv2d(cols, wg, in_coff=g * cg, cin=cg, out=dd.view(NI * h * w, 1, 1, mid), out_coff=g * og)
+            wg(cols, in_coff=g * cg, cin=cg, out=dd.view(NI * h * w, 1, 1, mid), out_coff=g * og)
         depth = self.depth_out(dd, out_dtype=torch.float32)
         return depth, merge_in
 

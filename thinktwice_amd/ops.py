@@ -81,6 +81,7 @@ class _ConvDesc(ctypes.Structure):
         ("res2", ctypes.c_void_p), ("res2_cstride", _c), ("res2_coff", _c),
         ("act", _c), ("dtype", _c), ("out_dtype", _c),
         ("gather_idx", ctypes.c_void_p), ("m_dev", ctypes.c_void_p), ("splitk_ws", ctypes.c_void_p),
+        ("weight_x3", ctypes.c_void_p),
     ]
 
 
@@ -88,7 +89,7 @@ def _dp(t):
     return None if t is None else t.data_ptr()
 
 
-def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None, out_dtype=None):
+def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None, out_dtype=None, w_x3=None):
     """Sparse convolution as a gathered GEMM on MFMA: feats [R_in, C] rows, nbr int32 [M, taps]
     (rulebook, -1 = no input), m_dev device int (live output rows), w [Cout,1,taps,C] -> [M, Cout]."""
     require_cuda(feats, nbr, w)
@@ -105,6 +106,7 @@ def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None
     d.res1 = _dp(res); d.res1_cstride = 0 if res is None else res.shape[-1]
     d.act = act; d.dtype = dtype_code(feats); d.out_dtype = dtype_code(out)
     d.gather_idx = nbr.data_ptr(); d.m_dev = _dp(m_dev)
+    d.weight_x3 = _dp(w_x3)
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -118,7 +120,7 @@ def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None
 def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=None, res1_coff=0,
            res2=None, res2_coff=0, out=None, out_coff=0, in_coff=0, cin=None, pixel_shuffle2=False,
            shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None, splitk_ws=None,
-           in_cstride=None):
+           in_cstride=None, w_x3=None):
     """Channel-last implicit-GEMM convolution on MFMA (tt_conv2d_fwd).
 
     x   [N,H,W,Cs]  (f32 or bf16); channels [in_coff, in_coff+cin) are convolved
@@ -165,6 +167,9 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
         splitk_ws = torch.zeros(N * OH * OW, Cout, dtype=torch.float32, device=x.device)
     if splitk_ws is not None:
         d.splitk_ws = splitk_ws.data_ptr()
+    if w_x3 is not None:
+        assert x.dtype == torch.float32 and w_x3.shape == w.shape and w_x3.is_contiguous()
+        d.weight_x3 = w_x3.data_ptr()
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -322,6 +327,7 @@ def concat_rows(out, pieces, coff=0):
     out[r, ...] = src[(r // div) % mod if mod else r // div, :C]  (None: zeros).  One launch (tt_concat_rows)."""
     o2 = out.reshape(-1, out.shape[-1])
     assert o2.data_ptr() == out.data_ptr() and o2.dtype == torch.float32 and 1 <= len(pieces) <= 8
+    assert o2.stride(1) == 1, "concat_rows: `out` rows must be element-contiguous"
     n = len(pieces)
     srcs = (ctypes.c_void_p * n)()
     strides, widths, coffs, divs, mods = ((ctypes.c_int * n)() for _ in range(5))
@@ -330,6 +336,8 @@ def concat_rows(out, pieces, coff=0):
         if src is not None:
             s2 = src.reshape(-1, src.shape[-1])
             assert s2.dtype == torch.float32 and s2.stride(1) == 1 and s2.shape[1] >= C
+            need = mod if mod else -(-o2.shape[0] // div)          # source rows the mapping reaches
+            assert s2.shape[0] >= need, f"concat_rows: piece {i} has {s2.shape[0]} rows, mapping reads {need}"
             srcs[i], strides[i] = s2.data_ptr(), s2.stride(0)
         else:
             srcs[i], strides[i] = None, 0

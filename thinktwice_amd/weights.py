@@ -8,8 +8,32 @@ conv epilogue applies.
 import torch
 
 
+X3 = "f32x3"      # precision mode: f32 storage, bf16x3 MFMA arithmetic (pre-split weights beside the f32 ones)
+
+
+def storage_dtype(dtype):
+    """torch dtype activations / plain weights are stored in for a precision mode."""
+    return torch.float32 if dtype == X3 else dtype
+
+
 def vec_of(dtype):
-    return 4 if dtype == torch.float32 else 8
+    return 4 if storage_dtype(dtype) == torch.float32 else 8
+
+
+def split_pairs_x3(w):
+    """f32 weights [Cout, ..., K-contiguous] with K % 16 == 0 -> the same shape (f32-typed bit container) holding, per
+    16 K elements, 64 B = [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] in bf16 with hi = bf16(w), lo = bf16(w - hi)
+    (round to nearest even both): the B operand of conv_igemm_glds_kernel<..., X3>."""
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    co = w.shape[0]
+    k = w.numel() // co
+    if k % 16 != 0:
+        return None
+    flat = w.reshape(co, k // 16, 16)
+    hi = flat.to(torch.bfloat16)
+    lo = (flat - hi.float()).to(torch.bfloat16)
+    pair = torch.stack([hi, lo], 2).contiguous()            # (co, k/16, 2, 16) bf16 = 64 B per group
+    return pair.view(torch.float32).reshape(w.shape).contiguous()
 
 
 def pad_to(n, m):
@@ -19,6 +43,7 @@ def pad_to(n, m):
 def prep_conv_weight(w, dtype, cin_pad=None):
     """[Cout,Cin,KH,KW] -> [Cout,KH,KW,Cin_p] contiguous in `dtype` (zero-padded input channels)."""
     Cout, Cin, KH, KW = w.shape
+    dtype = storage_dtype(dtype)
     cp = cin_pad or pad_to(Cin, vec_of(dtype))
     out = torch.zeros(Cout, KH, KW, cp, dtype=dtype, device=w.device)
     out[..., :Cin] = w.permute(0, 2, 3, 1).to(dtype)
@@ -50,7 +75,7 @@ def fold_bn(bn_weight, bn_bias, running_mean, running_var, eps, conv_bias=None):
 def to_channel_last(x, dtype=None, c_pad=None):
     """[N,C,H,W] -> [N,H,W,Cp] contiguous (zero-padded channels)."""
     N, C, H, W = x.shape
-    dtype = dtype or x.dtype
+    dtype = storage_dtype(dtype or x.dtype)
     cp = c_pad or pad_to(C, vec_of(dtype))
     out = torch.zeros(N, H, W, cp, dtype=dtype, device=x.device)
     out[..., :C] = x.permute(0, 2, 3, 1).to(dtype)
