@@ -141,6 +141,51 @@ typedef struct tt_conv_desc {
 int tt_conv2d_fwd(const tt_conv_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------
+ * A chain of nn.Linear layers over R rows in ONE launch (the decoder's row-batched MLPs:
+ * thinktwice_decoder.py:26-260 query_linear / ffn / output_proj / mlp / traj_offset_module / ctrl_offset_module /
+ * flattened_BEV_feat_update_module and the coarse heads :419-445; MSDA sampling_offsets / attention_weights,
+ * multi_scale_deformable_attn_function.py:431-447).  A workgroup owns 32 rows and walks the whole chain with the
+ * intermediates in LDS; bf16x3 arithmetic (see tt_conv_desc.weight_x3).
+ *   stage s:  y = act( W_s . in + bias + side_w . side[m, :side_k] + res[m, res_coff + n] )
+ *   in = the chain input x (in_sel = -1) or the output of an earlier stage (in_sel = its index)
+ * w: pair-format weights [N rounded up to 32][Kp] (weights.py::split_pairs_x3 of the zero-padded f32 matrix),
+ * Kp % 16 == 0.  `out` (nullable): f32 rows in global memory.  Outputs that a later stage reads stay in LDS
+ * (<= 160 KiB in total per 32 rows, checked).
+ * ---------------------------------------------------------------------- */
+typedef struct tt_chain_stage {
+    const void* w; const float* bias;
+    int K, Kp, N, act, in_sel;
+    const float* res; int res_stride, res_coff;
+    const float* side; const float* side_w; int side_stride, side_k;
+    float* out; int out_stride, out_coff;
+} tt_chain_stage;
+/* n_split > 1 (single stage only): the N columns are dealt over n_split workgroups per 32 rows (few rows, wide N:
+ * the BEV update's broadcast-channel term, 2048 -> 9 x 128) */
+int tt_mlp_chain(const float* x, long long R, int x_stride, int nstages, const tt_chain_stage* stages, int n_split,
+                 void* stream);
+
+/* ------------------------------------------------------------------------
+ * Spatial half of a refinement layer as persistent per-sample kernels (csrc/dec_spatial.hip), bf16x3 arithmetic.
+ * All weight tensors are pair format (weights.py::split_pairs_x3), K order tap-major / channel-minor.
+ * ---------------------------------------------------------------------- */
+/* SpatialGRU (dense_heads/utils.py:53-106): inp6 [B][4][6] (waypoint xy, softplus ctrl), state [B][441][32] f32
+ * channel-last -> fut [B][4][441][32].  w0/wx/b0/w2/b2: arrays of 3 (conv_update, conv_reset, conv_state_tilde):
+ * w0 = state part of the .0 conv [32][9*32], wx = its constant-input part f32 [9][6][32], w2 = the .2 conv.
+ * scratch: [B][2][441][32] f32. */
+int tt_dec_gru(int B, const float* inp6, const float* state, float* fut, float* scratch, const void* const* w0,
+               const float* const* wx, const float* const* b0, const void* const* w2, const float* const* b2,
+               const void* wd0, const float* bd0, const void* wd2, const float* bd2, void* stream);
+/* grid2feat (encoder_decoder_framework.py:228-234, thinktwice_decoder.py:405-415): maps x [441][32] -> [256];
+ * 17 weight sets in the order documented in dec_spatial.hip; mids (nullable): the three SE-block outputs. */
+int tt_dec_flatten(int maps, const float* in, float* out, float* mids_or_null, const void* const* w,
+                   const float* const* b, const float* bn_scale, const float* bn_shift, void* stream);
+/* BEV_feat_update_module + residual (thinktwice_decoder.py:221-225,257): bev [B][441][32], G [B][9][128] = the
+ * broadcast-channel term per tap (tt_mlp_chain over h), w0 [128][9*32] (bev part), w2[4] [32][9*32] per hidden chunk. */
+int tt_dec_bev_update(int B, const float* bev, const float* G, float* out, long long out_bstride, float* out2,
+                      long long out2_bstride, const void* w0, const float* b0, const void* const* w2, const float* b2,
+                      void* stream);
+
+/* ------------------------------------------------------------------------
  * HBM-bound glue of the forward (channel-last; `dtype` = storage type of the activation).
  * Each replaces a torch call of the reference forward (call sites cited).
  * ---------------------------------------------------------------------- */
@@ -230,6 +275,24 @@ int tt_msda_sample_strided(int B, const void* value, int value_dtype, int value_
 /* SpatialCrossAttention "mask & average" incl. its batch-coupling bug (MSDA:338-342):
  * out (B, 4*256) = sum_{s=B}^{max_len-1} x[b,cam,s,:] / B. */
 int tt_sca_reduce(int B, const float* x, const int* max_len, float* out, void* stream);
+
+/* Composite-decoder variants of the four row producers above with the nn.LayerNorm that follows them folded in
+ * (query_linear.0 thinktwice_decoder.py:131, ffn.norm MSDA:262, output_proj.0 DEC:141, mlp.0 DEC:197): each output
+ * feeds tt_mlp_chain directly.  tt_look_query_ln: `ctrl` raw (raw_ctrl=1: softplus applied here) or softplus'ed. */
+int tt_look_query_ln(int B, const int* query_of_slot, const float* ref_packed, const float* wp, const float* ctrl,
+                     int raw_ctrl, const float* temporal_embedding, const float* static_embedding,
+                     const float* measurement_feat, const float* flattened_feat, const void* const* level_maps,
+                     const int* level_hw, int maps_dtype, const float* gamma, const float* beta, float eps, float* out,
+                     int row_stride, void* stream);
+int tt_msda_sample_ln(int B, const void* value, int value_dtype, int value_cstride, int value_coff,
+                      const float* offsets, const float* logits, const float* ref_packed, const int* level_hw,
+                      const float* gamma, const float* beta, float eps, float* out, float* out_ln, void* stream);
+int tt_sca_reduce_ln(int B, const float* x, const int* max_len, const float* gamma, const float* beta, float eps,
+                     float* out, void* stream);
+/* row (b, t) of the refinement layer's mlp input: LayerNorm(cat([fflat(b,t) | look(b) | 0 | temporal(t) | meas(b)])) */
+int tt_dec_merge_in(int B, const float* fflat, const float* look, const float* temporal_embedding,
+                    const float* measurement_feat, const float* gamma, const float* beta, float eps, float* out,
+                    void* stream);
 
 /* ------------------------------------------------------------------------
  * LiDAR branch (backbones/lidarnet.py:87-96; bodies are third-party: mmcv Voxelization, mmdet3d

@@ -23,12 +23,15 @@ def _inputs(B, hw=(128, 256), seed=0):
     return cam_bev, lidar, fpn, batch, l2i, ida
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["layerwise", "composite"])
 @pytest.mark.parametrize("B", [1, 2, 3, -2])
-def test_fusion_and_decoder_match_oracle(B):
+def test_fusion_and_decoder_match_oracle(B, fused, monkeypatch):
     """B < 0: |B| samples with a degenerate lidar2img (all zeros) -> no look point projects into any camera, every
     (sample, cam) hit count and max_len are 0 and the look feature is the pure-bias path."""
     no_hits = B < 0
     B = abs(B)
+    # composite = decoder_fused.py (~16 launches per layer, bf16x3 arithmetic); layerwise = one launch per op, exact f32
+    monkeypatch.setenv("TT_DEC_FUSED", "1" if fused else "0")
     from oracle import model_ref as M
     from thinktwice_amd import config, params, weights
     from thinktwice_amd.encoder_decoder import EncoderDecoder
@@ -63,6 +66,7 @@ def test_fusion_and_decoder_match_oracle(B):
     assert _rel(meas.cpu(), meas_r) < 1e-4
     assert _rel(flat.cpu(), flat_r) < 1e-4
     # look-module bookkeeping is integer work: bit exact
+    assert (dec.fused is not None) == fused
     for L in range(5):
         cnt, ml = out["_look_info"][L]
         np.testing.assert_array_equal(cnt.cpu().numpy(), ref["_look_info"][L]["count"].numpy())
@@ -77,7 +81,8 @@ def test_fusion_and_decoder_match_oracle(B):
     assert max(errs.values()) < 1e-3, errs
 
 
-def test_decoder_teacher_forcing_pass_matches_oracle():
+@pytest.mark.parametrize("fused", [False, True], ids=["layerwise", "composite"])
+def test_decoder_teacher_forcing_pass_matches_oracle(fused, monkeypatch):
     """SURVEY 8f-4 (forward half): the teacher-forcing pass (DEC:491-533) -- five layers fed the expert waypoints and
     inv_softplus(expert Beta parameters) -- against the oracle, which reproduces the reference's training forward
     bit-exactly (golden F10).  The ordinary outputs must be unaffected by the extra pass."""
@@ -87,6 +92,7 @@ def test_decoder_teacher_forcing_pass_matches_oracle():
     from thinktwice_amd.fusion import BEVFusion
     from thinktwice_amd.decoder import ThinkTwiceDecoder
     from thinktwice_amd.layers import linear_from_sd
+    monkeypatch.setenv("TT_DEC_FUSED", "1" if fused else "0")
     B, hw = 2, (128, 256)
     cfg = config.model_config(final_dim=hw)
     sd = params.init_params(cfg, seed=0, parts=("fusion", "decoder"))
@@ -133,4 +139,4 @@ def test_decoder_with_fused_concat_matches_oracle(monkeypatch):
                       temporal.unsqueeze(0).expand(B, 4, 128), meas.unsqueeze(1).expand(B, 4, 128)], -1).view(B * 4, 1024)
     assert torch.equal(hin, want)
     monkeypatch.setattr(D, "_FUSED_CONCAT", True)
-    test_fusion_and_decoder_match_oracle(2)
+    test_fusion_and_decoder_match_oracle(2, False, monkeypatch)

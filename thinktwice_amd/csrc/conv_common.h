@@ -35,6 +35,7 @@ struct ConvArgs {
     int res_vec;         // 1: residual chunks are 8/16 B aligned (vector loads)
     int splits;          // split-K factor (gridDim.y)
     int tiles_n;
+    int m_begin;         // first output row of this launch (tail-split launches of the LDS-DMA kernel), else 0
 };
 
 template <typename T> struct Mfma;

@@ -348,7 +348,7 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
     a.out_fast = (!d->pixel_shuffle2 && a.out_nstride == (long long)d->OH * d->OW * d->out_cstride) ? 1 : 0;
     TT_REQUIRE(!(d->pixel_shuffle2 && (d->res1 || d->res2)),
                "tt_conv2d_fwd: residuals are not supported with pixel_shuffle2");
-    a.tiles_n = 1; a.cin_fast = 0;
+    a.tiles_n = 1; a.cin_fast = 0; a.m_begin = 0;
     {
         const int co_vec = d->out_dtype == TT_F32 ? 4 : 8;
         const int osz = d->out_dtype == TT_F32 ? 4 : 2;

@@ -85,7 +85,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
     const int tile_n = L % tiles_n, tile_m = L / tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
     int Mlim = p.M;
     if (GATHER && p.m_dev) {           // sparse conv: live output rows are only known on the device
         const int md = *p.m_dev;
@@ -424,12 +424,15 @@ static const void* zero_page() {
 }
 
 template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false>
-static int launch_glds(ConvArgs& a, hipStream_t st) {
+static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0) {
     constexpr int BM = 256;
     constexpr int WTN = BN / WAVES_N;
     const void* zp = zero_page();
     if (!zp) return 0;
-    const int tiles_m = div_up(a.M, BM), tiles_n = div_up(a.Cout, BN);
+    // rows [m_begin, M) by default; `m_tiles_limit` > 0 restricts the launch to that many row tiles from m_begin
+    int tiles_m = div_up(a.M - a.m_begin, BM);
+    if (m_tiles_limit > 0 && m_tiles_limit < tiles_m) tiles_m = m_tiles_limit;
+    const int tiles_n = div_up(a.Cout, BN);
     size_t smem = (size_t)STAGES * (BM + BN) * BKB;
     const size_t epi = (size_t)(WAVES_M * WAVES_N) * 32 * (WTN + 4) * 4;
     if (smem < epi) smem = epi;
@@ -448,6 +451,27 @@ static int launch_glds(ConvArgs& a, hipStream_t st) {
     return 1;
 }
 
+// Tail split of a 256x256-tile launch.  With T tiles on 256 CUs (one workgroup per CU: 128 KiB of LDS) the launch
+// takes ceil(T / 256) rounds; when the last round is less than a quarter full (the 512 -> 512 DepthNet layers: 784
+// tiles = 3 rounds + 16 tiles, i.e. 23 % of the launch spent on 2 % of the work) the row tiles of that remainder are
+// peeled off into a second launch of 256x64 tiles (4x as many, 1/4 the work each) that fills the chip.
+// Returns the number of row tiles the MAIN launch should cover (0: no split).
+static int tail_split_rows(const ConvArgs& a) {
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = getenv("TT_CONV_TAIL_SPLIT");   // A/B knob
+        enabled = e ? atoi(e) : 1;
+    }
+    if (!enabled || a.Cout % 256 != 0) return 0;
+    const int tiles_m = div_up(a.M, 256), tiles_n = a.Cout / 256;
+    const long long T = (long long)tiles_m * tiles_n;
+    const int rounds = (int)((T + kNumCU - 1) / kNumCU);
+    const int last = (int)(T - (long long)kNumCU * (rounds - 1));
+    if (rounds < 2 || rounds > 8 || last > kNumCU / 4) return 0;
+    const int peel = div_up(last, tiles_n);            // row tiles moved to the tail launch
+    return peel < tiles_m ? tiles_m - peel : 0;
+}
+
 // bf16x3 arithmetic on f32 storage (see the kernel's template comment).  `a.weight` must already point at the
 // pre-split weights.  Returns 0 when the shape is outside the DMA kernel's contract (the caller then runs the exact
 // f32 path on the plain weights).
@@ -462,7 +486,15 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
     if (a.m_dev || a.M < 2048 || a.Cout < 64 || a.KH * a.KW > 32) return 0;
     if (a.Cin % 32 != 0 || a.K < 64) return 0;       // 128 B rows = 32 f32 of one tap per K tile, >= 2 tiles
     // the split costs 8/TN VALU per MFMA: widest wave tile along N that the layer allows
-    if (a.Cout % 256 == 0 || a.Cout > 512) return launch_glds<float, 256, 4, 2, 128, 2, false, true>(a, st);   // 8 x (64 x 128)
+    if (a.Cout % 256 == 0 || a.Cout > 512) {                                                                   // 8 x (64 x 128)
+        if (const int main_rows = tail_split_rows(a)) {
+            launch_glds<float, 256, 4, 2, 128, 2, false, true>(a, st, main_rows);
+            ConvArgs t = a;
+            t.m_begin = main_rows * 256;
+            return launch_glds<float, 64, 8, 1, 128, 2, false, true>(t, st);
+        }
+        return launch_glds<float, 256, 4, 2, 128, 2, false, true>(a, st);
+    }
     if (a.Cout > 64) return launch_glds<float, 128, 8, 1, 128, 2, false, true>(a, st);                         // 8 x (32 x 128)
     return launch_glds<float, 64, 8, 1, 128, 2, false, true>(a, st);                                           // 8 x (32 x 64)
 }
@@ -529,7 +561,15 @@ static int launch_glds16(ConvArgs& a, int dtype, hipStream_t st, int min_tiles) 
             else if (a.K <= 512) v = 1;
             else v = 0;
         }
-        if (v == 6 && a.Cout % 256 == 0 && a.Cin % 64 == 0) return launch_glds<T16, 256, 2, 4, 128, 2>(a, st);
+        if (v == 6 && a.Cout % 256 == 0 && a.Cin % 64 == 0) {
+            if (const int main_rows = tail_split_rows(a)) {
+                launch_glds<T16, 256, 2, 4, 128, 2>(a, st, main_rows);
+                ConvArgs t = a;
+                t.m_begin = main_rows * 256;
+                return launch_glds<T16, 64, 8, 1, 128, 2>(t, st);
+            }
+            return launch_glds<T16, 256, 2, 4, 128, 2>(a, st);
+        }
         // not measured yet (added after the round's GPU budget was spent): the same 256x256 / 128 B-row / 2-stage tile
         // as sixteen 64x64 waves = 4 waves per SIMD at a 128-register budget, to test whether the loop is issue-bound
         // with 2 lock-stepped waves per SIMD

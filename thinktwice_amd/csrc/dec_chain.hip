@@ -8,9 +8,11 @@
 //
 // Arithmetic: "bf16x3" on the bf16 MFMA (the exact-f32 MFMA is 16x slower): every f32 operand is a bf16 (hi, lo) pair,
 // a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi accumulated in f32 (relative error ~1e-5 per dot product).  Weights arrive
-// pre-split from the host ("pair format": per 16 K elements 64 B = [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15],
-// weights.py::split_pairs_x3); intermediates are split ONCE when a stage writes them to LDS, in the same format, so a
-// wave's A fragment is two ds_read_b128 with no conversion; the chain input is split when it is loaded from HBM.
+// pre-split from the host in FRAGMENT-MAJOR order (weights.py::split_pairs_frag: per 32-column block and 16-wide K
+// step one contiguous KiB of hi halves + one of lo halves, indexed by lane), so a wave's B operand is two fully
+// coalesced 1 KiB loads; intermediates are split ONCE when a stage writes them to LDS ("pair format": per row, per 16
+// K elements 64 B = [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15]), so a wave's A fragment is two ds_read_b128 with no
+// conversion; the chain input is split when it is loaded from HBM.
 //
 // Layout of a stage: out[32 rows][N] = A[32][K] * W^T.  v_mfma_f32_32x32x16_bf16: lane l supplies row / column
 // (l & 31) and the 8-element K chunk (l >> 5) of a 16-element K step.  The 8 waves of the workgroup take the 32-column
@@ -21,12 +23,13 @@
 
 namespace tt {
 
-constexpr int kChainMaxStages = 8;
+constexpr int kChainMaxStages = 12;
 constexpr int kChainWaves = 8;
-constexpr int kChainNBW = 4;      // accumulator blocks per wave per pass
+constexpr int kChainNBW = 2;      // accumulator blocks per wave per pass
+constexpr int kChainPF = 4;       // weight K-steps in flight per wave
 
 struct ChainStage {
-    const void* w;        // pair-format weights [N padded to 32][Kp]
+    const void* w;        // fragment-major pair-format weights of the [N padded to 32][Kp] matrix
     const float* bias;    // [N] or null
     const float* res;     // optional residual rows (global f32): v += res[m * res_stride + res_coff + n]
     const float* side;    // optional extra input columns (global f32 [R][side_stride]): v += sum_j side[m][j] * side_w[n][j]
@@ -44,6 +47,7 @@ struct ChainArgs {
     const float* x;
     long long R;
     int x_stride, nstages;
+    int nbw;              // 32-column blocks per wave per pass (1..kChainNBW); 1 when N is split over gridDim.y
     ChainStage st[kChainMaxStages];
 };
 
@@ -78,9 +82,9 @@ __device__ __forceinline__ void lds_store_pair(unsigned char* buf, int stride, i
 __global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_kernel(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
+    const int r_ = lane & 31, h_ = lane >> 5;
     const long long m0 = (long long)blockIdx.x * 32;
-    const long long m = m0 + r;
+    const long long m = m0 + r_;
     const bool row_ok = m < a.R;
 
     for (int s = 0; s < a.nstages; ++s) {
@@ -92,16 +96,25 @@ __global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_kernel(const Chain
         const int astride = from_x ? 0 : a.st[S.in_sel].lds_stride;
         const float* xrow = a.x + (row_ok ? m : 0) * a.x_stride;
 
-        for (int nb0 = wave; nb0 < NB; nb0 += kChainWaves * kChainNBW) {
-            // this pass: blocks nb0, nb0 + 8, nb0 + 16, nb0 + 24 (those < NB)
+        const int per_pass = kChainWaves * a.nbw;
+        for (int base = per_pass * blockIdx.y; base < NB; base += per_pass * gridDim.y) {
+            // launder the lane-derived indices: the row / column address arithmetic of the epilogue is invariant across
+            // passes and stages and would otherwise be hoisted and kept live through the K loops (spills)
+            int r = r_, h = h_;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(r), "+v"(h));
+#endif
+            // this pass: blocks nb0, nb0 + 8, ... (nbw of them, those < NB); gridDim.y > 1 splits a single wide stage
+            const int nb0 = base + wave;
             const unsigned char* bptr[kChainNBW];
             bool live[kChainNBW];
 #pragma unroll
             for (int q = 0; q < kChainNBW; ++q) {
                 const int nb = nb0 + q * kChainWaves;
-                live[q] = nb < NB;
-                bptr[q] = reinterpret_cast<const unsigned char*>(S.w) +
-                          ((size_t)((live[q] ? nb : nb0) * 32 + r) * S.Kp) * 4 + h * 16;
+                live[q] = q < a.nbw && nb < NB;
+                // fragment-major weights: block nb, step ks at ((nb * nsteps + ks) * 2 + plane) KiB, lane-contiguous
+                bptr[q] = reinterpret_cast<const unsigned char*>(S.w) + (size_t)(live[q] ? nb : 0) * nsteps * 2048 +
+                          (h * 32 + r) * 16;
             }
             f32x16 acc[kChainNBW];
 #pragma unroll
@@ -109,52 +122,67 @@ __global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_kernel(const Chain
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
 
-            auto load_a = [&](int ks, uint4& ah, uint4& al) {
-                if (from_x) {
-                    const int k0 = ks * 16 + h * 8;
-                    float v[8];
-                    if (row_ok && k0 + 8 <= S.K) {
-                        const float4 t0 = *reinterpret_cast<const float4*>(xrow + k0);
-                        const float4 t1 = *reinterpret_cast<const float4*>(xrow + k0 + 4);
-                        v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
-                        v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (row_ok && k0 + e < S.K) ? xrow[k0 + e] : 0.f;
-                    }
-                    split8(v, ah, al);
-                } else {
-                    const unsigned char* p = abuf + (size_t)r * astride + ks * 64 + h * 16;
-                    ah = *reinterpret_cast<const uint4*>(p);
-                    al = *reinterpret_cast<const uint4*>(p + 32);
-                }
-            };
+            // Weight ring of kChainPF K-steps; every load is UNCONDITIONAL (step clamped to the last one, dead blocks
+            // re-read block 0, rows beyond R re-read row 0) so the compiler counts the outstanding loads statically
+            // instead of draining them at every loop head.
+            const int last = nsteps - 1;
             auto load_b = [&](int ks, uint4 (&bh)[kChainNBW], uint4 (&bl)[kChainNBW]) {
+                const int kk = ks < last ? ks : last;
 #pragma unroll
                 for (int q = 0; q < kChainNBW; ++q) {
-                    if (live[q]) {
-                        const unsigned char* p = bptr[q] + (size_t)ks * 64;
-                        bh[q] = *reinterpret_cast<const uint4*>(p);
-                        bl[q] = *reinterpret_cast<const uint4*>(p + 32);
-                    }
+                    const unsigned char* p = bptr[q] + (size_t)kk * 2048;
+                    bh[q] = *reinterpret_cast<const uint4*>(p);
+                    bl[q] = *reinterpret_cast<const uint4*>(p + 1024);
                 }
             };
-
-            uint4 ah[2], al[2], bh[2][kChainNBW], bl[2][kChainNBW];
-            load_a(0, ah[0], al[0]);
-            load_b(0, bh[0], bl[0]);
-            for (int ks = 0; ks < nsteps; ks += 2) {
+            uint4 bh[kChainPF][kChainNBW], bl[kChainPF][kChainNBW];
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int k = ks + half;
-                    if (k < nsteps) {
-                        if (k + 1 < nsteps) {
-                            load_a(k + 1, ah[half ^ 1], al[half ^ 1]);
-                            load_b(k + 1, bh[half ^ 1], bl[half ^ 1]);
+            for (int p = 0; p < kChainPF; ++p) load_b(p, bh[p], bl[p]);
+            if (from_x) {
+                // A from HBM/L2 (f32 rows, x_stride >= Kp checked by the host): a ring of raw fragments, split on use
+                const float* xa = xrow + h * 8;
+                float4 ar0[kChainPF], ar1[kChainPF];
+#pragma unroll
+                for (int p = 0; p < kChainPF; ++p) {
+                    const int kk = p < last ? p : last;
+                    ar0[p] = *reinterpret_cast<const float4*>(xa + kk * 16);
+                    ar1[p] = *reinterpret_cast<const float4*>(xa + kk * 16 + 4);
+                }
+#pragma unroll 1
+                for (int ks = 0; ks < nsteps; ks += kChainPF) {
+#pragma unroll
+                    for (int p = 0; p < kChainPF; ++p) {
+                        const int k = ks + p;
+                        const float v[8] = {ar0[p].x, ar0[p].y, ar0[p].z, ar0[p].w, ar1[p].x, ar1[p].y, ar1[p].z, ar1[p].w};
+                        uint4 ah, al;
+                        split8(v, ah, al);
+                        if (k < nsteps) {
+#pragma unroll
+                            for (int q = 0; q < kChainNBW; ++q)
+                                if (live[q]) mfma3(ah, al, bh[p][q], bl[p][q], acc[q]);
                         }
+                        const int kn = k + kChainPF < last ? k + kChainPF : last;
+                        ar0[p] = *reinterpret_cast<const float4*>(xa + kn * 16);
+                        ar1[p] = *reinterpret_cast<const float4*>(xa + kn * 16 + 4);
+                        load_b(k + kChainPF, bh[p], bl[p]);
+                    }
+                }
+            } else {
+                const unsigned char* pa = abuf + (size_t)r * astride + h * 16;
+#pragma unroll 1
+                for (int ks = 0; ks < nsteps; ks += kChainPF) {
 #pragma unroll
-                        for (int q = 0; q < kChainNBW; ++q)
-                            if (live[q]) mfma3(ah[half], al[half], bh[half][q], bl[half][q], acc[q]);
+                    for (int p = 0; p < kChainPF; ++p) {
+                        const int k = ks + p;
+                        const int kk = k < last ? k : last;
+                        const uint4 ah = *reinterpret_cast<const uint4*>(pa + kk * 64);
+                        const uint4 al = *reinterpret_cast<const uint4*>(pa + kk * 64 + 32);
+                        if (k < nsteps) {
+#pragma unroll
+                            for (int q = 0; q < kChainNBW; ++q)
+                                if (live[q]) mfma3(ah, al, bh[p][q], bl[p][q], acc[q]);
+                        }
+                        load_b(k + kChainPF, bh[p], bl[p]);
                     }
                 }
             }
@@ -177,7 +205,9 @@ __global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_kernel(const Chain
                     float v = acc[q][i] + bias;
                     if (S.side && ok) {
                         const float* sp = S.side + mr * S.side_stride;
-                        for (int j = 0; j < S.side_k; ++j) v += sp[j] * sw[j];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (j < S.side_k) v += sp[j] * sw[j];
                     }
                     if (S.res && ok) v += S.res[mr * S.res_stride + S.res_coff + n];
                     v = apply_act(v, S.act);
@@ -196,11 +226,13 @@ __global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_kernel(const Chain
 using namespace tt;
 
 extern "C" int tt_mlp_chain(const float* x, long long R, int x_stride, int nstages, const tt_chain_stage* st,
-                            void* stream) {
+                            int n_split, void* stream) {
     TT_REQUIRE(x && st && R > 0 && nstages >= 1 && nstages <= kChainMaxStages, "tt_mlp_chain: bad arguments");
+    TT_REQUIRE(n_split >= 1 && (n_split == 1 || nstages == 1), "tt_mlp_chain: n_split > 1 needs a single stage");
     TT_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride % 4 == 0, "tt_mlp_chain: x must be 16 B aligned rows");
     ChainArgs a;
     a.x = x; a.R = R; a.x_stride = x_stride; a.nstages = nstages;
+    a.nbw = n_split > 1 ? 1 : kChainNBW;
     // LDS plan: an output is kept while a LATER stage reads it; buffers are placed first-fit over the live ranges
     int last_use[kChainMaxStages];
     for (int s = 0; s < nstages; ++s) last_use[s] = -1;
@@ -216,7 +248,9 @@ extern "C" int tt_mlp_chain(const float* x, long long R, int x_stride, int nstag
                    "tt_mlp_chain: stage %d: K=%d Kp=%d N=%d", s, d.K, d.Kp, d.N);
         TT_REQUIRE((reinterpret_cast<uintptr_t>(d.w) & 15) == 0, "tt_mlp_chain: stage %d weights unaligned", s);
         TT_REQUIRE(d.side_k >= 0 && d.side_k <= 8 && (!d.side || d.side_w), "tt_mlp_chain: stage %d side input", s);
-        TT_REQUIRE(d.in_sel >= 0 || x_stride >= d.K, "tt_mlp_chain: stage %d: x rows shorter than K", s);
+        TT_REQUIRE(d.in_sel >= 0 || x_stride >= d.Kp,
+                   "tt_mlp_chain: stage %d: x rows (stride %d) must cover the padded K = %d (finite padding)", s, x_stride,
+                   d.Kp);
         TT_REQUIRE(d.in_sel < 0 || st[d.in_sel].N == d.K, "tt_mlp_chain: stage %d: K=%d but stage %d has N=%d", s, d.K,
                    d.in_sel, d.in_sel >= 0 ? st[d.in_sel].N : 0);
         ChainStage& S = a.st[s];
@@ -230,19 +264,34 @@ extern "C" int tt_mlp_chain(const float* x, long long R, int x_stride, int nstag
             const int np = (d.N + 15) / 16 * 16;          // the consumer's Kp
             S.lds_stride = np * 4 + 16;
             len[s] = (size_t)32 * S.lds_stride;
-            // first fit against the buffers still live at stage s (those with last_use >= s, i.e. read at or after s)
+            // Two-ended placement against the buffers still live at stage s (those read at or after s): a buffer goes
+            // to the END of the 160 KiB window when its input sits in the lower half, else to the start -- a chain then
+            // ping-pongs between the two ends and a long-lived buffer in the middle never splits the free space.
+            constexpr size_t kBudget = 160 * 1024;
+            auto clashes = [&](size_t pos) -> int {
+                for (int t = 0; t < s; ++t)
+                    if (len[t] != 0 && last_use[t] >= s && pos < off[t] + len[t] && off[t] < pos + len[s]) return t;
+                return -1;
+            };
+            const bool in_low = d.in_sel < 0 || off[d.in_sel] + len[d.in_sel] / 2 < kBudget / 2;
+            bool placed = false;
             size_t pos = 0;
-            bool moved = true;
-            while (moved) {
-                moved = false;
-                for (int t = 0; t < s; ++t) {
-                    if (len[t] == 0 || last_use[t] < s) continue;
-                    if (pos < off[t] + len[t] && off[t] < pos + len[s]) {
-                        pos = (off[t] + len[t] + 15) / 16 * 16;
-                        moved = true;
-                    }
+            for (int attempt = 0; attempt < 2 && !placed; ++attempt) {
+                const bool top = (attempt == 0) ? (d.in_sel >= 0 && in_low) : !(d.in_sel >= 0 && in_low);
+                if (top) {
+                    if (len[s] > kBudget) break;
+                    long long p = (long long)((kBudget - len[s]) / 16 * 16);
+                    int t;
+                    while (p >= 0 && (t = clashes((size_t)p)) >= 0) p = ((long long)off[t] - (long long)len[s]) / 16 * 16;
+                    if (p >= 0 && clashes((size_t)p) < 0) { pos = (size_t)p; placed = true; }
+                } else {
+                    size_t p = 0;
+                    int t;
+                    while ((t = clashes(p)) >= 0) p = (off[t] + len[t] + 15) / 16 * 16;
+                    if (p + len[s] <= kBudget) { pos = p; placed = true; }
                 }
             }
+            TT_REQUIRE(placed, "tt_mlp_chain: intermediates of stage %d do not fit in 160 KiB of LDS", s);
             off[s] = pos;
             S.lds_off = (int)pos;
             if (pos + len[s] > total) total = pos + len[s];
@@ -260,6 +309,7 @@ extern "C" int tt_mlp_chain(const float* x, long long R, int x_stride, int nstag
         attr = 160 * 1024;
     }
     const unsigned blocks = (unsigned)((R + 31) / 32);
-    hipLaunchKernelGGL(mlp_chain_kernel, dim3(blocks), dim3(kChainWaves * 64), total, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(mlp_chain_kernel, dim3(blocks, (unsigned)n_split), dim3(kChainWaves * 64), total,
+                       (hipStream_t)stream, a);
     return check_launch("tt_mlp_chain");
 }

@@ -1,0 +1,511 @@
+// Spatial half of the look-and-predict decoder as persistent per-sample kernels (one launch per stage instead of ~120):
+//   tt_dec_gru         SpatialGRU, 4 steps x 8 convs on the 21x21x32 BEV state (dense_heads/utils.py:53-106,
+//                      thinktwice_decoder.py:26-47 PredictionModule)
+//   tt_dec_flatten     conv21_10 -> MLP10 -> conv10_4 -> MLP4 -> conv4_2 -> MLP2 -> output_fc, the grid2feat network
+//                      (encoder_decoder_framework.py:228-234, thinktwice_decoder.py:405-415; SEBasicBlock code/utils.py:84-121)
+//   tt_dec_bev_update  BEV_feat_update_module on cat([bev, h broadcast]) + residual (thinktwice_decoder.py:221-225,257)
+//
+// One workgroup owns one sample (one map): the maps live in LDS for the whole kernel, the convolutions are implicit
+// GEMMs on the bf16 MFMA in "bf16x3" arithmetic (see dec_chain.hip), separated by workgroup barriers only.
+//   * LDS maps are stored in PAIR FORMAT: per pixel, per 16 channels, 64 B = [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]
+//     (bf16), i.e. a wave's A fragment for (pixel = lane & 31, channel half = lane >> 5) is two ds_read_b128 with no
+//     conversion; a value is split once, when the producing epilogue stores it.  Pixel stride = Cp*4 + 16 B, an odd
+//     number of 16 B slots, so the 32 consecutive pixels of a row block hit distinct LDS slots.
+//   * Weights stream from L2 straight into the B operand registers (a ring of PF K-steps in flight), stored
+//     FRAGMENT-MAJOR on the host so that each load instruction covers one contiguous KiB (lane-scattered 16 B pieces
+//     of 64 different rows ran the address coalescer at ~0.4 lines/clock: 20 us per 21x21 conv instead of ~3).
+//   * Spatially CONSTANT input channels (the 6 GRU input channels, the 2048 broadcast `h` channels of the BEV update)
+//     never enter the GEMM: their contribution is sum over the VALID taps of G[tap][n] = W[n, tap, const] . x, which
+//     depends on the pixel only through its border class (3 row classes x 3 column classes); the 9 class sums are
+//     tabulated once per conv and added in the epilogue.  The BEV update's K drops from 18,720 to 288 that way.
+#include "conv_common.h"
+
+namespace tt {
+
+__device__ __forceinline__ void mfma3s(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16& c) {
+    Mfma<uint16_t>::run(al, bh, c);
+    Mfma<uint16_t>::run(ah, bl, c);
+    Mfma<uint16_t>::run(ah, bh, c);
+}
+
+__device__ __forceinline__ void pair_store(unsigned char* map, int PS, int pix, int c, float v) {
+    const uint16_t hi = f32_to_bf16(v);
+    const uint16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
+    unsigned char* p = map + (size_t)pix * PS + (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
+    *reinterpret_cast<uint16_t*>(p) = hi;
+    *reinterpret_cast<uint16_t*>(p + 32) = lo;
+}
+
+__device__ __forceinline__ float pair_load(const unsigned char* map, int PS, int pix, int c) {
+    const unsigned char* p = map + (size_t)pix * PS + (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
+    return bf16_to_f32(*reinterpret_cast<const uint16_t*>(p)) + bf16_to_f32(*reinterpret_cast<const uint16_t*>(p + 32));
+}
+
+// Implicit-GEMM convolution of an LDS-resident pair-format map by the whole workgroup.
+//   in_map: H x W pixels, Cp channels (multiple of 16), pixel stride PS; `zero`: >= 64 zeroed bytes (padding taps)
+//   w: fragment-major pair-format weights (weights.py::split_pairs_frag) of the [N rounded up to 32][KH*KW*Cp]
+//      matrix (K order tap-major, channel-minor): a wave's B operand is two contiguous, fully coalesced 1 KiB loads
+//   work items = (32-row block, group of NBG 32-column blocks), dealt to the waves round-robin (item % nwaves)
+//   epi(m, n, v, i): called for every accumulator element of a valid (m < OH*OW, n < N) output; i = register index
+template <int NBG, int PF, typename Epi>
+__device__ __forceinline__ void conv_lds(const unsigned char* in_map, int H, int W, int Cp, int PS,
+                                         const unsigned char* zero, int stride, int pad, int KH, int KW,
+                                         const unsigned char* w, int N, int OH, int OW, int wave, int nwaves, int lane,
+                                         Epi epi) {
+    // Launder the lane id: everything below (row / pixel / address arithmetic of 16 accumulator rows per conv) is
+    // invariant across the calls of a kernel, and the compiler would otherwise hoist all of it out of the step loop
+    // and keep ~100 registers of addresses alive (measured: 570 B/lane of spills at the 128-register budget).
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lane));
+#endif
+    const int M = OH * OW, MB = (M + 31) >> 5, NB = (N + 31) >> 5, NG = (NB + NBG - 1) / NBG;
+    const int gpt = Cp >> 4;                       // K steps (16 channels) per tap
+    const int nsteps = KH * KW * gpt;
+    const size_t blk_bytes = (size_t)nsteps * 2048;   // fragment-major weights: bytes per 32-row block
+    const int r = lane & 31, h = lane >> 5;
+    for (int item = wave; item < MB * NG; item += nwaves) {
+        const int mb = item / NG, ng = item - mb * NG;
+        const int m = mb * 32 + r;
+        const bool m_ok = m < M;
+        const int oh = m_ok ? m / OW : 0, ow = m_ok ? m - (m / OW) * OW : 0;
+        const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+        f32x16 acc[NBG];
+        const unsigned char* bp[NBG];
+        bool live[NBG];
+#pragma unroll
+        for (int q = 0; q < NBG; ++q) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+            const int nb = ng * NBG + q;
+            live[q] = nb < NB;
+            bp[q] = w + (size_t)(live[q] ? nb : 0) * blk_bytes + (h * 32 + r) * 16;
+        }
+        // Weight ring: PF K-steps in flight.  Every load is UNCONDITIONAL (the step index is clamped to the last
+        // step, dead blocks re-read block 0): with loads under branches the compiler cannot count what is outstanding
+        // and drains the ring (vmcnt(0)) at every loop head.
+        uint4 bh[PF][NBG], bl[PF][NBG];
+        const int last = nsteps - 1;
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int kp = p < last ? p : last;
+#pragma unroll
+            for (int q = 0; q < NBG; ++q) {
+                bh[p][q] = *reinterpret_cast<const uint4*>(bp[q] + (size_t)kp * 2048);
+                bl[p][q] = *reinterpret_cast<const uint4*>(bp[q] + (size_t)kp * 2048 + 1024);
+            }
+        }
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < nsteps; ks0 += PF) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int ks = ks0 + p;
+                if (ks < nsteps) {
+                    const int tap = ks / gpt, g = ks - tap * gpt;
+                    const int kh = tap / KW, kw = tap - kh * KW;
+                    const int ih = ih0 + kh, iw = iw0 + kw;
+                    const bool ok = m_ok && ih >= 0 && ih < H && iw >= 0 && iw < W;
+                    const unsigned char* ap = ok ? in_map + (size_t)(ih * W + iw) * PS + g * 64 + h * 16 : zero + h * 16;
+                    const uint4 ah = *reinterpret_cast<const uint4*>(ap);
+                    const uint4 al = *reinterpret_cast<const uint4*>(ok ? ap + 32 : ap);
+#pragma unroll
+                    for (int q = 0; q < NBG; ++q)
+                        if (live[q]) mfma3s(ah, al, bh[p][q], bl[p][q], acc[q]);
+                }
+                {
+                    const int kn = ks + PF < last ? ks + PF : last;
+#pragma unroll
+                    for (int q = 0; q < NBG; ++q) {
+                        bh[p][q] = *reinterpret_cast<const uint4*>(bp[q] + (size_t)kn * 2048);
+                        bl[p][q] = *reinterpret_cast<const uint4*>(bp[q] + (size_t)kn * 2048 + 1024);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NBG; ++q) {
+            if (!live[q]) continue;
+            const int n = (ng * NBG + q) * 32 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int mm = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (mm < M && n < N) epi(mm, n, acc[q][i], i);
+            }
+        }
+    }
+}
+
+// border class of pixel (y, x) of an H x W map for a 3x3 / pad 1 conv: 3 * row class + column class
+__device__ __forceinline__ int border_class(int y, int x, int H, int W) {
+    const int rc = y == 0 ? 0 : (y == H - 1 ? 2 : 1);
+    const int cc = x == 0 ? 0 : (x == W - 1 ? 2 : 1);
+    return rc * 3 + cc;
+}
+// is tap (kh, kw) of a 3x3 / pad 1 conv inside the map for a pixel of border class cls?
+__device__ __forceinline__ bool tap_valid(int cls, int kh, int kw) {
+    const int rc = cls / 3, cc = cls - rc * 3;
+    return !((rc == 0 && kh == 0) || (rc == 2 && kh == 2) || (cc == 0 && kw == 0) || (cc == 2 && kw == 2));
+}
+
+// ------------------------------------------------------------------------------------------------ conv-GRU
+constexpr int kGruWaves = 14;            // one 32-pixel row block of the 441-pixel map per wave
+constexpr int kMapHW = 21, kMapPix = 441, kMapC = 32;
+constexpr int kPS32 = kMapC * 4 + 16;    // 144 B per pixel
+
+struct GruArgs {
+    const float* inp6;        // [B][4][6]   (waypoint xy, softplus(ctrl) x4) per future step
+    const float* state;       // [B][441][32] f32 channel-last BEV state
+    float* fut;               // [B][4][441][32] f32
+    float* scratch;           // [B][2][441][32] f32: update gate and previous state of the running step (each element
+                              // is written and re-read by the SAME lane, so plain stores / loads need no fence)
+    const unsigned char* w0[3];   // conv_update.0 / conv_reset.0 / conv_state_tilde.0: state part, pair [32][9*32]
+    const float* wx[3];           // ... constant-input part, f32 [9][6][32]
+    const float* b0[3];
+    const unsigned char* w2[3];   // .2 convs, pair [32][9*32]
+    const float* b2[3];
+    const unsigned char* wd0; const float* bd0;   // conv_decoder.0 / .2
+    const unsigned char* wd2; const float* bd2;
+};
+
+__global__ __launch_bounds__(kGruWaves * 64) void dec_gru_kernel(const GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Smap = smem;                                   // state (or (1-r)*state) map
+    unsigned char* Hmap = smem + kMapPix * kPS32;                 // hidden map of the current two-conv block
+    unsigned char* zero = Hmap + kMapPix * kPS32;                 // 64 zero bytes
+    float* Gc = reinterpret_cast<float*>(zero + 64);              // [3 convs][9 classes][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    if (tid < 16) reinterpret_cast<uint32_t*>(zero)[tid] = 0u;
+    for (int e = tid; e < kMapPix * kMapC; e += kGruWaves * 64) {
+        const int pix = e >> 5, c = e & 31;
+        pair_store(Smap, kPS32, pix, c, a.state[(size_t)b * kMapPix * kMapC + e]);
+    }
+    float* ug = a.scratch + (size_t)b * 2 * kMapPix * kMapC;
+    float* sg = ug + kMapPix * kMapC;
+    for (int t = 0; t < 4; ++t) {
+        // class sums of the constant-input contribution of the three first convs (+ their bias)
+        const float* x = a.inp6 + ((size_t)b * 4 + t) * 6;
+        if (tid < 3 * 288) {        // thread = (conv, class, n); the conv index is wave-uniform per 288-thread group
+            const int cv = tid / 288, e = tid - cv * 288, cls = e >> 5, n = e & 31;
+            const float* wxc = cv == 0 ? a.wx[0] : (cv == 1 ? a.wx[1] : a.wx[2]);
+            const float* b0c = cv == 0 ? a.b0[0] : (cv == 1 ? a.b0[1] : a.b0[2]);
+            float xv[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) xv[j] = x[j];
+            float s = b0c[n];
+#pragma unroll 3
+            for (int tap = 0; tap < 9; ++tap) {
+                float g = 0.f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) g += wxc[(tap * 6 + j) * 32 + n] * xv[j];      // 18 independent loads in flight
+                if (tap_valid(cls, tap / 3, tap % 3)) s += g;
+            }
+            Gc[tid] = s;
+        }
+        __syncthreads();
+        auto first_conv = [&](int cv) {    // H = relu(conv_cv.0([x, S]))
+            conv_lds<1, 4>(Smap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w0[cv], 32, kMapHW, kMapHW, wave,
+                           kGruWaves, lane, [&](int m, int n, float v, int) {
+                               const int y = m / kMapHW, xx = m - y * kMapHW;
+                               v += Gc[(cv * 9 + border_class(y, xx, kMapHW, kMapHW)) * 32 + n];
+                               pair_store(Hmap, kPS32, m, n, v > 0.f ? v : 0.f);
+                           });
+        };
+        first_conv(0);
+        __syncthreads();
+        conv_lds<1, 4>(Hmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w2[0], 32, kMapHW, kMapHW, wave, kGruWaves,
+                       lane, [&](int m, int n, float v, int) { ug[m * kMapC + n] = 1.f / (1.f + expf(-(v + a.b2[0][n]))); });
+        __syncthreads();
+        first_conv(1);
+        __syncthreads();
+        conv_lds<1, 4>(Hmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w2[1], 32, kMapHW, kMapHW, wave, kGruWaves,
+                       lane, [&](int m, int n, float v, int) {
+                           const float rg = 1.f / (1.f + expf(-(v + a.b2[1][n])));
+                           const float s = pair_load(Smap, kPS32, m, n);
+                           sg[m * kMapC + n] = s;
+                           pair_store(Smap, kPS32, m, n, (1.f - rg) * s);     // own element only: no other reader now
+                       });
+        __syncthreads();
+        first_conv(2);
+        __syncthreads();
+        conv_lds<1, 4>(Hmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w2[2], 32, kMapHW, kMapHW, wave, kGruWaves,
+                       lane, [&](int m, int n, float v, int) {
+                           const float cand = v + a.b2[2][n];
+                           const float u = ug[m * kMapC + n];
+                           pair_store(Smap, kPS32, m, n, (1.f - u) * sg[m * kMapC + n] + u * cand);
+                       });
+        __syncthreads();
+        conv_lds<1, 4>(Smap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.wd0, 32, kMapHW, kMapHW, wave, kGruWaves,
+                       lane, [&](int m, int n, float v, int) {
+                           v += a.bd0[n];
+                           pair_store(Hmap, kPS32, m, n, v > 0.f ? v : 0.f);
+                       });
+        __syncthreads();
+        float* fo = a.fut + (((size_t)b * 4 + t) * kMapPix) * kMapC;
+        conv_lds<1, 4>(Hmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.wd2, 32, kMapHW, kMapHW, wave, kGruWaves,
+                       lane, [&](int m, int n, float v, int) { fo[(size_t)m * kMapC + n] = v + a.bd2[n]; });
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ grid2feat
+// One workgroup per 21x21x32 map.  Weight sets (pair format, eval BatchNorm scale folded into the rows, shift = bias):
+//   0 conv21_10 | 1 2 MLP10.conv1/2 | 3 4 MLP10.se.fc1/2 | 5 conv10_4 | 6 7 MLP4.conv1/2 | 8 9 MLP4.se.fc1/2 |
+//   10 conv4_2 | 11 12 MLP2.conv1/2 | 13 14 MLP2.se.fc1/2 | 15 output_fc.0 (as a 2x2 conv over the 2x2x256 map) |
+//   16 output_fc.3
+constexpr int kFlatWaves = 8;
+constexpr int kFlatSets = 17;
+
+struct FlatArgs {
+    const float* in;          // [maps][441][32] f32 channel-last
+    float* out;               // [maps][256] f32
+    float* mids;              // optional [maps][(100*64 + 16*128 + 4*256)] f32: the 10x10, 4x4, 2x2 block outputs
+    const unsigned char* w[kFlatSets];
+    const float* b[kFlatSets];
+    const float* bn_scale;    // output_fc.2 (eval BatchNorm1d) scale / shift [512]
+    const float* bn_shift;
+};
+
+__device__ __forceinline__ int ps_of(int C) { return C * 4 + 16; }
+
+// SEBasicBlock (code/utils.py:99-121) on an LDS map, IN PLACE: X (C channels; input, residual and output) ->
+// Y1 = relu(bn1(conv1 X)) (2C channels) -> Y2 = relu(bn2(conv2 Y1)) (C) -> gate = sigmoid(fc2 relu(fc1 pool(Y2))) ->
+// X = relu(Y2 * gate + X).  `vec`: scratch for two 1-pixel maps of C channels + C floats of gate.
+__device__ __forceinline__ void se_block(const FlatArgs& a, int set, int HW, int C, unsigned char* X, unsigned char* Y1,
+                                         unsigned char* Y2, unsigned char* vec, const unsigned char* zero, int wave,
+                                         int lane, int tid) {
+    const int PS = ps_of(C), PS1 = ps_of(2 * C), M = HW * HW;
+    conv_lds<1, 4>(X, HW, HW, C, PS, zero, 1, 1, 3, 3, a.w[set], 2 * C, HW, HW, wave, kFlatWaves, lane,
+                   [&](int m, int n, float v, int) { v += a.b[set][n]; pair_store(Y1, PS1, m, n, v > 0.f ? v : 0.f); });
+    __syncthreads();
+    conv_lds<1, 4>(Y1, HW, HW, 2 * C, PS1, zero, 1, 1, 3, 3, a.w[set + 1], C, HW, HW, wave, kFlatWaves, lane,
+                   [&](int m, int n, float v, int) { v += a.b[set + 1][n]; pair_store(Y2, PS, m, n, v > 0.f ? v : 0.f); });
+    __syncthreads();
+    unsigned char* s0 = vec;                       // pooled vector as a 1-pixel map
+    unsigned char* s1 = vec + ps_of(C);            // fc1 output
+    float* gate = reinterpret_cast<float*>(vec + 2 * ps_of(C));
+    for (int c = tid; c < C; c += kFlatWaves * 64) {
+        float sum = 0.f, mx = -INFINITY;
+        for (int m = 0; m < M; ++m) {
+            const float v = pair_load(Y2, PS, m, c);
+            sum += v;
+            mx = fmaxf(mx, v);
+        }
+        pair_store(s0, PS, 0, c, 0.5f * (sum / (float)M) + 0.5f * mx);
+    }
+    __syncthreads();
+    conv_lds<1, 4>(s0, 1, 1, C, PS, zero, 1, 0, 1, 1, a.w[set + 2], C, 1, 1, wave, kFlatWaves, lane,
+                   [&](int, int n, float v, int) { v += a.b[set + 2][n]; pair_store(s1, PS, 0, n, v > 0.f ? v : 0.f); });
+    __syncthreads();
+    conv_lds<1, 4>(s1, 1, 1, C, PS, zero, 1, 0, 1, 1, a.w[set + 3], C, 1, 1, wave, kFlatWaves, lane,
+                   [&](int, int n, float v, int) { gate[n] = 1.f / (1.f + expf(-(v + a.b[set + 3][n]))); });
+    __syncthreads();
+    for (int e = tid; e < M * C; e += kFlatWaves * 64) {
+        const int m = e / C, c = e - m * C;
+        const float v = pair_load(Y2, PS, m, c) * gate[c] + pair_load(X, PS, m, c);
+        pair_store(X, PS, m, c, v > 0.f ? v : 0.f);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kFlatWaves * 64) void dec_flatten_kernel(const FlatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int map = blockIdx.x;
+    // LDS plan (bytes).  Region A [0, 63504): the input map; once conv21_10 has consumed it, MLP10's 128-channel hidden
+    // map; after MLP10 the 4x4 and 2x2 maps.  Region B: the 10x10x64 map X10 and MLP10's Y2.  Then zero page, vectors.
+    constexpr int kIn = kMapPix * kPS32;                               // 63504
+    constexpr int kOffB = (kIn + 15) / 16 * 16;
+    constexpr int kSz10 = 100 * (64 * 4 + 16);                         // 27200
+    constexpr int kZero = kOffB + 2 * kSz10;
+    constexpr int kVec = kZero + 64;                                   // 2 x (256*4+16) + 256*4
+    unsigned char* Rin = smem;
+    unsigned char* X10 = smem + kOffB;
+    unsigned char* Y10b = X10 + kSz10;
+    unsigned char* Y10a = smem;                                        // 100 x (128*4+16) = 52800 B, in region A
+    unsigned char* zero = smem + kZero;
+    unsigned char* vec = smem + kVec;
+    constexpr int kSz4 = 16 * (128 * 4 + 16), kSz4h = 16 * (256 * 4 + 16);     // 8448, 16640
+    constexpr int kSz2 = 4 * (256 * 4 + 16), kSz2h = 4 * (512 * 4 + 16);       // 4160, 8256
+    unsigned char* X4 = smem;                                          // region A again (MLP10 is finished by then)
+    unsigned char* Y4a = X4 + kSz4;
+    unsigned char* Y4b = Y4a + kSz4h;
+    unsigned char* X2 = Y4b + kSz4;
+    unsigned char* Y2a = X2 + kSz2;
+    unsigned char* Y2b = Y2a + kSz2h;
+    unsigned char* H512 = Y2b + kSz2;                                  // 1-pixel map of 512 channels (2064 B)
+    static_assert(2 * kSz4 + kSz4h + 2 * kSz2 + kSz2h + 2064 <= kIn, "region A overflow");
+
+    if (tid < 16) reinterpret_cast<uint32_t*>(zero)[tid] = 0u;
+    const float* src = a.in + (size_t)map * kMapPix * kMapC;
+    for (int e = tid; e < kMapPix * kMapC; e += kFlatWaves * 64) pair_store(Rin, kPS32, e >> 5, e & 31, src[e]);
+    __syncthreads();
+    // conv21_10: 3x3 stride 2, no padding, 32 -> 64, ReLU
+    conv_lds<1, 4>(Rin, kMapHW, kMapHW, 32, kPS32, zero, 2, 0, 3, 3, a.w[0], 64, 10, 10, wave, kFlatWaves, lane,
+                   [&](int m, int n, float v, int) { v += a.b[0][n]; pair_store(X10, ps_of(64), m, n, v > 0.f ? v : 0.f); });
+    __syncthreads();
+    se_block(a, 1, 10, 64, X10, Y10a, Y10b, vec, zero, wave, lane, tid);            // X10 updated in place
+    float* mid = a.mids ? a.mids + (size_t)map * (100 * 64 + 16 * 128 + 4 * 256) : nullptr;
+    if (mid)
+        for (int e = tid; e < 100 * 64; e += kFlatWaves * 64) mid[e] = pair_load(X10, ps_of(64), e >> 6, e & 63);
+    // conv10_4: 3x3 stride 2, no padding, 64 -> 128, ReLU (region A is free again)
+    conv_lds<1, 4>(X10, 10, 10, 64, ps_of(64), zero, 2, 0, 3, 3, a.w[5], 128, 4, 4, wave, kFlatWaves, lane,
+                   [&](int m, int n, float v, int) { v += a.b[5][n]; pair_store(X4, ps_of(128), m, n, v > 0.f ? v : 0.f); });
+    __syncthreads();
+    se_block(a, 6, 4, 128, X4, Y4a, Y4b, vec, zero, wave, lane, tid);
+    if (mid)
+        for (int e = tid; e < 16 * 128; e += kFlatWaves * 64) mid[100 * 64 + e] = pair_load(X4, ps_of(128), e >> 7, e & 127);
+    // conv4_2: 3x3 stride 1, no padding, 128 -> 256, ReLU
+    conv_lds<1, 4>(X4, 4, 4, 128, ps_of(128), zero, 1, 0, 3, 3, a.w[10], 256, 2, 2, wave, kFlatWaves, lane,
+                   [&](int m, int n, float v, int) { v += a.b[10][n]; pair_store(X2, ps_of(256), m, n, v > 0.f ? v : 0.f); });
+    __syncthreads();
+    se_block(a, 11, 2, 256, X2, Y2a, Y2b, vec, zero, wave, lane, tid);
+    if (mid)
+        for (int e = tid; e < 4 * 256; e += kFlatWaves * 64)
+            mid[100 * 64 + 16 * 128 + e] = pair_load(X2, ps_of(256), e >> 8, e & 255);
+    // output_fc.0 over the pixel-major flattening of the 2x2x256 map = a 2x2 "valid" conv; ReLU; BatchNorm1d (eval)
+    conv_lds<1, 4>(X2, 2, 2, 256, ps_of(256), zero, 1, 0, 2, 2, a.w[15], 512, 1, 1, wave, kFlatWaves, lane,
+                   [&](int, int n, float v, int) {
+                       v += a.b[15][n];
+                       v = v > 0.f ? v : 0.f;
+                       pair_store(H512, ps_of(512), 0, n, v * a.bn_scale[n] + a.bn_shift[n]);
+                   });
+    __syncthreads();
+    float* dst = a.out + (size_t)map * 256;
+    conv_lds<1, 4>(H512, 1, 1, 512, ps_of(512), zero, 1, 0, 1, 1, a.w[16], 256, 1, 1, wave, kFlatWaves, lane,
+                   [&](int, int n, float v, int) { v += a.b[16][n]; dst[n] = v > 0.f ? v : 0.f; });
+}
+
+// ------------------------------------------------------------------------------------------------ BEV update
+// new_bev = conv2(relu(conv0(cat([bev, h broadcast])))) + bev  (thinktwice_decoder.py:221-225,257).  The 2048 broadcast
+// channels enter as G[b][tap][n] = W0[n, 32:, tap] . h[b] (one wide linear over the B rows, tt_mlp_chain) and are added
+// per border class; the 128 hidden channels are produced and consumed 32 at a time so that both maps fit in LDS.
+struct BevArgs {
+    const float* bev;         // [B][441][32] f32
+    const float* G;           // [B][9][128] f32
+    float* out;               // new bev, f32, row (b, pixel) at out + b*out_bstride + pixel*32
+    float* out2;              // optional second copy (the stacked per-layer outputs), same addressing with out2_bstride
+    long long out_bstride, out2_bstride;
+    const unsigned char* w0;  // pair [128][9*32]: the bev part of BEV_feat_update_module.0
+    const float* b0;          // [128]
+    const unsigned char* w2[4];   // pair [32][9*32] each: BEV_feat_update_module.2 restricted to hidden channels 32c..32c+31
+    const float* b2;          // [32]
+};
+
+__global__ __launch_bounds__(kGruWaves * 64) void dec_bev_update_kernel(const BevArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Bmap = smem;
+    unsigned char* Hmap = smem + kMapPix * kPS32;
+    unsigned char* zero = Hmap + kMapPix * kPS32;
+    float* Gc = reinterpret_cast<float*>(zero + 64);              // [9 classes][128], bias included
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    if (tid < 16) reinterpret_cast<uint32_t*>(zero)[tid] = 0u;
+    const float* src = a.bev + (size_t)b * kMapPix * kMapC;
+    for (int e = tid; e < kMapPix * kMapC; e += kGruWaves * 64) pair_store(Bmap, kPS32, e >> 5, e & 31, src[e]);
+    const float* g = a.G + (size_t)b * 9 * 128;
+    for (int e = tid; e < 9 * 128; e += kGruWaves * 64) {
+        const int cls = e >> 7, n = e & 127;
+        float s = a.b0[n];
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw)
+                if (tap_valid(cls, kh, kw)) s += g[(kh * 3 + kw) * 128 + n];
+        Gc[e] = s;
+    }
+    __syncthreads();
+    f32x16 acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+    for (int c = 0; c < 4; ++c) {
+        conv_lds<1, 4>(Bmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w0 + (size_t)c * 32 * (9 * 32 * 4), 32,
+                       kMapHW, kMapHW, wave, kGruWaves, lane, [&](int m, int n, float v, int) {
+                           const int y = m / kMapHW, x = m - y * kMapHW;
+                           v += Gc[border_class(y, x, kMapHW, kMapHW) * 128 + c * 32 + n];
+                           pair_store(Hmap, kPS32, m, n, v > 0.f ? v : 0.f);
+                       });
+        __syncthreads();
+        conv_lds<1, 4>(Hmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w2[c], 32, kMapHW, kMapHW, wave, kGruWaves,
+                       lane, [&](int, int, float v, int i) { acc2[i] += v; });
+        __syncthreads();
+    }
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int m = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (m < kMapPix) {
+            const float v = acc2[i] + a.b2[r] + src[(size_t)m * kMapC + r];
+            a.out[(size_t)b * a.out_bstride + (size_t)m * kMapC + r] = v;
+            if (a.out2) a.out2[(size_t)b * a.out2_bstride + (size_t)m * kMapC + r] = v;
+        }
+    }
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" int tt_dec_gru(int B, const float* inp6, const float* state, float* fut, float* scratch, const void* const* w0,
+                          const float* const* wx, const float* const* b0, const void* const* w2, const float* const* b2,
+                          const void* wd0, const float* bd0, const void* wd2, const float* bd2, void* stream) {
+    TT_REQUIRE(B > 0 && inp6 && state && fut && scratch && w0 && wx && b0 && w2 && b2 && wd0 && bd0 && wd2 && bd2, "tt_dec_gru: null");
+    GruArgs a;
+    a.inp6 = inp6; a.state = state; a.fut = fut; a.scratch = scratch;
+    for (int c = 0; c < 3; ++c) {
+        TT_REQUIRE(w0[c] && wx[c] && b0[c] && w2[c] && b2[c], "tt_dec_gru: null weight %d", c);
+        a.w0[c] = (const unsigned char*)w0[c]; a.wx[c] = wx[c]; a.b0[c] = b0[c];
+        a.w2[c] = (const unsigned char*)w2[c]; a.b2[c] = b2[c];
+    }
+    a.wd0 = (const unsigned char*)wd0; a.bd0 = bd0; a.wd2 = (const unsigned char*)wd2; a.bd2 = bd2;
+    const size_t smem = (size_t)2 * kMapPix * kPS32 + 64 + 3 * 9 * 32 * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gru_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+        attr = true;
+    }
+    hipLaunchKernelGGL(dec_gru_kernel, dim3((unsigned)B), dim3(kGruWaves * 64), smem, (hipStream_t)stream, a);
+    return check_launch("tt_dec_gru");
+}
+
+extern "C" int tt_dec_flatten(int maps, const float* in, float* out, float* mids_or_null, const void* const* w,
+                              const float* const* b, const float* bn_scale, const float* bn_shift, void* stream) {
+    TT_REQUIRE(maps > 0 && in && out && w && b && bn_scale && bn_shift, "tt_dec_flatten: null");
+    FlatArgs a;
+    a.in = in; a.out = out; a.mids = mids_or_null; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
+    for (int i = 0; i < kFlatSets; ++i) {
+        TT_REQUIRE(w[i] && b[i], "tt_dec_flatten: null weight set %d", i);
+        a.w[i] = (const unsigned char*)w[i];
+        a.b[i] = b[i];
+    }
+    const size_t smem = (size_t)((kMapPix * kPS32 + 15) / 16 * 16) + 2 * 100 * (64 * 4 + 16) + 64 +
+                        2 * (256 * 4 + 16) + 256 * 4 + 64;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_flatten_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = true;
+    }
+    hipLaunchKernelGGL(dec_flatten_kernel, dim3((unsigned)maps), dim3(kFlatWaves * 64), smem, (hipStream_t)stream, a);
+    return check_launch("tt_dec_flatten");
+}
+
+extern "C" int tt_dec_bev_update(int B, const float* bev, const float* G, float* out, long long out_bstride, float* out2,
+                                 long long out2_bstride, const void* w0, const float* b0, const void* const* w2,
+                                 const float* b2, void* stream) {
+    TT_REQUIRE(B > 0 && bev && G && out && w0 && b0 && w2 && b2, "tt_dec_bev_update: null");
+    BevArgs a;
+    a.bev = bev; a.G = G; a.out = out; a.out2 = out2; a.out_bstride = out_bstride; a.out2_bstride = out2_bstride;
+    a.w0 = (const unsigned char*)w0; a.b0 = b0; a.b2 = b2;
+    for (int c = 0; c < 4; ++c) {
+        TT_REQUIRE(w2[c], "tt_dec_bev_update: null w2[%d]", c);
+        a.w2[c] = (const unsigned char*)w2[c];
+    }
+    const size_t smem = (size_t)2 * kMapPix * kPS32 + 64 + 9 * 128 * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bev_update_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = true;
+    }
+    hipLaunchKernelGGL(dec_bev_update_kernel, dim3((unsigned)B), dim3(kGruWaves * 64), smem, (hipStream_t)stream, a);
+    return check_launch("tt_dec_bev_update");
+}

@@ -208,6 +208,172 @@ __global__ __launch_bounds__(256) void sca_reduce_kernel(const float* __restrict
     out[(long long)bc * 256 + c] = s;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fused row producers of the composite decoder: the same gathers / reductions as above with the nn.LayerNorm that the
+// reference applies next (query_linear.0, ffn.norm, output_proj.0, mlp.0) folded in, so that each feeds tt_mlp_chain
+// directly (one launch instead of producer + tt_layernorm_rows).
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();                                   // previous use of `red` is over
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// look_gather_query + LayerNorm(1543) (thinktwice_decoder.py:131-150 query_linear.0).  `ctrl` is the RAW control
+// parameters when raw_ctrl != 0 (softplus applied here, DEC:239), else already softplus'ed.
+template <typename T>
+__global__ __launch_bounds__(256) void look_query_ln_kernel(
+    const int* __restrict__ query_of_slot, const float* __restrict__ ref_packed, const float* __restrict__ wp,
+    const float* __restrict__ ctrl, int raw_ctrl, const float* __restrict__ temporal, const float* __restrict__ stat,
+    const float* __restrict__ meas, const float* __restrict__ flat, LevelMaps maps, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float* __restrict__ out, int row_stride) {
+    __shared__ float srow[1544];
+    __shared__ float red[4];
+    const long long row = blockIdx.x;               // (b*4+cam)*120 + slot
+    const int bc = (int)(row / kQ);
+    const int b = bc / kCams;
+    const int q = query_of_slot[row];
+    const int t = threadIdx.x;
+    if (q < 0) {
+        for (int i = t; i < 1543; i += 256) srow[i] = 0.f;
+    } else {
+        const int pt = q / 15, zi = q % 15;
+        if (t < 4) {
+            float c = (pt < 4) ? ctrl[(b * 4 + pt) * 4 + t] : 0.f;
+            if (raw_ctrl && pt < 4) c = apply_act(c, TT_ACT_SOFTPLUS);
+            srow[t] = c;
+        }
+        if (t == 4) {
+            const float sx[4] = {5.f, 0.f, 0.f, -5.f};
+            const float sy[4] = {0.f, -5.f, 5.f, 0.f};
+            srow[4] = (pt < 4) ? wp[(b * 4 + pt) * 2 + 0] : sx[pt - 4];
+            srow[5] = (pt < 4) ? wp[(b * 4 + pt) * 2 + 1] : sy[pt - 4];
+            srow[6] = (float)(-4.0 + (double)zi);
+        }
+        if (t < 128) {
+            srow[7 + t] = (pt < 4) ? temporal[pt * 128 + t] : stat[(pt - 4) * 128 + t];
+            srow[135 + t] = meas[b * 128 + t];
+        }
+        srow[263 + t] = flat[b * 256 + t];
+        const float rx = ref_packed[row * 2 + 0], ry = ref_packed[row * 2 + 1];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const T* map = reinterpret_cast<const T*>(maps.p[l]) + (long long)bc * maps.H[l] * maps.W[l] * 256;
+            srow[519 + t * 4 + l] = bilinear_cl<T>(map, maps.H[l], maps.W[l], 256, t, rx, ry);
+        }
+    }
+    __syncthreads();
+    float s = 0.f;
+    for (int i = t; i < 1543; i += 256) s += srow[i];
+    const float mean = block_sum256(s, red) / 1543.f;
+    float qq = 0.f;
+    for (int i = t; i < 1543; i += 256) {
+        const float d = srow[i] - mean;
+        qq += d * d;
+    }
+    const float rstd = 1.f / sqrtf(block_sum256(qq, red) / 1543.f + eps);
+    float* o = out + row * row_stride;
+    for (int i = t; i < row_stride; i += 256) o[i] = (i < 1543) ? (srow[i] - mean) * rstd * gamma[i] + beta[i] : 0.f;
+}
+
+// msda_sample + LayerNorm(256) (ffn.norm, multi_scale_deformable_attn_function.py:262): out = raw attention rows (the
+// residual of the ffn), out_ln = their LayerNorm (the ffn input)
+template <typename T>
+__global__ __launch_bounds__(256) void msda_sample_ln_kernel(const T* __restrict__ value,
+                                                             const float* __restrict__ offsets,
+                                                             const float* __restrict__ logits,
+                                                             const float* __restrict__ ref, LevelMaps lv, int S, int vcs,
+                                                             int vco, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             float* __restrict__ out, float* __restrict__ out_ln) {
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    const int bc = (int)(row / kQ);
+    const int t = threadIdx.x, head = t >> 5;
+    const float* lg = logits + row * 256 + head * 32;
+    float mx = -INFINITY;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) mx = fmaxf(mx, lg[i]);
+    float den = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) den += expf(lg[i] - mx);
+    const float rx = ref[row * 2 + 0], ry = ref[row * 2 + 1];
+    const float* of = offsets + row * 512 + head * 64;
+    float acc = 0.f;
+    long long start = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const int H = lv.H[l], W = lv.W[l];
+        const T* map = value + ((long long)bc * S + start) * vcs + vco;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const float w = expf(lg[l * 8 + p] - mx) / den;
+            const float nx = rx + of[(l * 8 + p) * 2 + 0] / (float)W;
+            const float ny = ry + of[(l * 8 + p) * 2 + 1] / (float)H;
+            acc += w * bilinear_cl<T>(map, H, W, vcs, t, nx, ny);
+        }
+        start += (long long)H * W;
+    }
+    out[row * 256 + t] = acc;
+    const float mean = block_sum256(acc, red) / 256.f;
+    const float d = acc - mean;
+    const float rstd = 1.f / sqrtf(block_sum256(d * d, red) / 256.f + eps);
+    out_ln[row * 256 + t] = d * rstd * gamma[t] + beta[t];
+}
+
+// sca_reduce + LayerNorm(1024) (output_proj.0): one block per sample
+__global__ __launch_bounds__(256) void sca_reduce_ln_kernel(const float* __restrict__ x, const int* __restrict__ max_len,
+                                                            int B, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            float* __restrict__ out) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, c = threadIdx.x;
+    const int ml = min(*max_len, kQ);
+    float v[kCams];
+    float s = 0.f;
+#pragma unroll
+    for (int cam = 0; cam < kCams; ++cam) {
+        float a = 0.f;
+        for (int k = B; k < ml; ++k) a += x[((long long)(b * kCams + cam) * kQ + k) * 256 + c] / (float)B;
+        v[cam] = a;
+        s += a;
+    }
+    const float mean = block_sum256(s, red) / 1024.f;
+    float qq = 0.f;
+#pragma unroll
+    for (int cam = 0; cam < kCams; ++cam) qq += (v[cam] - mean) * (v[cam] - mean);
+    const float rstd = 1.f / sqrtf(block_sum256(qq, red) / 1024.f + eps);
+#pragma unroll
+    for (int cam = 0; cam < kCams; ++cam)
+        out[(long long)b * 1024 + cam * 256 + c] = (v[cam] - mean) * rstd * gamma[cam * 256 + c] + beta[cam * 256 + c];
+}
+
+// mlp.0 input of a refinement layer (thinktwice_decoder.py:247-250): row (b, t) = LayerNorm(cat([future flat (b,t) 256 |
+// look (b) 256 | zeros 256 (LiDAR look, DEC:186) | temporal (t) 128 | measurement (b) 128]))
+__global__ __launch_bounds__(256) void dec_merge_in_kernel(const float* __restrict__ fflat, const float* __restrict__ look,
+                                                           const float* __restrict__ temporal,
+                                                           const float* __restrict__ meas, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           float* __restrict__ out) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, b = row >> 2, t = row & 3, c = threadIdx.x;
+    float v[4];
+    v[0] = fflat[(long long)row * 256 + c];
+    v[1] = look[(long long)b * 256 + c];
+    v[2] = 0.f;
+    v[3] = c < 128 ? temporal[t * 128 + c] : meas[(long long)b * 128 + c - 128];
+    const float mean = block_sum256((v[0] + v[1]) + (v[2] + v[3]), red) / 1024.f;
+    float qq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) qq += (v[k] - mean) * (v[k] - mean);
+    const float rstd = 1.f / sqrtf(block_sum256(qq, red) / 1024.f + eps);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        out[(long long)row * 1024 + k * 256 + c] = (v[k] - mean) * rstd * gamma[k * 256 + c] + beta[k * 256 + c];
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -297,4 +463,68 @@ extern "C" int tt_sca_reduce(int B, const float* x, const int* max_len, float* o
     TT_REQUIRE(x && max_len && out, "tt_sca_reduce: null");
     hipLaunchKernelGGL(sca_reduce_kernel, dim3(B * kCams), dim3(256), 0, (hipStream_t)stream, x, max_len, B, out);
     return check_launch("tt_sca_reduce");
+}
+
+extern "C" int tt_look_query_ln(int B, const int* query_of_slot, const float* ref_packed, const float* wp,
+                                const float* ctrl, int raw_ctrl, const float* temporal_embedding,
+                                const float* static_embedding, const float* measurement_feat, const float* flattened_feat,
+                                const void* const* level_maps, const int* level_hw, int maps_dtype, const float* gamma,
+                                const float* beta, float eps, float* out, int row_stride, void* stream) {
+    TT_REQUIRE(query_of_slot && ref_packed && wp && ctrl && level_maps && level_hw && gamma && beta && out,
+               "tt_look_query_ln: null");
+    TT_REQUIRE(row_stride >= 1543 && row_stride <= 1543 + 256, "tt_look_query_ln: row_stride %d", row_stride);
+    LevelMaps m;
+    fill_levels(m, level_maps, level_hw);
+    const unsigned rows_n = (unsigned)(B * kCams * kQ);
+    hipStream_t st = (hipStream_t)stream;
+#define QLN(T)                                                                                                        \
+    hipLaunchKernelGGL(look_query_ln_kernel<T>, dim3(rows_n), dim3(256), 0, st, query_of_slot, ref_packed, wp, ctrl,  \
+                       raw_ctrl, temporal_embedding, static_embedding, measurement_feat, flattened_feat, m, gamma,   \
+                       beta, eps, out, row_stride)
+    if (maps_dtype == TT_F32) QLN(float);
+    else if (maps_dtype == TT_F16) QLN(f16_t);
+    else QLN(uint16_t);
+#undef QLN
+    return check_launch("tt_look_query_ln");
+}
+
+extern "C" int tt_msda_sample_ln(int B, const void* value, int value_dtype, int value_cstride, int value_coff,
+                                 const float* offsets, const float* logits, const float* ref_packed, const int* level_hw,
+                                 const float* gamma, const float* beta, float eps, float* out, float* out_ln,
+                                 void* stream) {
+    TT_REQUIRE(value && offsets && logits && ref_packed && level_hw && gamma && beta && out && out_ln,
+               "tt_msda_sample_ln: null");
+    TT_REQUIRE(value_cstride >= 256 && value_coff >= 0 && value_coff + 256 <= value_cstride,
+               "tt_msda_sample_ln: channel window outside the row");
+    LevelMaps m;
+    fill_levels(m, nullptr, level_hw);
+    int S = 0;
+    for (int l = 0; l < 4; ++l) S += m.H[l] * m.W[l];
+    const unsigned rows_n = (unsigned)(B * kCams * kQ);
+    hipStream_t st = (hipStream_t)stream;
+#define MLN(T)                                                                                                     \
+    hipLaunchKernelGGL(msda_sample_ln_kernel<T>, dim3(rows_n), dim3(256), 0, st, (const T*)value, offsets, logits, \
+                       ref_packed, m, S, value_cstride, value_coff, gamma, beta, eps, out, out_ln)
+    if (value_dtype == TT_F32) MLN(float);
+    else if (value_dtype == TT_F16) MLN(f16_t);
+    else MLN(uint16_t);
+#undef MLN
+    return check_launch("tt_msda_sample_ln");
+}
+
+extern "C" int tt_sca_reduce_ln(int B, const float* x, const int* max_len, const float* gamma, const float* beta,
+                                float eps, float* out, void* stream) {
+    TT_REQUIRE(x && max_len && gamma && beta && out, "tt_sca_reduce_ln: null");
+    hipLaunchKernelGGL(sca_reduce_ln_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, max_len, B, gamma, beta, eps,
+                       out);
+    return check_launch("tt_sca_reduce_ln");
+}
+
+extern "C" int tt_dec_merge_in(int B, const float* fflat, const float* look, const float* temporal_embedding,
+                               const float* measurement_feat, const float* gamma, const float* beta, float eps,
+                               float* out, void* stream) {
+    TT_REQUIRE(fflat && look && temporal_embedding && measurement_feat && gamma && beta && out, "tt_dec_merge_in: null");
+    hipLaunchKernelGGL(dec_merge_in_kernel, dim3(B * 4), dim3(256), 0, (hipStream_t)stream, fflat, look,
+                       temporal_embedding, measurement_feat, gamma, beta, eps, out);
+    return check_launch("tt_dec_merge_in");
 }

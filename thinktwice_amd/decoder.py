@@ -144,6 +144,14 @@ class ThinkTwiceDecoder:
         self.vproj_all = conv_from_weight(torch.cat([lay.vproj.w for lay in self.layers], 0).contiguous(),
                                           self.wdtype, shift=self.vproj_all_shift)                  # (L*256,1,1,256)
         self.vshift_all = [torch.cat([lay.vshift[l] for lay in self.layers], 1).contiguous() for l in range(4)]
+        # composite execution (decoder_fused.py: ~16 launches per refinement layer, bf16x3 arithmetic).  Default: on for
+        # every precision mode except the exact-f32 parity mode; TT_DEC_FUSED=0/1 overrides.
+        want = os.environ.get("TT_DEC_FUSED")
+        use_fused = (self.wdtype != torch.float32) if want is None else want == "1"
+        self.fused = None
+        if use_fused:
+            from .decoder_fused import FusedDecoder
+            self.fused = FusedDecoder(self, sd, p)
         self.loaded = True
         return self
 
@@ -189,6 +197,9 @@ class ThinkTwiceDecoder:
         device; look_feature_metadata = [lidar2img (B,4,4,4), ida_mat (B,4,4,4), fpn (4 x (tensor, coff, C))
         channel-last, lidar feature (unused: the LiDAR look branch is zeroed, DEC:186)]."""
         flat, bev, meas = flattend_BEV_feat, BEV_feat, measurement_feat
+        if self.fused is not None:
+            return self._forward_fused(flat, bev, meas, parent_module, teacher_forcing_data, look_feature_metadata,
+                                       channel_last_out)
         B = flat.shape[0]
         dev = flat.device
         outs = {}
@@ -401,6 +412,109 @@ class ThinkTwiceDecoder:
         fut_nchw = ops.nhwc_to_nchw(s_fut.view(B * self.refine_num * 4, H, W, 32)).view(B, self.refine_num, 4, 32, H, W)
         # DEC:481 re-views the (B,R,4,...) stack as (B,4,R,...) and transposes (memory reinterpretation)
         outs["refine_future_BEV_feature"] = fut_nchw.view(B, 4, self.refine_num, 32, H, W).transpose(1, 2)
+        return outs
+
+    # ------------------------------------------------------------------ composite path
+    def _forward_fused(self, flat, bev, meas, parent_module, teacher, meta, channel_last_out):
+        """Same outputs as `forward`, sequenced through decoder_fused.FusedDecoder.  Per-layer results are kept
+        layer-major (R, B, ...) so that every kernel writes and reads contiguous slices; the (B, R, ...) tensors of the
+        reference's torch.stack(dim=1) are produced once at the end."""
+        fz = self.fused
+        B, dev = flat.shape[0], flat.device
+        R, R1 = self.refine_num, self.refine_num + 1
+        H, W = bev.shape[1:3]
+        flat, meas, bev = flat.contiguous(), meas.contiguous(), bev.contiguous()
+        outs = {}
+        wp_lm = torch.empty(R1, B, 4, 2, dtype=F32, device=dev)
+        ctrl_lm = torch.empty(R1, B, 4, 4, dtype=F32, device=dev)
+        fz.coarse_heads(flat, meas, outs, wp_lm[0], ctrl_lm[0])
+        lidar2img = meta[0].to(dev, F32).contiguous()
+        ida_mat = meta[1].to(dev, F32).contiguous()
+        mlvl = [self.fpn_linear[i](t, in_coff=off, cin=c) for i, (t, off, c) in enumerate(meta[2])]
+        level_hw = [(m.shape[1], m.shape[2]) for m in mlvl]
+        S = sum(h * w for h, w in level_hw)
+        main = torch.cuda.current_stream(dev)
+        fork = getattr(parent_module, "use_side_stream", True)
+        vready = None
+        if fork:
+            if self._vstream is None:
+                self._vstream = torch.cuda.Stream(dev)
+            if self._branch is None:
+                self._branch = torch.cuda.Stream(dev)
+            self._vstream.wait_stream(main)
+            with torch.cuda.stream(self._vstream):
+                value_all = self._project_values(mlvl, B, S)
+            value_all.record_stream(main)
+            vready = self._vstream
+        else:
+            value_all = self._project_values(mlvl, B, S)
+        ctx = (lidar2img, ida_mat, mlvl, level_hw, value_all, vready)
+        streams = (main, self._branch if fork else None)
+
+        def run(inputs_of, wp_dst, ctrl_dst, s_bev, s_flat, s_fut, residual, wait_values):
+            cur_bev, cur_flat = bev.view(B, H * W, 32), flat
+            info = []
+            for L in range(R):
+                wp_in, ctrl_in = inputs_of(L)
+                info.append(fz.layer(L, wp_in, ctrl_in, cur_bev, cur_flat, meas, ctx, s_fut[L], s_bev[L], s_flat[L],
+                                     wp_dst(L), ctrl_dst(L), residual, streams, wait_values and L == 0))
+                cur_bev, cur_flat = s_bev[L], s_flat[L]
+            if fork:
+                main.wait_stream(self._branch)          # last BEV update
+            return info
+
+        def bufs():
+            return (torch.empty(R, B, H * W, 32, dtype=F32, device=dev), torch.empty(R, B, 256, dtype=F32, device=dev),
+                    torch.empty(R, B, 4, H * W, 32, dtype=F32, device=dev))
+
+        s_bev, s_flat, s_fut = bufs()
+        look_info = run(lambda L: (wp_lm[L], ctrl_lm[L]), lambda L: wp_lm[L + 1], lambda L: ctrl_lm[L + 1],
+                        s_bev, s_flat, s_fut, True, True)
+
+        def to_br(t):        # (R, B, ...) -> contiguous (B, R, ...): the reference's torch.stack(dim=1)
+            return t.transpose(0, 1).contiguous()
+
+        def nchw(t, lead):   # (*lead, H*W, 32) channel-last -> (*lead, 32, H, W)
+            n = 1
+            for v in lead:
+                n *= v
+            return ops.nhwc_to_nchw(t.reshape(n, H, W, 32)).view(*lead, 32, H, W)
+
+        if teacher is not None:
+            tf = teacher
+            t_wp = tf["waypoints"].to(dev, F32).contiguous()
+            spx = torch.cat([torch.cat([tf["action_mu"], tf["action_sigma"]], -1).unsqueeze(1),
+                             torch.cat([torch.stack(list(tf["future_action_mu"][:-1]), 1),
+                                        torch.stack(list(tf["future_action_sigma"][:-1]), 1)], -1)], 1).to(dev, F32)
+            t_ctrl = (spx + torch.log(-torch.expm1(-spx))).contiguous()      # inv_softplus (DEC:22-23)
+            t_dwp = torch.empty(R, B, 4, 2, dtype=F32, device=dev)
+            t_dctrl = torch.empty(R, B, 4, 4, dtype=F32, device=dev)
+            t_bev, t_flat, t_fut = bufs()
+            run(lambda L: (t_wp, t_ctrl), lambda L: t_dwp[L], lambda L: t_dctrl[L], t_bev, t_flat, t_fut, False, False)
+            outs["teacher_pred_wp_offset"], outs["teacher_pred_ctrl_offset_lis"] = to_br(t_dwp), to_br(t_dctrl)
+            outs["teacher_refine_flattned_BEV_feature"] = to_br(t_flat)
+            if channel_last_out:
+                outs["_teacher_refine_bev_cl"] = to_br(t_bev).view(B, R, H, W, 32)
+                outs["_teacher_fut_cl"] = to_br(t_fut).view(B, R, 4, H, W, 32)
+            else:
+                outs["teacher_refine_BEV_feature"] = to_br(nchw(t_bev, (R, B)))
+                outs["teacher_future_BEV_feature"] = to_br(nchw(t_fut, (R, B, 4)))
+        ct = ops.ew(3, ctrl_lm.view(R1 * B * 4, 4), act=_lib.ACT_SOFTPLUS_CLAMP).view(R1, B, 4, 4).transpose(0, 1)
+        outs["pred_wp"] = to_br(wp_lm)
+        outs["mu_branches"], outs["sigma_branches"] = ct[:, :, 0, :2], ct[:, :, 0, 2:]
+        outs["future_mu"], outs["future_sigma"] = ct[:, :, 1:, :2], ct[:, :, 1:, 2:]
+        outs["refine_flattned_BEV_feature"] = to_br(s_flat)
+        outs["_look_info"] = look_info
+        if channel_last_out:
+            outs["_bev_cl"] = bev
+            outs["_refine_bev_cl"] = to_br(s_bev).view(B, R, H, W, 32)
+            outs["_refine_fut_cl"] = to_br(s_fut).view(B, R, 4, H, W, 32)
+            return outs
+        outs["bev_feature"] = ops.nhwc_to_nchw(bev)
+        outs["refine_BEV_feature"] = to_br(nchw(s_bev, (R, B)))
+        fut_nchw = to_br(nchw(s_fut, (R, B, 4)))                            # (B, R, 4, 32, H, W) contiguous
+        # DEC:481 re-views the (B,R,4,...) stack as (B,4,R,...) and transposes (memory reinterpretation)
+        outs["refine_future_BEV_feature"] = fut_nchw.view(B, 4, R, 32, H, W).transpose(1, 2)
         return outs
 
     __call__ = forward

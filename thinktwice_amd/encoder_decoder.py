@@ -18,13 +18,16 @@ F32 = torch.float32
 class EncoderDecoder:
     def __init__(self, img_encoder, decoder, lidar_encoder=None, num_cams=4, use_depth=False, use_seg=False,
                  downsample_factor=16, seg_downsample_factor=2, train_cfg=None, test_cfg=None,
-                 dtype=torch.float32, device="cuda", cfg=None):
+                 dtype=torch.float32, device="cuda", cfg=None, lidar_dtype=None):
         self.config = train_cfg if train_cfg is not None else cfg
         self.num_cams = num_cams
         self.dtype = dtype
         self.device = torch.device(device)
         self.img_encoder = build_backbone(img_encoder, dtype=dtype, device=device)
-        self.lidar_encoder = build_backbone(lidar_encoder, device=device, dtype=dtype) if lidar_encoder is not None else None
+        # precision mode of the LiDAR branch (default: the model's; its own knob because the sparse encoder is the one
+        # part of the forward whose 16-bit rounding barely reaches the outputs)
+        self.lidar_encoder = (build_backbone(lidar_encoder, device=device, dtype=dtype if lidar_dtype is None else lidar_dtype)
+                              if lidar_encoder is not None else None)
         dec = dict(decoder)
         dec.setdefault("config", self.config)
         self.decoder = build_head(dec, dtype=dtype, device=device)

@@ -7,11 +7,11 @@ from . import decoder, encoder_decoder, lidarnet, lss  # noqa: F401  (register m
 from .registry import build_model
 
 
-def build_thinktwice(dtype=torch.float32, device="cuda", **overrides):
+def build_thinktwice(dtype=torch.float32, device="cuda", lidar_dtype=None, **overrides):
     cfg = _config.model_config(**overrides)
     model = build_model(dict(type="EncoderDecoder", img_encoder=cfg["img_encoder"], decoder=cfg["decoder"],
                              lidar_encoder=cfg["lidar_encoder"], num_cams=cfg["num_cams"], train_cfg=cfg["cfg"],
-                             test_cfg=cfg["cfg"]), dtype=dtype, device=device)
+                             test_cfg=cfg["cfg"]), dtype=dtype, device=device, lidar_dtype=lidar_dtype)
     return model, cfg
 
 

@@ -402,3 +402,143 @@ def sca_reduce(x, max_len, B):
     out = torch.empty(B, 1024, dtype=torch.float32, device=x.device)
     check(lib().tt_sca_reduce(_c(B), ptr(x), ptr(max_len), ptr(out), _st(x)), "tt_sca_reduce")
     return out
+
+
+# ----------------------------------------------------------------------------- decoder row chains (tt_mlp_chain)
+class _ChainStage(ctypes.Structure):
+    _fields_ = [
+        ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("K", _c), ("Kp", _c), ("N", _c), ("act", _c), ("in_sel", _c),
+        ("res", ctypes.c_void_p), ("res_stride", _c), ("res_coff", _c),
+        ("side", ctypes.c_void_p), ("side_w", ctypes.c_void_p), ("side_stride", _c), ("side_k", _c),
+        ("out", ctypes.c_void_p), ("out_stride", _c), ("out_coff", _c),
+    ]
+
+
+class ChainLinear:
+    """One nn.Linear prepared for tt_mlp_chain: weight [N, K] (+ optional leading `side_k` columns that multiply a
+    separate few-column input, e.g. cat([wp, h]) @ W^T = W[:, :2] wp + W[:, 2:] h) -> pair-format bf16x3 operand."""
+
+    def __init__(self, w, bias, act=0, side_k=0, device="cuda"):
+        from . import weights
+        w = w.detach().to(device=device, dtype=torch.float32)
+        self.side_k = side_k
+        self.side_w = w[:, :side_k].contiguous() if side_k else None
+        w = w[:, side_k:]
+        self.N, self.K = w.shape
+        assert self.K % 4 == 0, "ChainLinear: K must be a multiple of 4"
+        self.Kp = (self.K + 15) // 16 * 16
+        wp = torch.zeros((self.N + 31) // 32 * 32, self.Kp, dtype=torch.float32, device=device)
+        wp[: self.N, : self.K] = w
+        self.w = weights.split_pairs_frag(wp)
+        self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.act = act
+
+
+def mlp_chain(x, stages, n_split=1):
+    """x (R, >= K0) f32 rows (row-strided ok).  stages: list of dicts {lin: ChainLinear, src: -1 | earlier stage index,
+    res: (tensor (R, *), coff) | None, side: tensor (R, >= side_k) | None, out: (tensor (R, *), coff) | None}."""
+    require_cuda(x)
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    R = x.shape[0]
+    n = len(stages)
+    arr = (_ChainStage * n)()
+    for i, st in enumerate(stages):
+        lin = st["lin"]
+        d = arr[i]
+        d.w = lin.w.data_ptr(); d.bias = _dp(lin.bias)
+        d.K, d.Kp, d.N, d.act, d.in_sel = lin.K, lin.Kp, lin.N, lin.act, st.get("src", i - 1)
+        res = st.get("res")
+        if res is not None:
+            t, coff = res
+            assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] >= R and t.shape[1] >= coff + lin.N
+            d.res, d.res_stride, d.res_coff = t.data_ptr(), t.stride(0), coff
+        side = st.get("side")
+        if lin.side_k:
+            assert side is not None and side.dtype == torch.float32 and side.dim() == 2 and side.stride(1) == 1
+            assert side.shape[0] >= R and side.shape[1] >= lin.side_k
+            d.side, d.side_w, d.side_stride, d.side_k = side.data_ptr(), lin.side_w.data_ptr(), side.stride(0), lin.side_k
+        out = st.get("out")
+        if out is not None:
+            t, coff = out
+            assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] >= R and t.shape[1] >= coff + lin.N
+            d.out, d.out_stride, d.out_coff = t.data_ptr(), t.stride(0), coff
+    check(lib().tt_mlp_chain(ptr(x), _ll(R), _c(x.stride(0)), _c(n), arr, _c(n_split), _st(x)), "tt_mlp_chain")
+
+
+# ----------------------------------------------------------------------------- composite decoder kernels
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def look_query_ln(qos, ref, wp, ctrl, raw_ctrl, temporal, static, meas, flat, maps, gamma, beta, row_stride=1552,
+                  eps=1e-5):
+    """look_gather_query + LayerNorm(1543) in one launch -> (B*4*120, row_stride) rows, zero padded."""
+    B = wp.shape[0]
+    assert flat.is_contiguous() and meas.is_contiguous() and wp.is_contiguous() and ctrl.is_contiguous()
+    out = torch.empty(B * 4 * 120, row_stride, dtype=torch.float32, device=wp.device)
+    arr, hw = _level_args(maps)
+    check(lib().tt_look_query_ln(_c(B), ptr(qos), ptr(ref), ptr(wp), ptr(ctrl), _c(1 if raw_ctrl else 0), ptr(temporal),
+                                 ptr(static), ptr(meas), ptr(flat), arr, hw, _c(dtype_code(maps[0])), ptr(gamma),
+                                 ptr(beta), _f(eps), ptr(out), _c(row_stride), _st(wp)), "tt_look_query_ln")
+    return out
+
+
+def msda_sample_ln(value, offsets, logits, ref, level_hw, B, coff, gamma, beta, eps=1e-5):
+    """msda_sample + LayerNorm(256): -> (raw rows, normalised rows), both (B*4*120, 256) f32."""
+    R = B * 4 * 120
+    out = torch.empty(R, 256, dtype=torch.float32, device=value.device)
+    out_ln = torch.empty(R, 256, dtype=torch.float32, device=value.device)
+    hw = (ctypes.c_int * 8)(*[v for pair in level_hw for v in pair])
+    check(lib().tt_msda_sample_ln(_c(B), ptr(value), _c(dtype_code(value)), _c(value.shape[-1]), _c(coff), ptr(offsets),
+                                  ptr(logits), ptr(ref), hw, ptr(gamma), ptr(beta), _f(eps), ptr(out), ptr(out_ln),
+                                  _st(value)), "tt_msda_sample_ln")
+    return out, out_ln
+
+
+def sca_reduce_ln(x, max_len, B, gamma, beta, eps=1e-5):
+    out = torch.empty(B, 1024, dtype=torch.float32, device=x.device)
+    check(lib().tt_sca_reduce_ln(_c(B), ptr(x), ptr(max_len), ptr(gamma), ptr(beta), _f(eps), ptr(out), _st(x)),
+          "tt_sca_reduce_ln")
+    return out
+
+
+def dec_merge_in(fflat, look, temporal, meas, gamma, beta, eps=1e-5):
+    B = look.shape[0]
+    assert fflat.is_contiguous() and look.is_contiguous() and meas.is_contiguous()
+    out = torch.empty(B * 4, 1024, dtype=torch.float32, device=look.device)
+    check(lib().tt_dec_merge_in(_c(B), ptr(fflat), ptr(look), ptr(temporal), ptr(meas), ptr(gamma), ptr(beta), _f(eps),
+                                ptr(out), _st(look)), "tt_dec_merge_in")
+    return out
+
+
+def dec_gru(wts, inp6, state, fut):
+    """wts: dict from decoder_fused.prep_gru; inp6 (B,4,6), state (B,441,32), fut (B,4,441,32) all f32 contiguous."""
+    B = state.shape[0]
+    assert inp6.is_contiguous() and state.is_contiguous() and fut.is_contiguous()
+    scratch = torch.empty(B, 2, 441, 32, dtype=torch.float32, device=state.device)
+    check(lib().tt_dec_gru(_c(B), ptr(inp6), ptr(state), ptr(fut), ptr(scratch), wts["w0"], wts["wx"], wts["b0"],
+                           wts["w2"], wts["b2"], ptr(wts["wd0"]), ptr(wts["bd0"]), ptr(wts["wd2"]), ptr(wts["bd2"]),
+                           _st(state)), "tt_dec_gru")
+    return fut
+
+
+def dec_flatten(wts, maps, want_mids=False):
+    """maps (N,441,32) f32 contiguous -> (N,256) [, mids (N, 100*64 + 16*128 + 4*256)]."""
+    N = maps.shape[0]
+    assert maps.is_contiguous() and maps.dtype == torch.float32
+    out = torch.empty(N, 256, dtype=torch.float32, device=maps.device)
+    mids = torch.empty(N, 100 * 64 + 16 * 128 + 4 * 256, dtype=torch.float32, device=maps.device) if want_mids else None
+    check(lib().tt_dec_flatten(_c(N), ptr(maps), ptr(out), ptr(mids), wts["w"], wts["b"], ptr(wts["bn_scale"]),
+                               ptr(wts["bn_shift"]), _st(maps)), "tt_dec_flatten")
+    return (out, mids) if want_mids else out
+
+
+def dec_bev_update(wts, bev, G, out):
+    """bev (B,441,32), G (B,1152) -> out (B,441,32) (all f32 contiguous)."""
+    B = bev.shape[0]
+    assert bev.is_contiguous() and G.is_contiguous() and out.is_contiguous()
+    check(lib().tt_dec_bev_update(_c(B), ptr(bev), ptr(G), ptr(out), _ll(441 * 32), None, _ll(0), ptr(wts["w0"]),
+                                  ptr(wts["b0"]), wts["w2"], ptr(wts["b2"]), _st(bev)), "tt_dec_bev_update")
+    return out

@@ -40,6 +40,23 @@ def pad_to(n, m):
     return (n + m - 1) // m * m
 
 
+def split_pairs_frag(w):
+    """f32 matrix [N, K] (N % 32 == 0, K % 16 == 0) -> FRAGMENT-MAJOR pair format for kernels that load the MFMA B
+    operand straight from memory (csrc/dec_chain.hip, csrc/dec_spatial.hip): per (32-row block nb, 16-wide K step ks)
+    2 KiB = [hi plane: lane 0..63 x 16 B | lo plane: lane x 16 B], lane = (k half h) * 32 + (row r), the 16 B being the
+    8 bf16 of W[nb*32 + r][ks*16 + h*8 : +8].  A wave's fragment load is then ONE contiguous KiB (8 full cache lines)
+    instead of 64 rows x 16 B scattered over 64 lines.  Returned as an f32-typed bit container of N*K elements."""
+    assert w.dtype == torch.float32 and w.dim() == 2 and w.shape[0] % 32 == 0 and w.shape[1] % 16 == 0
+    N, K = w.shape
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+
+    def frag(t):                                   # [N, K] -> [NB, nsteps, h, r, e]
+        return t.reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4)
+    out = torch.stack([frag(hi), frag(lo)], 2).contiguous()          # [NB, nsteps, plane, h, r, e]
+    return out.view(torch.float32).reshape(-1).contiguous()
+
+
 def prep_conv_weight(w, dtype, cin_pad=None):
     """[Cout,Cin,KH,KW] -> [Cout,KH,KW,Cin_p] contiguous in `dtype` (zero-padded input channels)."""
     Cout, Cin, KH, KW = w.shape
