@@ -136,6 +136,10 @@ typedef struct tt_conv_desc {
      * and the layer fits the LDS-DMA kernel it runs in "bf16x3" arithmetic -- a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on
      * the bf16 MFMA, ~1e-5 relative error, 16/3 of the f32-MFMA rate; otherwise the exact f32 path on `weight`. */
     const void* weight_x3;
+    /* optional (gather mode): the tile plan of tt_sp_tile_plan for gather_idx -- output tile i covers rows
+     * row_perm[256 i .. 256 i + 255] and multiplies only the taps set in the union of their masks */
+    const int* row_perm;
+    const unsigned* row_mask;
 } tt_conv_desc;
 
 int tt_conv2d_fwd(const tt_conv_desc* d, void* stream);
@@ -324,6 +328,14 @@ int tt_sp_rulebook(const int* out_coords, const int* out_rows, long long max_out
                    const int* kernel_stride_pad, const int* in_dims_zyx, const int* in_vol, int* nbr,
                    void* stream);
 /* the sparse convolution itself = tt_conv2d_fwd with gather_idx = this rulebook (MFMA gathered GEMM) */
+/* Tile plan of a rulebook for the mask-sorted gathered GEMM: row_perm = the output rows sorted by their tap-occupancy
+ * mask (bit t = tap t has an input), row_mask_sorted = the masks in that order (rows beyond *num_rows: 0xFFFFFFFF, last).
+ * A 256-row tile of the sorted order then visits only the UNION of its rows' taps instead of all KV (spconv's
+ * "implicit GEMM with mask sort"); pairs (nullable, pre-zeroed) += the number of existing (row, tap) pairs. */
+long long tt_sp_tile_plan_workspace_bytes(long long max_rows);
+int tt_sp_tile_plan(const int* nbr, const int* num_rows, long long max_rows, int KV, void* workspace,
+                    long long workspace_bytes, int* row_perm, unsigned* row_mask_sorted,
+                    unsigned long long* pairs_or_null, void* stream);
 /* SparseConvTensor.dense() + view(N, C*D, H, W) (lidarnet.py:53-56), channel-last: dense
  * [B, H, W, C*D] with channel c*D+z; `dense` must be pre-zeroed. */
 int tt_sp_to_dense(const void* feats, const int* coords, const int* num_rows, long long max_rows, int C,

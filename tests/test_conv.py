@@ -250,6 +250,56 @@ def test_gathered_sparse_conv_matches_torch(dt, Cin, Cout, rows_in, M, live):
     assert err < tol, err
 
 
+@pytest.mark.parametrize("dt,Cin,Cout", [(torch.bfloat16, 16, 16), (torch.bfloat16, 32, 64), (torch.bfloat16, 64, 64),
+                                         (torch.bfloat16, 128, 128), (torch.float16, 32, 32), ("f32x3", 16, 32),
+                                         ("f32x3", 64, 64), ("f32x3", 128, 128)])
+def test_planned_sparse_conv_skips_empty_taps_and_matches_torch(dt, Cin, Cout):
+    """Mask-sorted gathered GEMM (tt_sp_tile_plan + tt_conv2d_fwd row_perm / row_mask): rows carry 1-3 of the 27 taps
+    (what a LiDAR rulebook looks like), the plan sorts them by mask and every 256-row tile walks only the union of its
+    taps.  Same result as the unplanned launch and as an explicit gather + matmul; rows >= live are not written."""
+    from thinktwice_amd import ops, weights
+    x3 = dt == "f32x3"
+    dt = torch.float32 if x3 else dt
+    g = torch.Generator().manual_seed(Cin + Cout)
+    taps, rows_in, M, live = 27, 4000, 7000, 6500
+    feats = torch.randn(rows_in, Cin, generator=g).to(dt)
+    w = (torch.randn(Cout, 1, taps, Cin, generator=g) * (3 * Cin) ** -0.5).to(dt)
+    nbr = torch.full((M, taps), -1, dtype=torch.int32)
+    for _ in range(3):      # up to 3 taps per row, the centre tap for most rows
+        t = torch.randint(0, taps, (M,), generator=g)
+        t[torch.rand(M, generator=g) < 0.5] = 13
+        nbr[torch.arange(M), t] = torch.randint(0, rows_in, (M,), generator=g, dtype=torch.int32)
+    nbr[:5] = -1            # rows without any tap: pure bias
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.3
+    res = torch.randn(M, Cout, generator=g).to(dt)
+    m_dev = torch.tensor([live], dtype=torch.int32).cuda()
+    wd, nd, fd = w.cuda(), nbr.cuda(), feats.cuda()
+    wx = weights.split_pairs_x3(wd) if x3 else None
+    plan = ops.sp_tile_plan(nd, m_dev)
+    # the plan is a permutation of the live rows, sorted by mask
+    perm = plan[0].cpu()[:live].long()
+    assert torch.equal(torch.sort(perm).values, torch.arange(live))
+    masks = ((nbr[:live] >= 0).long() << torch.arange(taps)).sum(1)
+    assert torch.equal(plan[1].cpu()[:live].long() & 0xFFFFFFFF, masks[perm])
+    assert bool((masks[perm][1:] >= masks[perm][:-1]).all())
+    kw = dict(scale=scale.cuda(), shift=shift.cuda(), act=1, res=res.cuda(), w_x3=wx)
+    sentinel = 123.0
+    outs = []
+    for pl in (plan, None):
+        pre = torch.full((M, Cout), sentinel, dtype=dt, device="cuda")
+        out = ops.gather_conv(fd, nd, m_dev, wd, plan=pl, **kw)
+        outs.append(out.float().cpu())
+    torch.cuda.synchronize()
+    f32 = feats.float()
+    gathered = torch.where((nbr >= 0).unsqueeze(-1), f32[nbr.clamp_min(0).long()], torch.zeros(()))
+    ref = torch.relu(gathered.reshape(M, -1) @ w.float().reshape(Cout, -1).t() * scale + shift + res.float())
+    tol = 1e-4 if dt == torch.float32 else (3e-3 if dt == torch.float16 else 2e-2)
+    for got in outs:
+        err = float((got[:live] - ref[:live]).abs().max() / ref[:live].abs().max())
+        assert err < tol, err
+
+
 def test_row_run_stem_matches_conv7x7s2():
     """bf16 7x7/2 stem as a KH=7, KW=1, Cin=64 'row-run' convolution over a zero-bordered 8-channel image
     (lss.py _ResNet50.stem_rr) == F.conv2d(x, w, stride=2, padding=3) on the same rounded operands."""

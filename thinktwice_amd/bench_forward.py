@@ -77,9 +77,15 @@ class ForwardWorkload:
         self.model.use_side_stream = True
         rec = []
         for r in ops.CONV_PROFILE:
-            if len(r) > 4:      # sparse launch: FLOPs of the LIVE rows only
+            if len(r) > 4:      # sparse launch: FLOPs of the EXISTING (row, tap) pairs of the live rows only
                 rows_live = min(int(r[5]), int(r[4].item())) if r[4] is not None else int(r[5])
-                r = (r[0] * rows_live, r[1], r[2], r[3].replace("M<=", f"M={rows_live} of <="))
+                if len(r) > 6 and r[6] is not None:
+                    taps_per_row, flop_per_pair = r[6]
+                    pairs = int(taps_per_row[:rows_live].sum().item())
+                    r = (flop_per_pair * pairs, r[1], r[2],
+                         r[3].replace("M<=", f"M={rows_live} of <=") + f" pairs={pairs / max(rows_live, 1):.1f}/row")
+                else:
+                    r = (r[0] * rows_live, r[1], r[2], r[3].replace("M<=", f"M={rows_live} of <="))
             rec.append(r)
         ops.CONV_PROFILE = None
         flops = sum(r[0] for r in rec)

@@ -20,6 +20,8 @@ struct ConvArgs {
     const void* res2;
     const int* gather;   // GATHER mode: [M][KH*KW] input row per (output row, tap), -1 = none
     const int* m_dev;    // optional device-side row count (rows >= *m_dev are skipped)
+    const int* row_perm;         // GATHER, optional: tile slot -> actual output row (rows sorted by tap mask)
+    const unsigned* row_mask;    //   "       the sorted masks (bit t = tap t present), 0xFFFFFFFF beyond the live rows
     float* ws;           // split-K: f32 [M][Cout] partial-sum workspace (pre-zeroed), else null
     long long in_nstride, out_nstride;
     int N, H, W, Cin, in_cstride, in_coff;
@@ -227,18 +229,22 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
 #pragma unroll
                 for (int g0 = 0; g0 < NPASS; g0 += PG) {
                     RV r1[R1 ? PG : 1];
+                    int mrow[PG];             // actual output row (sparse tile plan: tile slot -> row_perm[slot])
+#pragma unroll
+                    for (int q = 0; q < PG; ++q) {
+                        const int m = mb + (g0 + q) * rpp + row_in_pass;
+                        mrow[q] = p.row_perm ? p.row_perm[m] : m;
+                    }
                     if constexpr (R1) {
 #pragma unroll
-                        for (int q = 0; q < PG; ++q) {
-                            const int m = mb + (g0 + q) * rpp + row_in_pass;
+                        for (int q = 0; q < PG; ++q)
                             r1[q] = *reinterpret_cast<const RV*>(reinterpret_cast<const T*>(p.res1) +
-                                                                (long long)m * p.res1_cstride + p.res1_coff + co);
-                        }
+                                                                (long long)mrow[q] * p.res1_cstride + p.res1_coff + co);
                     }
 #pragma unroll
                     for (int q = 0; q < PG; ++q) {
                         const int rl = (g0 + q) * rpp + row_in_pass;
-                        const int mr = mb + rl;
+                        const int mr = mrow[q];
                         float v[CO];
 #pragma unroll
                         for (int e = 0; e < CO; e += 4) {
@@ -271,7 +277,8 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                     v[e] = t0.x; v[e + 1] = t0.y; v[e + 2] = t0.z; v[e + 3] = t0.w;
                 }
                 int n = 0;
-                const long long o = out_offset(m, co, n);
+                const int mo = p.row_perm ? p.row_perm[m] : m;       // sparse tile plan (row-linear output only)
+                const long long o = out_offset(mo, co, n);
                 if (sn_loop) {
                     const float* sn = p.shift_n + (long long)(n % p.shift_n_mod) * cout_real + co;
 #pragma unroll
@@ -282,7 +289,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                     const void* rb = which ? p.res2 : p.res1;
                     if (!rb) continue;
                     const T* rp = reinterpret_cast<const T*>(rb) +
-                                  (long long)m * (which ? p.res2_cstride : p.res1_cstride) +
+                                  (long long)mo * (which ? p.res2_cstride : p.res1_cstride) +
                                   (which ? p.res2_coff : p.res1_coff) + co;
                     if (rvec) {
                         add_rv(v, *reinterpret_cast<const RV*>(rp));
@@ -354,9 +361,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
             }
             float v = sC[rl * LDC + cl];
             const int n = m / ohw;
+            const int mo = p.row_perm ? p.row_perm[m] : m;           // sparse tile plan (row-linear output only)
             long long o;
             if (p.out_fast) {
-                o = (long long)m * p.out_cstride + p.out_coff + co;
+                o = (long long)mo * p.out_cstride + p.out_coff + co;
             } else {
                 const int rem = m - n * ohw;
                 int oh = rem / p.OW, ow = rem - oh * p.OW;
@@ -370,9 +378,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
             }
             if (p.shift_n) v += p.shift_n[(n % p.shift_n_mod) * cout_real + co];
             if (p.res1)
-                v += Elem<T>::ld(reinterpret_cast<const T*>(p.res1) + (long long)m * p.res1_cstride + p.res1_coff + co);
+                v += Elem<T>::ld(reinterpret_cast<const T*>(p.res1) + (long long)mo * p.res1_cstride + p.res1_coff + co);
             if (p.res2)
-                v += Elem<T>::ld(reinterpret_cast<const T*>(p.res2) + (long long)m * p.res2_cstride + p.res2_coff + co);
+                v += Elem<T>::ld(reinterpret_cast<const T*>(p.res2) + (long long)mo * p.res2_cstride + p.res2_coff + co);
             v = apply_act(v, act);
             if (p.out_dtype == TT_F32)
                 reinterpret_cast<float*>(p.out)[o] = v;

@@ -328,6 +328,9 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
     a.scale = d->scale; a.shift = d->shift; a.shift_n = d->shift_n;
     a.res1 = d->res1; a.res2 = d->res2;
     a.gather = d->gather_idx; a.m_dev = d->m_dev;
+    a.row_perm = d->gather_idx ? d->row_perm : nullptr;
+    a.row_mask = d->gather_idx ? d->row_mask : nullptr;
+    TT_REQUIRE(!a.row_perm == !a.row_mask, "tt_conv2d_fwd: row_perm and row_mask come together");
     a.ws = d->splitk_ws;
     TT_REQUIRE(!d->gather_idx || (d->H == 1 && d->W == 1 && d->OH == 1 && d->OW == 1 && d->KH == 1 &&
                                   !d->pixel_shuffle2),
@@ -374,6 +377,8 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
         if (try_launch_conv_glds_x3(ax, st)) return check_launch("tt_conv2d_fwd(glds x3)");
     }
     if (!d->splitk_ws && try_launch_conv_glds(a, d->dtype, st)) return check_launch("tt_conv2d_fwd(glds)");
+    a.row_perm = nullptr;      // the tile plan is an LDS-DMA-kernel feature: the other kernels walk rows and taps in
+    a.row_mask = nullptr;      // natural order (same result)
     if (d->dtype == TT_F32) return dispatch_conv<float>(a, st);
     if (d->dtype == TT_F16) return dispatch_conv<f16_t>(a, st);
     return dispatch_conv<uint16_t>(a, st);

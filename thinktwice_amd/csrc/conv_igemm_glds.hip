@@ -116,7 +116,9 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         const int oh = r / p.OW, ow = r - oh * p.OW;
         a_h0[j] = oh * p.stride - p.pad;
         a_w0[j] = ow * p.stride - p.pad;
-        a_base[j] = GATHER ? (long long)mm * p.KW : (long long)n * p.in_nstride + p.in_coff;   // GATHER: rulebook row
+        // GATHER: rulebook row; with a tile plan the tile's slot `mm` stands for output row row_perm[mm]
+        a_base[j] = GATHER ? (long long)((p.row_perm && a_ok[j]) ? p.row_perm[mm] : mm) * p.KW
+                           : (long long)n * p.in_nstride + p.in_coff;
     }
     // Dense path: everything about a slot that does not change over the K loop is folded into ONE pointer (the
     // chunk's address for tap (0,0), possibly outside the image) and ONE bitmask (bit t = tap t of this row is
@@ -157,7 +159,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         b_ptr[j] = wgt + b_base[j] + b_c[j];
     }
 
-    const int nk = (p.K + BK - 1) / BK;
+    int nk = (p.K + BK - 1) / BK;
 
     // K order: channel chunk OUTER, filter tap INNER (Cin % BK == 0: one tap per K tile).  The KH*KW taps of one
     // BK-channel chunk re-read the same (tile + halo) pixels back to back, so the re-reads hit the XCD's 4 MiB L2
@@ -171,7 +173,68 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     int g_cur[NIA];                                    // rulebook entries of the next tile to issue
     int g_t = 0;                                       // K tile of the next rulebook fetch
     const int cin_shift = 31 - __clz(p.Cin), cin_mask = p.Cin - 1;
+    // Tile plan (tt_sp_tile_plan): the rows of this tile were sorted by tap mask, so the tile only walks the UNION of
+    // their taps.  K tile t of the compact walk covers tap(s) "the (t*TPT + s)-th set bit of the union" (TPT taps per
+    // 128 B row when Cin < BK) or one BK-channel slice of one tap (Cin >= BK).  Both walkers below (rulebook fetch, one
+    // tile ahead; DMA issue) pop the same bit sequence; everything is wave-uniform scalar work.
+    constexpr int TPTMAX = 4;
+    const bool planned = GATHER && p.row_mask != nullptr;
+    unsigned umask = 0;
+    if (planned) {
+        unsigned* uw = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) *uw = 0u;
+        __syncthreads();
+        if (tid < BM && m0 + tid < Mlim) atomicOr(uw, p.row_mask[m0 + tid]);
+        __syncthreads();
+        umask = *uw;
+        __syncthreads();                               // every wave has read it before the first DMA lands there
+        umask = __builtin_amdgcn_readfirstlane(umask);
+        const int nt = __popc(umask);
+        nk = p.Cin >= BK ? nt * (p.Cin / BK) : (nt * p.Cin + BK - 1) / BK;
+    }
+    struct TapWalk {
+        unsigned rem;
+        int sub, cur;
+    };
+    TapWalk wf{umask, 0, -1}, wi{umask, 0, -1};
+    auto next_taps = [&](TapWalk& w, int (&tp)[TPTMAX]) {
+        if (p.Cin >= BK) {
+            if (w.sub == 0) {
+                w.cur = w.rem ? __builtin_ctz(w.rem) : -1;
+                w.rem &= w.rem - 1;
+            }
+            tp[0] = w.cur;
+            if (++w.sub == p.Cin / BK) w.sub = 0;
+        } else {
+            const int tpt = BK >> cin_shift;           // taps per K tile (<= TPTMAX, dispatcher)
+#pragma unroll
+            for (int i = 0; i < TPTMAX; ++i) {
+                tp[i] = -1;
+                if (i < tpt && w.rem) {
+                    tp[i] = __builtin_ctz(w.rem);
+                    w.rem &= w.rem - 1;
+                }
+            }
+        }
+    };
+    auto pick = [&](const int (&tp)[TPTMAX], int slot) {    // tap of 16 B chunk `slot` (= element offset >> cin_shift)
+        int t = tp[0];
+#pragma unroll
+        for (int i = 1; i < TPTMAX; ++i) t = (slot == i) ? tp[i] : t;
+        return t;
+    };
     auto fetch_rulebook = [&]() {
+        if (planned) {
+            int tp[TPTMAX];
+            next_taps(wf, tp);
+#pragma unroll
+            for (int j = 0; j < NIA; ++j) {
+                const int t = p.Cin >= BK ? tp[0] : pick(tp, a_c[j] >> cin_shift);
+                g_cur[j] = (a_ok[j] && t >= 0) ? p.gather[a_base[j] + t] : -1;
+            }
+            ++g_t;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NIA; ++j) {
             const int k = g_t * BK + a_c[j];
@@ -210,12 +273,19 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
             }
             __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(st + (wave + NW * j) * 1024), 16, 0, 0);
         }
+        int tpi[TPTMAX];
+        if (planned) next_taps(wi, tpi);
 #pragma unroll
         for (int j = 0; j < NIB; ++j) {
             if (dbg_skip_b) break;
             // dense: K % BK == 0 (Cin % BK == 0); gather: the last K tile may be ragged (27 taps of 16/32 channels)
-            const bool ok = b_ok[j] && (!GATHER || (k0 + b_c[j] < p.K));
+            bool ok = b_ok[j] && (!GATHER || (k0 + b_c[j] < p.K));
             const T* src = ok ? b_ptr[j] + k0 : zp;
+            if (planned) {      // compact walk: weight row offset = tap * Cin + channel
+                const int t = p.Cin >= BK ? tpi[0] : pick(tpi, b_c[j] >> cin_shift);
+                ok = b_ok[j] && t >= 0;
+                src = ok ? b_ptr[j] - b_c[j] + (long long)t * p.Cin + ((k0 + b_c[j]) & cin_mask) : zp;
+            }
             __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(st + BM * BKB + ((wave + NW * j) % NB_INSTR) * 1024),
                                              16, 0, 0);
         }
@@ -229,8 +299,8 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (GATHER) fetch_rulebook();
-    issue_tile(0);
+    if (GATHER && nk > 0) fetch_rulebook();
+    if (nk > 0) issue_tile(0);
     if (GATHER && nk > 1) fetch_rulebook();            // for tile 1; lands while tile 0 streams in
     if (STAGES == 3 && nk > 1) issue_tile(1);
 

@@ -164,6 +164,31 @@ __global__ void rulebook_kernel(const int* __restrict__ out_coords, const int* _
     nbr[o * KV + k] = r;
 }
 
+// Tap-occupancy mask of every output row of a rulebook (bit t = tap t has an input row), 0xFFFFFFFF for rows beyond
+// the live count so that they sort last; vals = row index.  `pairs` (nullable) accumulates the number of existing
+// (output row, tap) pairs = the real multiply count of the sparse convolution.
+__global__ void sp_row_masks_kernel(const int* __restrict__ nbr, const int* __restrict__ rows_n, long long max_rows, int KV,
+                                    unsigned* __restrict__ keys, unsigned* __restrict__ vals,
+                                    unsigned long long* __restrict__ pairs) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned cnt = 0;
+    if (o < max_rows) {
+        unsigned m = 0xFFFFFFFFu;
+        if (o < *rows_n) {
+            m = 0;
+            for (int t = 0; t < KV; ++t) m |= (nbr[o * KV + t] >= 0 ? 1u : 0u) << t;
+            cnt = __popc(m);
+        }
+        keys[o] = m;
+        vals[o] = (unsigned)o;
+    }
+    if (pairs) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(pairs, (unsigned long long)cnt);
+    }
+}
+
 template <typename T>
 __global__ void sp_to_dense_kernel(const T* __restrict__ f, const int* __restrict__ coords,
                                    const int* __restrict__ rows_n, long long max_rows, int C, Dims3 d,
@@ -319,4 +344,34 @@ extern "C" int tt_sp_to_dense(const void* feats, const int* coords, const int* n
         hipLaunchKernelGGL(sp_to_dense_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint16_t*)feats, coords, num_rows, max_rows, C, d, (uint16_t*)dense);
     return check_launch("tt_sp_to_dense");
+}
+
+extern "C" long long tt_sp_tile_plan_workspace_bytes(long long max_rows) {
+    size_t sort_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr,
+                                       (unsigned*)nullptr, (int)max_rows);
+    return (long long)(2 * align256(sizeof(unsigned) * max_rows) + align256(sort_bytes));
+}
+
+extern "C" int tt_sp_tile_plan(const int* nbr, const int* num_rows, long long max_rows, int KV, void* workspace,
+                               long long workspace_bytes, int* row_perm, unsigned* row_mask_sorted,
+                               unsigned long long* pairs_or_null, void* stream) {
+    TT_REQUIRE(nbr && num_rows && workspace && row_perm && row_mask_sorted, "tt_sp_tile_plan: null");
+    TT_REQUIRE(KV >= 1 && KV <= 31 && max_rows > 0 && max_rows < (1ll << 31), "tt_sp_tile_plan: KV=%d max_rows=%lld", KV,
+               max_rows);
+    TT_REQUIRE(workspace_bytes >= tt_sp_tile_plan_workspace_bytes(max_rows), "tt_sp_tile_plan: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)workspace;
+    unsigned* keys = (unsigned*)w;
+    unsigned* vals = (unsigned*)(w + align256(sizeof(unsigned) * max_rows));
+    void* tmp = w + 2 * align256(sizeof(unsigned) * max_rows);
+    size_t tmp_bytes = (size_t)(workspace_bytes - 2 * (long long)align256(sizeof(unsigned) * max_rows));
+    hipLaunchKernelGGL(sp_row_masks_kernel, dim3((unsigned)div_up(max_rows, 256)), dim3(256), 0, st, nbr, num_rows, max_rows,
+                       KV, keys, vals, pairs_or_null);
+    if (hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, row_mask_sorted, vals, (unsigned*)row_perm, (int)max_rows, 0,
+                                           32, st) != hipSuccess) {
+        set_error("tt_sp_tile_plan: radix sort failed");
+        return -2;
+    }
+    return check_launch("tt_sp_tile_plan");
 }

@@ -7,6 +7,7 @@ points (B,Np,5) -> hard voxelise + mean VFE -> sparse 3-D conv encoder -> dense 
 counts on the device (no `coors[-1,0]+1` host sync, lidarnet.py:90).
 """
 import ctypes
+import os
 
 import torch
 
@@ -16,6 +17,12 @@ from .ops import _c, _ll, check, lib, ptr
 from .registry import BACKBONES, MIDDLE_ENCODERS
 
 F32 = torch.float32
+# A/B knob, default OFF: mask-sorted tiles of the gathered GEMM (tt_sp_tile_plan).  Measured on the bench workload
+# (gpurun_out/r2_bench_x3_plan{0,1}.json -> profiles/r02_sparse_tile_plan_ab.txt): it wins only where rows carry ~1 tap
+# (first SubM level / first strided conv: 0.87 -> 0.41 ms) and LOSES at 6-23 taps per row (9.5 -> 15.0 ms on the
+# 1.65 M-row level): sorting by mask scatters spatial neighbours over different tiles, so the gathered input rows stop
+# hitting L2, and the tap union of a tile is nearly full there anyway.
+_TILE_PLAN = os.environ.get("TT_SPARSE_TILE_PLAN", "0") == "1"
 
 
 def _pow2(n):
@@ -33,6 +40,7 @@ class _Level:
         self.dims_c = (ctypes.c_int * 3)(*self.dims)
         self.vol = vol
         self._subm = None
+        self._subm_plan = None
 
     def volume(self):
         if self.vol is None:
@@ -50,7 +58,12 @@ class _Level:
             check(lib().tt_sp_rulebook(ptr(self.coords), ptr(self.rows), _ll(self.max_rows), g, self.dims_c,
                                        ptr(self.volume()), ptr(nbr), ops.cur_stream(nbr.device)), "tt_sp_rulebook")
             self._subm = nbr
+            self._subm_plan = ops.sp_tile_plan(nbr, self.rows) if _TILE_PLAN else None
         return self._subm
+
+    def subm_plan(self):
+        self.subm_rulebook()
+        return self._subm_plan
 
 
 def _sp_weight(w, dev, dtype):
@@ -72,10 +85,11 @@ def _bn1d(sd, p, dev, eps=1e-3):
     return s.to(dev).contiguous(), t.to(dev).contiguous()
 
 
-def _sp_conv(feats, nbr, level, w, bn, res=None, relu=True):
-    """SubMConv3d / SparseConv3d + BN1d (+ residual) + ReLU as ONE gathered MFMA GEMM."""
+def _sp_conv(feats, nbr, level, w, bn, res=None, relu=True, plan=None):
+    """SubMConv3d / SparseConv3d + BN1d (+ residual) + ReLU as ONE gathered MFMA GEMM (with the rulebook's tile plan:
+    rows sorted by tap mask, each 256-row tile multiplies only the taps that exist in it)."""
     return ops.gather_conv(feats, nbr, level.rows, w[0], scale=bn[0], shift=bn[1], res=res,
-                           act=_lib.ACT_RELU if relu else _lib.ACT_NONE, w_x3=w[1])
+                           act=_lib.ACT_RELU if relu else _lib.ACT_NONE, w_x3=w[1], plan=plan)
 
 
 @MIDDLE_ENCODERS.register_module()
@@ -141,7 +155,8 @@ class SparseEncoder_fp32:
         nbr = torch.empty(max_out, KV, dtype=torch.int32, device=dev)
         check(lib().tt_sp_rulebook(ptr(coords), ptr(rows), _ll(max_out), g, lvl.dims_c, ptr(lvl.volume()), ptr(nbr), st),
               "tt_sp_rulebook")
-        return _sp_conv(feats, nbr, new, w, bn), new
+        plan = ops.sp_tile_plan(nbr, rows) if _TILE_PLAN else None
+        return _sp_conv(feats, nbr, new, w, bn, plan=plan), new
 
     def forward(self, voxel_features, coors, num_rows, max_rows, batch_size):
         """-> dense channel-last (B, H, W, C*D) f32 (== spatial_features.view(N, C*D, H, W))."""
@@ -151,14 +166,14 @@ class SparseEncoder_fp32:
         f0 = torch.zeros(max_rows, cp, dtype=self.dtype, device=dev)      # channel-padded voxel features
         nf = voxel_features.shape[1]
         ops.copy_nhwc(voxel_features.view(max_rows, 1, 1, nf), f0.view(max_rows, 1, 1, cp), C=nf)
-        x = _sp_conv(f0, lvl.subm_rulebook(), lvl, self.w_in, self.bn_in)
+        x = _sp_conv(f0, lvl.subm_rulebook(), lvl, self.w_in, self.bn_in, plan=lvl.subm_plan())
         for st in self.stages:
             for item in st:
                 if item[0] == "block":
                     _, w1, b1, w2, b2 = item
                     nbr = lvl.subm_rulebook()
-                    y = _sp_conv(x, nbr, lvl, w1, b1)
-                    x = _sp_conv(y, nbr, lvl, w2, b2, res=x)       # relu(bn2(conv2) + identity)
+                    y = _sp_conv(x, nbr, lvl, w1, b1, plan=lvl.subm_plan())
+                    x = _sp_conv(y, nbr, lvl, w2, b2, res=x, plan=lvl.subm_plan())   # relu(bn2(conv2) + identity)
                 else:
                     _, w, bn, pd = item
                     x, lvl = self._down(x, lvl, w, bn, (3, 3, 3), (2, 2, 2), pd, batch_size)

@@ -81,7 +81,7 @@ class _ConvDesc(ctypes.Structure):
         ("res2", ctypes.c_void_p), ("res2_cstride", _c), ("res2_coff", _c),
         ("act", _c), ("dtype", _c), ("out_dtype", _c),
         ("gather_idx", ctypes.c_void_p), ("m_dev", ctypes.c_void_p), ("splitk_ws", ctypes.c_void_p),
-        ("weight_x3", ctypes.c_void_p),
+        ("weight_x3", ctypes.c_void_p), ("row_perm", ctypes.c_void_p), ("row_mask", ctypes.c_void_p),
     ]
 
 
@@ -89,7 +89,24 @@ def _dp(t):
     return None if t is None else t.data_ptr()
 
 
-def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None, out_dtype=None, w_x3=None):
+SPARSE_PAIRS = None   # bench.py: device int64 counter of existing (row, tap) pairs, filled by sp_tile_plan
+
+
+def sp_tile_plan(nbr, m_dev):
+    """Tile plan of a rulebook (tt_sp_tile_plan): (row_perm int32 [M], row_mask int32-typed uint32 [M]) -- the output
+    rows sorted by tap-occupancy mask, so that a 256-row tile of the gathered GEMM only visits the union of its taps."""
+    require_cuda(nbr, m_dev)
+    M, KV = nbr.shape
+    ws_bytes = int(lib().tt_sp_tile_plan_workspace_bytes(_ll(M)))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=nbr.device)
+    perm = torch.empty(M, dtype=torch.int32, device=nbr.device)
+    mask = torch.empty(M, dtype=torch.int32, device=nbr.device)
+    check(lib().tt_sp_tile_plan(ptr(nbr), ptr(m_dev), _ll(M), _c(KV), ptr(ws), _ll(ws_bytes), ptr(perm), ptr(mask),
+                                ptr(SPARSE_PAIRS), cur_stream(nbr.device)), "tt_sp_tile_plan")
+    return perm, mask
+
+
+def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None, out_dtype=None, w_x3=None, plan=None):
     """Sparse convolution as a gathered GEMM on MFMA: feats [R_in, C] rows, nbr int32 [M, taps]
     (rulebook, -1 = no input), m_dev device int (live output rows), w [Cout,1,taps,C] -> [M, Cout]."""
     require_cuda(feats, nbr, w)
@@ -107,13 +124,17 @@ def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None
     d.act = act; d.dtype = dtype_code(feats); d.out_dtype = dtype_code(out)
     d.gather_idx = nbr.data_ptr(); d.m_dev = _dp(m_dev)
     d.weight_x3 = _dp(w_x3)
+    if plan is not None:
+        d.row_perm, d.row_mask = plan[0].data_ptr(), plan[1].data_ptr()
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     check(lib().tt_conv2d_fwd(ctypes.byref(d), cur_stream(feats.device)), "tt_conv2d_fwd(gather)")
     if CONV_PROFILE is not None:
         e1.record()
-        CONV_PROFILE.append((2.0 * Cout * KW * Cin, e0, e1, f"sparse M<={M} N={Cout} K={KW * Cin}", m_dev, M))
+        # FLOP accounting over the EXISTING (row, tap) pairs: per-row tap counts of the rulebook (measurement only)
+        CONV_PROFILE.append((2.0 * Cout * KW * Cin, e0, e1, f"sparse M<={M} N={Cout} K={KW * Cin}", m_dev, M,
+                             ((nbr >= 0).sum(1), 2.0 * Cout * Cin)))
     return out
 
 
