@@ -367,6 +367,13 @@ int tt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float beta1, float beta2, float eps, float weight_decay, int step,
                   const float* grad_scale_or_null, void* stream);
 
+/* SURVEY 8f-1, LiDAR side: merge of the two 180-degree half sweeps of the closed-loop tick
+ * (leaderboard/team_code/thinktwice_agent.py:340-352).  prev / now: (n, 4) f32 (x, y, z, intensity) device rows;
+ * rel_transform_3x4: HOST pointer to the first three rows of inv(T_now) @ T_prev (row-major); out: (n_prev + n_now, 4)
+ * = [transformed prev | now] with z += z_shift (2.5). */
+int tt_lidar_merge_half_sweeps(const float* prev_xyzi, int n_prev, const float* now_xyzi, int n_now,
+                               const float* rel_transform_3x4, float z_shift, float* out_xyzi, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

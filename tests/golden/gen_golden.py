@@ -473,8 +473,29 @@ def gen_f13():
           meta=np.array([B, hw[0], hw[1], npts, seed]), oracle_vs_reference_worst_rel_err=np.array([worst]))
 
 
+# ---------------------------------------------------------------------------
+# F15: pose matrices of the closed-loop agent (leaderboard/team_code/thinktwice_agent.py:47-92), produced by executing
+#      the reference's OWN function definitions (extracted with ast at generation time: importing the module needs carla)
+# ---------------------------------------------------------------------------
+def gen_f15():
+    import ast
+    import math
+    path = os.path.join(ref_stubs.REF_ROOT if hasattr(ref_stubs, "REF_ROOT") else "/root/reference", "leaderboard",
+                        "team_code", "thinktwice_agent.py")
+    tree = ast.parse(open(path).read())
+    want = {"obtain_transform_matrix", "InverseRotateVector", "obtain_inv_transform_matrix"}
+    mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want], type_ignores=[])
+    ns = {"math": math, "np": np}
+    exec(compile(mod, path, "exec"), ns)
+    rng = np.random.default_rng(15)
+    poses = np.concatenate([rng.uniform(-200, 200, (24, 2)), rng.uniform(-2 * np.pi, 2 * np.pi, (24, 1))], 1)
+    fwd = np.stack([ns["obtain_transform_matrix"](*p) for p in poses])
+    inv = np.stack([ns["obtain_inv_transform_matrix"](*p) for p in poses])
+    _save("f15_agent_transforms.npz", poses=poses, fwd=fwd, inv=inv)
+
+
 FIXTURES = {"F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8, "F9": gen_f9, "F10": gen_f10, "F11": gen_f11,
-            "F13": gen_f13, "F14": gen_f14}
+            "F13": gen_f13, "F14": gen_f14, "F15": gen_f15}
 
 
 def main():

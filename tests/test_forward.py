@@ -131,6 +131,38 @@ def test_forward_16bit_modes_small(golden_dir, dt, tol, tol_inter):
     print(f"{dt} trunk: rel errs vs reference golden", errs)
 
 
+def test_mmcv_style_checkpoint_loading_through_the_module_shell(golden_dir):
+    """B2: EncoderDecoder is an nn.Module shell; a checkpoint reaches it the way mmcv's load_checkpoint / load_state_dict
+    deliver it (mmcv/runner/checkpoint.py: strip the DataParallel `module.` prefix, then walk the module tree calling
+    `_load_from_state_dict`), and `state_dict()` hands the same reference-format dict back."""
+    from thinktwice_amd import model as tm, params, synth
+    pack = np.load(os.path.join(golden_dir, "f7_forward_small_b2.npz"))
+    B, H, W, npts, seed = (int(v) for v in pack["meta"])
+    m, cfg = tm.build_thinktwice(final_dim=(H, W))
+    assert isinstance(m, torch.nn.Module)
+    sd = params.init_params(cfg, seed=seed)
+    ckpt = {"state_dict": {"module." + k: v for k, v in sd.items()}, "meta": {}}
+
+    def mmcv_load_state_dict(module, state_dict):        # the loader's tree walk, restated
+        state_dict = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        missing, unexpected, errs = [], [], []
+
+        def load(mod, prefix=""):
+            mod._load_from_state_dict(state_dict, prefix, {}, True, missing, unexpected, errs)
+            for name, child in mod._modules.items():
+                if child is not None:
+                    load(child, prefix + name + ".")
+        load(module)
+        assert not errs
+    mmcv_load_state_dict(m, ckpt["state_dict"])
+    m.eval()
+    out = m.forward_inference(tm.batch_to_device(synth.make_batch(B, img_hw=(H, W), num_points=npts)))
+    torch.cuda.synchronize()
+    _check_against_pack(pack, out, 1e-3)
+    back = m.state_dict()
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in list(sd)[:50])
+
+
 def test_forward_refuses_missing_weights():
     from thinktwice_amd import _lib, model as tm
     m, _ = tm.build_thinktwice(final_dim=(128, 256))

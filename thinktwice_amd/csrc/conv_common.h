@@ -38,6 +38,7 @@ struct ConvArgs {
     int splits;          // split-K factor (gridDim.y)
     int tiles_n;
     int m_begin;         // first output row of this launch (tail-split launches of the LDS-DMA kernel), else 0
+    int flags;           // bit 0: s_setprio(1) around the MFMA groups of the LDS-DMA kernel (TT_GLDS_SETPRIO=1, A/B knob)
 };
 
 template <typename T> struct Mfma;

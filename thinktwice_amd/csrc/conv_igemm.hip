@@ -353,6 +353,14 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
                "tt_conv2d_fwd: residuals are not supported with pixel_shuffle2");
     a.tiles_n = 1; a.cin_fast = 0; a.m_begin = 0;
     {
+        static int setprio = -1;
+        if (setprio < 0) {
+            const char* e = getenv("TT_GLDS_SETPRIO");
+            setprio = e ? atoi(e) : 0;
+        }
+        a.flags = setprio ? 1 : 0;
+    }
+    {
         const int co_vec = d->out_dtype == TT_F32 ? 4 : 8;
         const int osz = d->out_dtype == TT_F32 ? 4 : 2;
         const int cr = d->pixel_shuffle2 ? d->Cout / 4 : d->Cout;

@@ -349,6 +349,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         return v;
     };
 
+    const bool prio = (p.flags & 1) != 0;
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed for THIS wave once at most one younger tile (LPT loads) is outstanding
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -426,12 +427,16 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                 }
                 const uint4 bhv = __builtin_bit_cast(uint4, bh[buf]);
                 const uint4 blv = __builtin_bit_cast(uint4, bl[buf]);
+                if (prio) __builtin_amdgcn_s_setprio(1);
+                // term-major order: consecutive MFMAs write different accumulators (a back-to-back pair on the same
+                // accumulator waits for the first one's last pass); small terms first
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    Mfma<uint16_t>::run(al[i], bhv, acc[i][j]);     // small terms first
-                    Mfma<uint16_t>::run(ah[i], blv, acc[i][j]);
-                    Mfma<uint16_t>::run(ah[i], bhv, acc[i][j]);
-                }
+                for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(al[i], bhv, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(ah[i], blv, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(ah[i], bhv, acc[i][j]);
+                if (prio) __builtin_amdgcn_s_setprio(0);
                 (void)kc;
             }
             continue;
@@ -466,6 +471,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
 #pragma unroll
                 for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read(sbase + fb_pre[kc + 1][j]);
             }
+            if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -474,6 +480,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                     const uint4 bv = __builtin_bit_cast(uint4, fb[cur][j]);
                     Mfma<T>::run(av, bv, acc[i][j]);
                 }
+            if (prio) __builtin_amdgcn_s_setprio(0);
         }
     }
     // Measured and NOT kept (profiles/r01_conv_microbench_tiles.txt): deferring each tile's last k-step past the next

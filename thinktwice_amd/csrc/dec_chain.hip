@@ -64,10 +64,13 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-__device__ __forceinline__ void mfma3(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16& c) {
-    Mfma<uint16_t>::run(al, bh, c);     // small terms first
-    Mfma<uint16_t>::run(ah, bl, c);
+// the cross terms and the main term go to two accumulators (summed in the epilogue): a back-to-back MFMA pair on the
+// same accumulator waits for the first one's last pass
+__device__ __forceinline__ void mfma3(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16& c,
+                                      f32x16& c2) {
+    Mfma<uint16_t>::run(al, bh, c2);
     Mfma<uint16_t>::run(ah, bh, c);
+    Mfma<uint16_t>::run(ah, bl, c2);
 }
 
 // store one f32 value as a (hi, lo) bf16 pair at element (row, col) of a pair-format LDS buffer
@@ -116,11 +119,11 @@ __global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_kernel(const Chain
                 bptr[q] = reinterpret_cast<const unsigned char*>(S.w) + (size_t)(live[q] ? nb : 0) * nsteps * 2048 +
                           (h * 32 + r) * 16;
             }
-            f32x16 acc[kChainNBW];
+            f32x16 acc[kChainNBW], acc2[kChainNBW];
 #pragma unroll
             for (int q = 0; q < kChainNBW; ++q)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[q][i] = acc2[q][i] = 0.f;
 
             // Weight ring of kChainPF K-steps; every load is UNCONDITIONAL (step clamped to the last one, dead blocks
             // re-read block 0, rows beyond R re-read row 0) so the compiler counts the outstanding loads statically
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_kernel(const Chain
                         if (k < nsteps) {
 #pragma unroll
                             for (int q = 0; q < kChainNBW; ++q)
-                                if (live[q]) mfma3(ah, al, bh[p][q], bl[p][q], acc[q]);
+                                if (live[q]) mfma3(ah, al, bh[p][q], bl[p][q], acc[q], acc2[q]);
                         }
                         const int kn = k + kChainPF < last ? k + kChainPF : last;
                         ar0[p] = *reinterpret_cast<const float4*>(xa + kn * 16);
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_kernel(const Chain
                         if (k < nsteps) {
 #pragma unroll
                             for (int q = 0; q < kChainNBW; ++q)
-                                if (live[q]) mfma3(ah, al, bh[p][q], bl[p][q], acc[q]);
+                                if (live[q]) mfma3(ah, al, bh[p][q], bl[p][q], acc[q], acc2[q]);
                         }
                         load_b(k + kChainPF, bh[p], bl[p]);
                     }
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_kernel(const Chain
                     const int rr = (i & 3) + 8 * (i >> 2) + 4 * h;
                     const long long mr = m0 + rr;
                     const bool ok = n_ok && mr < a.R;
-                    float v = acc[q][i] + bias;
+                    float v = (acc[q][i] + acc2[q][i]) + bias;
                     if (S.side && ok) {
                         const float* sp = S.side + mr * S.side_stride;
 #pragma unroll

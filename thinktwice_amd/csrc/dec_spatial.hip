@@ -22,10 +22,13 @@
 
 namespace tt {
 
-__device__ __forceinline__ void mfma3s(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16& c) {
-    Mfma<uint16_t>::run(al, bh, c);
-    Mfma<uint16_t>::run(ah, bl, c);
+// the three products of a K step go to TWO accumulators (summed at the end): a back-to-back MFMA pair on the same
+// accumulator waits for the first one's last pass, and these kernels have a single output block per wave
+__device__ __forceinline__ void mfma3s(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16& c,
+                                       f32x16& c2) {
+    Mfma<uint16_t>::run(al, bh, c2);
     Mfma<uint16_t>::run(ah, bh, c);
+    Mfma<uint16_t>::run(ah, bl, c2);
 }
 
 __device__ __forceinline__ void pair_store(unsigned char* map, int PS, int pix, int c, float v) {
@@ -69,13 +72,13 @@ __device__ __forceinline__ void conv_lds(const unsigned char* in_map, int H, int
         const bool m_ok = m < M;
         const int oh = m_ok ? m / OW : 0, ow = m_ok ? m - (m / OW) * OW : 0;
         const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
-        f32x16 acc[NBG];
+        f32x16 acc[NBG], acc2[NBG];
         const unsigned char* bp[NBG];
         bool live[NBG];
 #pragma unroll
         for (int q = 0; q < NBG; ++q) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[q][i] = acc2[q][i] = 0.f;
             const int nb = ng * NBG + q;
             live[q] = nb < NB;
             bp[q] = w + (size_t)(live[q] ? nb : 0) * blk_bytes + (h * 32 + r) * 16;
@@ -109,7 +112,7 @@ __device__ __forceinline__ void conv_lds(const unsigned char* in_map, int H, int
                     const uint4 al = *reinterpret_cast<const uint4*>(ok ? ap + 32 : ap);
 #pragma unroll
                     for (int q = 0; q < NBG; ++q)
-                        if (live[q]) mfma3s(ah, al, bh[p][q], bl[p][q], acc[q]);
+                        if (live[q]) mfma3s(ah, al, bh[p][q], bl[p][q], acc[q], acc2[q]);
                 }
                 {
                     const int kn = ks + PF < last ? ks + PF : last;
@@ -128,7 +131,7 @@ __device__ __forceinline__ void conv_lds(const unsigned char* in_map, int H, int
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int mm = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (mm < M && n < N) epi(mm, n, acc[q][i], i);
+                if (mm < M && n < N) epi(mm, n, acc[q][i] + acc2[q][i], i);
             }
         }
     }

@@ -323,31 +323,31 @@ __global__ __launch_bounds__(256) void msda_sample_ln_kernel(const T* __restrict
     out_ln[row * 256 + t] = d * rstd * gamma[t] + beta[t];
 }
 
-// sca_reduce + LayerNorm(1024) (output_proj.0): one block per sample
-__global__ __launch_bounds__(256) void sca_reduce_ln_kernel(const float* __restrict__ x, const int* __restrict__ max_len,
-                                                            int B, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float eps,
-                                                            float* __restrict__ out) {
-    __shared__ float red[4];
-    const int b = blockIdx.x, c = threadIdx.x;
+// sca_reduce + LayerNorm(1024) (output_proj.0): one block of 1024 threads per sample, thread = (camera, channel)
+__global__ __launch_bounds__(1024) void sca_reduce_ln_kernel(const float* __restrict__ x, const int* __restrict__ max_len,
+                                                             int B, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             float* __restrict__ out) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, cam = threadIdx.x >> 8, c = threadIdx.x & 255;
     const int ml = min(*max_len, kQ);
-    float v[kCams];
-    float s = 0.f;
+    float a = 0.f;
+    for (int k = B; k < ml; ++k) a += x[((long long)(b * kCams + cam) * kQ + k) * 256 + c] / (float)B;
+    auto block_sum = [&](float v) {
 #pragma unroll
-    for (int cam = 0; cam < kCams; ++cam) {
-        float a = 0.f;
-        for (int k = B; k < ml; ++k) a += x[((long long)(b * kCams + cam) * kQ + k) * 256 + c] / (float)B;
-        v[cam] = a;
-        s += a;
-    }
-    const float mean = block_sum256(s, red) / 1024.f;
-    float qq = 0.f;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        float t = 0.f;
 #pragma unroll
-    for (int cam = 0; cam < kCams; ++cam) qq += (v[cam] - mean) * (v[cam] - mean);
-    const float rstd = 1.f / sqrtf(block_sum256(qq, red) / 1024.f + eps);
-#pragma unroll
-    for (int cam = 0; cam < kCams; ++cam)
-        out[(long long)b * 1024 + cam * 256 + c] = (v[cam] - mean) * rstd * gamma[cam * 256 + c] + beta[cam * 256 + c];
+        for (int w = 0; w < 16; ++w) t += red[w];
+        return t;
+    };
+    const float mean = block_sum(a) / 1024.f;
+    const float d = a - mean;
+    const float rstd = 1.f / sqrtf(block_sum(d * d) / 1024.f + eps);
+    out[(long long)b * 1024 + cam * 256 + c] = d * rstd * gamma[cam * 256 + c] + beta[cam * 256 + c];
 }
 
 // mlp.0 input of a refinement layer (thinktwice_decoder.py:247-250): row (b, t) = LayerNorm(cat([future flat (b,t) 256 |
@@ -515,7 +515,7 @@ extern "C" int tt_msda_sample_ln(int B, const void* value, int value_dtype, int 
 extern "C" int tt_sca_reduce_ln(int B, const float* x, const int* max_len, const float* gamma, const float* beta,
                                 float eps, float* out, void* stream) {
     TT_REQUIRE(x && max_len && gamma && beta && out, "tt_sca_reduce_ln: null");
-    hipLaunchKernelGGL(sca_reduce_ln_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, max_len, B, gamma, beta, eps,
+    hipLaunchKernelGGL(sca_reduce_ln_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, max_len, B, gamma, beta, eps,
                        out);
     return check_launch("tt_sca_reduce_ln");
 }

@@ -74,6 +74,30 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreArgs a, const uint8_
         for (int c = 3; c < a.Cp; ++c) Elem<T>::st(out + t * a.Cp + c, 0.f);
 }
 
+// LiDAR half-sweep merge of the agent tick (leaderboard/team_code/thinktwice_agent.py:340-352): the simulator runs at
+// 20 Hz, the LiDAR at 10 Hz, so every tick delivers a 180-degree half sweep; the previous half sweep is moved into the
+// current ego frame (rigid planar transform, rows of `mat` = first three rows of inv(T_now) @ T_prev), the two halves
+// are concatenated [previous | current] and the sensor height (z += 2.5) is added to every point.  Points are
+// (x, y, z, intensity) f32.
+__global__ void lidar_merge_kernel(const float* __restrict__ prev, int n_prev, const float* __restrict__ now, int n_now,
+                                   float m00, float m01, float m02, float m03, float m10, float m11, float m12, float m13,
+                                   float m20, float m21, float m22, float m23, float z_shift, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_prev + n_now) return;
+    float4 p;
+    if (i < n_prev) {
+        const float4 q = reinterpret_cast<const float4*>(prev)[i];
+        p.x = m00 * q.x + m01 * q.y + m02 * q.z + m03;
+        p.y = m10 * q.x + m11 * q.y + m12 * q.z + m13;
+        p.z = m20 * q.x + m21 * q.y + m22 * q.z + m23;
+        p.w = q.w;
+    } else {
+        p = reinterpret_cast<const float4*>(now)[i - n_prev];
+    }
+    p.z += z_shift;
+    reinterpret_cast<float4*>(out)[i] = p;
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -102,4 +126,17 @@ extern "C" int tt_preprocess_images(const uint8_t* raw_hwc, int num_images, int 
     else
         TT_REQUIRE(false, "tt_preprocess_images: bad dtype");
     return check_launch("tt_preprocess_images");
+}
+
+extern "C" int tt_lidar_merge_half_sweeps(const float* prev_xyzi, int n_prev, const float* now_xyzi, int n_now,
+                                          const float* rel_transform_3x4, float z_shift, float* out_xyzi, void* stream) {
+    TT_REQUIRE(now_xyzi && out_xyzi && rel_transform_3x4 && n_now >= 0 && n_prev >= 0 && (n_prev == 0 || prev_xyzi),
+               "tt_lidar_merge_half_sweeps: bad arguments");
+    const int n = n_prev + n_now;
+    if (n == 0) return 0;
+    const float* m = rel_transform_3x4;
+    hipLaunchKernelGGL(lidar_merge_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, prev_xyzi,
+                       n_prev, now_xyzi, n_now, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10], m[11],
+                       z_shift, out_xyzi);
+    return check_launch("tt_lidar_merge_half_sweeps");
 }

@@ -258,5 +258,9 @@ class FusedDecoder:
         fin = torch.empty(B, 2304, dtype=F32, device=dev)
         ops.concat_rows(fin, [(cur_flat, 256, 1, 0), (hb, 2048, 1, 0)])
         f_ = lay.flat
-        ops.mlp_chain(fin, [{"lin": f_[0], "src": -1}, {"lin": f_[1], "src": 0, "res": (cur_flat, 0), "out": (flat_out, 0)}])
+        # 2304 -> 512 over <= 32 rows is a 4.7 MB weight stream: deal its 16 column blocks over 4 workgroups (a single one
+        # took 122 us), then the 512 -> 256 tail + residual as its own small launch
+        f1 = torch.empty(B, 512, dtype=F32, device=dev)
+        ops.mlp_chain(fin, [{"lin": f_[0], "src": -1, "out": (f1, 0)}], n_split=4)
+        ops.mlp_chain(f1, [{"lin": f_[1], "src": -1, "res": (cur_flat, 0), "out": (flat_out, 0)}])
         return count, max_len

@@ -15,10 +15,18 @@ F32 = torch.float32
 
 
 @DETECTORS.register_module()
-class EncoderDecoder:
+class EncoderDecoder(torch.nn.Module):
+    """A torch.nn.Module SHELL: it registers no parameters or sub-modules (the weights live in kernel layouts inside the
+    plain-Python sub-objects), but it has the Module surface the reference's callers rely on -- `eval()`, `to()`,
+    `state_dict()`, and `_load_from_state_dict`, the hook through which mmcv's `load_checkpoint(model, path)` /
+    `load_state_dict(module, state_dict)` (mmcv/runner/checkpoint.py, used at thinktwice_agent.py:170-171 and
+    train.py:238) hand a checkpoint to a module tree."""
+
     def __init__(self, img_encoder, decoder, lidar_encoder=None, num_cams=4, use_depth=False, use_seg=False,
                  downsample_factor=16, seg_downsample_factor=2, train_cfg=None, test_cfg=None,
                  dtype=torch.float32, device="cuda", cfg=None, lidar_dtype=None):
+        super().__init__()
+        self._ref_sd = None
         self.config = train_cfg if train_cfg is not None else cfg
         self.num_cams = num_cams
         self.dtype = dtype
@@ -53,6 +61,10 @@ class EncoderDecoder:
         self.training = False
         return self
 
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
     def to(self, *a, **k):
         return self
 
@@ -65,9 +77,25 @@ class EncoderDecoder:
     def init_weights(self):
         pass
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        """torch / mmcv checkpoint loaders walk the module tree calling this hook; the root (this shell has no
+        children) takes the whole dict."""
+        sub = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)} if prefix else dict(state_dict)
+        sub.pop("_metadata", None)
+        self.load_state_dict(sub)
+
+    def state_dict(self, destination=None, prefix="", keep_vars=False):
+        """The reference-format state_dict this model was loaded from (what torch.save(model.state_dict()) stores)."""
+        out = destination if destination is not None else {}
+        for k, v in (self._ref_sd or {}).items():
+            out[prefix + k] = v
+        return out
+
     def load_state_dict(self, sd, strict=False):
         """Accepts the reference's checkpoint `state_dict` (optionally with a `module.` prefix)."""
-        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items() if k != "_metadata"}
+        self._ref_sd = sd
         dev = self.device
         self.img_encoder.load_state_dict(sd, "img_encoder")
         if self.lidar_encoder is not None:
@@ -149,8 +177,9 @@ class EncoderDecoder:
     def train_step(self, data, optimizer):
         return self.forward_train(data)
 
-    def __call__(self, **kwargs):
-        return self.forward_train(kwargs)
+    def forward(self, is_eval=True, **kwargs):
+        """EncoderDecoder.forward (encoder_decoder_framework.py:393-407): the training entry of the mmcv runner."""
+        return self.train_step(kwargs, None)
 
 
 class PrevSweepCache:

@@ -13,7 +13,8 @@ def main():
     a = sys.argv[1:]
     N, H, W, Cin, Cout, k = (int(v) for v in a[:6])
     stride = int(a[6]) if len(a) > 6 else 1
-    dt = torch.bfloat16 if (len(a) <= 7 or a[7] == "bf16") else torch.float32
+    mode = a[7] if len(a) > 7 else "bf16"
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}.get(mode, torch.float32)
     iters = int(a[8]) if len(a) > 8 else 20
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.randn(N, H, W, Cin, device="cuda", generator=g).to(dt)
@@ -22,19 +23,22 @@ def main():
     act = int(os.environ.get("TT_MB_ACT", "0"))
     res = torch.randn(N, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, Cout, device="cuda").to(dt) \
         if os.environ.get("TT_MB_RES") else None
+    from thinktwice_amd import weights
+    wx = weights.split_pairs_x3(w) if mode == "x3" else None
+    conv = lambda: ops.conv2d(x, w, stride=stride, pad=pad, act=act, res1=res, w_x3=wx)
     for _ in range(3):
-        y = ops.conv2d(x, w, stride=stride, pad=pad, act=act, res1=res)
+        y = conv()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        y = ops.conv2d(x, w, stride=stride, pad=pad, act=act, res1=res)
+        y = conv()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     M = y.shape[0] * y.shape[1] * y.shape[2]
     fl = 2.0 * M * Cout * k * k * Cin
-    print(f"M={M} N={Cout} K={k*k*Cin} {dt}: {ms:.3f} ms  {fl/ms/1e9:.1f} TF/s  env VARIANT={os.environ.get('TT_GLDS_VARIANT')} MINK={os.environ.get('TT_GLDS_MIN_KTILES')} ACT={act} RES={res is not None} SCALAR_EPI={os.environ.get('TT_CONV_SCALAR_EPI')}")
+    print(f"M={M} N={Cout} K={k*k*Cin} {mode}: {ms:.3f} ms  {fl/ms/1e9:.1f} TF/s  env SETPRIO={os.environ.get('TT_GLDS_SETPRIO')} VARIANT={os.environ.get('TT_GLDS_VARIANT')} MINK={os.environ.get('TT_GLDS_MIN_KTILES')} ACT={act} RES={res is not None} SCALAR_EPI={os.environ.get('TT_CONV_SCALAR_EPI')}")
     # reference point: a plain device copy of the output-sized tensor (read + write M*N elements)
     src = torch.empty_like(y)
     for _ in range(3):

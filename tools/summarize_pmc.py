@@ -25,7 +25,7 @@ def main():
     res = {}
     for d in sys.argv[1:]:
         for (name, c), (n, tot) in load(d).items():
-            short = name.split("(")[0][-60:]
+            short = name.split("(")[0].replace("void ", "").replace("tt::", "")[:110]    # keep the kernel name itself
             res.setdefault(short, {})[c] = {"dispatches": n, "sum": tot, "per_dispatch": tot / max(n, 1)}
     print(json.dumps(res, indent=1))
 
