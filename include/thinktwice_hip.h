@@ -63,6 +63,21 @@ int tt_voxel_pool_fwd_ws(int batch_size, int num_points, int num_channels,
                          float* output_features, int32_t* pos_memo,
                          void* workspace, long long workspace_bytes, void* stream);
 
+/* Planned forward for STATIC geometry (fixed camera rig: the same geom_xyz every frame; closed-loop ticks, the bench).
+ * tt_voxel_pool_plan_build sorts the in-range points by (sample, cell) once; tt_voxel_pool_fwd_planned then streams
+ * the point rows cell by cell with no index work, no atomics, deterministic.  Same result as tt_voxel_pool_fwd
+ * (output_features is accumulated into, pre-zero it like the reference does). */
+long long tt_voxel_pool_plan_bytes(int batch_size, int num_points, int num_voxel_x, int num_voxel_y);
+long long tt_voxel_pool_plan_workspace_bytes(int batch_size, int num_points);
+int tt_voxel_pool_plan_build(int batch_size, int num_points, int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                             const int32_t* geom_xyz, void* workspace, long long workspace_bytes, void* plan,
+                             long long plan_bytes, void* stream);
+long long tt_voxel_pool_planned_workspace_bytes(int batch_size, int num_points, int num_channels, int num_voxel_x,
+                                                int num_voxel_y);
+int tt_voxel_pool_fwd_planned(int batch_size, int num_points, int num_channels, int num_voxel_x, int num_voxel_y,
+                              const void* plan, const float* input_features, float* output_features, void* workspace,
+                              long long workspace_bytes, void* stream);
+
 /* A9: VoxelPooling.backward (ops/voxel_pooling/voxel_pooling.py:57-69):
  * grad_in[b,p,:] = grad_out[b,:,y,x] for kept points, 0 elsewhere.
  * grad_out is the [B,Y,X,C] (channel-last) view of the reference's [B,C,Y,X]. */

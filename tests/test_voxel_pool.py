@@ -111,6 +111,32 @@ def test_hip_voxel_pool_matches_oracle_random(B, Np, C):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,Np,C", [(1, 1, 4), (2, 63, 256), (3, 1000, 256), (1, 4097, 512), (2, 20000, 256),
+                                    (1, 9000, 64), (3, 8193, 1024)])
+def test_planned_voxel_pool_matches_oracle_random(B, Np, C):
+    """Static-geometry plan (tt_voxel_pool_plan_build + tt_voxel_pool_fwd_planned): same sums as the oracle, bit-identical
+    between two calls (no atomics), and it accumulates into a pre-filled output like the reference kernel does."""
+    from thinktwice_amd.voxel_pooling import VoxelPoolPlan
+    rng = np.random.default_rng(B * 1000 + Np + C)
+    geom = np.stack([rng.integers(-2, 23, (B, Np)), rng.integers(-2, 23, (B, Np)),
+                     rng.integers(-1, 2, (B, Np))], -1).astype(np.int32)
+    if Np > 5000:
+        geom[0, 100:4000] = (5, 7, 0)                 # one long run: many segments of a single cell
+    feats = rng.standard_normal((B, Np, C), dtype=np.float32)
+    ref, _ = c_ref.voxel_pool_fwd(geom, feats, (21, 21, 1))
+    plan = VoxelPoolPlan(torch.from_numpy(geom).cuda(), (21, 21, 1))
+    fd = torch.from_numpy(feats).cuda()
+    a = plan(fd)
+    b = plan(fd)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(a.permute(0, 2, 3, 1).cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    assert torch.equal(a, b)
+    pre = torch.full((B, 21, 21, C), 2.0, device="cuda")
+    plan.forward_into(fd, pre)
+    np.testing.assert_allclose(pre.cpu().numpy(), ref + 2.0, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
 def test_hip_voxel_pool_edge_cases():
     from thinktwice_amd.voxel_pooling import voxel_pooling, voxel_pooling_forward_wrapper
     # empty input
@@ -167,6 +193,10 @@ def test_hip_frustum_index_bit_exact_and_full_size_pool():
     inr = ((idx_o >= 0) & (idx_o < vn.int())).all(-1)
     want = feats.double()[inr].sum(0)
     np.testing.assert_allclose(out.double().sum((0, 2, 3)).cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-2)
+    # the static-geometry plan of the same (real) geometry gives the same BEV
+    from thinktwice_amd.voxel_pooling import VoxelPoolPlan
+    planned = VoxelPoolPlan(geom, vn)(feats.cuda()).permute(0, 2, 3, 1).cpu().numpy()
+    assert np.abs(planned - ref).max() / np.abs(ref).max() < 1e-5
 
 
 @pytest.mark.gpu

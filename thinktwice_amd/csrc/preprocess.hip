@@ -130,10 +130,11 @@ extern "C" int tt_preprocess_images(const uint8_t* raw_hwc, int num_images, int 
 
 extern "C" int tt_lidar_merge_half_sweeps(const float* prev_xyzi, int n_prev, const float* now_xyzi, int n_now,
                                           const float* rel_transform_3x4, float z_shift, float* out_xyzi, void* stream) {
-    TT_REQUIRE(now_xyzi && out_xyzi && rel_transform_3x4 && n_now >= 0 && n_prev >= 0 && (n_prev == 0 || prev_xyzi),
+    TT_REQUIRE(rel_transform_3x4 && n_now >= 0 && n_prev >= 0 && (n_prev == 0 || prev_xyzi) && (n_now == 0 || now_xyzi),
                "tt_lidar_merge_half_sweeps: bad arguments");
     const int n = n_prev + n_now;
     if (n == 0) return 0;
+    TT_REQUIRE(out_xyzi, "tt_lidar_merge_half_sweeps: null output");
     const float* m = rel_transform_3x4;
     hipLaunchKernelGGL(lidar_merge_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, prev_xyzi,
                        n_prev, now_xyzi, n_now, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10], m[11],

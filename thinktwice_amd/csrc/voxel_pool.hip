@@ -12,6 +12,10 @@
 // rows of out-of-range points are never fetched, consecutive points that fall
 // in the same BEV cell are summed in registers and flushed with one atomic per
 // channel (wave-level pre-reduction), and 4 row loads are kept in flight per wave.
+#include <stdlib.h>
+
+#include <hipcub/hipcub.hpp>
+
 #include "tt_common.h"
 
 namespace tt {
@@ -146,6 +150,8 @@ __global__ __launch_bounds__(256) void voxel_pool_rows_kernel(
 constexpr int kChunk = 2048;
 constexpr int kMaxCells = 2048;
 
+// NV = float4 chunks per lane (ceil(C / 256)), RF = point rows in flight per wave (1 KiB loads each)
+template <int NV, int RF>
 __global__ __launch_bounds__(512) void voxel_pool_p1_kernel(
     int num_points, int C, int X, int Y, int Z, int chunks_per_sample, int smax,
     const int32_t* __restrict__ geom, const float* __restrict__ feats, float* __restrict__ out,
@@ -234,23 +240,23 @@ __global__ __launch_bounds__(512) void voxel_pool_p1_kernel(
         float4 acc[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = beg; k < end; k += 4) {
-            float4 row[4][4];
+        for (int k = beg; k < end; k += RF) {
+            float4 row[RF][NV];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < RF; ++j)
                 if (k + j < end) {
                     const float4* src = reinterpret_cast<const float4*>(feats + (p0 + sorted[k + j]) * (long long)C);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
+                    for (int v = 0; v < NV; ++v) {
                         const int ch = lane + 64 * v;
                         row[j][v] = (ch < c4) ? src[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < RF; ++j)
                 if (k + j < end) {
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
+                    for (int v = 0; v < NV; ++v) {
                         acc[v].x += row[j][v].x; acc[v].y += row[j][v].y;
                         acc[v].z += row[j][v].z; acc[v].w += row[j][v].w;
                     }
@@ -703,6 +709,161 @@ __global__ __launch_bounds__(256) void lift_splat_strip_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Planned forward for STATIC geometry (a fixed camera rig: geom_xyz is the same every frame).  The plan sorts the
+// in-range points by (sample, BEV cell) once (CSR: `order` = point indices grouped by cell, `cell_start`) and cuts
+// every cell's run into segments of kSeg rows.  A forward is then pure streaming with no index work:
+//   segments kernel : one wave per segment, kSegRF point rows (1 KiB each) in flight, register accumulation, one
+//                     partial row per segment to the workspace (plain stores);
+//   cells kernel    : one wave per (sample, cell) adds its segments' partial rows, in order, to the caller's output.
+// No atomics, deterministic; HBM traffic = the in-range rows + 4 B per row of indices + 2 x 1/kSeg of the rows.
+// ---------------------------------------------------------------------------
+constexpr int kSeg = 64;
+constexpr int kSegRF = 16;
+
+__global__ void vp_plan_keys_kernel(long long total, int num_points, int X, int Y, int Z, const int32_t* __restrict__ geom,
+                                    unsigned* __restrict__ keys, unsigned* __restrict__ vals, unsigned invalid_key) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const int x = geom[p * 3], y = geom[p * 3 + 1], z = geom[p * 3 + 2];
+    unsigned k = invalid_key;
+    if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) k = (unsigned)((p / num_points) * (long long)(X * Y) + y * X + x);
+    keys[p] = k;
+    vals[p] = (unsigned)p;
+}
+
+// cell_start[k] = first sorted position with key >= k (k = 0 .. nkeys), by binary search; one thread per key
+__global__ void vp_plan_starts_kernel(const unsigned* __restrict__ sorted_keys, long long total, int nkeys,
+                                      int* __restrict__ cell_start) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nkeys) return;
+    long long lo = 0, hi = total;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (sorted_keys[mid] < (unsigned)k) lo = mid + 1;
+        else hi = mid;
+    }
+    cell_start[k] = (int)lo;
+}
+
+// seg_off[k] = number of segments of the cells before k (exclusive scan of ceil(count / kSeg)), k = 0 .. nkeys;
+// a single workgroup (nkeys is a few thousand)
+__global__ __launch_bounds__(1024) void vp_plan_segments_kernel(const int* __restrict__ cell_start, int nkeys,
+                                                                int* __restrict__ seg_off) {
+    __shared__ int carry_sh;
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_sh = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < nkeys; k0 += 1024) {
+        const int k = k0 + tid;
+        const int v = (k < nkeys) ? (cell_start[k + 1] - cell_start[k] + kSeg - 1) / kSeg : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry_sh;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (k < nkeys) seg_off[k] = before + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry_sh = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) seg_off[nkeys] = carry_sh;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void vp_planned_segments_kernel(int C, int nkeys, const int* __restrict__ order,
+                                                                  const int* __restrict__ cell_start,
+                                                                  const int* __restrict__ seg_off,
+                                                                  const float* __restrict__ feats,
+                                                                  float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int g = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);      // segment
+    const int nseg = seg_off[nkeys];
+    if (g >= nseg) return;
+    // the cell of segment g: last k with seg_off[k] <= g (binary search over a few thousand entries)
+    int lo = 0, hi = nkeys;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (seg_off[mid] <= g) lo = mid;
+        else hi = mid;
+    }
+    const int beg = cell_start[lo] + (g - seg_off[lo]) * kSeg;
+    const int end = min(beg + kSeg, cell_start[lo + 1]);
+    const int my = (beg + lane < end) ? order[beg + lane] : 0;
+    const int c4 = C >> 2;
+    float4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < end - beg; k += kSegRF) {
+        float4 row[kSegRF][NV];
+#pragma unroll
+        for (int j = 0; j < kSegRF; ++j)
+            if (k + j < end - beg) {
+                const long long pt = (unsigned)__builtin_amdgcn_readlane(my, (k + j) & 63);
+                const float4* src = reinterpret_cast<const float4*>(feats + pt * (long long)C);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int ch = lane + 64 * v;
+                    row[j][v] = (ch < c4) ? src[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < kSegRF; ++j)
+            if (k + j < end - beg) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    acc[v].x += row[j][v].x; acc[v].y += row[j][v].y;
+                    acc[v].z += row[j][v].z; acc[v].w += row[j][v].w;
+                }
+            }
+    }
+    float4* dst = reinterpret_cast<float4*>(partial + (long long)g * C);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int ch = lane + 64 * v;
+        if (ch < c4) dst[ch] = acc[v];
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(64) void vp_planned_cells_kernel(int C, const int* __restrict__ seg_off,
+                                                              const float* __restrict__ partial, float* __restrict__ out) {
+    const int key = blockIdx.x, lane = threadIdx.x;
+    const int s0 = seg_off[key], s1 = seg_off[key + 1];
+    if (s0 == s1) return;
+    const int c4 = C >> 2;
+    float4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sg = s0; sg < s1; ++sg) {
+        const float4* src = reinterpret_cast<const float4*>(partial + (long long)sg * C);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int ch = lane + 64 * v;
+            if (ch < c4) {
+                const float4 t = src[ch];
+                acc[v].x += t.x; acc[v].y += t.y; acc[v].z += t.z; acc[v].w += t.w;
+            }
+        }
+    }
+    float4* dst = reinterpret_cast<float4*>(out + (long long)key * C);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int ch = lane + 64 * v;
+        if (ch < c4) {
+            float4 o = dst[ch];
+            o.x += acc[v].x; o.y += acc[v].y; o.z += acc[v].z; o.w += acc[v].w;
+            dst[ch] = o;
+        }
+    }
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -789,9 +950,23 @@ extern "C" int tt_voxel_pool_fwd_ws(int batch_size, int num_points, int num_chan
     float* partial = reinterpret_cast<float*>(workspace);
     const long long part_bytes = (long long)nchunks * smax * C * 4;
     int* slot_table = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + ((part_bytes + 255) / 256) * 256);
-    hipLaunchKernelGGL(voxel_pool_p1_kernel, dim3((unsigned)nchunks), dim3(512), 0, st, num_points, C,
-                       num_voxel_x, num_voxel_y, num_voxel_z, cps, smax, geom_xyz, input_features,
-                       output_features, pos_memo, partial, slot_table);
+    static int rf = -1;
+    if (rf < 0) {
+        const char* e = getenv("TT_VP_ROWS_IN_FLIGHT");     // A/B knob: 4 / 8 / 16 rows per wave (C <= 256 only)
+        rf = e ? atoi(e) : 16;   // measured 0.302 / 0.287 / 0.277 ms per launch for 4 / 8 / 16 (profiles/r02_voxel_pool_*)
+    }
+#define TT_P1(NV, RF)                                                                                              \
+    hipLaunchKernelGGL((voxel_pool_p1_kernel<NV, RF>), dim3((unsigned)nchunks), dim3(512), 0, st, num_points, C,    \
+                       num_voxel_x, num_voxel_y, num_voxel_z, cps, smax, geom_xyz, input_features, output_features, \
+                       pos_memo, partial, slot_table)
+    if (C <= 256) {
+        if (rf >= 16) TT_P1(1, 16);
+        else if (rf >= 8) TT_P1(1, 8);
+        else TT_P1(1, 4);
+    } else {
+        TT_P1(4, 4);
+    }
+#undef TT_P1
     hipLaunchKernelGGL(voxel_pool_p2_kernel, dim3((unsigned)(batch_size * cells)), dim3(64), 0, st, C, cells, cps,
                        smax, partial, slot_table, output_features);
     return check_launch("tt_voxel_pool_fwd_ws");
@@ -884,4 +1059,98 @@ extern "C" int tt_lift_splat_fwd(int batch_size, int num_cams, int D, int fH, in
         TT_REQUIRE(false, "tt_lift_splat_fwd: bad dtype %d", dtype);
     }
     return check_launch("tt_lift_splat_fwd");
+}
+
+// ---- static-geometry plan ------------------------------------------------------------------------------------
+static size_t vp_align(size_t v) { return (v + 255) / 256 * 256; }
+
+extern "C" long long tt_voxel_pool_plan_bytes(int batch_size, int num_points, int num_voxel_x, int num_voxel_y) {
+    const long long total = (long long)batch_size * num_points;
+    const long long nkeys = (long long)batch_size * num_voxel_x * num_voxel_y;
+    // order [total] + cell_start [nkeys + 1] + seg_off [nkeys + 1]
+    return (long long)(vp_align(4 * total) + 2 * vp_align(4 * (nkeys + 1)));
+}
+
+extern "C" long long tt_voxel_pool_plan_workspace_bytes(int batch_size, int num_points) {
+    const long long total = (long long)batch_size * num_points;
+    size_t sort_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr,
+                                       (unsigned*)nullptr, (int)total);
+    return (long long)(3 * vp_align(4 * total) + vp_align(sort_bytes));
+}
+
+extern "C" int tt_voxel_pool_plan_build(int batch_size, int num_points, int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                        const int32_t* geom_xyz, void* workspace, long long workspace_bytes, void* plan,
+                                        long long plan_bytes, void* stream) {
+    TT_REQUIRE(geom_xyz && workspace && plan, "tt_voxel_pool_plan_build: null pointer");
+    const long long total = (long long)batch_size * num_points;
+    const long long nkeys = (long long)batch_size * num_voxel_x * num_voxel_y;
+    TT_REQUIRE(total > 0 && total < (1ll << 31) && nkeys < (1ll << 30), "tt_voxel_pool_plan_build: sizes");
+    TT_REQUIRE(workspace_bytes >= tt_voxel_pool_plan_workspace_bytes(batch_size, num_points) &&
+                   plan_bytes >= tt_voxel_pool_plan_bytes(batch_size, num_points, num_voxel_x, num_voxel_y),
+               "tt_voxel_pool_plan_build: buffers too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)workspace;
+    unsigned* keys = (unsigned*)w;
+    unsigned* vals = (unsigned*)(w + vp_align(4 * total));
+    unsigned* keys_sorted = (unsigned*)(w + 2 * vp_align(4 * total));
+    void* tmp = w + 3 * vp_align(4 * total);
+    size_t tmp_bytes = (size_t)(workspace_bytes - 3 * (long long)vp_align(4 * total));
+    char* pl = (char*)plan;
+    int* order = (int*)pl;
+    int* cell_start = (int*)(pl + vp_align(4 * total));
+    int* seg_off = (int*)(pl + vp_align(4 * total) + vp_align(4 * (nkeys + 1)));
+    hipLaunchKernelGGL(vp_plan_keys_kernel, dim3((unsigned)div_up(total, 256)), dim3(256), 0, st, total, num_points,
+                       num_voxel_x, num_voxel_y, num_voxel_z, geom_xyz, keys, vals, (unsigned)nkeys);
+    int bits = 1;
+    while ((1ll << bits) <= nkeys) ++bits;
+    if (hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_sorted, vals, (unsigned*)order, (int)total, 0, bits,
+                                           st) != hipSuccess) {
+        set_error("tt_voxel_pool_plan_build: radix sort failed");
+        return -2;
+    }
+    hipLaunchKernelGGL(vp_plan_starts_kernel, dim3((unsigned)div_up(nkeys + 1, 256)), dim3(256), 0, st, keys_sorted, total,
+                       (int)nkeys, cell_start);
+    hipLaunchKernelGGL(vp_plan_segments_kernel, dim3(1), dim3(1024), 0, st, cell_start, (int)nkeys, seg_off);
+    return check_launch("tt_voxel_pool_plan_build");
+}
+
+extern "C" long long tt_voxel_pool_planned_workspace_bytes(int batch_size, int num_points, int num_channels,
+                                                           int num_voxel_x, int num_voxel_y) {
+    const long long total = (long long)batch_size * num_points;
+    const long long nkeys = (long long)batch_size * num_voxel_x * num_voxel_y;
+    return (total / kSeg + nkeys + 1) * (long long)num_channels * 4;       // one partial row per segment (upper bound)
+}
+
+extern "C" int tt_voxel_pool_fwd_planned(int batch_size, int num_points, int num_channels, int num_voxel_x,
+                                         int num_voxel_y, const void* plan, const float* input_features,
+                                         float* output_features, void* workspace, long long workspace_bytes, void* stream) {
+    TT_REQUIRE(plan && input_features && output_features && workspace, "tt_voxel_pool_fwd_planned: null pointer");
+    const int C = num_channels;
+    TT_REQUIRE(C % 4 == 0 && C <= 1024 && !(reinterpret_cast<uintptr_t>(input_features) & 15) &&
+                   !(reinterpret_cast<uintptr_t>(output_features) & 15), "tt_voxel_pool_fwd_planned: C %% 4, 16 B alignment");
+    TT_REQUIRE(workspace_bytes >= tt_voxel_pool_planned_workspace_bytes(batch_size, num_points, C, num_voxel_x, num_voxel_y),
+               "tt_voxel_pool_fwd_planned: workspace too small");
+    const long long total = (long long)batch_size * num_points;
+    const long long nkeys = (long long)batch_size * num_voxel_x * num_voxel_y;
+    const char* pl = (const char*)plan;
+    const int* order = (const int*)pl;
+    const int* cell_start = (const int*)(pl + vp_align(4 * total));
+    const int* seg_off = (const int*)(pl + vp_align(4 * total) + vp_align(4 * (nkeys + 1)));
+    hipStream_t st = (hipStream_t)stream;
+    const long long max_seg = total / kSeg + nkeys + 1;
+    float* partial = (float*)workspace;
+    const unsigned blocks = (unsigned)div_up(max_seg, 4);          // 4 waves per workgroup
+    if (C <= 256) {
+        hipLaunchKernelGGL(vp_planned_segments_kernel<1>, dim3(blocks), dim3(256), 0, st, C, (int)nkeys, order, cell_start,
+                           seg_off, input_features, partial);
+        hipLaunchKernelGGL(vp_planned_cells_kernel<1>, dim3((unsigned)nkeys), dim3(64), 0, st, C, seg_off, partial,
+                           output_features);
+    } else {
+        hipLaunchKernelGGL(vp_planned_segments_kernel<4>, dim3(blocks), dim3(256), 0, st, C, (int)nkeys, order, cell_start,
+                           seg_off, input_features, partial);
+        hipLaunchKernelGGL(vp_planned_cells_kernel<4>, dim3((unsigned)nkeys), dim3(64), 0, st, C, seg_off, partial,
+                           output_features);
+    }
+    return check_launch("tt_voxel_pool_fwd_planned");
 }

@@ -96,3 +96,49 @@ def voxel_pooling_forward_wrapper(batch_size, num_points, num_channels, num_voxe
     _pool_launch(int(batch_size), int(num_points), int(num_channels), int(num_voxel_x), int(num_voxel_y),
                  int(num_voxel_z), geom_xyz, input_features, output_features, pos_memo)
     return 1
+
+
+class VoxelPoolPlan:
+    """Static-geometry plan of the voxel-pool forward (tt_voxel_pool_plan_build / tt_voxel_pool_fwd_planned): for a
+    fixed camera rig `geom_xyz` is the same every frame (LSS.get_geometry depends on the calibration only), so the
+    in-range points are sorted by (sample, cell) ONCE and every forward streams the point rows cell by cell -- no index
+    work, no atomics, deterministic.  `plan(feats)` == `voxel_pooling(geom_xyz, feats, voxel_num)`."""
+
+    def __init__(self, geom_xyz, voxel_num):
+        _lib.require_cuda(geom_xyz)
+        assert geom_xyz.is_contiguous() and geom_xyz.dtype == torch.int32
+        g = geom_xyz.reshape(geom_xyz.shape[0], -1, 3)
+        self.B, self.Np = g.shape[0], g.shape[1]
+        self.vx, self.vy, self.vz = _voxel_num_tuple(voxel_num)
+        L, ci = _lib.lib(), ctypes.c_int
+        L.tt_voxel_pool_plan_bytes.restype = ctypes.c_longlong
+        L.tt_voxel_pool_plan_workspace_bytes.restype = ctypes.c_longlong
+        L.tt_voxel_pool_planned_workspace_bytes.restype = ctypes.c_longlong
+        pb = int(L.tt_voxel_pool_plan_bytes(ci(self.B), ci(self.Np), ci(self.vx), ci(self.vy)))
+        wb = int(L.tt_voxel_pool_plan_workspace_bytes(ci(self.B), ci(self.Np)))
+        self.plan = torch.empty(pb, dtype=torch.uint8, device=g.device)
+        ws = torch.empty(wb, dtype=torch.uint8, device=g.device)
+        _lib.check(L.tt_voxel_pool_plan_build(ci(self.B), ci(self.Np), ci(self.vx), ci(self.vy), ci(self.vz), _lib.ptr(g),
+                                              _lib.ptr(ws), ctypes.c_longlong(wb), _lib.ptr(self.plan),
+                                              ctypes.c_longlong(pb), _lib.cur_stream(g.device)), "tt_voxel_pool_plan_build")
+        self._ws = None
+
+    def forward_into(self, input_features, out):
+        """Accumulate into `out` (B, Y, X, C) f32, like voxel_pooling_forward_wrapper does into output_features."""
+        _lib.require_cuda(input_features, out)
+        f = input_features.reshape(self.B, self.Np, -1)
+        assert f.is_contiguous() and f.dtype == torch.float32 and out.is_contiguous()
+        C = f.shape[-1]
+        L, ci = _lib.lib(), ctypes.c_int
+        wb = int(L.tt_voxel_pool_planned_workspace_bytes(ci(self.B), ci(self.Np), ci(C), ci(self.vx), ci(self.vy)))
+        if self._ws is None or self._ws.numel() < wb:
+            self._ws = torch.empty(wb, dtype=torch.uint8, device=f.device)
+        _lib.check(L.tt_voxel_pool_fwd_planned(ci(self.B), ci(self.Np), ci(C), ci(self.vx), ci(self.vy), _lib.ptr(self.plan),
+                                               _lib.ptr(f), _lib.ptr(out), _lib.ptr(self._ws), ctypes.c_longlong(wb),
+                                               _lib.cur_stream(f.device)), "tt_voxel_pool_fwd_planned")
+        return out
+
+    def __call__(self, input_features):
+        C = input_features.shape[-1]
+        out = input_features.new_zeros(self.B, self.vy, self.vx, C)
+        return self.forward_into(input_features, out).permute(0, 3, 1, 2)
