@@ -562,8 +562,26 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
     }
     if (a.m_dev || a.M < 2048 || a.Cout < 64 || a.KH * a.KW > 32) return 0;
     if (a.Cin % 32 != 0 || a.K < 64) return 0;       // 128 B rows = 32 f32 of one tap per K tile, >= 2 tiles
-    // the split costs 8/TN VALU per MFMA: widest wave tile along N that the layer allows
-    if (a.Cout % 256 == 0 || a.Cout > 512) {                                                                   // 8 x (64 x 128)
+    // Tile width along N.  The widest wave tile the layer allows is the most efficient per tile (the operand split costs
+    // 8/TN VALU per MFMA; measured ~1.0 / 0.85 / 0.63 relative MFMA rate for the 256 / 128 / 64 wide tiles), but a
+    // launch with fewer workgroups than the chip holds (batch-1 ticks: 49 row tiles x 2 on 256 CUs) is bound by its
+    // rounds, not by the per-tile rate: pick the width with the smallest  rounds x (BN / rate).
+    const int tiles_m = div_up(a.M, 256);
+    auto cost = [&](int bn, double rate) {      // the busiest CU runs ceil(tiles / 256) tiles at the tile's measured rate
+        const long long tiles = (long long)tiles_m * div_up(a.Cout, bn);
+        return (double)((tiles + kNumCU - 1) / kNumCU) * bn / rate;
+    };
+    const bool wide = a.Cout % 256 == 0 || a.Cout > 512;
+    const double c256 = wide ? cost(256, 1.0) : 1e30;
+    const double c128 = a.Cout > 64 ? cost(128, 0.85) : 1e30;
+    const double c64 = cost(64, 0.63);
+    static const int force = [] { const char* e = getenv("TT_GLDS_X3_TILE"); return e ? atoi(e) : 0; }();   // A/B knob
+    int bn = (c256 <= c128 && c256 <= c64) ? 256 : (c128 <= c64 ? 128 : 64);
+    if (force == 256 && wide) bn = 256;
+    if (force == 128 && a.Cout > 64) bn = 128;
+    if (force == 64) bn = 64;
+    if (force == 1) bn = wide ? 256 : (a.Cout > 64 ? 128 : 64);          // the pre-cost-model rule
+    if (bn == 256) {                                                                                           // 8 x (64 x 128)
         if (const int main_rows = tail_split_rows(a)) {
             launch_glds<float, 256, 4, 2, 128, 2, false, true>(a, st, main_rows);
             ConvArgs t = a;
@@ -572,7 +590,7 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
         }
         return launch_glds<float, 256, 4, 2, 128, 2, false, true>(a, st);
     }
-    if (a.Cout > 64) return launch_glds<float, 128, 8, 1, 128, 2, false, true>(a, st);                         // 8 x (32 x 128)
+    if (bn == 128) return launch_glds<float, 128, 8, 1, 128, 2, false, true>(a, st);                           // 8 x (32 x 128)
     return launch_glds<float, 64, 8, 1, 128, 2, false, true>(a, st);                                           // 8 x (32 x 64)
 }
 

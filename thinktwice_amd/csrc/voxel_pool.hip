@@ -150,8 +150,19 @@ __global__ __launch_bounds__(256) void voxel_pool_rows_kernel(
 constexpr int kChunk = 2048;
 constexpr int kMaxCells = 2048;
 
+// Point rows are read exactly once: a non-temporal 16 B load keeps them from displacing the index / partial lines in
+// L2 and MALL (measured 0.61 -> 0.75 of HBM peak on the planned path, profiles/r02_voxel_pool_*).
+typedef float vp_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 vp_load_row16(const float4* p, bool nt) {
+    if (nt) {
+        const vp_f4 t = __builtin_nontemporal_load(reinterpret_cast<const vp_f4*>(p));
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
+    return *p;
+}
+
 // NV = float4 chunks per lane (ceil(C / 256)), RF = point rows in flight per wave (1 KiB loads each)
-template <int NV, int RF>
+template <int NV, int RF, bool NT>
 __global__ __launch_bounds__(512) void voxel_pool_p1_kernel(
     int num_points, int C, int X, int Y, int Z, int chunks_per_sample, int smax,
     const int32_t* __restrict__ geom, const float* __restrict__ feats, float* __restrict__ out,
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(512) void voxel_pool_p1_kernel(
 #pragma unroll
                     for (int v = 0; v < NV; ++v) {
                         const int ch = lane + 64 * v;
-                        row[j][v] = (ch < c4) ? src[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        row[j][v] = (ch < c4) ? vp_load_row16(src + ch, NT) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
 #pragma unroll
@@ -776,7 +787,7 @@ __global__ __launch_bounds__(1024) void vp_plan_segments_kernel(const int* __res
     if (tid == 0) seg_off[nkeys] = carry_sh;
 }
 
-template <int NV>
+template <int NV, int RF, bool NT>
 __global__ __launch_bounds__(256) void vp_planned_segments_kernel(int C, int nkeys, const int* __restrict__ order,
                                                                   const int* __restrict__ cell_start,
                                                                   const int* __restrict__ seg_off,
@@ -800,21 +811,21 @@ __global__ __launch_bounds__(256) void vp_planned_segments_kernel(int C, int nke
     float4 acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < end - beg; k += kSegRF) {
-        float4 row[kSegRF][NV];
+    for (int k = 0; k < end - beg; k += RF) {
+        float4 row[RF][NV];
 #pragma unroll
-        for (int j = 0; j < kSegRF; ++j)
+        for (int j = 0; j < RF; ++j)
             if (k + j < end - beg) {
                 const long long pt = (unsigned)__builtin_amdgcn_readlane(my, (k + j) & 63);
                 const float4* src = reinterpret_cast<const float4*>(feats + pt * (long long)C);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const int ch = lane + 64 * v;
-                    row[j][v] = (ch < c4) ? src[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    row[j][v] = (ch < c4) ? vp_load_row16(src + ch, NT) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
-        for (int j = 0; j < kSegRF; ++j)
+        for (int j = 0; j < RF; ++j)
             if (k + j < end - beg) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
@@ -831,33 +842,57 @@ __global__ __launch_bounds__(256) void vp_planned_segments_kernel(int C, int nke
     }
 }
 
+// One workgroup of 4 waves per (sample, cell): wave w sums segments s0 + w, s0 + w + 4, ... with 4 partial rows in flight,
+// then the four wave sums are combined in a fixed order through LDS (deterministic).
 template <int NV>
-__global__ __launch_bounds__(64) void vp_planned_cells_kernel(int C, const int* __restrict__ seg_off,
-                                                              const float* __restrict__ partial, float* __restrict__ out) {
-    const int key = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void vp_planned_cells_kernel(int C, const int* __restrict__ seg_off,
+                                                               const float* __restrict__ partial, float* __restrict__ out) {
+    __shared__ float4 red[3][NV * 64];
+    const int key = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s0 = seg_off[key], s1 = seg_off[key + 1];
     if (s0 == s1) return;
     const int c4 = C >> 2;
     float4 acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int sg = s0; sg < s1; ++sg) {
-        const float4* src = reinterpret_cast<const float4*>(partial + (long long)sg * C);
+    for (int sg = s0 + wave; sg < s1; sg += 16) {
+        float4 t[4][NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int ch = lane + 64 * v;
-            if (ch < c4) {
-                const float4 t = src[ch];
-                acc[v].x += t.x; acc[v].y += t.y; acc[v].z += t.z; acc[v].w += t.w;
+        for (int j = 0; j < 4; ++j) {
+            const int sj = sg + 4 * j;
+            const float4* src = reinterpret_cast<const float4*>(partial + (long long)min(sj, s1 - 1) * C);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int ch = lane + 64 * v;
+                t[j][v] = (ch < c4) ? src[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (sg + 4 * j < s1) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    acc[v].x += t[j][v].x; acc[v].y += t[j][v].y; acc[v].z += t[j][v].z; acc[v].w += t[j][v].w;
+                }
+            }
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) red[wave - 1][v * 64 + lane] = acc[v];
+    }
+    __syncthreads();
+    if (wave > 0) return;
     float4* dst = reinterpret_cast<float4*>(out + (long long)key * C);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int ch = lane + 64 * v;
         if (ch < c4) {
             float4 o = dst[ch];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const float4 r = red[w][v * 64 + lane];
+                acc[v].x += r.x; acc[v].y += r.y; acc[v].z += r.z; acc[v].w += r.w;
+            }
             o.x += acc[v].x; o.y += acc[v].y; o.z += acc[v].z; o.w += acc[v].w;
             dst[ch] = o;
         }
@@ -955,10 +990,18 @@ extern "C" int tt_voxel_pool_fwd_ws(int batch_size, int num_points, int num_chan
         const char* e = getenv("TT_VP_ROWS_IN_FLIGHT");     // A/B knob: 4 / 8 / 16 rows per wave (C <= 256 only)
         rf = e ? atoi(e) : 16;   // measured 0.302 / 0.287 / 0.277 ms per launch for 4 / 8 / 16 (profiles/r02_voxel_pool_*)
     }
+    static const bool nt = [] { const char* e = getenv("TT_VP_NT"); return e ? atoi(e) != 0 : true; }();
 #define TT_P1(NV, RF)                                                                                              \
-    hipLaunchKernelGGL((voxel_pool_p1_kernel<NV, RF>), dim3((unsigned)nchunks), dim3(512), 0, st, num_points, C,    \
-                       num_voxel_x, num_voxel_y, num_voxel_z, cps, smax, geom_xyz, input_features, output_features, \
-                       pos_memo, partial, slot_table)
+    do {                                                                                                           \
+        if (nt)                                                                                                    \
+            hipLaunchKernelGGL((voxel_pool_p1_kernel<NV, RF, true>), dim3((unsigned)nchunks), dim3(512), 0, st,    \
+                               num_points, C, num_voxel_x, num_voxel_y, num_voxel_z, cps, smax, geom_xyz,          \
+                               input_features, output_features, pos_memo, partial, slot_table);                    \
+        else                                                                                                       \
+            hipLaunchKernelGGL((voxel_pool_p1_kernel<NV, RF, false>), dim3((unsigned)nchunks), dim3(512), 0, st,   \
+                               num_points, C, num_voxel_x, num_voxel_y, num_voxel_z, cps, smax, geom_xyz,          \
+                               input_features, output_features, pos_memo, partial, slot_table);                    \
+    } while (0)
     if (C <= 256) {
         if (rf >= 16) TT_P1(1, 16);
         else if (rf >= 8) TT_P1(1, 8);
@@ -1141,16 +1184,22 @@ extern "C" int tt_voxel_pool_fwd_planned(int batch_size, int num_points, int num
     const long long max_seg = total / kSeg + nkeys + 1;
     float* partial = (float*)workspace;
     const unsigned blocks = (unsigned)div_up(max_seg, 4);          // 4 waves per workgroup
+    static const int rf = [] { const char* e = getenv("TT_VP_PLAN_ROWS_IN_FLIGHT"); return e ? atoi(e) : 32; }();
+    static const bool nt = [] { const char* e = getenv("TT_VP_NT"); return e ? atoi(e) != 0 : true; }();
+#define TT_VP_SEG(NV_, RF_, NT_)                                                                                        \
+    hipLaunchKernelGGL((vp_planned_segments_kernel<NV_, RF_, NT_>), dim3(blocks), dim3(256), 0, st, C, (int)nkeys, order, \
+                       cell_start, seg_off, input_features, partial)
     if (C <= 256) {
-        hipLaunchKernelGGL(vp_planned_segments_kernel<1>, dim3(blocks), dim3(256), 0, st, C, (int)nkeys, order, cell_start,
-                           seg_off, input_features, partial);
-        hipLaunchKernelGGL(vp_planned_cells_kernel<1>, dim3((unsigned)nkeys), dim3(64), 0, st, C, seg_off, partial,
+        if (rf >= 32) { if (nt) TT_VP_SEG(1, 32, true); else TT_VP_SEG(1, 32, false); }
+        else if (rf >= 16) { if (nt) TT_VP_SEG(1, 16, true); else TT_VP_SEG(1, 16, false); }
+        else { if (nt) TT_VP_SEG(1, 8, true); else TT_VP_SEG(1, 8, false); }
+        hipLaunchKernelGGL(vp_planned_cells_kernel<1>, dim3((unsigned)nkeys), dim3(256), 0, st, C, seg_off, partial,
                            output_features);
     } else {
-        hipLaunchKernelGGL(vp_planned_segments_kernel<4>, dim3(blocks), dim3(256), 0, st, C, (int)nkeys, order, cell_start,
-                           seg_off, input_features, partial);
-        hipLaunchKernelGGL(vp_planned_cells_kernel<4>, dim3((unsigned)nkeys), dim3(64), 0, st, C, seg_off, partial,
+        if (nt) TT_VP_SEG(4, 4, true); else TT_VP_SEG(4, 4, false);
+        hipLaunchKernelGGL(vp_planned_cells_kernel<4>, dim3((unsigned)nkeys), dim3(256), 0, st, C, seg_off, partial,
                            output_features);
     }
+#undef TT_VP_SEG
     return check_launch("tt_voxel_pool_fwd_planned");
 }
