@@ -382,6 +382,39 @@ int tt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float beta1, float beta2, float eps, float weight_decay, int step,
                   const float* grad_scale_or_null, void* stream);
 
+/* ----------------------------------------------------------------------
+ * SURVEY 8f-4 / row A24, loss half of the training forward: device reductions for every term of
+ * ThinkTwiceDecoder.loss (thinktwice_decoder.py:536-619), the focal segmentation loss (utils.py:31-47 at
+ * encoder_decoder_framework.py:172-176) and the depth BCE (encoder_decoder_framework.py:179-190, 441-481).
+ * One launch per term, f64 accumulation, workgroup partials combined in index order by the last workgroup
+ * (bit-reproducible).  `workspace`: tt_loss_workspace_bytes() bytes, ZEROED once by the caller, reusable by
+ * consecutive calls on one stream.  Outputs are device floats.
+ * ---------------------------------------------------------------------- */
+long long tt_loss_workspace_bytes(void);
+/* pred [n_outer][repeat][inner] against target [n_outer][inner] (broadcast over `repeat`; NULL = zeros),
+ * F.smooth_l1_loss(beta=1).  reduce != 0: out[0] = scale * mean(min(l, clamp_max)) (clamp_max <= 0: no clamp,
+ * torch.clamp(..., -5, 5) of DEC:51-52 is clamp_max = 5); reduce == 0: out[i] = scale * l_i (reduction='none'). */
+int tt_loss_smooth_l1(const float* pred, const float* target, long long n_outer, int repeat, long long inner,
+                      float clamp_max, float scale, int reduce, float* out, void* workspace, void* stream);
+/* out[0] = scale * mean KL(Beta(target_alpha, target_beta) || Beta(pred_alpha, pred_beta)), target [n_outer][inner]
+ * broadcast over pred [n_outer][repeat][inner] (torch.distributions.kl_divergence, DEC:553-556, 571-573) */
+int tt_loss_beta_kl(const float* target_alpha, const float* target_beta, const float* pred_alpha,
+                    const float* pred_beta, long long n_outer, int repeat, long long inner, float scale, float* out,
+                    void* workspace, void* stream);
+/* out[c] = mean_r |pred[r][c] - target[r][c]|, cols <= 8, pred rows pred_row_stride floats apart (DEC:544-551).
+ * With pred_beta / target_beta non-NULL the operands are Beta parameters and their modes mapped to [-1, 1]
+ * (_get_action_beta, DEC:622-637) are compared. */
+int tt_loss_l1_cols(const float* pred, const float* pred_beta, long long pred_row_stride, const float* target,
+                    const float* target_beta, long long rows, int cols, float* out, void* workspace, void* stream);
+/* logits_cl: channel-last [BN][H/factor][W/factor][row_stride >= num_classes]; labels [BN][H][W] float class ids
+ * (255 = ignore) sampled at (y*factor, x*factor); out[0] = 10 * focal(alpha .5, gamma 2) of the mean cross entropy */
+int tt_loss_seg_focal(const float* logits_cl, int row_stride, int num_classes, const float* labels, int BN, int H,
+                      int W, int factor, float* out, void* workspace, void* stream);
+/* logits_cl: channel-last [BN][H/factor][W/factor][row_stride >= D]; gt_depth [BN][H][W] metres (0 = no return);
+ * bins of d_step from d_lo; out[0] = sum of BCE-with-logits over the foreground cells / max(1, #foreground) */
+int tt_loss_depth_bce(const float* logits_cl, int row_stride, int D, const float* gt_depth, int BN, int H, int W,
+                      int factor, float d_lo, float d_step, float* out, void* workspace, void* stream);
+
 /* SURVEY 8f-1, LiDAR side: merge of the two 180-degree half sweeps of the closed-loop tick
  * (leaderboard/team_code/thinktwice_agent.py:340-352).  prev / now: (n, 4) f32 (x, y, z, intensity) device rows;
  * rel_transform_3x4: HOST pointer to the first three rows of inv(T_now) @ T_prev (row-major); out: (n_prev + n_now, 4)

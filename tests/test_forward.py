@@ -242,3 +242,45 @@ def test_prev_sweep_cache_matches_two_sweep_forward():
     b1["img"] = b["img"][:, 1:].contiguous()
     one = m.forward_inference(b1, prev_bev=key_a)
     assert float((one["pred_wp"] - cached["pred_wp"]).abs().max()) < 1e-5      # split-K atomics reorder sums
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_forward_train_losses_match_reference_golden_f10(mode):
+    """Row A24 / SURVEY 8f-4 (loss half): `forward_train` = forward + teacher-forcing pass + every loss term as a device
+    reduction (csrc/losses.hip), against the reference's own `forward_train` outputs (golden F10, B=2 128x256, running-
+    statistics BN); then `train_step` / `model(**batch)` return dict(loss, log_vars, num_samples) with the total of
+    `_parse_losses` (EDF:140-145, 409-439)."""
+    from thinktwice_amd import model as tm, params, synth
+    pack = np.load(os.path.join(os.path.dirname(__file__), "golden", "f10_train_losses_b2.npz"))
+    B, H, W, npts, seed = (int(v) for v in pack["meta"])
+    dtype = torch.float32 if mode == "f32" else "f32x3"
+    m, cfg = tm.build_thinktwice(final_dim=(H, W), dtype=dtype)
+    m.load_state_dict(params.init_params(cfg, seed=seed))
+    batch = synth.make_batch(B, img_hw=(H, W), num_points=npts)
+    batch.update(synth.make_train_targets(B, img_hw=(H, W)))
+    losses = m.forward_train(batch)
+    torch.cuda.synchronize()
+    names = [k for k in pack.files if k not in ("meta", "oracle_vs_reference_worst_rel_err")]
+    assert list(losses.keys()) == names, (list(losses.keys()), names)       # same terms, same order
+    tol = 1e-3 if mode == "f32" else 2e-3
+    worst = {}
+    for k in names:
+        got, want = losses[k].detach().cpu().numpy(), pack[k]
+        assert got.shape == want.shape, (k, got.shape, want.shape)
+        worst[k] = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6))
+    print(mode, "loss rel errs:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) < tol, worst
+    from thinktwice_amd.losses import LossReducer                           # the reductions are bit-reproducible
+    red, x = LossReducer("cuda"), torch.randn(8, 5, 4, 32, 21, 21, device="cuda")
+    t = torch.randn(8, 4, 32, 21, 21, device="cuda")
+    assert torch.equal(red.smooth_l1(x, t, clamp_max=5.0, scale=0.25), red.smooth_l1(x, t, clamp_max=5.0, scale=0.25))
+    ref = torch.clamp(torch.nn.functional.smooth_l1_loss(x, t.unsqueeze(1).expand_as(x), reduction="none"), max=5.0).mean()
+    assert abs(float(red.smooth_l1(x, t, clamp_max=5.0)) - float(ref)) < 1e-6 * float(ref) + 1e-7
+    out = m.train_step(batch, None)
+    want_total = sum(float(pack[k].mean()) for k in names if "loss" in k)
+    assert out["num_samples"] == B and set(out) == {"loss", "log_vars", "num_samples"}
+    assert abs(float(out["loss"]) - want_total) / abs(want_total) < tol
+    assert abs(out["log_vars"]["loss"] - want_total) / abs(want_total) < tol and set(names) < set(out["log_vars"])
+    out2 = m(**batch)                                                       # the mmcv runner's entry (EDF:393-407)
+    assert abs(float(out2["loss"]) - float(out["loss"])) < 1e-5 * abs(float(out["loss"]))   # forward has f32 atomics

@@ -42,6 +42,11 @@ class EncoderDecoder(torch.nn.Module):
         self.training = False
         self.loaded = False
         self._side = None
+        self._loss_red = None
+        tc = self.config or {}                                                   # EDF:42-43: train_cfg decides
+        self.use_depth, self.use_seg = bool(tc.get("use_depth", False)), bool(tc.get("use_seg", False))
+        self.downsample_factor, self.seg_downsample_factor = downsample_factor, seg_downsample_factor
+        self.d_bound = dict(img_encoder).get("d_bound")
         self.use_side_stream = True
         c = self.config or {}
         if "turn_KP" in c:   # EDF:47-48
@@ -168,14 +173,42 @@ class EncoderDecoder(torch.nn.Module):
                             channel_last_out=channel_last_out)
         pred["_cam_bev_cl"], pred["_lidar_bev_cl"], pred["_flat"], pred["_meas"] = cam_bev, lidar, flat, meas
         pred["_key_bev_cl"], pred["_seg_cl"] = cam["_key_bev_cl"], cam["_seg_cl"]
+        pred["_depth_cl"], pred["_mid_bev_cl"] = cam["_depth_cl"], mids
         return pred
 
     def forward_train(self, batch):
-        raise _lib.TTError("training step (losses, backward, optimizer) is a later scope row (SURVEY 8f-4); the forward "
-                           "half incl. the teacher-forcing pass is forward_inference(batch, teacher=...)")
+        """EncoderDecoder.forward_train (encoder_decoder_framework.py:147-191): the forward with the decoder's
+        teacher-forcing pass, then every loss term as a device reduction (thinktwice_amd/losses.py, csrc/losses.hip).
+        BatchNorm layers use their running statistics -- what the reference computes under model.eval() and what a
+        frozen-BN fine-tune runs (golden F10); batch-statistics BN and the backward pass are not implemented
+        (SURVEY 8f-4), so the returned losses carry no autograd graph."""
+        from . import losses as LS
+        if self._loss_red is None:
+            self._loss_red = LS.LossReducer(self.device)
+        red = self._loss_red
+        teacher = {k: batch[k] for k in LS.TEACHER_KEYS}
+        teacher = {k: ([t.to(self.device) for t in v] if isinstance(v, (list, tuple)) else v.to(self.device))
+                   for k, v in teacher.items()}
+        pred = self.forward_inference(batch, teacher=teacher)
+        mids = [None if m is None else ops.nhwc_to_nchw(m) for m in pred["_mid_bev_cl"]]
+        out = LS.decoder_loss(red, self.config, batch, pred, mids)
+        if self.use_seg:                                                      # EDF:172-176
+            out["seg_loss"] = red.seg_focal(pred["_seg_cl"].float().contiguous(), batch["seg"], num_classes=12,
+                                            factor=self.seg_downsample_factor)
+        if self.use_depth:                                                    # EDF:179-190
+            out["depth_loss"] = red.depth_bce(pred["_depth_cl"].float().contiguous(), batch["depth"], self.d_bound,
+                                              self.downsample_factor)
+        return out
 
-    def train_step(self, data, optimizer):
-        return self.forward_train(data)
+    def _parse_losses(self, losses):
+        from . import losses as LS
+        return LS.parse_losses(losses)
+
+    def train_step(self, data, optimizer=None):
+        """encoder_decoder_framework.py:140-145: dict(loss, log_vars, num_samples).  `optimizer` is unused, as in the
+        reference (the mmcv OptimizerHook steps it); here there is no backward to step on yet."""
+        loss, log_vars = self._parse_losses(self.forward_train(data))
+        return dict(loss=loss, log_vars=log_vars, num_samples=data["img"].shape[0])
 
     def forward(self, is_eval=True, **kwargs):
         """EncoderDecoder.forward (encoder_decoder_framework.py:393-407): the training entry of the mmcv runner."""

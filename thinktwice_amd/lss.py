@@ -332,7 +332,7 @@ class LSS:
         bev = self.bev_merge(bev_cat) if T_all > 1 else bev_cat
         fpn = [(t[:BN], off, c) for (t, off, c) in self._fpn_views(bufs)]
         outs = {"lidar2img": consts["lidar2img"], "ida_mat": consts["ida_mat"], "_fpn_cl": fpn, "_bev_cl": bev,
-                "_geom": geom, "_key_bev_cl": bev_cat[..., :OC], "_seg_cl": seg[:BN]}
+                "_geom": geom, "_key_bev_cl": bev_cat[..., :OC], "_seg_cl": seg[:BN], "_depth_cl": depth[:BN]}
         if channel_last:
             return outs
         outs["bev"] = ops.nhwc_to_nchw(bev)
