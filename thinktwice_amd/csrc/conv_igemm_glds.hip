@@ -66,7 +66,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     constexpr int LPT = NIA + NIB;                    // DMA loads per thread per tile
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    static_assert(!X3 || (sizeof(T) == 4 && BKB == 128 && STAGES == 2), "x3: f32 storage, 128 B rows, 2 stages");
+    static_assert(!X3 || (sizeof(T) == 4 && BKB == 128), "x3: f32 storage, 128 B rows");
     static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
     static_assert(NA_INSTR % NW == 0 && NIA >= 1 && NIB >= 1, "tile too small for the wave count");
 
@@ -392,7 +392,15 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(bh[buf]));
                 asm volatile("" : "+v"(bl[buf]));
-                if (j == 0) {
+                if (TT_GLDS_DEBUG && p.act == 96) {          // debug: no operand split (raw bits as operands)
+                    if (j == 0) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            ah[i] = __builtin_bit_cast(uint4, ra0[i]);
+                            al[i] = __builtin_bit_cast(uint4, ra1[i]);
+                        }
+                    }
+                } else if (j == 0) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         asm volatile("" : "+v"(ra0[i]));
@@ -422,18 +430,25 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                             ra1[i] = lds_read(sbase + (fa_pre[kc2][i] ^ 16u));
                         }
                     }
-                    bh[buf ^ 1] = lds_read(sbase + fb_pre[kc2][j2]);
-                    bl[buf ^ 1] = lds_read(sbase + (fb_pre[kc2][j2] ^ 32u));
+                    if (!(TT_GLDS_DEBUG && p.act == 95)) {   // debug 95: weight fragments read once per tile
+                        bh[buf ^ 1] = lds_read(sbase + fb_pre[kc2][j2]);
+                        bl[buf ^ 1] = lds_read(sbase + (fb_pre[kc2][j2] ^ 32u));
+                    } else {
+                        bh[buf ^ 1] = bh[buf];
+                        bl[buf ^ 1] = bl[buf];
+                    }
                 }
                 const uint4 bhv = __builtin_bit_cast(uint4, bh[buf]);
                 const uint4 blv = __builtin_bit_cast(uint4, bl[buf]);
                 if (prio) __builtin_amdgcn_s_setprio(1);
                 // term-major order: consecutive MFMAs write different accumulators (a back-to-back pair on the same
                 // accumulator waits for the first one's last pass); small terms first
+                if (!(TT_GLDS_DEBUG && p.act == 94)) {       // debug 94: one MFMA per fragment pair instead of three
 #pragma unroll
-                for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(al[i], bhv, acc[i][j]);
+                    for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(al[i], bhv, acc[i][j]);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(ah[i], blv, acc[i][j]);
+                    for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(ah[i], blv, acc[i][j]);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(ah[i], bhv, acc[i][j]);
                 if (prio) __builtin_amdgcn_s_setprio(0);
@@ -590,8 +605,16 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
         }
         return launch_glds<float, 256, 4, 2, 128, 2, false, true>(a, st);
     }
-    if (bn == 128) return launch_glds<float, 128, 8, 1, 128, 2, false, true>(a, st);                           // 8 x (32 x 128)
-    return launch_glds<float, 64, 8, 1, 128, 2, false, true>(a, st);                                           // 8 x (32 x 64)
+    // TT_GLDS_X3_STAGES=3: three LDS stages for the narrow tiles (two K tiles in flight per workgroup).  Measured and NOT
+    // the default: the 64-wide tile then holds 120 KiB and loses its second workgroup per CU (N=64 K=576: 2.13 -> 2.66 ms,
+    // K=64: 0.73 -> 0.86 ms); the 128-wide tile is unchanged (1.79 / 1.84 ms).
+    static const int stages = [] { const char* e = getenv("TT_GLDS_X3_STAGES"); return e ? atoi(e) : 2; }();   // A/B knob
+    if (bn == 128) {                                                                                           // 8 x (32 x 128)
+        if (stages == 3) return launch_glds<float, 128, 8, 1, 128, 3, false, true>(a, st);
+        return launch_glds<float, 128, 8, 1, 128, 2, false, true>(a, st);
+    }
+    if (stages == 3) return launch_glds<float, 64, 8, 1, 128, 3, false, true>(a, st);                          // 8 x (32 x 64)
+    return launch_glds<float, 64, 8, 1, 128, 2, false, true>(a, st);
 }
 
 // T16 = uint16_t (bf16) or f16_t (IEEE half): same tiles, same MFMA rate.
