@@ -1,5 +1,6 @@
 """Host-side logic that needs no GPU: the closed-loop previous-sweep cache driver and the img_metas constants that
 a captured graph takes as inputs."""
+import pytest
 import torch
 
 
@@ -127,3 +128,15 @@ def test_reference_config_file_builds_the_model_verbatim():
     same(ours["lidar_encoder"], cfg.model.lidar_encoder)
     same(ours["cfg"], cfg.model.train_cfg)
     assert cfg.optimizer == {"type": "AdamW", "lr": 1e-4, "weight_decay": 1e-7}
+
+
+def test_lidar_voxelize_refuses_clouds_that_could_exceed_max_voxels():
+    """the max_voxels cap of mmcv hard voxelization is not implemented; the product path must say so
+    (before touching the device) instead of diverging silently."""
+    import torch
+    from thinktwice_amd import _lib, config, lidarnet
+    cfg = config.model_config()["lidar_encoder"]
+    net = lidarnet.LidarNet.__new__(lidarnet.LidarNet)
+    net.vl = cfg["pts_voxel_layer"]
+    with pytest.raises(_lib.TTError, match="max_voxels"):
+        net.voxelize(torch.zeros(1, 160001, 5))

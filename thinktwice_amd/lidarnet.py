@@ -215,9 +215,17 @@ class LidarNet:
         return self
 
     def voxelize(self, pts):
-        """MVXTwoStageDetector.voxelize + HardSimpleVFE on the device (eval: max_voxels[1])."""
+        """MVXTwoStageDetector.voxelize + HardSimpleVFE on the device.  mmcv's hard voxelization keeps at most
+        max_voxels (120000 train / 160000 eval, per sample) voxels in first-appearance order; a sample has at most one
+        voxel per point, so the cap cannot bind while Np <= max_voxels (65536 points per sweep in the reference data).
+        The cap itself is not implemented: a larger cloud is refused instead of silently diverging."""
         B, Np, nf = pts.shape
         vl = self.vl
+        cap = vl.get("max_voxels", (120000, 160000))
+        cap = cap[1] if isinstance(cap, (tuple, list)) else cap
+        if Np > cap:
+            raise _lib.TTError(f"LidarNet.voxelize: {Np} points per sample can exceed max_voxels={cap}; the first-"
+                               f"appearance voxel cap of mmcv hard voxelization is not implemented")
         rng, vs = vl["point_cloud_range"], vl["voxel_size"]
         grid = [int(round((rng[3 + d] - rng[d]) / vs[d])) for d in range(3)]
         n = B * Np
