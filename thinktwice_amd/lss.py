@@ -9,6 +9,8 @@ batch of B*T*4 images (BN is in eval mode, so per-image results are unchanged), 
 channel-offset writes, the depth softmax / outer product / permute / voxel pooling chain
 (lss.py:583-632) is one fused lift-splat kernel that never materialises the 514 MB/sample volume.
 """
+import os
+
 import torch
 
 from . import _lib, camera, layers, ops, weights
@@ -29,12 +31,19 @@ class _ResNet50:
         # zero-bordered image, i.e. a KH=7, KW=1, Cin=64 convolution over a tensor whose "pixels" overlap (pixel
         # stride 8 elements).  K tiles become whole cache lines and the layer runs on the LDS-DMA kernel instead of
         # the 3-channel im2col path (Cin=8 is below every DMA tile).  Same products, different summation order.
-        self.stem_rr = None
+        # bf16x3 mode: the same with 4-channel f32 pixels (16 B): 8 pixels = 32 f32 = one 128 B K tile of the x3 kernel.
+        self.stem_rr, self.stem_rr_x3 = None, None
         if weights.storage_dtype(dtype) != torch.float32:     # 16-bit storage (bf16 or IEEE half)
             w = sd[p + ".conv1.weight"].to(device)                      # (64, 3, 7, 7)
             wr = torch.zeros(w.shape[0], 7, 1, 64, dtype=dtype, device=device)
             wr[:, :, 0, :56] = torch.nn.functional.pad(w.permute(0, 2, 3, 1), (0, 5)).reshape(w.shape[0], 7, 56).to(dtype)
             self.stem_rr = wr.contiguous()
+        elif dtype == weights.X3 and os.environ.get("TT_X3_STEM_ROWRUN", "1") == "1":
+            w = sd[p + ".conv1.weight"].to(device).float()
+            wr = torch.zeros(w.shape[0], 7, 1, 32, dtype=torch.float32, device=device)
+            wr[:, :, 0, :28] = torch.nn.functional.pad(w.permute(0, 2, 3, 1), (0, 1)).reshape(w.shape[0], 7, 28)
+            self.stem_rr = wr.contiguous()
+            self.stem_rr_x3 = weights.split_pairs_x3(self.stem_rr)
         self.blocks = []
         for li, nb in enumerate((3, 4, 6, 3), start=1):
             stage = []
@@ -59,7 +68,8 @@ class _ResNet50:
         if bordered:      # x: (NI, H+6, W+8, 8) with the image at (3, 3)
             NI, Hp, Wp, _ = x.shape
             y = ops.conv2d(x, self.stem_rr, stride=2, pad=0, scale=self.stem.scale, shift=self.stem.shift,
-                           act=self.stem.act, in_cstride=8, out_hw=((Hp - 6) // 2, (Wp - 8) // 2))
+                           act=self.stem.act, in_cstride=self.cin_pad, out_hw=((Hp - 6) // 2, (Wp - 8) // 2),
+                           w_x3=self.stem_rr_x3)
         else:
             y = self.stem(x)
         x = ops.maxpool3x3s2(y)
