@@ -103,3 +103,37 @@ def test_flat_gradient_all_reduce_two_ranks_gloo():
     np.testing.assert_array_equal(a0, a1)
     assert np.all(a0[-4:] == 0.0) and not np.allclose(l0, l1)   # dead parameter: zeros; the ranks really differed
     assert abs(n0 - float(np.linalg.norm(a0))) < 1e-4 and n0 == n1
+
+
+def _loss_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from thinktwice_amd.losses import parse_losses
+    losses = {"wp_loss": torch.tensor(1.0 + rank), "value_loss": torch.tensor([[0.5], [1.5 + rank]]),
+              "lateral_offset": torch.tensor(10.0 * (rank + 1)), "aux": [torch.tensor(2.0), torch.tensor([4.0, 6.0])]}
+    loss, log_vars = parse_losses(losses)
+    q.put((rank, float(loss), dict(log_vars)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_parse_losses_two_ranks_gloo():
+    """EncoderDecoder._parse_losses (encoder_decoder_framework.py:409-439) under torch.distributed: the returned loss is
+    the LOCAL sum of the entries whose name contains 'loss' (each reduced by its mean; lists summed), the logged values
+    are averaged over the ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_loss_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, v0), (_, l1, v1) = out
+    assert abs(l0 - (1.0 + 1.0)) < 1e-6 and abs(l1 - (2.0 + 1.5)) < 1e-6          # wp_loss + mean(value_loss); local
+    assert v0 == v1                                                               # logged values are rank means
+    assert abs(v0["wp_loss"] - 1.5) < 1e-6 and abs(v0["value_loss"] - 1.25) < 1e-6
+    assert abs(v0["lateral_offset"] - 15.0) < 1e-6 and abs(v0["aux"] - 7.0) < 1e-6
+    assert abs(v0["loss"] - 2.75) < 1e-6 and list(v0) == ["wp_loss", "value_loss", "lateral_offset", "aux", "loss"]

@@ -6,7 +6,7 @@ ROOT="$GRAFT_REPO_ROOT"
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd $ROOT; export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/${TAG}_pytest.log
+timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/${TAG}_pytest.log
 TT_BENCH_DUMP=$OUT/${TAG}_conv_shapes.json timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"
 cd /tmp
 export TT_BENCH_F32=0 TT_BENCH_BF16=0 TT_BENCH_TICK=0 TT_BENCH_VOXEL=0 TT_BENCH_H2D=0
