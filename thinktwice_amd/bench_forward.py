@@ -71,14 +71,17 @@ class ForwardWorkload:
         forward divided by the summed launch durations (HIP events on the launch stream)."""
         torch.cuda.synchronize()
         ops.CONV_PROFILE = []
+        ops.CONV_BYTES = []
         self.model.use_side_stream = False     # per-launch timing needs the launches serialised on one stream
         self.model.forward_inference(self.batch, channel_last_out=True)   # eager: the graph replay bypasses the hook
         torch.cuda.synchronize()
         self.model.use_side_stream = True
         rec = []
-        for r in ops.CONV_PROFILE:
+        compulsory = 0
+        for r, nb in zip(ops.CONV_PROFILE, ops.CONV_BYTES):
             if len(r) > 4:      # sparse launch: FLOPs of the EXISTING (row, tap) pairs of the live rows only
                 rows_live = min(int(r[5]), int(r[4].item())) if r[4] is not None else int(r[5])
+                compulsory += nb[0] * rows_live + nb[1]
                 if len(r) > 6 and r[6] is not None:
                     taps_per_row, flop_per_pair = r[6]
                     pairs = int(taps_per_row[:rows_live].sum().item())
@@ -86,8 +89,11 @@ class ForwardWorkload:
                          r[3].replace("M<=", f"M={rows_live} of <=") + f" pairs={pairs / max(rows_live, 1):.1f}/row")
                 else:
                     r = (r[0] * rows_live, r[1], r[2], r[3].replace("M<=", f"M={rows_live} of <="))
+            else:
+                compulsory += nb
             rec.append(r)
         ops.CONV_PROFILE = None
+        ops.CONV_BYTES = None
         flops = sum(r[0] for r in rec)
         ms = sum(r[1].elapsed_time(r[2]) for r in rec)
         ach = flops / (ms * 1e-3) / 1e12
@@ -143,7 +149,12 @@ class ForwardWorkload:
                   "executed_mfma_frac": round(3 * ach / peak, 4)}
         return {"kernel": "conv_igemm_glds_kernel (all conv/linear launches of one forward)", "bound": "mfma",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), **x3,
-                "traffic": traffic, "traffic_note": traffic_note, "launches": len(rec),
+                "traffic": traffic, "traffic_note": traffic_note,
+                "compulsory_bytes": int(compulsory),
+                "traffic_over_compulsory": None if not traffic else round(traffic / compulsory, 3),
+                "compulsory_note": "every operand of every launch moved once: input pixels it touches + output + weights "
+                                   "+ residual rows (+ one rulebook row per sparse output row), in the storage dtype",
+                "launches": len(rec),
                 "conv_ms_per_step": round(ms, 3),
                 "algorithmic_gflop_per_step": round(flops / 1e9, 1),
                 "slowest_launches": [{"gflop": round(r[0] / 1e9, 2), "ms": round(r[1].elapsed_time(r[2]), 3),

@@ -65,6 +65,8 @@ def lift_splat(depth_logits, context, geom_xyz, voxel_num, batch_size, num_cams,
 # ----------------------------------------------------------------------------- conv / linear
 _AUTO_SPLITK = os.environ.get("TT_CONV_AUTO_SPLITK", "1") == "1"
 CONV_PROFILE = None   # bench.py sets this to a list to collect (flops, start, end, shape) per launch
+CONV_BYTES = None     # same order as CONV_PROFILE: compulsory HBM bytes of the launch (each operand moved once);
+                      # dense: int; sparse: (bytes per live output row, fixed bytes)
 
 class _ConvDesc(ctypes.Structure):
     _fields_ = [
@@ -135,6 +137,10 @@ def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None
         # FLOP accounting over the EXISTING (row, tap) pairs: per-row tap counts of the rulebook (measurement only)
         CONV_PROFILE.append((2.0 * Cout * KW * Cin, e0, e1, f"sparse M<={M} N={Cout} K={KW * Cin}", m_dev, M,
                              ((nbr >= 0).sum(1), 2.0 * Cout * Cin)))
+        if CONV_BYTES is not None:      # one input row and one output row (+ residual row) per live output row, rulebook row
+            esz, osz = feats.element_size(), out.element_size()
+            CONV_BYTES.append((Cin * esz + Cout * osz + (Cout * esz if res is not None else 0) + KW * 4,
+                               w.numel() * w.element_size()))
     return out
 
 
@@ -200,6 +206,12 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
         e1.record()
         CONV_PROFILE.append((2.0 * N * OH * OW * Cout * KH * KW * Cin, e0, e1,
                              f"M={N * OH * OW} N={Cout} K={KH * KW * Cin} k{KH}x{KW}s{stride}"))
+        if CONV_BYTES is not None:
+            esz, osz = x.element_size(), out.element_size()
+            m_out = N * OH * OW
+            in_px = min(N * H * W, m_out * KH * KW)           # a strided 1x1 layer only touches the pixels it samples
+            CONV_BYTES.append(in_px * (in_cstride or Cin) * esz + m_out * Cout * osz + w.numel() * w.element_size() +
+                              m_out * Cout * esz * ((res1 is not None) + (res2 is not None)))
     return out
 
 
