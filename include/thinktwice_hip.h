@@ -35,6 +35,9 @@ extern "C" {
 #define TT_ACT_SOFTPLUS_CLAMP 5  /* clamp(softplus(x), min=1e-3): thinktwice_decoder.py:484 */
 
 const char* tt_last_error(void);
+/* measurement aid: name (template arguments spelled like rocprofv3 prints them) of the kernel that the last
+ * tt_conv2d_fwd call of this thread launched; "" before the first call */
+const char* tt_conv_last_kernel(void);
 int tt_version(void);
 
 /* ------------------------------------------------------------------------

@@ -72,6 +72,7 @@ class ForwardWorkload:
         torch.cuda.synchronize()
         ops.CONV_PROFILE = []
         ops.CONV_BYTES = []
+        ops.CONV_KERNELS = []
         self.model.use_side_stream = False     # per-launch timing needs the launches serialised on one stream
         self.model.forward_inference(self.batch, channel_last_out=True)   # eager: the graph replay bypasses the hook
         torch.cuda.synchronize()
@@ -92,8 +93,10 @@ class ForwardWorkload:
             else:
                 compulsory += nb
             rec.append(r)
+        kernels = list(ops.CONV_KERNELS)
         ops.CONV_PROFILE = None
         ops.CONV_BYTES = None
+        ops.CONV_KERNELS = None
         flops = sum(r[0] for r in rec)
         ms = sum(r[1].elapsed_time(r[2]) for r in rec)
         ach = flops / (ms * 1e-3) / 1e12
@@ -140,6 +143,21 @@ class ForwardWorkload:
                                   "flop_per_hbm_byte": round(2.0 * 256 * nv / ((256 + nv) * esz), 1),
                                   "note": "all four levels' value_proj GEMMs (five layers fused along N); bound by "
                                           "whichever of mfma_frac / hbm_frac is larger"}
+        # the dominant kernel (most time) on its own: what `rocprofv3 --kernel-trace --stats` lists under the same name
+        by_k = {}
+        for r, kname in zip(rec, kernels):
+            a = by_k.setdefault(kname.replace(" + tail", ""), [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += r[1].elapsed_time(r[2])
+            a[2] += r[0]
+        dk, dv = max(by_k.items(), key=lambda kv: kv[1][1])
+        mult = 3 if self.dtype == "bf16x3" and dk.endswith("true>") else 1
+        dom_tf = dv[2] / (dv[1] * 1e-3) / 1e12
+        dominant = {"kernel": dk, "launches": dv[0], "avg_launch_ms": round(dv[1] / dv[0], 4),
+                    "ms_per_step": round(dv[1], 3), "algorithmic_tflops": round(dom_tf, 1), "frac": round(dom_tf / peak, 4),
+                    "mfma_per_product": mult, "executed_mfma_frac": round(mult * dom_tf / peak, 4),
+                    "note": "HIP events around each launch of this kernel in one serialised forward; a tail-split launch "
+                            "(256x64 tiles over the last row tiles) is timed with its main launch"}
         traffic, traffic_note = self._pmc_traffic()
         x3 = {}
         if self.dtype == "bf16x3":
@@ -149,6 +167,7 @@ class ForwardWorkload:
                   "executed_mfma_frac": round(3 * ach / peak, 4)}
         return {"kernel": "conv_igemm_glds_kernel (all conv/linear launches of one forward)", "bound": "mfma",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), **x3,
+                "dominant_kernel": dominant,
                 "traffic": traffic, "traffic_note": traffic_note,
                 "compulsory_bytes": int(compulsory),
                 "traffic_over_compulsory": None if not traffic else round(traffic / compulsory, 3),

@@ -4,6 +4,8 @@
 #include "tt_common.h"
 
 namespace tt {
+extern thread_local char g_conv_kernel[96];   // common.cpp: label of the kernel the last conv launch used
+
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

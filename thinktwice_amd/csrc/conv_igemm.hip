@@ -283,6 +283,8 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
         a.splits = sp < 1 ? 1 : sp;
     }
     if (a.splits <= 1) a.ws = nullptr;
+    snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_igemm_kernel<%s, %d, %d>%s", sizeof(T) == 4 ? "float" : "16-bit",
+             BM, BN, a.ws ? " split-K" : "");
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)a.splits), dim3(256), smem, st, a);
     if (a.ws) {
         const long long tot = (long long)a.M * a.Cout;
@@ -376,7 +378,10 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
         a.res_vec = (res_ok(d->res1, d->res1_cstride, d->res1_coff) && res_ok(d->res2, d->res2_cstride, d->res2_coff)) ? 1 : 0;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (!d->splitk_ws && try_launch_conv_small(a, d->dtype, st)) return check_launch("tt_conv2d_fwd(small)");
+    if (!d->splitk_ws && try_launch_conv_small(a, d->dtype, st)) {
+        snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_small_kernel");
+        return check_launch("tt_conv2d_fwd(small)");
+    }
     if (!d->splitk_ws && d->weight_x3 && d->dtype == TT_F32) {
         TT_REQUIRE((reinterpret_cast<uintptr_t>(d->weight_x3) & 15) == 0 && a.K % 16 == 0,
                    "tt_conv2d_fwd: weight_x3 needs 16-byte alignment and K %% 16 == 0 (K = %d)", a.K);

@@ -538,6 +538,10 @@ static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0) {
     a.tiles_n = tiles_n;
     a.splits = 1;
     a.ws = nullptr;
+    if (a.m_begin == 0)      // (the tail launch of a split keeps the main launch's label)
+        snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_igemm_glds_kernel<%s, %d, %d, %d, %d, %d, %s, %s>%s",
+                 sizeof(T) == 4 ? "float" : "16-bit", BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER ? "true" : "false",
+                 X3 ? "true" : "false", m_tiles_limit > 0 ? " + tail" : "");
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(WAVES_M * WAVES_N * 64), smem, st, a, zp,
                        tiles_m, tiles_n);
     return 1;

@@ -65,6 +65,7 @@ def lift_splat(depth_logits, context, geom_xyz, voxel_num, batch_size, num_cams,
 # ----------------------------------------------------------------------------- conv / linear
 _AUTO_SPLITK = os.environ.get("TT_CONV_AUTO_SPLITK", "1") == "1"
 CONV_PROFILE = None   # bench.py sets this to a list to collect (flops, start, end, shape) per launch
+CONV_KERNELS = None   # same order as CONV_PROFILE: tt_conv_last_kernel() of the launch
 CONV_BYTES = None     # same order as CONV_PROFILE: compulsory HBM bytes of the launch (each operand moved once);
                       # dense: int; sparse: (bytes per live output row, fixed bytes)
 
@@ -89,6 +90,12 @@ class _ConvDesc(ctypes.Structure):
 
 def _dp(t):
     return None if t is None else t.data_ptr()
+
+
+def _last_conv_kernel():
+    L = lib()
+    L.tt_conv_last_kernel.restype = ctypes.c_char_p
+    return L.tt_conv_last_kernel().decode()
 
 
 SPARSE_PAIRS = None   # bench.py: device int64 counter of existing (row, tap) pairs, filled by sp_tile_plan
@@ -137,6 +144,8 @@ def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None
         # FLOP accounting over the EXISTING (row, tap) pairs: per-row tap counts of the rulebook (measurement only)
         CONV_PROFILE.append((2.0 * Cout * KW * Cin, e0, e1, f"sparse M<={M} N={Cout} K={KW * Cin}", m_dev, M,
                              ((nbr >= 0).sum(1), 2.0 * Cout * Cin)))
+        if CONV_KERNELS is not None:
+            CONV_KERNELS.append(_last_conv_kernel())
         if CONV_BYTES is not None:      # one input row and one output row (+ residual row) per live output row, rulebook row
             esz, osz = feats.element_size(), out.element_size()
             CONV_BYTES.append((Cin * esz + Cout * osz + (Cout * esz if res is not None else 0) + KW * 4,
@@ -206,6 +215,8 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
         e1.record()
         CONV_PROFILE.append((2.0 * N * OH * OW * Cout * KH * KW * Cin, e0, e1,
                              f"M={N * OH * OW} N={Cout} K={KH * KW * Cin} k{KH}x{KW}s{stride}"))
+        if CONV_KERNELS is not None:
+            CONV_KERNELS.append(_last_conv_kernel())
         if CONV_BYTES is not None:
             esz, osz = x.element_size(), out.element_size()
             m_out = N * OH * OW
