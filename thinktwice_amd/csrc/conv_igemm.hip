@@ -360,7 +360,10 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
             const char* e = getenv("TT_GLDS_SETPRIO");
             setprio = e ? atoi(e) : 0;
         }
-        a.flags = setprio ? 1 : 0;
+        // TT_GLDS_X3_PIPE=1: bf16x3 body with the second k-step's operand split and the next tile's DMA issue placed behind
+        // MFMAs already issued (measured: +-1 % either way on the large layers, 16 more registers; default off)
+        static const int x3_pipe = [] { const char* e = getenv("TT_GLDS_X3_PIPE"); return e ? atoi(e) : 0; }();
+        a.flags = (setprio ? 1 : 0) | (x3_pipe ? 0 : 2);
     }
     {
         const int co_vec = d->out_dtype == TT_F32 ? 4 : 8;

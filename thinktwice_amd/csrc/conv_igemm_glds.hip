@@ -40,7 +40,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // footprint as f32).  Each product is three v_mfma_f32_32x32x16_bf16: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with f32
 // accumulation -- 16 mantissa bits per operand (relative error ~1e-5 per dot product instead of bf16's 4e-3) at
 // 16/3 of the exact-f32 MFMA rate.  This is the precision mode whose outputs meet the 1e-3 tolerance.
-template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false>
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false,
+          bool PP = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64,
                              ((256 / WAVES_M / 32) * (BN / WAVES_N / 32) >= 16)  ? 1      // 128x128 per wave: 512 regs
                              : ((256 / WAVES_M / 32) * (BN / WAVES_N / 32) >= 8) ? 2      // 128x64 per wave: 256 regs
@@ -53,9 +54,18 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     constexpr int VEC = Elem<T>::kVec;
     constexpr int BK = BKB / (int)sizeof(T);          // BKB = K bytes per row per tile (64 or 128)
     constexpr int CPR = BKB / 16;                     // 16 B chunks per row
-    static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
+    // STAGES = 23: asymmetric ring -- THREE activation stages, TWO weight stages (x3 256x256 tile: 3 x 32 + 2 x 32 KiB =
+    // the whole 160 KiB).  The weight tiles are L2-resident for every workgroup of the launch; the activation tiles are the
+    // ones that miss (one tap in nine), so they get the second tile of lookahead.
+    constexpr bool ASYM = STAGES == 23;
+    constexpr int SA = ASYM ? 3 : STAGES, SB = ASYM ? 2 : STAGES;
+    static_assert(STAGES == 2 || STAGES == 3 || ASYM, "2 or 3 LDS stages, or 23 = 3 activation + 2 weight stages");
     static_assert(!GATHER || STAGES == 2, "gather mode is written for the 2-stage pipeline");
+    constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
     constexpr int STAGE_BYTES = (BM + BN) * BKB;
+    // byte offset of tile kt's activation / weight stage from the start of the dynamic LDS
+    auto off_a = [](int kt) { return ASYM ? (kt % 3) * A_BYTES : (kt % SA) * STAGE_BYTES; };
+    auto off_b = [](int kt) { return ASYM ? 3 * A_BYTES + (kt % 2) * B_BYTES : (kt % SB) * STAGE_BYTES + A_BYTES; };
     constexpr int NA_INSTR = BM * CPR / 64;           // 1 KiB wave-instructions in the A tile
     constexpr int NB_INSTR = BN * CPR / 64;
     constexpr int NW = WAVES_M * WAVES_N;             // waves per workgroup (8 or 16)
@@ -242,22 +252,34 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         }
         ++g_t;
     };
-    auto issue_tile = [&](int kt) {
-        unsigned char* st = smem + (kt % STAGES) * STAGE_BYTES;
-        const int kh = it_kh, kw = it_kw, ci = it_ci;
-        const int k0 = GATHER ? kt * BK                // position of this tile in the [KH][KW][Cin] weight row
-                              : (kh * p.KW + kw) * p.Cin + ci;
+    // The activation and the weight stream walk the same (channel chunk, tap) sequence; with the asymmetric ring the
+    // activation walker runs one tile ahead of the weight walker, so each keeps its own position.
+    // The LDS destination of a DMA instruction is wave-uniform (it goes to M0): keep it in scalar registers instead of
+    // deriving it from threadIdx through a VALU add + v_readfirstlane per load.
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_dma_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    struct KWalk {
+        int kh, kw, ci;
+    };
+    KWalk wa{0, 0, 0}, wb{0, 0, 0};
+    auto advance = [&](KWalk& w) {
+        if (++w.kw == p.KW) {
+            w.kw = 0;
+            if (++w.kh == p.KH) {
+                w.kh = 0;
+                w.ci += BK;
+            }
+        }
+    };
+    auto issue_a = [&](int kt) {
+        const unsigned st = lds_dma_base + (unsigned)off_a(kt);
+        const int kh = wa.kh, kw = wa.kw, ci = wa.ci;
+        const int k0 = kt * BK;                        // GATHER: position of this tile in the [KH][KW][Cin] weight row
         // wave-uniform (SALU): tap index and the element offset of tap (kh, kw), channel ci from tap (0, 0), channel 0
         const int tap = kh * p.KW + kw;
         const long long tap_off = ((long long)(kh * p.dil) * p.W + kw * p.dil) * p.in_cstride + ci;
-        if (++it_kw == p.KW) {
-            it_kw = 0;
-            if (++it_kh == p.KH) {
-                it_kh = 0;
-                it_ci += BK;
-            }
-        }
-        const bool dbg_skip_a = TT_GLDS_DEBUG && p.act == 98 && kt > 0, dbg_skip_b = TT_GLDS_DEBUG && p.act == 97 && kt > 0;
+        advance(wa);
+        const bool dbg_skip_a = TT_GLDS_DEBUG && p.act == 98 && kt > 0;
 #pragma unroll
         for (int j = 0; j < NIA; ++j) {
             if (dbg_skip_a) break;
@@ -271,8 +293,15 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
             } else {
                 src = ((a_mask[j] >> tap) & 1u) ? a_ptr[j] + tap_off : zp;
             }
-            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(st + (wave + NW * j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(uintptr_t)(st + (unsigned)(wave_s + NW * j) * 1024u), 16, 0, 0);
         }
+    };
+    auto issue_b = [&](int kt) {
+        const unsigned st = lds_dma_base + (unsigned)off_b(kt);
+        const int k0 = GATHER ? kt * BK                // position of this tile in the [KH][KW][Cin] weight row
+                              : (wb.kh * p.KW + wb.kw) * p.Cin + wb.ci;
+        advance(wb);
+        const bool dbg_skip_b = TT_GLDS_DEBUG && p.act == 97 && kt > 0;
         int tpi[TPTMAX];
         if (planned) next_taps(wi, tpi);
 #pragma unroll
@@ -286,8 +315,21 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                 ok = b_ok[j] && t >= 0;
                 src = ok ? b_ptr[j] - b_c[j] + (long long)t * p.Cin + ((k0 + b_c[j]) & cin_mask) : zp;
             }
-            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(st + BM * BKB + ((wave + NW * j) % NB_INSTR) * 1024),
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(uintptr_t)(st + (unsigned)((wave_s + NW * j) % NB_INSTR) * 1024u),
                                              16, 0, 0);
+        }
+    };
+    auto issue_tile = [&](int kt) {
+        issue_a(kt);
+        issue_b(kt);
+    };
+    // what goes out right after the barrier of tile kt
+    auto issue_ahead = [&](int kt) {
+        if (ASYM) {
+            if (kt + 1 < nk) issue_b(kt + 1);          // weights first: the counted wait at the next tile's top lets the
+            if (kt + 2 < nk) issue_a(kt + 2);          // younger activation loads stay in flight
+        } else if (kt + STAGES - 1 < nk) {
+            issue_tile(kt + STAGES - 1);
         }
     };
 
@@ -303,6 +345,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     if (nk > 0) issue_tile(0);
     if (GATHER && nk > 1) fetch_rulebook();            // for tile 1; lands while tile 0 streams in
     if (STAGES == 3 && nk > 1) issue_tile(1);
+    if (ASYM && nk > 1) issue_a(1);
 
     // fragment addressing: row = tile row + (lane&31); 16 B chunk c16 = 2*kc + (lane>>5), swizzled.
     // The fragment reads are INLINE ASM: hipcc treats every ds_read of this array as aliasing the
@@ -350,10 +393,129 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     };
 
     const bool prio = (p.flags & 1) != 0;
+    if constexpr (PP) {
+        // ---- ping-pong schedule (bf16x3, dense, 8 waves = two groups of one wave per SIMD) -------------------------------
+        // A k-step is a READ phase (12 ds_read_b128, the operand split, the next tile's DMA issue) and an MFMA phase (24
+        // MFMAs), separated by barriers.  Group 1 executes ONE extra barrier before the loop, so it runs one phase behind
+        // group 0: between any two barriers one group's waves keep the four matrix pipes busy while the other group's
+        // waves read, split and issue -- the two waves of a SIMD no longer hit the same phase at the same time (the
+        // lock-step that left the pipe at ~53 % in the single-phase loop).  Hazards, per tile kt with stage S(kt):
+        //  * WAR  DMA(kt+1) -> S(kt-1): issued in a wave's read phase of (kt, 0); the last reads of S(kt-1) (group 1's
+        //    read phase of (kt-1, 1)) retired before the barrier every wave has passed by then;
+        //  * RAW  reads of S(kt+1) start with group 0's read phase of (kt+1, 0): every wave drains its own DMA(kt+1)
+        //    (`vmcnt(0)`) before the barrier that opens that phase -- group 0 after its MFMAs of (kt, 1), group 1 at the
+        //    end of its read phase of (kt, 1).
+        static_assert(X3 && !GATHER && STAGES == 2 && NW == 8, "ping-pong: dense bf16x3, symmetric 2-stage ring, 8 waves");
+        const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");        // tile 0 is published
+        if (grp == 1) asm volatile("s_barrier" ::: "memory");
+#endif
+        u32x4 ra0[TM], ra1[TM], bh[TN], bl[TN];
+        u32x4 ah[TM], al[TM];
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned sbase = lds_base + (unsigned)off_a(kt);
+            const unsigned sbase_b = lds_base + (unsigned)(off_b(kt) - A_BYTES);
+#pragma unroll
+            for (int kc = 0; kc < NKC_; ++kc) {
+                // ---- read phase.  The next tile's DMA goes out first, half per k-step (activations, then weights): hipcc
+                // puts an `s_waitcnt lgkmcnt(0)` in front of the first global_load_lds of a block, which would drain the
+                // fragment reads if they were already in flight.
+                if (kt + 1 < nk) {
+                    if (kc == 0) issue_a(kt + 1);
+                    if (kc == NKC_ - 1) issue_b(kt + 1);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ra0[i] = lds_read(sbase + fa_pre[kc][i]);
+                    ra1[i] = lds_read(sbase + (fa_pre[kc][i] ^ 16u));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (TT_GLDS_DEBUG && p.act == 95 && (kt > 0 || kc > 0)) break;   // debug: weight fragments read once
+                    bh[j] = lds_read(sbase_b + fb_pre[kc][j]);
+                    bl[j] = lds_read(sbase_b + (fb_pre[kc][j] ^ 32u));
+                }
+#if defined(__HIP_DEVICE_COMPILE__)
+                // the activation reads went out first and LDS returns in order: all but the 2 * TN weight reads
+                if constexpr (TN == 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                else if constexpr (TN == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    asm volatile("" : "+v"(ra0[i]));
+                    asm volatile("" : "+v"(ra1[i]));
+                    if (TT_GLDS_DEBUG && p.act == 96) {      // debug: no operand split
+                        ah[i] = ra0[i];
+                        al[i] = ra1[i];
+                        continue;
+                    }
+                    const float x[8] = {__uint_as_float(ra0[i].x), __uint_as_float(ra0[i].y), __uint_as_float(ra0[i].z),
+                                        __uint_as_float(ra0[i].w), __uint_as_float(ra1[i].x), __uint_as_float(ra1[i].y),
+                                        __uint_as_float(ra1[i].z), __uint_as_float(ra1[i].w)};
+                    uint32_t h[4], l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);                       // round to nearest even
+                        const float r0 = x[2 * e] - __uint_as_float(h[e] << 16);           // exact in f32
+                        const float r1 = x[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
+                        l[e] = pack_bf16x2(r0, r1);
+                    }
+                    ah[i] = u32x4{h[0], h[1], h[2], h[3]};
+                    al[i] = u32x4{l[0], l[1], l[2], l[3]};
+                    // pin the split INSIDE the read phase: without these the compiler sinks the conversions below the
+                    // barrier, next to their first use, i.e. into the MFMA phase
+                    asm volatile("" : "+v"(ah[i]));
+                    asm volatile("" : "+v"(al[i]));
+                }
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (kc == NKC_ - 1 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    asm volatile("" : "+v"(bh[j]));
+                    asm volatile("" : "+v"(bl[j]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                if (TT_GLDS_DEBUG && p.act == 93) continue;  // debug: no MFMA phase at all (and no second barrier)
+                // ---- MFMA phase (term-major: consecutive MFMAs write different accumulators; small terms first)
+                if (prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const uint4 bhv = __builtin_bit_cast(uint4, bh[j]);
+                    const uint4 blv = __builtin_bit_cast(uint4, bl[j]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(__builtin_bit_cast(uint4, al[i]), bhv, acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(__builtin_bit_cast(uint4, ah[i]), blv, acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(__builtin_bit_cast(uint4, ah[i]), bhv, acc[i][j]);
+                }
+                if (prio) __builtin_amdgcn_s_setprio(0);
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);
+                if (kc == NKC_ - 1 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+#endif
+            }
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (grp == 0) asm volatile("s_barrier" ::: "memory");   // re-align the two groups
+#endif
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed for THIS wave once at most one younger tile (LPT loads) is outstanding
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (STAGES == 3 && kt + 1 < nk) {
+        if (ASYM && kt + 1 < nk) {                     // outstanding in issue order: A(kt) B(kt) A(kt+1)
+            if constexpr (NIA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (NIA == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if constexpr (NIA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (STAGES == 3 && kt + 1 < nk) {
             if constexpr (LPT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (LPT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if constexpr (LPT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -367,7 +529,11 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         asm volatile("s_barrier" ::: "memory");   // publishes tile kt; everyone is done reading tile kt-1
 #endif
 
-        const unsigned sbase = lds_base + (unsigned)((kt % STAGES) * STAGE_BYTES);
+        // fragment offsets carry the activation / weight split of a symmetric stage (weights at + A_BYTES): the two bases
+        // below make the same offsets address the asymmetric ring
+        const unsigned sbase_a = lds_base + (unsigned)off_a(kt);
+        const unsigned sbase_b = lds_base + (unsigned)(off_b(kt) - A_BYTES);
+        const unsigned sbase = sbase_a;
         if constexpr (X3) {
             // bf16x3 body.  A k-step is 16 f32 of K: 2 reads per A fragment (raw f32), the split (6 VALU per element
             // pair, once per k-step), then per output column block j: 2 reads (weights hi, lo) and 3 MFMAs per row
@@ -375,64 +541,74 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
             // issued before the MFMAs of sub-step s, into the registers sub-step s-1 has released (one B fragment pair
             // per buffer keeps the 64 x 128 wave tile inside 256 registers).
             constexpr int NS = NKC_ * TN;
+            constexpr bool SPLIT_PIPE = TM <= TN - 1;    // a k-step needs TM sub-steps after its first one to hide the splits
+            // Schedule (pipe = 0: the round-2a order, everything of a k-step split up front): the activation fragments of
+            // k-step kc+1 are read at sub-step (kc, 0) and split one fragment per sub-step AFTER that sub-step's MFMAs were
+            // issued, so the 24 VALU of a split run in the shadow of six MFMAs; only the first k-step of a tile (whose data
+            // cannot be read before the tile's barrier) is still split up front.  The next tile's DMA (address arithmetic
+            // + 8 issue slots) likewise goes out behind the first sub-step's MFMAs.
+            const bool pipe = (p.flags & 2) == 0;
+            const bool pipe_split = pipe && SPLIT_PIPE;
             u32x4 ra0[TM], ra1[TM], bh[2], bl[2];
-            uint4 ah[TM], al[TM];
+            uint4 ah[2][TM], al[2][TM];
+            auto split_frag = [&](int i, uint4& hi_out, uint4& lo_out) {
+                asm volatile("" : "+v"(ra0[i]));
+                asm volatile("" : "+v"(ra1[i]));
+                if (TT_GLDS_DEBUG && p.act == 96) {          // debug: no operand split (raw bits as operands)
+                    hi_out = __builtin_bit_cast(uint4, ra0[i]);
+                    lo_out = __builtin_bit_cast(uint4, ra1[i]);
+                    return;
+                }
+                const float x[8] = {__uint_as_float(ra0[i].x), __uint_as_float(ra0[i].y), __uint_as_float(ra0[i].z),
+                                    __uint_as_float(ra0[i].w), __uint_as_float(ra1[i].x), __uint_as_float(ra1[i].y),
+                                    __uint_as_float(ra1[i].z), __uint_as_float(ra1[i].w)};
+                uint32_t h[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);                       // round to nearest even
+                    const float r0 = x[2 * e] - __uint_as_float(h[e] << 16);           // exact in f32
+                    const float r1 = x[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
+                    l[e] = pack_bf16x2(r0, r1);
+                }
+                hi_out = make_uint4(h[0], h[1], h[2], h[3]);
+                lo_out = make_uint4(l[0], l[1], l[2], l[3]);
+            };
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ra0[i] = lds_read(sbase + fa_pre[0][i]);
                 ra1[i] = lds_read(sbase + (fa_pre[0][i] ^ 16u));
             }
-            bh[0] = lds_read(sbase + fb_pre[0][0]);
-            bl[0] = lds_read(sbase + (fb_pre[0][0] ^ 32u));
-            if (kt + STAGES - 1 < nk) issue_tile(kt + STAGES - 1);
-            if (GATHER && kt + 2 < nk) fetch_rulebook();
+            bh[0] = lds_read(sbase_b + fb_pre[0][0]);
+            bl[0] = lds_read(sbase_b + (fb_pre[0][0] ^ 32u));
+            if (!pipe) {
+                issue_ahead(kt);
+                if (GATHER && kt + 2 < nk) fetch_rulebook();
+            }
 #pragma unroll
             for (int ss = 0; ss < NS; ++ss) {
-                const int kc = ss / TN, j = ss % TN, buf = ss & 1;
+                const int kc = ss / TN, j = ss % TN, buf = ss & 1, ab = kc & 1;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(bh[buf]));
                 asm volatile("" : "+v"(bl[buf]));
-                if (TT_GLDS_DEBUG && p.act == 96) {          // debug: no operand split (raw bits as operands)
-                    if (j == 0) {
+                if (j == 0 && (kc == 0 || !pipe_split)) {    // up-front split (first k-step of the tile)
 #pragma unroll
-                        for (int i = 0; i < TM; ++i) {
-                            ah[i] = __builtin_bit_cast(uint4, ra0[i]);
-                            al[i] = __builtin_bit_cast(uint4, ra1[i]);
-                        }
-                    }
-                } else if (j == 0) {
+                    for (int i = 0; i < TM; ++i) split_frag(i, ah[ab][i], al[ab][i]);
+                }
+                // reads under this sub-step's MFMAs: the next sub-step's weight pair, and the next k-step's activations
+                // (at j == 0 when pipelined: their registers were released by the split above / one k-step ago)
+                const bool a_now = pipe_split ? (j == 0 && kc + 1 < NKC_) : (j == TN - 1 && kc + 1 < NKC_);
+                if (a_now) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
-                        asm volatile("" : "+v"(ra0[i]));
-                        asm volatile("" : "+v"(ra1[i]));
-                        const float x[8] = {__uint_as_float(ra0[i].x), __uint_as_float(ra0[i].y),
-                                            __uint_as_float(ra0[i].z), __uint_as_float(ra0[i].w),
-                                            __uint_as_float(ra1[i].x), __uint_as_float(ra1[i].y),
-                                            __uint_as_float(ra1[i].z), __uint_as_float(ra1[i].w)};
-                        uint32_t h[4], l[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);                       // round to nearest even
-                            const float r0 = x[2 * e] - __uint_as_float(h[e] << 16);           // exact in f32
-                            const float r1 = x[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
-                            l[e] = pack_bf16x2(r0, r1);
-                        }
-                        ah[i] = make_uint4(h[0], h[1], h[2], h[3]);
-                        al[i] = make_uint4(l[0], l[1], l[2], l[3]);
+                        ra0[i] = lds_read(sbase + fa_pre[kc + 1][i]);
+                        ra1[i] = lds_read(sbase + (fa_pre[kc + 1][i] ^ 16u));
                     }
                 }
-                if (ss + 1 < NS) {          // reads of the next sub-step, under this sub-step's MFMAs
+                if (ss + 1 < NS) {
                     const int kc2 = (ss + 1) / TN, j2 = (ss + 1) % TN;
-                    if (j2 == 0) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) {
-                            ra0[i] = lds_read(sbase + fa_pre[kc2][i]);
-                            ra1[i] = lds_read(sbase + (fa_pre[kc2][i] ^ 16u));
-                        }
-                    }
                     if (!(TT_GLDS_DEBUG && p.act == 95)) {   // debug 95: weight fragments read once per tile
-                        bh[buf ^ 1] = lds_read(sbase + fb_pre[kc2][j2]);
-                        bl[buf ^ 1] = lds_read(sbase + (fb_pre[kc2][j2] ^ 32u));
+                        bh[buf ^ 1] = lds_read(sbase_b + fb_pre[kc2][j2]);
+                        bl[buf ^ 1] = lds_read(sbase_b + (fb_pre[kc2][j2] ^ 32u));
                     } else {
                         bh[buf ^ 1] = bh[buf];
                         bl[buf ^ 1] = bl[buf];
@@ -445,14 +621,24 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                 // accumulator waits for the first one's last pass); small terms first
                 if (!(TT_GLDS_DEBUG && p.act == 94)) {       // debug 94: one MFMA per fragment pair instead of three
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(al[i], bhv, acc[i][j]);
+                    for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(al[ab][i], bhv, acc[i][j]);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(ah[i], blv, acc[i][j]);
+                    for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(ah[ab][i], blv, acc[i][j]);
                 }
 #pragma unroll
-                for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(ah[i], bhv, acc[i][j]);
+                for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(ah[ab][i], bhv, acc[i][j]);
                 if (prio) __builtin_amdgcn_s_setprio(0);
-                (void)kc;
+                if (pipe) {
+                    // work that hides behind the MFMAs just issued
+                    if (ss == 0) {
+                        issue_ahead(kt);
+                        if (GATHER && kt + 2 < nk) fetch_rulebook();
+                    }
+                    if (pipe_split && kc + 1 < NKC_ && j >= 1 && j - 1 < TM) {
+                        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");   // all but the newest weight pair: the A reads
+                        split_frag(j - 1, ah[ab ^ 1][j - 1], al[ab ^ 1][j - 1]);
+                    }
+                }
             }
             continue;
         }
@@ -461,11 +647,11 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[0][i] = lds_read(sbase + fa_pre[0][i]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[0][j] = lds_read(sbase + fb_pre[0][j]);
+        for (int j = 0; j < TN; ++j) fb[0][j] = lds_read(sbase_b + fb_pre[0][j]);
         // the next tile's DMA goes out AFTER the first fragment reads: its address arithmetic (~90 VALU/SALU) then
         // runs under the LDS latency instead of in front of it (every wave of the block is in this phase together,
         // so nothing else would cover that latency)
-        if (kt + STAGES - 1 < nk) issue_tile(kt + STAGES - 1);
+        issue_ahead(kt);
         if (GATHER && kt + 2 < nk) fetch_rulebook();   // for tile kt+2, consumed at the top of the next iteration
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) {
@@ -484,7 +670,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
 #pragma unroll
                 for (int i = 0; i < TM; ++i) fa[nxt][i] = lds_read(sbase + fa_pre[kc + 1][i]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read(sbase + fb_pre[kc + 1][j]);
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read(sbase_b + fb_pre[kc + 1][j]);
             }
             if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -515,7 +701,8 @@ static const void* zero_page() {
     return z;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false>
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false,
+          bool PP = false>
 static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0) {
     constexpr int BM = 256;
     constexpr int WTN = BN / WAVES_N;
@@ -525,10 +712,10 @@ static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0) {
     int tiles_m = div_up(a.M - a.m_begin, BM);
     if (m_tiles_limit > 0 && m_tiles_limit < tiles_m) tiles_m = m_tiles_limit;
     const int tiles_n = div_up(a.Cout, BN);
-    size_t smem = (size_t)STAGES * (BM + BN) * BKB;
+    size_t smem = STAGES == 23 ? (size_t)(3 * BM + 2 * BN) * BKB : (size_t)STAGES * (BM + BN) * BKB;
     const size_t epi = (size_t)(WAVES_M * WAVES_N) * 32 * (WTN + 4) * 4;
     if (smem < epi) smem = epi;
-    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER, X3>;
+    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER, X3, PP>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -541,7 +728,7 @@ static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0) {
     if (a.m_begin == 0)      // (the tail launch of a split keeps the main launch's label)
         snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_igemm_glds_kernel<%s, %d, %d, %d, %d, %d, %s, %s>%s",
                  sizeof(T) == 4 ? "float" : "16-bit", BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER ? "true" : "false",
-                 X3 ? "true" : "false", m_tiles_limit > 0 ? " + tail" : "");
+                 X3 ? (PP ? "true, true" : "true") : "false", m_tiles_limit > 0 ? " + tail" : "");
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(WAVES_M * WAVES_N * 64), smem, st, a, zp,
                        tiles_m, tiles_n);
     return 1;
@@ -601,13 +788,19 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
     if (force == 64) bn = 64;
     if (force == 1) bn = wide ? 256 : (a.Cout > 64 ? 128 : 64);          // the pre-cost-model rule
     if (bn == 256) {                                                                                           // 8 x (64 x 128)
-        if (const int main_rows = tail_split_rows(a)) {
-            launch_glds<float, 256, 4, 2, 128, 2, false, true>(a, st, main_rows);
+        // TT_GLDS_X3_ASYM=0: symmetric 2-stage ring instead of 3 activation + 2 weight stages (A/B knob)
+        static const bool asym = [] { const char* e = getenv("TT_GLDS_X3_ASYM"); return e ? atoi(e) != 0 : true; }();
+        const int main_rows = tail_split_rows(a);
+        static const int pp = [] { const char* e = getenv("TT_GLDS_X3_PINGPONG"); return e ? atoi(e) : 0; }();
+        if (pp) launch_glds<float, 256, 4, 2, 128, 2, false, true, true>(a, st, main_rows);
+        else if (asym) launch_glds<float, 256, 4, 2, 128, 23, false, true>(a, st, main_rows);
+        else launch_glds<float, 256, 4, 2, 128, 2, false, true>(a, st, main_rows);
+        if (main_rows) {
             ConvArgs t = a;
             t.m_begin = main_rows * 256;
             return launch_glds<float, 64, 8, 1, 128, 2, false, true>(t, st);
         }
-        return launch_glds<float, 256, 4, 2, 128, 2, false, true>(a, st);
+        return 1;
     }
     // TT_GLDS_X3_STAGES=3: three LDS stages for the narrow tiles (two K tiles in flight per workgroup).  Measured and NOT
     // the default: the 64-wide tile then holds 120 KiB and loses its second workgroup per CU (N=64 K=576: 2.13 -> 2.66 ms,
