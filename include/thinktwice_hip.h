@@ -418,6 +418,19 @@ int tt_loss_seg_focal(const float* logits_cl, int row_stride, int num_classes, c
 int tt_loss_depth_bce(const float* logits_cl, int row_stride, int D, const float* gt_depth, int BN, int H, int W,
                       int factor, float d_lo, float d_step, float* out, void* workspace, void* stream);
 
+/* ----------------------------------------------------------------------
+ * SURVEY 8f-4, backward of the convolution (what autograd + cuDNN do under loss.backward() in the reference,
+ * apis/mmdet_train.py:72-79).  Weight gradient of tt_conv2d_fwd's channel-last convolution:
+ *   dw[co][kh][kw][ci] (+)= sum_{n,oh,ow} dy[n][oh][ow][dy_coff + co] * x[n][oh*s - p + kh*d][ow*s - p + kw*d][x_coff + ci]
+ * exact f32 products on the f32 MFMA, deterministic (split partial sums added in a fixed order).  dw has the weight
+ * layout [Cout][KH][KW][cin_pad] (padding channels are written as 0).  The input gradient needs no entry of its own:
+ * it is tt_conv2d_fwd of dy with the 180-degree-rotated, Cin/Cout-transposed weights (thinktwice_amd/ops.py::conv2d_dgrad).
+ * ---------------------------------------------------------------------- */
+long long tt_conv2d_wgrad_workspace_bytes(int N, int OH, int Cout, int Cin, int cin_pad, int KH, int KW);
+int tt_conv2d_wgrad(const float* x, int N, int H, int W, int Cin, int x_cstride, int x_coff, const float* dy, int OH,
+                    int OW, int Cout, int dy_cstride, int dy_coff, int KH, int KW, int stride, int pad, int dil,
+                    int cin_pad, int accumulate, float* dw, void* workspace, long long workspace_bytes, void* stream);
+
 /* SURVEY 8f-1, LiDAR side: merge of the two 180-degree half sweeps of the closed-loop tick
  * (leaderboard/team_code/thinktwice_agent.py:340-352).  prev / now: (n, 4) f32 (x, y, z, intensity) device rows;
  * rel_transform_3x4: HOST pointer to the first three rows of inv(T_now) @ T_prev (row-major); out: (n_prev + n_now, 4)

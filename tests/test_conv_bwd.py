@@ -1,0 +1,74 @@
+"""Convolution backward: tt_conv2d_wgrad and the input gradient through tt_conv2d_fwd on rotated weights,
+against torch autograd of F.conv2d on the CPU (what the reference's loss.backward() computes for every Conv2d)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 20, 24, 64, 64, 3, 1, 1, 1),
+    (3, 17, 23, 32, 96, 3, 1, 1, 1),       # odd width (ragged pixel pair), Cout tail of the 64-wide tile
+    (2, 28, 28, 128, 64, 1, 1, 0, 1),      # 1x1
+    (2, 30, 32, 64, 128, 3, 2, 1, 1),      # stride 2 (ResNet downsampling 3x3)
+    (2, 30, 32, 64, 128, 1, 2, 0, 1),      # stride-2 1x1 (ResNet downsample branch)
+    (2, 24, 24, 64, 64, 3, 1, 6, 6),       # ASPP dilation 6
+    (4, 40, 48, 3, 64, 7, 2, 3, 1),        # stem: Cin = 3 (padded to 4 in the weight layout)
+    (1, 21, 21, 256, 256, 3, 1, 1, 1),     # BEV-level layer: few pixels, many channels
+    (8, 64, 96, 64, 64, 3, 1, 1, 1),       # many rows: split partial sums
+]
+
+
+def _ref(x, w, dy, stride, pad, dil):
+    x = x.clone().requires_grad_(True)
+    w = w.clone().requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, pad, dil)
+    y.backward(dy)
+    return x.grad, w.grad
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_wgrad_matches_autograd(case):
+    from thinktwice_amd import ops, weights
+    N, H, W, Cin, Cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5
+    OH, OW = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    dy = torch.randn(N, Cout, OH, OW, generator=g)
+    _, dw_ref = _ref(x, w, dy, stride, pad, dil)
+    cp = (Cin + 3) // 4 * 4
+    xq = weights.to_channel_last(x, torch.float32).cuda()                 # (N, H, W, cp), zero-padded channels
+    dyq = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dw = ops.conv2d_wgrad(xq, dyq, k, k, stride, pad, dil, cin=Cin, cin_pad=cp)
+    torch.cuda.synchronize()
+    got = dw[..., :Cin].permute(0, 3, 1, 2).cpu()
+    err = float((got - dw_ref).abs().max() / dw_ref.abs().max())
+    assert err < 2e-5, err
+    assert float(dw[..., Cin:].abs().max()) == 0.0 if cp > Cin else True
+    # accumulate into an existing gradient, bit-reproducible
+    dw2 = ops.conv2d_wgrad(xq, dyq, k, k, stride, pad, dil, cin=Cin, cin_pad=cp, out=dw.clone(), accumulate=True)
+    assert float((dw2 - 2 * dw).abs().max()) <= 1e-5 * float(dw.abs().max())       # (g + partials) vs 2 * sum: rounding only
+    assert torch.equal(ops.conv2d_wgrad(xq, dyq, k, k, stride, pad, dil, cin=Cin, cin_pad=cp), dw)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[3] >= 32])
+@pytest.mark.parametrize("x3", [False, True])
+def test_conv_dgrad_matches_autograd(case, x3):
+    from thinktwice_amd import ops, weights
+    N, H, W, Cin, Cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(Cin * 3 + Cout + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5
+    OH, OW = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    dy = torch.randn(N, Cout, OH, OW, generator=g)
+    dx_ref, _ = _ref(x, w, dy, stride, pad, dil)
+    wq = w.permute(0, 2, 3, 1).contiguous().cuda()                       # [Cout][KH][KW][Cin]
+    dyq = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dx = ops.conv2d_dgrad(dyq, wq, (H, W), stride, pad, dil, x3=x3)
+    torch.cuda.synchronize()
+    got = dx.permute(0, 3, 1, 2).cpu()
+    assert got.shape == dx_ref.shape
+    err = float((got - dx_ref).abs().max() / dx_ref.abs().max())
+    assert err < (2e-4 if x3 else 2e-5), err

@@ -510,6 +510,64 @@ def mlp_chain(x, stages, n_split=1):
     check(lib().tt_mlp_chain(ptr(x), _ll(R), _c(x.stride(0)), _c(n), arr, _c(n_split), _st(x)), "tt_mlp_chain")
 
 
+# ----------------------------------------------------------------------------- convolution backward (training step)
+def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, dil=1, cin=None, in_coff=0, cout=None, dy_coff=0, cin_pad=None,
+                 out=None, accumulate=False):
+    """Weight gradient of `conv2d` (tt_conv2d_wgrad): x [N,H,W,Cs] f32, dy [N,OH,OW,Cd] f32 (the gradient w.r.t. the
+    convolution's raw output) -> dw [cout][kh][kw][cin_pad] f32 in the weight layout (added to `out` if accumulate)."""
+    require_cuda(x, dy)
+    assert x.dtype == torch.float32 and dy.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous()
+    N, H, W, Cs = x.shape
+    N2, OH, OW, Cd = dy.shape
+    assert N2 == N
+    cin = cin or (Cs - in_coff)
+    cout = cout or (Cd - dy_coff)
+    cin_pad = cin_pad or cin
+    if out is None:
+        assert not accumulate
+        out = torch.empty(cout, kh, kw, cin_pad, dtype=torch.float32, device=x.device)
+    assert tuple(out.shape) == (cout, kh, kw, cin_pad) and out.is_contiguous()
+    L = lib()
+    L.tt_conv2d_wgrad_workspace_bytes.restype = ctypes.c_longlong
+    nb = int(L.tt_conv2d_wgrad_workspace_bytes(_c(N), _c(OH), _c(cout), _c(cin), _c(cin_pad), _c(kh), _c(kw)))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    check(L.tt_conv2d_wgrad(ptr(x), _c(N), _c(H), _c(W), _c(cin), _c(Cs), _c(in_coff), ptr(dy), _c(OH), _c(OW), _c(cout),
+                            _c(Cd), _c(dy_coff), _c(kh), _c(kw), _c(stride), _c(pad), _c(dil), _c(cin_pad),
+                            _c(1 if accumulate else 0), ptr(out), ptr(ws), _ll(nb), _st(x)), "tt_conv2d_wgrad")
+    return out
+
+
+def dgrad_weight(w):
+    """[Cout][KH][KW][Cin] -> [Cin][KH][KW][Cout] rotated by 180 degrees: the weights whose forward convolution over dy is
+    the input gradient (layout plumbing; re-derived whenever the weights change)."""
+    return w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+
+
+def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, dil=1, x3=True):
+    """Input gradient of `conv2d`: dy [N,OH,OW,Cout] f32, w [Cout][KH][KW][Cin] f32 -> dx [N,H,W,Cin] f32.
+    = tt_conv2d_fwd of dy (zero-inserted for stride > 1) with dgrad_weight(w) and padding dil*(K-1) - pad; `x3` runs it
+    in bf16x3 like the forward of the headline mode (else exact f32)."""
+    from . import weights
+    require_cuda(dy, w)
+    assert dy.dtype == torch.float32 and w.dtype == torch.float32
+    Cout, KH, KW, Cin = w.shape
+    H, W = in_hw
+    N, OH, OW, Cd = dy.shape
+    assert Cd == Cout
+    fh, fw = H + 2 * pad - dil * (KH - 1), W + 2 * pad - dil * (KW - 1)     # stride-1 output size of the forward conv
+    if stride > 1:
+        z = torch.zeros(N, fh, fw, Cout, dtype=torch.float32, device=dy.device)
+        z[:, :(OH - 1) * stride + 1:stride, :(OW - 1) * stride + 1:stride] = dy
+        dy = z
+    else:
+        assert (OH, OW) == (fh, fw), ((OH, OW), (fh, fw))
+    wt = dgrad_weight(w)
+    pad_h, pad_w = dil * (KH - 1) - pad, dil * (KW - 1) - pad
+    assert pad_h == pad_w and pad_h >= 0, "conv2d_dgrad: square kernels with pad <= dil*(K-1)"
+    wx = weights.split_pairs_x3(wt) if (x3 and Cout % 32 == 0) else None
+    return conv2d(dy, wt, stride=1, pad=pad_h, dil=dil, w_x3=wx)
+
+
 # ----------------------------------------------------------------------------- composite decoder kernels
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
