@@ -430,6 +430,16 @@ long long tt_conv2d_wgrad_workspace_bytes(int N, int OH, int Cout, int Cin, int 
 int tt_conv2d_wgrad(const float* x, int N, int H, int W, int Cin, int x_cstride, int x_coff, const float* dy, int OH,
                     int OW, int Cout, int dy_cstride, int dy_coff, int KH, int KW, int stride, int pad, int dil,
                     int cin_pad, int accumulate, float* dw, void* workspace, long long workspace_bytes, void* stream);
+/* Backward of tt_conv2d_fwd's fused epilogue  y = act(scale[c]*conv + shift[c] + res1 + res2)  from dy and the saved
+ * output y (all [M][*] channel-last f32 with channel stride / offset):  g = dy * act'(.)  (TT_ACT_NONE / RELU / SIGMOID);
+ * dconv = g * scale[c] (feeds tt_conv2d_wgrad and the dgrad convolution), dres = g (optional), dshift[c] (+)= sum_m g,
+ * dscale[c] (+)= sum_m g * conv.  Folded BatchNorm: dgamma = (dscale - mean*dshift)/sigma, dbeta = dshift.  Deterministic. */
+long long tt_conv_epilogue_bwd_workspace_bytes(int C);
+int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff, const float* y, int y_cstride, int y_coff,
+                         const float* res1, int res1_cstride, int res1_coff, const float* res2, int res2_cstride,
+                         int res2_coff, const float* scale, const float* shift, long long M, int C, int act, float* dconv,
+                         int dconv_cstride, int dconv_coff, float* dres, int dres_cstride, int dres_coff, float* dscale,
+                         float* dshift, int accumulate, void* workspace, long long workspace_bytes, void* stream);
 
 /* SURVEY 8f-1, LiDAR side: merge of the two 180-degree half sweeps of the closed-loop tick
  * (leaderboard/team_code/thinktwice_agent.py:340-352).  prev / now: (n, 4) f32 (x, y, z, intensity) device rows;

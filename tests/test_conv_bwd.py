@@ -72,3 +72,65 @@ def test_conv_dgrad_matches_autograd(case, x3):
     assert got.shape == dx_ref.shape
     err = float((got - dx_ref).abs().max() / dx_ref.abs().max())
     assert err < (2e-4 if x3 else 2e-5), err
+
+
+@pytest.mark.parametrize("act,nres,C", [(1, 0, 64), (1, 1, 256), (1, 2, 96), (0, 0, 320), (2, 0, 32), (0, 1, 1280)])
+def test_conv_epilogue_bwd_matches_autograd(act, nres, C):
+    """y = act(scale*conv + shift + res1 + res2): gradients w.r.t. conv, the residuals, scale and shift from dy and the
+    saved y (tt_conv_epilogue_bwd) against autograd; then a whole conv + folded-BN + ReLU + residual layer backward
+    (epilogue -> wgrad / dgrad) against autograd of the same layer."""
+    from thinktwice_amd import ops
+    g = torch.Generator().manual_seed(act * 100 + nres * 10 + C)
+    M = 1531
+    conv = torch.randn(M, C, generator=g, requires_grad=True)
+    scale = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    shift = (torch.randn(C, generator=g) * 0.3).requires_grad_(True)
+    res = [torch.randn(M, C, generator=g, requires_grad=True) for _ in range(nres)]
+    pre = conv * scale + shift + sum(res)
+    y = {0: pre, 1: torch.relu(pre), 2: torch.sigmoid(pre)}[act]
+    dy = torch.randn(M, C, generator=g)
+    y.backward(dy)
+    r = [t.detach().cuda() for t in res] + [None, None]
+    dconv, dres, dscale, dshift = ops.conv_epilogue_bwd(dy.cuda(), y.detach().cuda(), scale.detach().cuda(),
+                                                        shift.detach().cuda(), act, r[0], r[1], want_dres=nres > 0)
+    torch.cuda.synchronize()
+    tol = 2e-4 if act == 2 else 2e-5          # sigmoid recovers the pre-activation through logit(y)
+
+    def rel(a, b):
+        return float((a.cpu() - b).abs().max() / b.abs().max())
+    assert rel(dconv, conv.grad) < tol
+    assert rel(dshift, shift.grad) < tol and rel(dscale, scale.grad) < 5 * tol
+    if nres:
+        assert rel(dres, res[0].grad) < tol
+
+
+def test_conv_bn_relu_residual_layer_backward():
+    from thinktwice_amd import ops
+    g = torch.Generator().manual_seed(11)
+    N, H, W, Cin, Cout = 2, 24, 32, 64, 128
+    x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (Cin * 9) ** -0.5).requires_grad_(True)
+    gamma = (torch.rand(Cout, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(Cout, generator=g) * 0.2).requires_grad_(True)
+    mean, var = torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5
+    res = torch.randn(N, Cout, H, W, generator=g, requires_grad=True)
+    y = torch.relu(F.batch_norm(F.conv2d(x, w, None, 1, 1), mean, var, gamma, beta, False, 0.0, 1e-5) + res)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    y.backward(dy)
+    sigma = torch.sqrt(var + 1e-5)
+    scale, shift = (gamma / sigma).detach(), (beta - mean * gamma / sigma).detach()
+    cl = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()   # noqa: E731
+    xq, wq, yq, dyq, rq = cl(x), cl(w), cl(y), cl(dy), cl(res)
+    dconv, dres, dscale, dshift = ops.conv_epilogue_bwd(dyq, yq, scale.cuda(), shift.cuda(), 1, rq, want_dres=True)
+    dconv = dconv.view(N, H, W, Cout)
+    dw = ops.conv2d_wgrad(xq, dconv, 3, 3, 1, 1, 1)
+    dx = ops.conv2d_dgrad(dconv, wq, (H, W), 1, 1, 1, x3=True)
+    dgamma = (dscale.cpu() - mean * dshift.cpu()) / sigma
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return float((a.cpu() - b).abs().max() / b.abs().max())
+    assert rel(dw.permute(0, 3, 1, 2), w.grad) < 3e-5
+    assert rel(dx.permute(0, 3, 1, 2), x.grad) < 2e-4
+    assert rel(dres.view(N, H, W, Cout).permute(0, 3, 1, 2), res.grad) < 1e-6
+    assert rel(dgamma, gamma.grad) < 1e-4 and rel(dshift, beta.grad) < 3e-5

@@ -131,6 +131,90 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
     dw[i] = v;
 }
 
+// Backward of the fused conv epilogue  y = act(scale[c] * conv + shift[c] + res1 + res2)  (folded BatchNorm affine /
+// bias, residual adds, activation; conv_common.h's forward epilogue).  From dy and the SAVED OUTPUT y:
+//   g      = dy * act'(pre)           act' from y: ReLU y > 0; sigmoid y (1 - y); none 1 (GELU / softplus need pre: refused)
+//   dconv  = g * scale[c]             -> the dy of tt_conv2d_wgrad / conv2d_dgrad
+//   dres   = g                        -> gradient of every residual input (optional output)
+//   dshift[c] = sum_m g,   dscale[c] = sum_m g * conv = sum_m g * (pre - shift[c] - res) / scale[c]
+// with pre recovered from y (ReLU: pre = y wherever g != 0; sigmoid: logit(y); none: y).  The per-channel sums go through
+// per-workgroup partials added in index order (deterministic).  BatchNorm parameters follow on the host side from
+// scale = gamma / sigma, shift = beta - mu * scale:  dgamma = (dscale - mu * dshift) / sigma,  dbeta = dshift.
+constexpr int kEpiBlocks = 512;
+
+struct EpiBwdArgs {
+    const float* dy; const float* y; const float* res1; const float* res2;
+    const float* scale; const float* shift;
+    float* dconv; float* dres; float* partial;     // partial: [kEpiBlocks][2][C]
+    long long M;
+    int C, dy_cstride, dy_coff, y_cstride, y_coff, r1_cstride, r1_coff, r2_cstride, r2_coff;
+    int dconv_cstride, dconv_coff, dres_cstride, dres_coff, act;
+};
+
+__global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs a) {
+    __shared__ float red[2][256];
+    const int tid = threadIdx.x;
+    // thread (ty, tx): channel tx, tx + TX, ...; rows ty, ty + TY, ... of this workgroup's row range
+    const int TX = a.C < 256 ? a.C : 256, TY = 256 / TX;
+    const int tx = tid % TX, ty = tid / TX;
+    const long long rows_per = (a.M + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * rows_per, r1 = min(a.M, r0 + rows_per);
+    for (int c0 = 0; c0 < a.C; c0 += TX) {             // uniform trip count: the loop body holds barriers
+        const int c = c0 + tx;
+        const bool c_ok = c < a.C;
+        const float sc = (c_ok && a.scale) ? a.scale[c] : 1.f, sh = (c_ok && a.shift) ? a.shift[c] : 0.f;
+        float s_g = 0.f, s_gx = 0.f;
+        if (ty < TY && c_ok) {
+            for (long long m = r0 + ty; m < r1; m += TY) {
+                const float yv = a.y[m * a.y_cstride + a.y_coff + c];
+                float g = a.dy[m * a.dy_cstride + a.dy_coff + c];
+                float pre = yv;
+                if (a.act == TT_ACT_RELU) {
+                    g = yv > 0.f ? g : 0.f;
+                } else if (a.act == TT_ACT_SIGMOID) {
+                    g *= yv * (1.f - yv);
+                    pre = logf(yv / (1.f - yv));
+                }
+                float r = 0.f;
+                if (a.res1) r += a.res1[m * a.r1_cstride + a.r1_coff + c];
+                if (a.res2) r += a.res2[m * a.r2_cstride + a.r2_coff + c];
+                s_g += g;
+                s_gx += g * ((pre - sh - r) / sc);
+                a.dconv[m * a.dconv_cstride + a.dconv_coff + c] = g * sc;
+                if (a.dres) a.dres[m * a.dres_cstride + a.dres_coff + c] = g;
+            }
+        }
+        // add the TY row lanes of this channel (fixed order)
+        __syncthreads();
+        red[0][tid] = s_g;
+        red[1][tid] = s_gx;
+        __syncthreads();
+        if (ty == 0 && c_ok) {
+            float t0 = 0.f, t1 = 0.f;
+            for (int q = 0; q < TY; ++q) {
+                t0 += red[0][q * TX + tx];
+                t1 += red[1][q * TX + tx];
+            }
+            a.partial[((long long)blockIdx.x * 2 + 0) * a.C + c] = t0;
+            a.partial[((long long)blockIdx.x * 2 + 1) * a.C + c] = t1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_epilogue_bwd_finish_kernel(const float* __restrict__ partial, int blocks, int C,
+                                                                       int accumulate, float* __restrict__ dscale,
+                                                                       float* __restrict__ dshift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float g = 0.f, gx = 0.f;
+    for (int b = 0; b < blocks; ++b) {
+        g += partial[((long long)b * 2 + 0) * C + c];
+        gx += partial[((long long)b * 2 + 1) * C + c];
+    }
+    if (dshift) dshift[c] = (accumulate ? dshift[c] : 0.f) + g;
+    if (dscale) dscale[c] = (accumulate ? dscale[c] : 0.f) + gx;
+}
+
 static int wgrad_splits(int N, int OH, int Cout, int Cin, int taps) {
     const long long tiles = (long long)div_up(Cout, 64) * div_up(Cin, 64) * taps;
     long long s = (4LL * kNumCU + tiles - 1) / tiles;        // aim at >= 4 workgroups per CU
@@ -175,4 +259,32 @@ extern "C" int tt_conv2d_wgrad(const float* x, int N, int H, int W, int Cin, int
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, st, (const float*)workspace, n,
                        splits, accumulate, dw);
     return check_launch("tt_conv2d_wgrad");
+}
+
+extern "C" long long tt_conv_epilogue_bwd_workspace_bytes(int C) { return (long long)kEpiBlocks * 2 * C * 4; }
+
+extern "C" int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff, const float* y, int y_cstride, int y_coff,
+                                    const float* res1, int res1_cstride, int res1_coff, const float* res2, int res2_cstride,
+                                    int res2_coff, const float* scale, const float* shift, long long M, int C, int act,
+                                    float* dconv, int dconv_cstride, int dconv_coff, float* dres, int dres_cstride,
+                                    int dres_coff, float* dscale, float* dshift, int accumulate, void* workspace,
+                                    long long workspace_bytes, void* stream) {
+    TT_REQUIRE(dy && y && dconv && workspace && M > 0 && C > 0, "tt_conv_epilogue_bwd: bad argument");
+    TT_REQUIRE(act == TT_ACT_NONE || act == TT_ACT_RELU || act == TT_ACT_SIGMOID,
+               "tt_conv_epilogue_bwd: activation %d needs the pre-activation, which the forward does not keep", act);
+    TT_REQUIRE(workspace_bytes >= tt_conv_epilogue_bwd_workspace_bytes(C), "tt_conv_epilogue_bwd: workspace too small");
+    EpiBwdArgs a;
+    a.dy = dy; a.y = y; a.res1 = res1; a.res2 = res2; a.scale = scale; a.shift = shift;
+    a.dconv = dconv; a.dres = dres; a.partial = (float*)workspace;
+    a.M = M; a.C = C; a.dy_cstride = dy_cstride; a.dy_coff = dy_coff; a.y_cstride = y_cstride; a.y_coff = y_coff;
+    a.r1_cstride = res1_cstride; a.r1_coff = res1_coff; a.r2_cstride = res2_cstride; a.r2_coff = res2_coff;
+    a.dconv_cstride = dconv_cstride; a.dconv_coff = dconv_coff; a.dres_cstride = dres_cstride; a.dres_coff = dres_coff;
+    a.act = act;
+    const int blocks = (int)(M < kEpiBlocks ? M : kEpiBlocks);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (dscale || dshift)
+        hipLaunchKernelGGL(conv_epilogue_bwd_finish_kernel, dim3((unsigned)div_up(C, 256)), dim3(256), 0, st,
+                           (const float*)workspace, blocks, C, accumulate, dscale, dshift);
+    return check_launch("tt_conv_epilogue_bwd");
 }

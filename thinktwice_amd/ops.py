@@ -568,6 +568,36 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, dil=1, x3=True):
     return conv2d(dy, wt, stride=1, pad=pad_h, dil=dil, w_x3=wx)
 
 
+def conv_epilogue_bwd(dy, y, scale=None, shift=None, act=0, res1=None, res2=None, want_dres=False, dscale=None, dshift=None,
+                      accumulate=False, C=None, dy_coff=0, y_coff=0, res1_coff=0, res2_coff=0):
+    """Backward of conv2d's fused epilogue (tt_conv_epilogue_bwd): dy / y / res* [..., Cs] f32 channel-last views of the
+    same M rows -> (dconv [M, C] dense f32, dres [M, C] or None, dscale [C], dshift [C])."""
+    require_cuda(dy, y)
+    C = C or (y.shape[-1] - y_coff)
+    M = y.numel() // y.shape[-1]
+    assert dy.numel() // dy.shape[-1] == M and dy.dtype == torch.float32 and y.dtype == torch.float32
+    dev = y.device
+    dconv = torch.empty(M, C, dtype=torch.float32, device=dev)
+    dres = torch.empty(M, C, dtype=torch.float32, device=dev) if want_dres else None
+    if dscale is None:
+        dscale = torch.empty(C, dtype=torch.float32, device=dev)
+        dshift = torch.empty(C, dtype=torch.float32, device=dev)
+        accumulate = False
+    L = lib()
+    L.tt_conv_epilogue_bwd_workspace_bytes.restype = ctypes.c_longlong
+    nb = int(L.tt_conv_epilogue_bwd_workspace_bytes(_c(C)))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+
+    def cs(t):
+        return 0 if t is None else t.shape[-1]
+    check(L.tt_conv_epilogue_bwd(ptr(dy), _c(dy.shape[-1]), _c(dy_coff), ptr(y), _c(y.shape[-1]), _c(y_coff),
+                                 ptr(res1), _c(cs(res1)), _c(res1_coff), ptr(res2), _c(cs(res2)), _c(res2_coff),
+                                 ptr(scale), ptr(shift), _ll(M), _c(C), _c(act), ptr(dconv), _c(C), _c(0), ptr(dres),
+                                 _c(C), _c(0), ptr(dscale), ptr(dshift), _c(1 if accumulate else 0), ptr(ws), _ll(nb),
+                                 _st(y)), "tt_conv_epilogue_bwd")
+    return dconv, dres, dscale, dshift
+
+
 # ----------------------------------------------------------------------------- composite decoder kernels
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
