@@ -432,14 +432,23 @@ int tt_conv2d_wgrad(const float* x, int N, int H, int W, int Cin, int x_cstride,
                     int cin_pad, int accumulate, float* dw, void* workspace, long long workspace_bytes, void* stream);
 /* Backward of tt_conv2d_fwd's fused epilogue  y = act(scale[c]*conv + shift[c] + res1 + res2)  from dy and the saved
  * output y (all [M][*] channel-last f32 with channel stride / offset):  g = dy * act'(.)  (TT_ACT_NONE / RELU / SIGMOID);
- * dconv = g * scale[c] (feeds tt_conv2d_wgrad and the dgrad convolution), dres = g (optional), dshift[c] (+)= sum_m g,
- * dscale[c] (+)= sum_m g * conv.  Folded BatchNorm: dgamma = (dscale - mean*dshift)/sigma, dbeta = dshift.  Deterministic. */
+ * dconv = g * scale[c] (feeds tt_conv2d_wgrad and the dgrad convolution); dres / dres2 (optional): g added to
+ * (dres_accumulate) or written over the gradient windows of the two residual inputs -- overwrite is for a layer whose
+ * output was written in place over its residual; dshift[c] (+)= sum_m g, dscale[c] (+)= sum_m g * conv (skipped when
+ * scale is NULL; needs res1 / res2 to still hold their forward values).  Folded BatchNorm: dgamma = (dscale -
+ * mean*dshift)/sigma, dbeta = dshift.  Deterministic. */
 long long tt_conv_epilogue_bwd_workspace_bytes(int C);
 int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff, const float* y, int y_cstride, int y_coff,
                          const float* res1, int res1_cstride, int res1_coff, const float* res2, int res2_cstride,
                          int res2_coff, const float* scale, const float* shift, long long M, int C, int act, float* dconv,
-                         int dconv_cstride, int dconv_coff, float* dres, int dres_cstride, int dres_coff, float* dscale,
-                         float* dshift, int accumulate, void* workspace, long long workspace_bytes, void* stream);
+                         int dconv_cstride, int dconv_coff, float* dres, int dres_cstride, int dres_coff, float* dres2,
+                         int dres2_cstride, int dres2_coff, int dres_accumulate, float* dscale, float* dshift,
+                         int accumulate, void* workspace, long long workspace_bytes, void* stream);
+/* backward of tt_maxpool3x3s2 (F.max_pool2d(x,3,2,1)): dx[n][ih][iw][c] += sum of dy over the <= 4 windows whose FIRST
+ * maximum (scan order kh, kw, as torch) is this pixel; gather form, no atomics */
+int tt_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* backward of tt_upsample_nearest_add w.r.t. src: dsrc[n][sy][sx][c] += sum of ddst over the dst pixels that read (sy, sx) */
+int tt_upsample_nearest_add_bwd(const float* ddst, float* dsrc, int N, int H, int W, int C, int h, int w, void* stream);
 
 /* SURVEY 8f-1, LiDAR side: merge of the two 180-degree half sweeps of the closed-loop tick
  * (leaderboard/team_code/thinktwice_agent.py:340-352).  prev / now: (n, 4) f32 (x, y, z, intensity) device rows;

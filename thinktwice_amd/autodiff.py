@@ -1,0 +1,138 @@
+"""Reverse-mode tape for the training step: the backward pass the reference gets from torch.autograd under
+`loss.backward()` (apis/mmdet_train.py:72-79 through mmcv's OptimizerHook), issued here as explicit HIP backward kernels.
+
+The forward mirror (lss.py, ...) calls `ops.*`; while a tape is active (`with Tape() as tape:`) those calls append a backward
+closure.  `tape.backward()` runs the closures in reverse.  Gradients of activations live in buffers that mirror the
+forward's activation STORAGE (one zero-initialised f32 buffer per storage, so the channel-offset "concat" writes and the
+`t[:n]` views of the forward address the same gradient memory the same way); every backward op ACCUMULATES into its inputs'
+gradient windows.  Parameter gradients are collected under the reference's state_dict names and layouts
+(`tape.param_grads["img_encoder.img_backbone.layer1.0.conv1.weight"]` is [Cout, Cin, KH, KW]), which is what the gradient
+golden F13 (tests/golden/gen_golden.py) is keyed by.
+
+Covered so far: convolution with its fused epilogue (folded eval-mode BatchNorm affine or bias, ReLU / sigmoid / none, up to
+two residual inputs, in-place residual outputs), 3x3/2 max-pooling, the in-place nearest-upsample-add of the PAFPN top-down
+path -- i.e. the ResNet-50 + PAFPN camera trunk.  Everything else still raises when it is reached with a tape active.
+"""
+import torch
+
+from . import ops
+
+TAPE = None
+
+
+class ConvMeta:
+    """What a prepared Conv needs for its parameter gradients: state_dict names and the BatchNorm statistics folded into
+    its scale / shift (scale = gamma / sigma, shift = beta - mean * scale [+ bias * scale])."""
+
+    def __init__(self, name, cin, bn=None, mean=None, sigma=None, bias=None):
+        self.name, self.cin, self.bn, self.mean, self.sigma, self.bias = name, cin, bn, mean, sigma, bias
+
+
+CONV_META = {}          # id(weight tensor) -> ConvMeta, filled by layers.conv_from_sd
+
+
+class Tape:
+    def __init__(self, x3=True):
+        self.nodes = []
+        self.grads = {}             # storage data_ptr -> flat f32 gradient buffer covering the whole storage
+        self.param_grads = {}
+        self.x3 = x3                # input gradients through the bf16x3 kernel (else exact f32)
+        self._keep = []             # forward tensors the closures read: kept alive until backward() returns
+
+    def __enter__(self):
+        global TAPE
+        assert TAPE is None, "nested tapes are not supported"
+        TAPE = self
+        return self
+
+    def __exit__(self, *exc):
+        global TAPE
+        TAPE = None
+        return False
+
+    # ---- activation gradients
+    def grad(self, t):
+        """The gradient view of activation `t` (same shape / strides / storage offset inside its storage's buffer)."""
+        assert t.dtype == torch.float32, "training runs on f32 activation storage (dtype torch.float32 or 'f32x3')"
+        st = t.untyped_storage()
+        key = st.data_ptr()
+        buf = self.grads.get(key)
+        if buf is None:
+            buf = torch.zeros(st.nbytes() // 4, dtype=torch.float32, device=t.device)
+            self.grads[key] = buf
+            self._keep.append(t)
+        return buf.as_strided(t.shape, t.stride(), t.storage_offset())
+
+    def seed(self, t, g):
+        """d(loss)/d(t) += g  (the loss side of the graph)."""
+        self.grad(t).add_(g.to(t.device, torch.float32))
+
+    def add_param_grad(self, name, g):
+        if name in self.param_grads:
+            self.param_grads[name] = self.param_grads[name] + g
+        else:
+            self.param_grads[name] = g
+
+    def backward(self):
+        for fn in reversed(self.nodes):
+            fn()
+        self.nodes.clear()
+        self._keep.clear()
+
+    # ---- recorders (called from ops.* while the tape is active)
+    def conv(self, x, w, y, stride, pad, dil, scale, shift, act, in_coff, cin, out_coff, res1, res1_coff, res2, res2_coff,
+             pixel_shuffle2, in_cstride):
+        meta = CONV_META.get(id(w))
+        if meta is None or pixel_shuffle2 or in_cstride is not None:
+            raise NotImplementedError("tape: convolution form without a backward yet (unnamed weight, pixel shuffle or "
+                                      "row-run stem)")
+        Cout, KH, KW, cin_p = w.shape
+        self._keep += [x, y, res1, res2]
+        inplace1 = res1 is not None and res1.data_ptr() == y.data_ptr() and res1_coff == out_coff
+
+        def bwd():
+            gy = self.grad(y)
+            M = y.numel() // y.shape[-1]
+            N, H, W_, _ = x.shape
+            OH, OW = y.shape[1:3]
+            g1 = None if res1 is None else self.grad(res1)
+            g2 = None if res2 is None else self.grad(res2)
+            if inplace1:
+                # y overwrote res1: its old value is gone (so is dscale; such layers carry a bias only) and the gradient
+                # w.r.t. it is g itself, written over gy in place
+                assert scale is None and res2 is None, "in-place residual output: bias-only epilogue"
+                dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, y, None, shift, act, None, None, C=Cout,
+                                                                 dy_coff=out_coff, y_coff=out_coff, dres1=gy,
+                                                                 dres1_coff=out_coff, dres_accumulate=False)
+            else:
+                dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, y, scale, shift, act, res1, res2, C=Cout,
+                                                                 dy_coff=out_coff, y_coff=out_coff, res1_coff=res1_coff,
+                                                                 res2_coff=res2_coff, dres1=g1, dres1_coff=res1_coff,
+                                                                 dres2=g2, dres2_coff=res2_coff)
+            dconv = dconv.view(N, OH, OW, Cout)
+            # parameters
+            dw = ops.conv2d_wgrad(x, dconv, KH, KW, stride, pad, dil, cin=cin, in_coff=in_coff, cin_pad=cin_p)
+            self.add_param_grad(meta.name + ".weight", dw[..., :meta.cin].permute(0, 3, 1, 2).contiguous())
+            if meta.bn is not None:
+                # scale = gamma / sigma, shift = beta + (bias - mean) * gamma / sigma
+                off = meta.mean if meta.bias is None else meta.mean - meta.bias
+                self.add_param_grad(meta.bn + ".weight", (dscale - off * dshift) / meta.sigma)
+                self.add_param_grad(meta.bn + ".bias", dshift)
+                if meta.bias is not None:
+                    self.add_param_grad(meta.name + ".bias", dshift * scale)
+            elif meta.bias is not None:
+                self.add_param_grad(meta.name + ".bias", dshift)
+            # input: conv of dconv with the rotated weights, accumulated into x's gradient window
+            gx = self.grad(x)
+            ops.conv2d_dgrad(dconv, w, (H, W_), stride, pad, dil, x3=self.x3, out=gx, out_coff=in_coff)
+
+        self.nodes.append(bwd)
+
+    def maxpool3x3s2(self, x, y):
+        self._keep += [x, y]
+        self.nodes.append(lambda: ops.maxpool3x3s2_bwd(x, self.grad(y).contiguous(), self.grad(x)))
+
+    def upsample_nearest_add_(self, dst, src):
+        self._keep += [dst, src]
+        # dst += up(src) in place: d/d(old dst) is the identity (the gradient buffer is shared), d/d(src) pools it
+        self.nodes.append(lambda: ops.upsample_nearest_add_bwd(self.grad(dst).contiguous(), self.grad(src)))

@@ -145,10 +145,10 @@ constexpr int kEpiBlocks = 512;
 struct EpiBwdArgs {
     const float* dy; const float* y; const float* res1; const float* res2;
     const float* scale; const float* shift;
-    float* dconv; float* dres; float* partial;     // partial: [kEpiBlocks][2][C]
+    float* dconv; float* dres; float* dres2; float* partial;     // partial: [kEpiBlocks][2][C]
     long long M;
     int C, dy_cstride, dy_coff, y_cstride, y_coff, r1_cstride, r1_coff, r2_cstride, r2_coff;
-    int dconv_cstride, dconv_coff, dres_cstride, dres_coff, act;
+    int dconv_cstride, dconv_coff, dres_cstride, dres_coff, dres2_cstride, dres2_coff, dres_accumulate, act;
 };
 
 __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs a) {
@@ -179,9 +179,16 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
                 if (a.res1) r += a.res1[m * a.r1_cstride + a.r1_coff + c];
                 if (a.res2) r += a.res2[m * a.r2_cstride + a.r2_coff + c];
                 s_g += g;
-                s_gx += g * ((pre - sh - r) / sc);
+                if (a.scale) s_gx += g * ((pre - sh - r) / sc);   // (needs the pre-add residual values: see the header)
                 a.dconv[m * a.dconv_cstride + a.dconv_coff + c] = g * sc;
-                if (a.dres) a.dres[m * a.dres_cstride + a.dres_coff + c] = g;
+                if (a.dres) {
+                    float* d = a.dres + m * a.dres_cstride + a.dres_coff + c;
+                    *d = a.dres_accumulate ? *d + g : g;
+                }
+                if (a.dres2) {
+                    float* d = a.dres2 + m * a.dres2_cstride + a.dres2_coff + c;
+                    *d = a.dres_accumulate ? *d + g : g;
+                }
             }
         }
         // add the TY row lanes of this channel (fixed order)
@@ -267,7 +274,8 @@ extern "C" int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff
                                     const float* res1, int res1_cstride, int res1_coff, const float* res2, int res2_cstride,
                                     int res2_coff, const float* scale, const float* shift, long long M, int C, int act,
                                     float* dconv, int dconv_cstride, int dconv_coff, float* dres, int dres_cstride,
-                                    int dres_coff, float* dscale, float* dshift, int accumulate, void* workspace,
+                                    int dres_coff, float* dres2, int dres2_cstride, int dres2_coff, int dres_accumulate,
+                                    float* dscale, float* dshift, int accumulate, void* workspace,
                                     long long workspace_bytes, void* stream) {
     TT_REQUIRE(dy && y && dconv && workspace && M > 0 && C > 0, "tt_conv_epilogue_bwd: bad argument");
     TT_REQUIRE(act == TT_ACT_NONE || act == TT_ACT_RELU || act == TT_ACT_SIGMOID,
@@ -279,6 +287,7 @@ extern "C" int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff
     a.M = M; a.C = C; a.dy_cstride = dy_cstride; a.dy_coff = dy_coff; a.y_cstride = y_cstride; a.y_coff = y_coff;
     a.r1_cstride = res1_cstride; a.r1_coff = res1_coff; a.r2_cstride = res2_cstride; a.r2_coff = res2_coff;
     a.dconv_cstride = dconv_cstride; a.dconv_coff = dconv_coff; a.dres_cstride = dres_cstride; a.dres_coff = dres_coff;
+    a.dres2 = dres2; a.dres2_cstride = dres2_cstride; a.dres2_coff = dres2_coff; a.dres_accumulate = dres_accumulate;
     a.act = act;
     const int blocks = (int)(M < kEpiBlocks ? M : kEpiBlocks);
     hipStream_t st = (hipStream_t)stream;

@@ -1003,7 +1003,8 @@ extern "C" int tt_voxel_pool_fwd_ws(int batch_size, int num_points, int num_chan
                                input_features, output_features, pos_memo, partial, slot_table);                    \
     } while (0)
     if (C <= 256) {
-        if (rf >= 16) TT_P1(1, 16);
+        if (rf >= 32) TT_P1(1, 32);
+        else if (rf >= 16) TT_P1(1, 16);
         else if (rf >= 8) TT_P1(1, 8);
         else TT_P1(1, 4);
     } else {

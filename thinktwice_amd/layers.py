@@ -42,6 +42,12 @@ def conv_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, stride=1, pad=0, di
                                        sd[bn + ".running_var"], eps, bias)
     else:
         scale, shift = None, bias
+    if weight is None:      # what the training tape needs for this layer's parameter gradients (autodiff.py)
+        from . import autodiff
+        autodiff.CONV_META[id(wq)] = autodiff.ConvMeta(
+            name, w.shape[1], bn,
+            None if bn is None else _dev(sd[bn + ".running_mean"], device),
+            None if bn is None else torch.sqrt(_dev(sd[bn + ".running_var"], device) + eps), _dev(bias, device))
     return Conv(wq, _dev(scale, device), _dev(shift, device), stride, pad, dil, act, x3=dtype == weights.X3)
 
 

@@ -295,7 +295,9 @@ class LSS:
             consts = {k: v.to(img.device) for k, v in self.host_constants(img_metas, N).items()}
         NI = T * B * N
         # sweep-major image order: key sweep first (index 0 == reference sweep index -1)
-        border = self.backbone.stem_border() if (H % 2 == 0 and W % 2 == 0) else None
+        from . import autodiff
+        # (the row-run stem has no backward yet: a taped forward uses the plain 7x7 form)
+        border = self.backbone.stem_border() if (H % 2 == 0 and W % 2 == 0 and autodiff.TAPE is None) else None
         if border is not None:
             # zero-bordered image buffer for the row-run stem; the border is written once, the interior every call
             key = (NI, H, W, str(img.device))

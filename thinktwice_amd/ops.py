@@ -156,7 +156,7 @@ def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None
 def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=None, res1_coff=0,
            res2=None, res2_coff=0, out=None, out_coff=0, in_coff=0, cin=None, pixel_shuffle2=False,
            shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None, splitk_ws=None,
-           in_cstride=None, w_x3=None):
+           in_cstride=None, w_x3=None, _no_tape=False):
     """Channel-last implicit-GEMM convolution on MFMA (tt_conv2d_fwd).
 
     x   [N,H,W,Cs]  (f32 or bf16); channels [in_coff, in_coff+cin) are convolved
@@ -223,6 +223,11 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
             in_px = min(N * H * W, m_out * KH * KW)           # a strided 1x1 layer only touches the pixels it samples
             CONV_BYTES.append(in_px * (in_cstride or Cin) * esz + m_out * Cout * osz + w.numel() * w.element_size() +
                               m_out * Cout * esz * ((res1 is not None) + (res2 is not None)))
+    if not _no_tape:
+        from . import autodiff
+        if autodiff.TAPE is not None:
+            autodiff.TAPE.conv(x, w, out, stride, pad, dil, scale, shift, act, in_coff, cin, out_coff, res1, res1_coff,
+                               res2, res2_coff, pixel_shuffle2, in_cstride)
     return out
 
 
@@ -273,6 +278,9 @@ def maxpool3x3s2(x):
     out = torch.empty(N, (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1, C, dtype=x.dtype, device=x.device)
     check(lib().tt_maxpool3x3s2(ptr(x), ptr(out), _c(N), _c(H), _c(W), _c(C), _c(dtype_code(x)), _st(x)),
           "tt_maxpool3x3s2")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.maxpool3x3s2(x, out)
     return out
 
 
@@ -281,6 +289,9 @@ def upsample_nearest_add_(dst, src):
     check(lib().tt_upsample_nearest_add(ptr(dst), ptr(src), _c(N), _c(H), _c(W), _c(C), _c(src.shape[1]),
                                         _c(src.shape[2]), _c(dtype_code(dst)), _st(dst)),
           "tt_upsample_nearest_add")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.upsample_nearest_add_(dst, src)
     return dst
 
 
@@ -543,10 +554,11 @@ def dgrad_weight(w):
     return w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
 
 
-def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, dil=1, x3=True):
+def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, dil=1, x3=True, out=None, out_coff=0):
     """Input gradient of `conv2d`: dy [N,OH,OW,Cout] f32, w [Cout][KH][KW][Cin] f32 -> dx [N,H,W,Cin] f32.
     = tt_conv2d_fwd of dy (zero-inserted for stride > 1) with dgrad_weight(w) and padding dil*(K-1) - pad; `x3` runs it
-    in bf16x3 like the forward of the headline mode (else exact f32)."""
+    in bf16x3 like the forward of the headline mode (else exact f32).  With `out` the result is ADDED to the channel
+    window [out_coff, out_coff + Cin) of that gradient buffer (the conv's residual input is the buffer itself)."""
     from . import weights
     require_cuda(dy, w)
     assert dy.dtype == torch.float32 and w.dtype == torch.float32
@@ -565,20 +577,30 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, dil=1, x3=True):
     pad_h, pad_w = dil * (KH - 1) - pad, dil * (KW - 1) - pad
     assert pad_h == pad_w and pad_h >= 0, "conv2d_dgrad: square kernels with pad <= dil*(K-1)"
     wx = weights.split_pairs_x3(wt) if (x3 and Cout % 32 == 0) else None
-    return conv2d(dy, wt, stride=1, pad=pad_h, dil=dil, w_x3=wx)
+    if out is not None:
+        return conv2d(dy, wt, stride=1, pad=pad_h, dil=dil, w_x3=wx, out=out, out_coff=out_coff, res1=out,
+                      res1_coff=out_coff, _no_tape=True)
+    return conv2d(dy, wt, stride=1, pad=pad_h, dil=dil, w_x3=wx, _no_tape=True)
 
 
 def conv_epilogue_bwd(dy, y, scale=None, shift=None, act=0, res1=None, res2=None, want_dres=False, dscale=None, dshift=None,
-                      accumulate=False, C=None, dy_coff=0, y_coff=0, res1_coff=0, res2_coff=0):
+                      accumulate=False, C=None, dy_coff=0, y_coff=0, res1_coff=0, res2_coff=0, dres1=None, dres1_coff=0,
+                      dres2=None, dres2_coff=0, dres_accumulate=True):
     """Backward of conv2d's fused epilogue (tt_conv_epilogue_bwd): dy / y / res* [..., Cs] f32 channel-last views of the
-    same M rows -> (dconv [M, C] dense f32, dres [M, C] or None, dscale [C], dshift [C])."""
+    same M rows (row stride = last dim) -> (dconv [M, C] dense f32, dres, dscale [C], dshift [C]).  `dres1` / `dres2`:
+    gradient buffers of the residual inputs, g is added to (or, dres_accumulate=False, written over) their channel
+    windows; with want_dres a dense [M, C] copy of g is returned instead."""
     require_cuda(dy, y)
     C = C or (y.shape[-1] - y_coff)
     M = y.numel() // y.shape[-1]
     assert dy.numel() // dy.shape[-1] == M and dy.dtype == torch.float32 and y.dtype == torch.float32
     dev = y.device
     dconv = torch.empty(M, C, dtype=torch.float32, device=dev)
-    dres = torch.empty(M, C, dtype=torch.float32, device=dev) if want_dres else None
+    dres = None
+    if want_dres:
+        assert dres1 is None
+        dres = dres1 = torch.empty(M, C, dtype=torch.float32, device=dev)
+        dres1_coff, dres_accumulate = 0, False
     if dscale is None:
         dscale = torch.empty(C, dtype=torch.float32, device=dev)
         dshift = torch.empty(C, dtype=torch.float32, device=dev)
@@ -592,10 +614,31 @@ def conv_epilogue_bwd(dy, y, scale=None, shift=None, act=0, res1=None, res2=None
         return 0 if t is None else t.shape[-1]
     check(L.tt_conv_epilogue_bwd(ptr(dy), _c(dy.shape[-1]), _c(dy_coff), ptr(y), _c(y.shape[-1]), _c(y_coff),
                                  ptr(res1), _c(cs(res1)), _c(res1_coff), ptr(res2), _c(cs(res2)), _c(res2_coff),
-                                 ptr(scale), ptr(shift), _ll(M), _c(C), _c(act), ptr(dconv), _c(C), _c(0), ptr(dres),
-                                 _c(C), _c(0), ptr(dscale), ptr(dshift), _c(1 if accumulate else 0), ptr(ws), _ll(nb),
-                                 _st(y)), "tt_conv_epilogue_bwd")
-    return dconv, dres, dscale, dshift
+                                 ptr(scale), ptr(shift), _ll(M), _c(C), _c(act), ptr(dconv), _c(C), _c(0),
+                                 ptr(dres1), _c(cs(dres1)), _c(dres1_coff), ptr(dres2), _c(cs(dres2)), _c(dres2_coff),
+                                 _c(1 if dres_accumulate else 0), ptr(dscale if scale is not None else None), ptr(dshift),
+                                 _c(1 if accumulate else 0), ptr(ws), _ll(nb), _st(y)), "tt_conv_epilogue_bwd")
+    return dconv, dres, (dscale if scale is not None else None), dshift
+
+
+def maxpool3x3s2_bwd(x, dy, dx):
+    """dx += backward of maxpool3x3s2 (x: the forward input, dy: gradient of the pooled map); all f32 channel-last."""
+    require_cuda(x, dy, dx)
+    N, H, W, C = x.shape
+    assert x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous() and dx.shape == x.shape
+    check(lib().tt_maxpool3x3s2_bwd(ptr(x), ptr(dy), ptr(dx), _c(N), _c(H), _c(W), _c(C), _st(x)), "tt_maxpool3x3s2_bwd")
+    return dx
+
+
+def upsample_nearest_add_bwd(ddst, dsrc):
+    """dsrc += sum of ddst over the pixels that sampled it (backward of upsample_nearest_add_ w.r.t. src)."""
+    require_cuda(ddst, dsrc)
+    N, H, W, C = ddst.shape
+    _, h, w, _ = dsrc.shape
+    assert ddst.is_contiguous() and dsrc.is_contiguous()
+    check(lib().tt_upsample_nearest_add_bwd(ptr(ddst), ptr(dsrc), _c(N), _c(H), _c(W), _c(C), _c(h), _c(w), _st(ddst)),
+          "tt_upsample_nearest_add_bwd")
+    return dsrc
 
 
 # ----------------------------------------------------------------------------- composite decoder kernels
