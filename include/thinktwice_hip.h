@@ -410,9 +410,14 @@ int tt_loss_beta_kl(const float* target_alpha, const float* target_beta, const f
 int tt_loss_l1_cols(const float* pred, const float* pred_beta, long long pred_row_stride, const float* target,
                     const float* target_beta, long long rows, int cols, float* out, void* workspace, void* stream);
 /* logits_cl: channel-last [BN][H/factor][W/factor][row_stride >= num_classes]; labels [BN][H][W] float class ids
- * (255 = ignore) sampled at (y*factor, x*factor); out[0] = 10 * focal(alpha .5, gamma 2) of the mean cross entropy */
+ * (255 = ignore) sampled at (y*factor, x*factor); out[0] = 10 * focal(alpha .5, gamma 2) of the mean cross entropy;
+ * out[1], out[2] = that mean cross entropy and the number of contributing pixels (`aux` of the backward): out holds 3 floats.
+ * tt_loss_seg_focal_bwd: dlogits_cl = upstream (device scalar, NULL = 1) * d out[0] / d logits, padding channels 0. */
 int tt_loss_seg_focal(const float* logits_cl, int row_stride, int num_classes, const float* labels, int BN, int H,
                       int W, int factor, float* out, void* workspace, void* stream);
+int tt_loss_seg_focal_bwd(const float* logits_cl, int row_stride, int num_classes, const float* labels, int BN, int H,
+                          int W, int factor, const float* aux, const float* upstream_or_null, float* dlogits_cl,
+                          void* stream);
 /* logits_cl: channel-last [BN][H/factor][W/factor][row_stride >= D]; gt_depth [BN][H][W] metres (0 = no return);
  * bins of d_step from d_lo; out[0] = sum of BCE-with-logits over the foreground cells / max(1, #foreground) */
 int tt_loss_depth_bce(const float* logits_cl, int row_stride, int D, const float* gt_depth, int BN, int H, int W,
@@ -449,6 +454,8 @@ int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff, const flo
 int tt_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 /* backward of tt_upsample_nearest_add w.r.t. src: dsrc[n][sy][sx][c] += sum of ddst over the dst pixels that read (sy, sx) */
 int tt_upsample_nearest_add_bwd(const float* ddst, float* dsrc, int N, int H, int W, int C, int h, int w, void* stream);
+/* backward of tt_bilinear_up2 (x2, align_corners=True): dx [N][H][W][C] += weights^T dy [N][2H][2W][C] */
+int tt_bilinear_up2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 
 /* SURVEY 8f-1, LiDAR side: merge of the two 180-degree half sweeps of the closed-loop tick
  * (leaderboard/team_code/thinktwice_agent.py:340-352).  prev / now: (n, 4) f32 (x, y, z, intensity) device rows;

@@ -54,3 +54,51 @@ def test_camera_trunk_backward_matches_oracle_autograd(x3):
     bad = {k: e for k, e in worst.items() if e > tol}
     print("trunk backward: params", len(worst), "worst rel err", max(worst.values()))
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+
+
+def test_seg_loss_backward_through_unet_and_trunk_matches_oracle_autograd():
+    """A whole loss term end to end: focal segmentation loss (encoder_decoder_framework.py:172-176) -> UNet (transposed
+    convs, concat windows, x2 bilinear) -> PAFPN -> ResNet-50: d(seg_loss)/d(parameter) for every parameter on that path
+    against loss.backward() through the oracle."""
+    from oracle import model_ref as M, train_ref as TR
+    from thinktwice_amd import autodiff, config, params, weights
+    from thinktwice_amd.losses import LossReducer
+    from thinktwice_amd.lss import LSS
+    hw, B, N = (64, 128), 1, 2
+    cfg = config.model_config(final_dim=hw)
+    sd = params.init_params(cfg, seed=5, parts=("img_encoder",))
+    pre = ("img_encoder.img_backbone", "img_encoder.img_neck", "img_encoder.seg_net")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if k.startswith(pre) and v.is_floating_point() and not k.endswith(("running_mean", "running_var"))}
+    sdr = dict(sd)
+    sdr.update(leaves)
+    g = torch.Generator().manual_seed(9)
+    img = torch.randn(B * N, 3, *hw, generator=g)
+    labels = torch.randint(0, 12, (B, N, *hw), generator=g).float()
+    labels[torch.rand(B, N, *hw, generator=g) < 0.05] = 255.0
+    feats = M.pafpn(sdr, "img_encoder.img_neck", M.resnet50(sdr, "img_encoder.img_backbone", img))
+    loss = TR.seg_loss(M.unet(sdr, "img_encoder.seg_net", feats), labels)
+    loss.backward()
+
+    enc_cfg = {k: v for k, v in cfg["img_encoder"].items() if k != "type"}
+    enc = LSS(**enc_cfg, dtype="f32x3").load_state_dict(sd)
+    red = LossReducer("cuda")
+    x = weights.to_channel_last(img, torch.float32).cuda()
+    with autodiff.Tape(x3=True) as tape:
+        seg = enc._seg_net(enc._trunk(x))
+        got_loss = red.seg_focal(seg, labels, num_classes=12, factor=2)
+        tape.seed(seg, red.seg_focal_bwd(seg, labels, num_classes=12, factor=2))
+        tape.backward()
+    torch.cuda.synchronize()
+    assert abs(float(got_loss) - float(loss.detach())) < 1e-4 * abs(float(loss.detach()))
+    worst = {}
+    for k, v in leaves.items():
+        if v.grad is None:
+            continue
+        assert k in tape.param_grads, k
+        got = tape.param_grads[k].cpu()
+        assert got.shape == v.grad.shape, (k, got.shape, v.grad.shape)
+        worst[k] = float((got - v.grad).abs().max() / v.grad.abs().max().clamp_min(1e-12))
+    print("seg-loss backward: params", len(worst), "worst rel err", max(worst.values()))
+    bad = {k: e for k, e in worst.items() if e > 3e-3}
+    assert len(worst) > 200 and not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]

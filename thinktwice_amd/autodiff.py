@@ -10,8 +10,10 @@ gradient windows.  Parameter gradients are collected under the reference's state
 golden F13 (tests/golden/gen_golden.py) is keyed by.
 
 Covered so far: convolution with its fused epilogue (folded eval-mode BatchNorm affine or bias, ReLU / sigmoid / none, up to
-two residual inputs, in-place residual outputs), 3x3/2 max-pooling, the in-place nearest-upsample-add of the PAFPN top-down
-path -- i.e. the ResNet-50 + PAFPN camera trunk.  Everything else still raises when it is reached with a tape active.
+two residual inputs, in-place residual outputs), the 2x2/2 transposed convolution, 3x3/2 max-pooling, the in-place nearest-
+upsample-add of the PAFPN top-down path, the x2 bilinear upsampling -- i.e. the ResNet-50 + PAFPN camera trunk and the UNet
+segmentation head, end to end from the focal segmentation loss (losses.LossReducer.seg_focal_bwd).  Ops without a
+recorder contribute no gradient yet (the remaining branches of the model).
 """
 import torch
 
@@ -83,9 +85,10 @@ class Tape:
     def conv(self, x, w, y, stride, pad, dil, scale, shift, act, in_coff, cin, out_coff, res1, res1_coff, res2, res2_coff,
              pixel_shuffle2, in_cstride):
         meta = CONV_META.get(id(w))
-        if meta is None or pixel_shuffle2 or in_cstride is not None:
-            raise NotImplementedError("tape: convolution form without a backward yet (unnamed weight, pixel shuffle or "
-                                      "row-run stem)")
+        if meta is None or in_cstride is not None:
+            raise NotImplementedError("tape: convolution form without a backward yet (unnamed weight or row-run stem)")
+        if pixel_shuffle2:
+            return self._deconv2x2(meta, x, w, y, shift, act, in_coff, cin, out_coff, scale, res1, res2)
         Cout, KH, KW, cin_p = w.shape
         self._keep += [x, y, res1, res2]
         inplace1 = res1 is not None and res1.data_ptr() == y.data_ptr() and res1_coff == out_coff
@@ -127,6 +130,34 @@ class Tape:
             ops.conv2d_dgrad(dconv, w, (H, W_), stride, pad, dil, x3=self.x3, out=gx, out_coff=in_coff)
 
         self.nodes.append(bwd)
+
+    def _deconv2x2(self, meta, x, w, y, shift, act, in_coff, cin, out_coff, scale, res1, res2):
+        """ConvTranspose2d(k=2, s=2) = 1x1 GEMM to 4*Cout channels + pixel shuffle (layers.deconv2x2_from_sd): the
+        gradient is un-shuffled (a layout copy) and the layer is differentiated as the 1x1 convolution it is."""
+        if scale is not None or res1 is not None or res2 is not None or act != 0:
+            raise NotImplementedError("tape: transposed convolution with BatchNorm / residual / activation")
+        C4 = w.shape[0]
+        Cout = C4 // 4
+        self._keep += [x, y]
+
+        def bwd():
+            N, H, W_, _ = x.shape
+            gy = self.grad(y)[..., out_coff:out_coff + Cout]                         # [N, 2H, 2W, Cout] window
+            dconv = gy.reshape(N, H, 2, W_, 2, Cout).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W_, C4).contiguous()
+            _, _, _, dshift = ops.conv_epilogue_bwd(dconv, dconv, None, None, 0, C=C4)
+            dw = ops.conv2d_wgrad(x, dconv, 1, 1, 1, 0, 1, cin=cin, in_coff=in_coff, cin_pad=w.shape[-1])
+            # prepared rows are (dh*2+dw)*Cout + co; the reference weight is [Cin, Cout, 2, 2]
+            self.add_param_grad(meta.name + ".weight",
+                                dw[:, 0, 0, :meta.cin].reshape(2, 2, Cout, meta.cin).permute(3, 2, 0, 1).contiguous())
+            if meta.bias is not None:
+                self.add_param_grad(meta.name + ".bias", dshift.view(4, Cout).sum(0))
+            ops.conv2d_dgrad(dconv, w, (H, W_), 1, 0, 1, x3=self.x3, out=self.grad(x), out_coff=in_coff)
+
+        self.nodes.append(bwd)
+
+    def bilinear_up2(self, x, y):
+        self._keep += [x, y]
+        self.nodes.append(lambda: ops.bilinear_up2_bwd(self.grad(y).contiguous(), self.grad(x)))
 
     def maxpool3x3s2(self, x, y):
         self._keep += [x, y]

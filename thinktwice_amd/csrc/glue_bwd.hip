@@ -65,6 +65,44 @@ __global__ __launch_bounds__(256) void upsample_nearest_add_bwd_kernel(const flo
     }
 }
 
+// F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) backward: dx[y][x] += sum over the output pixels
+// whose 2x2 footprint contains (y, x) of weight * dy, with the weights recomputed exactly as the forward computes them.
+__global__ __launch_bounds__(256) void bilinear_up2_ac_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N,
+                                                                  int H, int W, int C) {
+    const int OH = 2 * H, OW = 2 * W;
+    const float sh = (OH > 1) ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+    const float sw = (OW > 1) ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    const long long total = (long long)N * H * W * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const long long n = r / H;
+        // outputs whose source coordinate lies in (y - 1, y + 1): a conservative index range, exact weights inside
+        const int oy0 = sh > 0.f ? max(0, (int)floorf((y - 1) / sh) - 1) : 0;
+        const int oy1 = sh > 0.f ? min(OH - 1, (int)ceilf((y + 1) / sh) + 1) : OH - 1;
+        const int ox0 = sw > 0.f ? max(0, (int)floorf((x - 1) / sw) - 1) : 0;
+        const int ox1 = sw > 0.f ? min(OW - 1, (int)ceilf((x + 1) / sw) + 1) : OW - 1;
+        float g = 0.f;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            const float fy = sh * oy;
+            const int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+            const float ly = fy - y0;
+            const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                const float fx = sw * ox;
+                const int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
+                const float lx = fx - x0;
+                const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+                if (wx != 0.f) g += wy * wx * dy[((n * OH + oy) * OW + ox) * C + c];
+            }
+        }
+        dx[i] += g;
+    }
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -88,4 +126,11 @@ extern "C" int tt_upsample_nearest_add_bwd(const float* ddst, float* dsrc, int N
     hipLaunchKernelGGL(upsample_nearest_add_bwd_kernel, dim3(bwd_grid((long long)N * h * w * C)), dim3(256), 0,
                        (hipStream_t)stream, ddst, dsrc, N, H, W, C, h, w);
     return check_launch("tt_upsample_nearest_add_bwd");
+}
+
+extern "C" int tt_bilinear_up2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    TT_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "tt_bilinear_up2_bwd: bad argument");
+    hipLaunchKernelGGL(bilinear_up2_ac_bwd_kernel, dim3(bwd_grid((long long)N * H * W * C)), dim3(256), 0,
+                       (hipStream_t)stream, dy, dx, N, H, W, C);
+    return check_launch("tt_bilinear_up2_bwd");
 }

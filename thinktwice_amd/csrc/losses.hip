@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_l1_cols_kernel(const float*
 __global__ __launch_bounds__(kLossThreads) void loss_seg_focal_kernel(const float* __restrict__ logits, int row_stride,
                                                                       int C, const float* __restrict__ labels, int BN,
                                                                       int H, int W, int factor, float* __restrict__ out,
-                                                                      LossWs* ws) {
+                                                                      float* __restrict__ aux, LossWs* ws) {
     __shared__ double sh[kLossThreads / 64];
     const int h = H / factor, w = W / factor;
     const long long total = (long long)BN * h * w;
@@ -199,6 +199,44 @@ __global__ __launch_bounds__(kLossThreads) void loss_seg_focal_kernel(const floa
         const float logpt = -(float)(tot[0] / tot[1]);
         const float pt = expf(logpt);
         out[0] = -((1.f - pt) * (1.f - pt)) * 0.5f * logpt * 10.f;
+        if (aux) {          // for the backward: mean cross entropy and the number of contributing pixels
+            aux[0] = -logpt;
+            aux[1] = (float)tot[1];
+        }
+    }
+}
+
+// d(focal seg loss) / d(logits): with u = mean CE, L = 5 (1 - e^-u)^2 u, dL/du = 5 [2 (1 - e^-u) e^-u u + (1 - e^-u)^2];
+// d u / d logit[pixel][c] = (softmax_c - [c == label]) / count for the contributing pixels, 0 elsewhere (and on the row's
+// padding channels).  `upstream`: device scalar d(total)/d(seg_loss) or NULL (= 1).
+__global__ __launch_bounds__(kLossThreads) void loss_seg_focal_bwd_kernel(const float* __restrict__ logits, int row_stride,
+                                                                          int C, const float* __restrict__ labels, int BN,
+                                                                          int H, int W, int factor,
+                                                                          const float* __restrict__ aux,
+                                                                          const float* __restrict__ upstream,
+                                                                          float* __restrict__ dlogits) {
+    const int h = H / factor, w = W / factor;
+    const long long total = (long long)BN * h * w;
+    const float u = aux[0], cnt = aux[1];
+    const float e = expf(-u);
+    const float coef = (upstream ? upstream[0] : 1.f) * 5.f * (2.f * (1.f - e) * e * u + (1.f - e) * (1.f - e)) / cnt;
+    for (long long i = (long long)blockIdx.x * kLossThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kLossThreads) {
+        const int x = (int)(i % w), y = (int)((i / w) % h);
+        const long long bn = i / ((long long)w * h);
+        const long long lab = (long long)labels[(bn * H + (long long)y * factor) * W + (long long)x * factor];
+        const float* v = logits + i * row_stride;
+        float* d = dlogits + i * row_stride;
+        if (lab == 255) {
+            for (int c = 0; c < row_stride; ++c) d[c] = 0.f;
+            continue;
+        }
+        float m = v[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, v[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(v[c] - m);
+        const float inv = 1.f / s;
+        for (int c = 0; c < row_stride; ++c)
+            d[c] = c < C ? coef * (expf(v[c] - m) * inv - (c == lab ? 1.f : 0.f)) : 0.f;
     }
 }
 
@@ -285,13 +323,24 @@ extern "C" int tt_loss_l1_cols(const float* pred, const float* pred_beta, long l
     return check_launch("tt_loss_l1_cols");
 }
 
+extern "C" int tt_loss_seg_focal_bwd(const float* logits_cl, int row_stride, int num_classes, const float* labels, int BN,
+                                     int H, int W, int factor, const float* aux, const float* upstream_or_null,
+                                     float* dlogits_cl, void* stream) {
+    TT_REQUIRE(logits_cl && labels && aux && dlogits_cl && BN > 0 && factor > 0 && H >= factor && W >= factor &&
+                   num_classes > 0 && row_stride >= num_classes, "tt_loss_seg_focal_bwd: bad argument");
+    const long long total = (long long)BN * (H / factor) * (W / factor);
+    hipLaunchKernelGGL(loss_seg_focal_bwd_kernel, dim3(loss_grid(total)), dim3(kLossThreads), 0, (hipStream_t)stream,
+                       logits_cl, row_stride, num_classes, labels, BN, H, W, factor, aux, upstream_or_null, dlogits_cl);
+    return check_launch("tt_loss_seg_focal_bwd");
+}
+
 extern "C" int tt_loss_seg_focal(const float* logits_cl, int row_stride, int num_classes, const float* labels, int BN,
                                  int H, int W, int factor, float* out, void* workspace, void* stream) {
     TT_REQUIRE(logits_cl && labels && out && workspace && BN > 0 && factor > 0 && H >= factor && W >= factor &&
                    num_classes > 0 && row_stride >= num_classes, "tt_loss_seg_focal: bad argument");
     const long long total = (long long)BN * (H / factor) * (W / factor);
     hipLaunchKernelGGL(loss_seg_focal_kernel, dim3(loss_grid(total)), dim3(kLossThreads), 0, (hipStream_t)stream,
-                       logits_cl, row_stride, num_classes, labels, BN, H, W, factor, out, (LossWs*)workspace);
+                       logits_cl, row_stride, num_classes, labels, BN, H, W, factor, out, out + 1, (LossWs*)workspace);
     return check_launch("tt_loss_seg_focal");
 }
 

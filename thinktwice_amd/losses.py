@@ -87,11 +87,23 @@ class LossReducer:
         B, N, H, W = labels.shape
         assert logits_cl.dtype == F32 and logits_cl.is_contiguous()
         assert tuple(logits_cl.shape[:3]) == (B * N, H // factor, W // factor), (logits_cl.shape, labels.shape)
-        out = self._out()
+        out = self._out(3)              # loss, mean cross entropy, contributing pixels (the last two feed the backward)
         check(lib().tt_loss_seg_focal(ptr(logits_cl), _c(logits_cl.shape[-1]), _c(num_classes), ptr(labels), _c(B * N),
                                       _c(H), _c(W), _c(factor), ptr(out), ptr(self.ws), cur_stream(self.device)),
               "tt_loss_seg_focal")
+        self.seg_aux = out[1:]
         return out[0]
+
+    def seg_focal_bwd(self, logits_cl, labels, num_classes=12, factor=2, upstream=None):
+        """d(seg loss)/d(logits) (channel-last, padding channels 0) for the logits / labels of the last seg_focal call;
+        `upstream`: device scalar d(total loss)/d(seg loss) or None (= 1)."""
+        labels = self._f(labels)
+        B, N, H, W = labels.shape
+        d = torch.empty_like(logits_cl)
+        check(lib().tt_loss_seg_focal_bwd(ptr(logits_cl), _c(logits_cl.shape[-1]), _c(num_classes), ptr(labels), _c(B * N),
+                                          _c(H), _c(W), _c(factor), ptr(self.seg_aux), ptr(upstream), ptr(d),
+                                          cur_stream(self.device)), "tt_loss_seg_focal_bwd")
+        return d
 
     def depth_bce(self, logits_cl, gt_depth, d_bound, factor=16):
         """logits_cl (B*N, H/f, W/f, >= D) channel-last depth logits; gt_depth (B, N, H, W) metres, 0 = no return."""

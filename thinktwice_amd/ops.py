@@ -300,6 +300,9 @@ def bilinear_up2(x):
     out = torch.empty(N, 2 * H, 2 * W, C, dtype=x.dtype, device=x.device)
     check(lib().tt_bilinear_up2(ptr(x), ptr(out), _c(N), _c(H), _c(W), _c(C), _c(dtype_code(x)), _st(x)),
           "tt_bilinear_up2")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.bilinear_up2(x, out)
     return out
 
 
@@ -627,6 +630,15 @@ def maxpool3x3s2_bwd(x, dy, dx):
     N, H, W, C = x.shape
     assert x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous() and dx.shape == x.shape
     check(lib().tt_maxpool3x3s2_bwd(ptr(x), ptr(dy), ptr(dx), _c(N), _c(H), _c(W), _c(C), _st(x)), "tt_maxpool3x3s2_bwd")
+    return dx
+
+
+def bilinear_up2_bwd(dy, dx):
+    """dx += backward of bilinear_up2 (align_corners x2)."""
+    require_cuda(dy, dx)
+    N, H, W, C = dx.shape
+    assert dy.is_contiguous() and dx.is_contiguous() and tuple(dy.shape) == (N, 2 * H, 2 * W, C)
+    check(lib().tt_bilinear_up2_bwd(ptr(dy), ptr(dx), _c(N), _c(H), _c(W), _c(C), _st(dy)), "tt_bilinear_up2_bwd")
     return dx
 
 
