@@ -422,6 +422,10 @@ int tt_loss_seg_focal_bwd(const float* logits_cl, int row_stride, int num_classe
  * bins of d_step from d_lo; out[0] = sum of BCE-with-logits over the foreground cells / max(1, #foreground) */
 int tt_loss_depth_bce(const float* logits_cl, int row_stride, int D, const float* gt_depth, int BN, int H, int W,
                       int factor, float d_lo, float d_step, float* out, void* workspace, void* stream);
+/* out of tt_loss_depth_bce holds 2 floats (loss, divisor = `aux` here); dlogits_cl = upstream * d loss / d logits */
+int tt_loss_depth_bce_bwd(const float* logits_cl, int row_stride, int D, const float* gt_depth, int BN, int H, int W,
+                          int factor, float d_lo, float d_step, const float* aux, const float* upstream_or_null,
+                          float* dlogits_cl, void* stream);
 
 /* ----------------------------------------------------------------------
  * SURVEY 8f-4, backward of the convolution (what autograd + cuDNN do under loss.backward() in the reference,
@@ -456,6 +460,14 @@ int tt_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H
 int tt_upsample_nearest_add_bwd(const float* ddst, float* dsrc, int N, int H, int W, int C, int h, int w, void* stream);
 /* backward of tt_bilinear_up2 (x2, align_corners=True): dx [N][H][W][C] += weights^T dy [N][2H][2W][C] */
 int tt_bilinear_up2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* backward of tt_channel_gate (sigmoid gate, no residual, no output activation): dx += dy * s, dgate[n][c] += s(1-s) sum dy*x */
+int tt_channel_gate_bwd(const float* x, const float* gate, const float* dy, float* dx, float* dgate, int N, int HW, int C,
+                        void* stream);
+/* backward of tt_spatial_pool mode 0 (mean): dx[n][p][coff + c] += dpool[n][c] / HW */
+int tt_spatial_mean_bwd(const float* dpool, float* dx, int N, int HW, int C, int cstride, int coff, void* stream);
+/* backward of tt_deform_im2col3x3: gx += (f32 atomics), goffsets[pix][2 tap (+1)] += the sampling-position gradients */
+int tt_deform_im2col3x3_bwd(const float* x, const float* offsets, const float* gcols, float* gx, float* goffsets, int N,
+                            int H, int W, int C, int off_cstride, int pad, void* stream);
 
 /* SURVEY 8f-1, LiDAR side: merge of the two 180-degree half sweeps of the closed-loop tick
  * (leaderboard/team_code/thinktwice_agent.py:340-352).  prev / now: (n, 4) f32 (x, y, z, intensity) device rows;

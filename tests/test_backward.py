@@ -102,3 +102,63 @@ def test_seg_loss_backward_through_unet_and_trunk_matches_oracle_autograd():
     print("seg-loss backward: params", len(worst), "worst rel err", max(worst.values()))
     bad = {k: e for k, e in worst.items() if e > 3e-3}
     assert len(worst) > 200 and not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+
+
+def test_depth_loss_backward_through_depthnet_and_trunk_matches_oracle_autograd():
+    """Depth BCE (encoder_decoder_framework.py:179-190) + a synthetic term on the context features -> DepthNet (camera-aware
+    SE gates from the BatchNorm1d'd camera vector, BasicBlocks, ASPP with its image-pooling branch folded into a per-image
+    shift, deformable conv incl. its offset branch) -> neck_conv -> PAFPN -> ResNet-50, against loss.backward() through
+    the oracle."""
+    from oracle import model_ref as M, train_ref as TR
+    from thinktwice_amd import autodiff, config, params, weights
+    from thinktwice_amd.losses import LossReducer
+    from thinktwice_amd.lss import LSS
+    hw, B, N = (64, 128), 1, 2
+    cfg = config.model_config(final_dim=hw)
+    sd = params.init_params(cfg, seed=6, parts=("img_encoder",))
+    p = "img_encoder"
+    pre = (p + ".img_backbone", p + ".img_neck", p + ".neck_conv", p + ".depth_net")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if k.startswith(pre) and v.is_floating_point() and not k.endswith(("running_mean", "running_var"))}
+    sdr = dict(sd)
+    sdr.update(leaves)
+    g = torch.Generator().manual_seed(10)
+    img = torch.randn(B * N, 3, *hw, generator=g)
+    mlp_in = torch.randn(B * N, 22, generator=g)
+    gt_depth = torch.rand(B, N, *hw, generator=g) * 45.0
+    gt_depth[torch.rand(B, N, *hw, generator=g) < 0.9] = 0.0
+    d_bound = cfg["img_encoder"]["d_bound"]
+    D = int((d_bound[1] - d_bound[0]) / d_bound[2])
+    fpn = M.pafpn(sdr, p + ".img_neck", M.resnet50(sdr, p + ".img_backbone", img))
+    df = M.depth_net(sdr, p + ".depth_net", M.conv(sdr, p + ".neck_conv", fpn[2]), mlp_in)
+    Rc = torch.randn(df[:, D:D + 256].shape, generator=g) * 0.01
+    loss = TR.depth_loss(df[:, :D], gt_depth, d_bound, 16) + (df[:, D:D + 256] * Rc).sum()
+    loss.backward()
+
+    enc_cfg = {k: v for k, v in cfg["img_encoder"].items() if k != "type"}
+    enc = LSS(**enc_cfg, dtype="f32x3").load_state_dict(sd)
+    red = LossReducer("cuda")
+    x = weights.to_channel_last(img, torch.float32).cuda()
+    with autodiff.Tape(x3=True) as tape:
+        bufs = enc._trunk(x)
+        fb, foff, _ = enc._fpn_views(bufs)[2]
+        src = enc.neck_conv(fb, in_coff=foff, cin=256)
+        depth, merge_in = enc._depth_net(src, mlp_in.cuda(), 1)
+        got = red.depth_bce(depth, gt_depth, d_bound, 16)
+        tape.seed(depth, red.depth_bce_bwd(depth, gt_depth, d_bound, 16))
+        tape.seed(merge_in[..., :256], Rc.permute(0, 2, 3, 1))
+        tape.backward()
+    torch.cuda.synchronize()
+    want_depth = TR.depth_loss(df[:, :D], gt_depth, d_bound, 16)
+    assert abs(float(got) - float(want_depth.detach())) < 1e-4 * abs(float(want_depth.detach()))
+    worst = {}
+    for k, v in leaves.items():
+        if v.grad is None:
+            continue
+        assert k in tape.param_grads, k
+        got_g = tape.param_grads[k].cpu()
+        assert got_g.shape == v.grad.shape, (k, got_g.shape, v.grad.shape)
+        worst[k] = float((got_g - v.grad).abs().max() / v.grad.abs().max().clamp_min(1e-12))
+    print("depth-loss backward: params", len(worst), "worst rel err", max(worst.values()))
+    bad = {k: e for k, e in worst.items() if e > 3e-3}
+    assert len(worst) > 240 and not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]

@@ -24,10 +24,39 @@ TAPE = None
 
 class ConvMeta:
     """What a prepared Conv needs for its parameter gradients: state_dict names and the BatchNorm statistics folded into
-    its scale / shift (scale = gamma / sigma, shift = beta - mean * scale [+ bias * scale])."""
+    its scale / shift (scale = gamma / sigma, shift = beta - mean * scale [+ bias * scale]).  `kind` says how the prepared
+    weight [Cout][KH][KW][cin_p] maps back to the reference parameter: "conv" [Cout, Cin, KH, KW]; "linear" [Cout, Cin];
+    "cin_slice" = input channels [c0, c1) of a wider conv weight (`full_shape`); "dcn_group" = output rows [r0, r1) of the
+    grouped deformable-conv weight, prepared as [og][1][9 taps][cg]."""
 
-    def __init__(self, name, cin, bn=None, mean=None, sigma=None, bias=None):
+    def __init__(self, name, cin, bn=None, mean=None, sigma=None, bias=None, kind="conv", full_shape=None, lo=0):
         self.name, self.cin, self.bn, self.mean, self.sigma, self.bias = name, cin, bn, mean, sigma, bias
+        self.kind, self.full_shape, self.lo = kind, full_shape, lo
+
+    def place_weight_grad(self, tape, dw):
+        g = dw[..., :self.cin]
+        if self.kind == "conv":
+            tape.add_param_grad(self.name + ".weight", g.permute(0, 3, 1, 2).contiguous())
+        elif self.kind == "linear":
+            tape.add_param_grad(self.name + ".weight", g[:, 0, 0, :].contiguous())
+        elif self.kind == "cin_slice":
+            full = tape.param_grads.get(self.name + ".weight")
+            if full is None:
+                full = torch.zeros(self.full_shape, dtype=torch.float32, device=dw.device)
+                tape.param_grads[self.name + ".weight"] = full
+            full[:, self.lo:self.lo + self.cin] += g.permute(0, 3, 1, 2)
+        elif self.kind == "dcn_group":
+            full = tape.param_grads.get(self.name + ".weight")
+            if full is None:
+                full = torch.zeros(self.full_shape, dtype=torch.float32, device=dw.device)
+                tape.param_grads[self.name + ".weight"] = full
+            og = dw.shape[0]
+            full[self.lo:self.lo + og] += g[:, 0].reshape(og, 3, 3, self.cin).permute(0, 3, 1, 2)
+        else:
+            raise NotImplementedError(self.kind)
+
+
+AFFINE_META = {}        # id(scale tensor) -> (bn name, mean, sigma), filled by layers.bn_affine
 
 
 CONV_META = {}          # id(weight tensor) -> ConvMeta, filled by layers.conv_from_sd
@@ -76,22 +105,29 @@ class Tape:
             self.param_grads[name] = g
 
     def backward(self):
-        for fn in reversed(self.nodes):
-            fn()
+        global TAPE
+        active, TAPE = TAPE, None          # the backward closures call forward ops too: nothing of that is recorded
+        try:
+            for fn in reversed(self.nodes):
+                fn()
+        finally:
+            TAPE = active
         self.nodes.clear()
         self._keep.clear()
 
     # ---- recorders (called from ops.* while the tape is active)
     def conv(self, x, w, y, stride, pad, dil, scale, shift, act, in_coff, cin, out_coff, res1, res1_coff, res2, res2_coff,
-             pixel_shuffle2, in_cstride):
+             pixel_shuffle2, in_cstride, shift_n=None, shift_n_mod=1):
         meta = CONV_META.get(id(w))
         if meta is None or in_cstride is not None:
             raise NotImplementedError("tape: convolution form without a backward yet (unnamed weight or row-run stem)")
         if pixel_shuffle2:
             return self._deconv2x2(meta, x, w, y, shift, act, in_coff, cin, out_coff, scale, res1, res2)
         Cout, KH, KW, cin_p = w.shape
-        self._keep += [x, y, res1, res2]
+        self._keep += [x, y, res1, res2, shift_n]
         inplace1 = res1 is not None and res1.data_ptr() == y.data_ptr() and res1_coff == out_coff
+        if shift_n is not None and (res1 is not None or res2 is not None):
+            raise NotImplementedError("tape: per-image shift together with residual inputs")
 
         def bwd():
             gy = self.grad(y)
@@ -107,6 +143,16 @@ class Tape:
                 dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, y, None, shift, act, None, None, C=Cout,
                                                                  dy_coff=out_coff, y_coff=out_coff, dres1=gy,
                                                                  dres1_coff=out_coff, dres_accumulate=False)
+            elif shift_n is not None:
+                # y = act(scale * conv + shift + shift_n[image]): the kernel's dscale = sum g * (pre - shift) / scale already
+                # holds the shift_n term; d(shift_n)[image] = sum over the image's pixels of g
+                gdense = torch.empty(M, Cout, dtype=torch.float32, device=y.device)
+                dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, y, scale, shift, act, None, None, C=Cout,
+                                                                 dy_coff=out_coff, y_coff=out_coff, dres1=gdense,
+                                                                 dres_accumulate=False)
+                imgs = shift_n.shape[0]
+                assert shift_n_mod == imgs == N, "tape: one shift row per image"
+                self.grad(shift_n).add_(ops.spatial_pool(gdense.view(N, OH, OW, Cout), 0), alpha=float(OH * OW))
             else:
                 dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, y, scale, shift, act, res1, res2, C=Cout,
                                                                  dy_coff=out_coff, y_coff=out_coff, res1_coff=res1_coff,
@@ -115,7 +161,7 @@ class Tape:
             dconv = dconv.view(N, OH, OW, Cout)
             # parameters
             dw = ops.conv2d_wgrad(x, dconv, KH, KW, stride, pad, dil, cin=cin, in_coff=in_coff, cin_pad=cin_p)
-            self.add_param_grad(meta.name + ".weight", dw[..., :meta.cin].permute(0, 3, 1, 2).contiguous())
+            meta.place_weight_grad(self, dw)
             if meta.bn is not None:
                 # scale = gamma / sigma, shift = beta + (bias - mean) * gamma / sigma
                 off = meta.mean if meta.bias is None else meta.mean - meta.bias
@@ -127,7 +173,15 @@ class Tape:
                 self.add_param_grad(meta.name + ".bias", dshift)
             # input: conv of dconv with the rotated weights, accumulated into x's gradient window
             gx = self.grad(x)
-            ops.conv2d_dgrad(dconv, w, (H, W_), stride, pad, dil, x3=self.x3, out=gx, out_coff=in_coff)
+            if KH == KW:
+                ops.conv2d_dgrad(dconv, w, (H, W_), stride, pad, dil, x3=self.x3, out=gx, out_coff=in_coff)
+            else:
+                # 1 x KW kernel over a 1 x KW "image" (the grouped deformable-conv GEMM over im2col columns): one 1x1
+                # input-gradient GEMM per tap, written to that tap's pixel of the column gradient
+                assert KH == 1 and H == 1 and W_ == KW and pad == 0 and stride == 1 and OH == 1 and OW == 1
+                for t in range(KW):
+                    d = ops.conv2d_dgrad(dconv, w[:, :, t:t + 1, :].contiguous(), (1, 1), 1, 0, 1, x3=False)
+                    gx[:, 0, t, in_coff:in_coff + cin] += d.view(N, cin)
 
         self.nodes.append(bwd)
 
@@ -154,6 +208,45 @@ class Tape:
             ops.conv2d_dgrad(dconv, w, (H, W_), 1, 0, 1, x3=self.x3, out=self.grad(x), out_coff=in_coff)
 
         self.nodes.append(bwd)
+
+    def affine_rows(self, x, scale, shift, act, out):
+        meta = AFFINE_META.get(id(scale))
+        if meta is None or act != 0:
+            raise NotImplementedError("tape: affine_rows without a registered BatchNorm / with an activation")
+        name, mean, sigma = meta
+        self._keep += [x, out]
+
+        def bwd():
+            R, C = x.shape
+            go = self.grad(out)
+            # y = scale * x + shift on the first C columns: the conv-epilogue backward with conv := x
+            _, _, dscale, dshift = ops.conv_epilogue_bwd(go, out, scale, shift, 0, C=C)
+            self.add_param_grad(name + ".weight", (dscale - mean * dshift) / sigma)
+            self.add_param_grad(name + ".bias", dshift)      # (x is an input of the model: no gradient needed)
+
+        self.nodes.append(bwd)
+
+    def channel_gate(self, x, gate, res, out, gate_act, out_act):
+        from . import _lib
+        if res is not None or out_act != 0 or gate_act != _lib.ACT_SIGMOID:
+            raise NotImplementedError("tape: channel gate with residual / output activation")
+        self._keep += [x, gate, out]
+        self.nodes.append(lambda: ops.channel_gate_bwd(x, gate, self.grad(out).contiguous(), self.grad(x), self.grad(gate)))
+
+    def spatial_pool(self, x, out, mode, C, coff):
+        if mode != 0:
+            raise NotImplementedError("tape: (mean + max) / 2 pooling")
+        self._keep += [x, out]
+        self.nodes.append(lambda: ops.spatial_mean_bwd(self.grad(out).contiguous(), self.grad(x), C, coff))
+
+    def repeat_rows(self, t, out, times):
+        self._keep += [t, out]
+        self.nodes.append(lambda: self.grad(t).add_(self.grad(out).view(times, *t.shape).sum(0)))
+
+    def deform_im2col3x3(self, x, offsets, cols, pad):
+        self._keep += [x, offsets, cols]
+        self.nodes.append(lambda: ops.deform_im2col3x3_bwd(x, offsets, self.grad(cols).contiguous(), self.grad(x),
+                                                           self.grad(offsets), pad))
 
     def bilinear_up2(self, x, y):
         self._keep += [x, y]

@@ -103,6 +103,94 @@ __global__ __launch_bounds__(256) void bilinear_up2_ac_bwd_kernel(const float* _
     }
 }
 
+// out = x * sigmoid(gate[n][c])  (SELayer, lss.py:158) backward:  dx += dy * s,  dgate[n][c] += s (1 - s) sum_hw dy * x.
+// One workgroup per (image, 64-channel slab): 4 pixel partitions x 64 channels, the partitions added through LDS.
+__global__ __launch_bounds__(256) void channel_gate_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                               const float* __restrict__ dy, float* __restrict__ dx,
+                                                               float* __restrict__ dgate, int HW, int C) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.y, cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s = 0.f, acc = 0.f;
+    if (c < C) {
+        s = 1.f / (1.f + expf(-gate[(long long)n * C + c]));
+        const long long base = (long long)n * HW * C + c;
+        for (int p = part; p < HW; p += 4) {
+            const float g = dy[base + (long long)p * C];
+            acc += g * x[base + (long long)p * C];
+            dx[base + (long long)p * C] += g * s;
+        }
+    }
+    red[part][cl] = acc;
+    __syncthreads();
+    if (part == 0 && c < C)
+        dgate[(long long)n * C + c] += s * (1.f - s) * (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+// mean over the pixels of an image (AdaptiveAvgPool2d(1)) backward: dx[n][p][coff + c] += dpool[n][c] / HW
+__global__ __launch_bounds__(256) void spatial_mean_bwd_kernel(const float* __restrict__ dpool, float* __restrict__ dx, int N,
+                                                               int HW, int C, int cstride, int coff) {
+    const long long total = (long long)N * HW * C;
+    const float inv = 1.f / (float)HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long np = i / C;
+        dx[np * cstride + coff + c] += dpool[(np / HW) * C + c] * inv;
+    }
+}
+
+// Deformable im2col (mmcv DCN v1, 3x3, deform_groups = 1) backward.  Forward (csrc/dcn.hip): cols[pix][tap][c] = bilinear
+// sample of x[n] at (y + tap/3 - pad + off[2 tap], x + tap%3 - pad + off[2 tap + 1]), zero outside.  From gcols:
+//   gx   += corner weight * gcols  (scattered with f32 atomics: a sample point can land anywhere)
+//   goff[pix][2 tap] = sum_c gcols * d(sample)/d(py),  goff[pix][2 tap + 1] = ... d(px)
+// One wave per (pixel, tap): lanes stride the channels, the two offset gradients are wave reductions.
+__global__ __launch_bounds__(256) void deform_im2col_bwd_kernel(const float* __restrict__ x, const float* __restrict__ off,
+                                                                const float* __restrict__ gcols, float* __restrict__ gx,
+                                                                float* __restrict__ goff, int N, int H, int W, int C,
+                                                                int off_cstride, int pad) {
+    const int lane = threadIdx.x & 63;
+    const long long total = (long long)N * H * W * 9;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6; i < total; i += ((long long)gridDim.x * 256) >> 6) {
+        const int tap = (int)(i % 9);
+        const long long pix = i / 9;
+        const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
+        const long long n = pix / ((long long)H * W);
+        const float py = (float)(yh + tap / 3 - pad) + off[pix * off_cstride + 2 * tap];
+        const float px = (float)(xw + tap % 3 - pad) + off[pix * off_cstride + 2 * tap + 1];
+        float gy_ = 0.f, gx_ = 0.f;
+        if (py > -1.f && py < (float)H && px > -1.f && px < (float)W) {
+            const int y0 = (int)floorf(py), x0 = (int)floorf(px);
+            const float ly = py - (float)y0, lx = px - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+            const bool v00 = y0 >= 0 && x0 >= 0, v01 = y0 >= 0 && x0 + 1 <= W - 1;
+            const bool v10 = y0 + 1 <= H - 1 && x0 >= 0, v11 = y0 + 1 <= H - 1 && x0 + 1 <= W - 1;
+            const long long b = n * H * W;
+            const float* g = gcols + (pix * 9 + tap) * C;
+            for (int c = lane; c < C; c += 64) {
+                const float gv = g[c];
+                const float a00 = v00 ? x[(b + (long long)y0 * W + x0) * C + c] : 0.f;
+                const float a01 = v01 ? x[(b + (long long)y0 * W + x0 + 1) * C + c] : 0.f;
+                const float a10 = v10 ? x[(b + (long long)(y0 + 1) * W + x0) * C + c] : 0.f;
+                const float a11 = v11 ? x[(b + (long long)(y0 + 1) * W + x0 + 1) * C + c] : 0.f;
+                gy_ += gv * (hx * (a10 - a00) + lx * (a11 - a01));
+                gx_ += gv * (hy * (a01 - a00) + ly * (a11 - a10));
+                if (v00) unsafeAtomicAdd(gx + (b + (long long)y0 * W + x0) * C + c, gv * hy * hx);
+                if (v01) unsafeAtomicAdd(gx + (b + (long long)y0 * W + x0 + 1) * C + c, gv * hy * lx);
+                if (v10) unsafeAtomicAdd(gx + (b + (long long)(y0 + 1) * W + x0) * C + c, gv * ly * hx);
+                if (v11) unsafeAtomicAdd(gx + (b + (long long)(y0 + 1) * W + x0 + 1) * C + c, gv * ly * lx);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            gy_ += __shfl_xor(gy_, o);
+            gx_ += __shfl_xor(gx_, o);
+        }
+        if (lane == 0) {
+            goff[pix * off_cstride + 2 * tap] += gy_;
+            goff[pix * off_cstride + 2 * tap + 1] += gx_;
+        }
+    }
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -133,4 +221,27 @@ extern "C" int tt_bilinear_up2_bwd(const float* dy, float* dx, int N, int H, int
     hipLaunchKernelGGL(bilinear_up2_ac_bwd_kernel, dim3(bwd_grid((long long)N * H * W * C)), dim3(256), 0,
                        (hipStream_t)stream, dy, dx, N, H, W, C);
     return check_launch("tt_bilinear_up2_bwd");
+}
+
+extern "C" int tt_channel_gate_bwd(const float* x, const float* gate, const float* dy, float* dx, float* dgate, int N, int HW,
+                                   int C, void* stream) {
+    TT_REQUIRE(x && gate && dy && dx && dgate && N > 0 && HW > 0 && C > 0, "tt_channel_gate_bwd: bad argument");
+    hipLaunchKernelGGL(channel_gate_bwd_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)N), dim3(256), 0, (hipStream_t)stream,
+                       x, gate, dy, dx, dgate, HW, C);
+    return check_launch("tt_channel_gate_bwd");
+}
+
+extern "C" int tt_spatial_mean_bwd(const float* dpool, float* dx, int N, int HW, int C, int cstride, int coff, void* stream) {
+    TT_REQUIRE(dpool && dx && N > 0 && HW > 0 && C > 0 && cstride >= coff + C, "tt_spatial_mean_bwd: bad argument");
+    hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(bwd_grid((long long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, dpool,
+                       dx, N, HW, C, cstride, coff);
+    return check_launch("tt_spatial_mean_bwd");
+}
+
+extern "C" int tt_deform_im2col3x3_bwd(const float* x, const float* offsets, const float* gcols, float* gx, float* goffsets,
+                                       int N, int H, int W, int C, int off_cstride, int pad, void* stream) {
+    TT_REQUIRE(x && offsets && gcols && gx && goffsets && off_cstride >= 18, "tt_deform_im2col3x3_bwd: bad argument");
+    hipLaunchKernelGGL(deform_im2col_bwd_kernel, dim3(bwd_grid((long long)N * H * W * 9 * 64)), dim3(256), 0,
+                       (hipStream_t)stream, x, offsets, gcols, gx, goffsets, N, H, W, C, off_cstride, pad);
+    return check_launch("tt_deform_im2col3x3_bwd");
 }

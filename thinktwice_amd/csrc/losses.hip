@@ -278,7 +278,41 @@ __global__ __launch_bounds__(kLossThreads) void loss_depth_bce_kernel(const floa
     double mine[2], tot[2];
     mine[0] = block_sum(acc, sh);
     mine[1] = block_sum(cnt, sh);
-    if (finish<2>(ws, mine, tot)) out[0] = (float)(tot[0] / fmax(1.0, tot[1]));
+    if (finish<2>(ws, mine, tot)) {
+        out[0] = (float)(tot[0] / fmax(1.0, tot[1]));
+        out[1] = (float)fmax(1.0, tot[1]);          // the divisor, for the backward
+    }
+}
+
+// d(depth BCE)/d(logits): (sigmoid(x_d) - [d == bin - 1]) / max(1, #foreground) on the foreground cells, 0 elsewhere
+__global__ __launch_bounds__(kLossThreads) void loss_depth_bce_bwd_kernel(const float* __restrict__ logits, int row_stride,
+                                                                          int D, const float* __restrict__ gt, int BN, int H,
+                                                                          int W, int factor, float d0, float dstep,
+                                                                          const float* __restrict__ aux,
+                                                                          const float* __restrict__ upstream,
+                                                                          float* __restrict__ dlogits) {
+    const int h = H / factor, w = W / factor;
+    const long long total = (long long)BN * h * w;
+    const float coef = (upstream ? upstream[0] : 1.f) / aux[0];
+    for (long long i = (long long)blockIdx.x * kLossThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kLossThreads) {
+        const int x = (int)(i % w), y = (int)((i / w) % h);
+        const long long bn = i / ((long long)w * h);
+        float g = 1e5f;
+        for (int dy = 0; dy < factor; ++dy) {
+            const float* row = gt + (bn * H + (long long)y * factor + dy) * W + (long long)x * factor;
+            for (int dx = 0; dx < factor; ++dx) {
+                const float t = row[dx];
+                g = fminf(g, t == 0.f ? 1e5f : t);
+            }
+        }
+        g = (g - (d0 - dstep)) / dstep;
+        if (!(g < (float)(D + 1) && g >= 0.f)) g = 0.f;
+        const int bin = (int)g;
+        const float* v = logits + i * row_stride;
+        float* d = dlogits + i * row_stride;
+        for (int c = 0; c < row_stride; ++c)
+            d[c] = (bin >= 1 && c < D) ? coef * (1.f / (1.f + expf(-v[c])) - (c == bin - 1 ? 1.f : 0.f)) : 0.f;
+    }
 }
 
 }  // namespace tt
@@ -342,6 +376,17 @@ extern "C" int tt_loss_seg_focal(const float* logits_cl, int row_stride, int num
     hipLaunchKernelGGL(loss_seg_focal_kernel, dim3(loss_grid(total)), dim3(kLossThreads), 0, (hipStream_t)stream,
                        logits_cl, row_stride, num_classes, labels, BN, H, W, factor, out, out + 1, (LossWs*)workspace);
     return check_launch("tt_loss_seg_focal");
+}
+
+extern "C" int tt_loss_depth_bce_bwd(const float* logits_cl, int row_stride, int D, const float* gt_depth, int BN, int H,
+                                     int W, int factor, float d_lo, float d_step, const float* aux,
+                                     const float* upstream_or_null, float* dlogits_cl, void* stream) {
+    TT_REQUIRE(logits_cl && gt_depth && aux && dlogits_cl && BN > 0 && factor > 0 && H >= factor && W >= factor && D > 0 &&
+                   row_stride >= D && d_step > 0.f, "tt_loss_depth_bce_bwd: bad argument");
+    const long long total = (long long)BN * (H / factor) * (W / factor);
+    hipLaunchKernelGGL(loss_depth_bce_bwd_kernel, dim3(loss_grid(total)), dim3(kLossThreads), 0, (hipStream_t)stream,
+                       logits_cl, row_stride, D, gt_depth, BN, H, W, factor, d_lo, d_step, aux, upstream_or_null, dlogits_cl);
+    return check_launch("tt_loss_depth_bce_bwd");
 }
 
 extern "C" int tt_loss_depth_bce(const float* logits_cl, int row_stride, int D, const float* gt_depth, int BN, int H,

@@ -32,8 +32,9 @@ def _dev(t, device):
 
 
 def conv_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, stride=1, pad=0, dil=1, act="none",
-                 cin_pad=None, weight=None):
-    """nn.Conv2d `name` (+ optional eval BatchNorm `bn`) -> Conv."""
+                 cin_pad=None, weight=None, cin_lo=0):
+    """nn.Conv2d `name` (+ optional eval BatchNorm `bn`) -> Conv.  `weight` (+ `cin_lo`): use this input-channel slice
+    [cin_lo, cin_lo + weight.shape[1]) of the layer's weight instead of the whole tensor."""
     w = sd[name + ".weight"] if weight is None else weight
     bias = sd.get(name + ".bias")
     wq = weights.prep_conv_weight(w.to(device), dtype, cin_pad)
@@ -42,12 +43,14 @@ def conv_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, stride=1, pad=0, di
                                        sd[bn + ".running_var"], eps, bias)
     else:
         scale, shift = None, bias
-    if weight is None:      # what the training tape needs for this layer's parameter gradients (autodiff.py)
-        from . import autodiff
-        autodiff.CONV_META[id(wq)] = autodiff.ConvMeta(
-            name, w.shape[1], bn,
-            None if bn is None else _dev(sd[bn + ".running_mean"], device),
-            None if bn is None else torch.sqrt(_dev(sd[bn + ".running_var"], device) + eps), _dev(bias, device))
+    # what the training tape needs for this layer's parameter gradients (autodiff.py)
+    from . import autodiff
+    full = sd[name + ".weight"]
+    autodiff.CONV_META[id(wq)] = autodiff.ConvMeta(
+        name, w.shape[1], bn,
+        None if bn is None else _dev(sd[bn + ".running_mean"], device),
+        None if bn is None else torch.sqrt(_dev(sd[bn + ".running_var"], device) + eps), _dev(bias, device),
+        kind="conv" if weight is None else "cin_slice", full_shape=tuple(full.shape), lo=cin_lo)
     return Conv(wq, _dev(scale, device), _dev(shift, device), stride, pad, dil, act, x3=dtype == weights.X3)
 
 
@@ -66,6 +69,12 @@ def linear_from_sd(sd, name, device, act="none", in_pad=None, dtype=torch.float3
                                        sd[bn + ".running_var"], eps, bias)
     else:
         scale, shift = None, bias
+    from . import autodiff
+    autodiff.CONV_META[id(wq)] = autodiff.ConvMeta(
+        name, w.shape[1], bn,
+        None if bn is None else _dev(sd[bn + ".running_mean"], device),
+        None if bn is None else torch.sqrt(_dev(sd[bn + ".running_var"], device) + eps), _dev(bias, device),
+        kind="linear")
     return Conv(wq, _dev(scale, device), _dev(shift, device), act=act, x3=dtype == weights.X3)
 
 
@@ -97,4 +106,8 @@ def unrows(x):
 def bn_affine(sd, bn, device, eps=1e-5):
     s, t = weights.fold_bn(sd[bn + ".weight"], sd[bn + ".bias"], sd[bn + ".running_mean"],
                            sd[bn + ".running_var"], eps)
-    return _dev(s, device), _dev(t, device)
+    s, t = _dev(s, device), _dev(t, device)
+    from . import autodiff
+    autodiff.AFFINE_META[id(s)] = (bn, _dev(sd[bn + ".running_mean"], device),
+                                   torch.sqrt(_dev(sd[bn + ".running_var"], device) + eps))
+    return s, t

@@ -112,11 +112,23 @@ class LossReducer:
         D = int((d_bound[1] - d_bound[0]) / d_bound[2])
         assert logits_cl.dtype == F32 and logits_cl.is_contiguous()
         assert tuple(logits_cl.shape[:3]) == (B * N, H // factor, W // factor) and logits_cl.shape[-1] >= D
-        out = self._out()
+        out = self._out(2)              # loss, divisor max(1, #foreground cells) (feeds the backward)
         check(lib().tt_loss_depth_bce(ptr(logits_cl), _c(logits_cl.shape[-1]), _c(D), ptr(gt_depth), _c(B * N), _c(H),
                                       _c(W), _c(factor), _f(d_bound[0]), _f(d_bound[2]), ptr(out), ptr(self.ws),
                                       cur_stream(self.device)), "tt_loss_depth_bce")
+        self.depth_aux = out[1:]
         return out[0]
+
+    def depth_bce_bwd(self, logits_cl, gt_depth, d_bound, factor=16, upstream=None):
+        """d(depth loss)/d(logits) for the logits / depth maps of the last depth_bce call."""
+        gt_depth = self._f(gt_depth)
+        B, N, H, W = gt_depth.shape
+        D = int((d_bound[1] - d_bound[0]) / d_bound[2])
+        d = torch.empty_like(logits_cl)
+        check(lib().tt_loss_depth_bce_bwd(ptr(logits_cl), _c(logits_cl.shape[-1]), _c(D), ptr(gt_depth), _c(B * N), _c(H),
+                                          _c(W), _c(factor), _f(d_bound[0]), _f(d_bound[2]), ptr(self.depth_aux),
+                                          ptr(upstream), ptr(d), cur_stream(self.device)), "tt_loss_depth_bce_bwd")
+        return d
 
 
 def decoder_loss(red, c, batch, pred, mid_bev):

@@ -143,7 +143,7 @@ class LSS:
         self.aspp_out = conv_from_sd(sd, a + ".conv1", dt, dev, bn=a + ".bn1", act="relu",
                                      weight=w1[:, : 4 * mid].contiguous())
         # global-pool branch enters conv1 as a per-image shift: bn_scale * (W[:, 4*mid:] @ x5)
-        self.aspp_gapw = conv_from_sd(sd, a + ".conv1", f32, dev, weight=w1[:, 4 * mid:].contiguous())
+        self.aspp_gapw = conv_from_sd(sd, a + ".conv1", f32, dev, weight=w1[:, 4 * mid:].contiguous(), cin_lo=4 * mid)
         self.aspp_gapw.scale, self.aspp_gapw.shift = self.aspp_out.scale, None
         q = d + ".depth_conv.4"
         self.dcn_off = conv_from_sd(sd, q + ".conv_offset", dt, dev, pad=1)
@@ -155,6 +155,9 @@ class LSS:
             wg = wd[g * og:(g + 1) * og].to(dev)                        # (og, cg, 3, 3)
             wg = wg.permute(0, 2, 3, 1).reshape(og, 1, 9, wg.shape[1])  # [Cout][1][tap][cin]
             self.dcn_w.append(conv_from_weight(wg.to(self.dtype).contiguous(), dt))
+            from . import autodiff
+            autodiff.CONV_META[id(self.dcn_w[-1].w)] = autodiff.ConvMeta(q, wd.shape[1], kind="dcn_group",
+                                                                         full_shape=tuple(wd.shape), lo=g * og)
         self.depth_out = conv_from_sd(sd, d + ".depth_conv.5", dt, dev)
         s = p + ".seg_net"
         self.up = {k: deconv2x2_from_sd(sd, f"{s}.{k}.up", dt, dev) for k in ("unet_layer4", "unet_layer3", "unet_layer2")}
@@ -218,8 +221,8 @@ class LSS:
         m24 = torch.zeros(mlp_in.shape[0], 24, dtype=torch.float32, device=dev)
         ops.affine_rows(mlp_in, self.bn22[0], self.bn22[1], out=m24)
         x = self.reduce(src)
-        g_ctx = self._se_gate("context", m24).repeat(T, 1)
-        g_dep = self._se_gate("depth", m24).repeat(T, 1)
+        g_ctx = ops.repeat_rows(self._se_gate("context", m24), T)
+        g_dep = ops.repeat_rows(self._se_gate("depth", m24), T)
         merge_in = torch.empty(NI, h, w, 384, dtype=dt, device=dev)
         self.context_conv(ops.channel_gate(x, g_ctx), out=merge_in, out_coff=0)
         d = ops.channel_gate(x, g_dep)

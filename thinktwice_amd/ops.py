@@ -227,7 +227,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
         from . import autodiff
         if autodiff.TAPE is not None:
             autodiff.TAPE.conv(x, w, out, stride, pad, dil, scale, shift, act, in_coff, cin, out_coff, res1, res1_coff,
-                               res2, res2_coff, pixel_shuffle2, in_cstride)
+                               res2, res2_coff, pixel_shuffle2, in_cstride, shift_n, shift_n_mod)
     return out
 
 
@@ -313,6 +313,9 @@ def spatial_pool(x, mode, C=None, coff=0):
     out = torch.empty(N, C, dtype=torch.float32, device=x.device)
     check(lib().tt_spatial_pool(ptr(x), ptr(out), _c(N), _c(H * W), _c(C), _c(Cs), _c(coff), _c(mode),
                                 _c(dtype_code(x)), _st(x)), "tt_spatial_pool")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.spatial_pool(x, out, mode, C, coff)
     return out
 
 
@@ -322,6 +325,9 @@ def channel_gate(x, gate, res=None, gate_act=_lib.ACT_SIGMOID, out_act=_lib.ACT_
     out = torch.empty_like(x) if out is None else out
     check(lib().tt_channel_gate(ptr(x), ptr(gate), ptr(res), ptr(out), _c(N), _c(H * W), _c(C), _c(gate_act),
                                 _c(out_act), _c(dtype_code(x)), _st(x)), "tt_channel_gate")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.channel_gate(x, gate, res, out, gate_act, out_act)
     return out
 
 
@@ -331,6 +337,9 @@ def affine_rows(x, scale, shift, act=0, out=None):
     out = torch.empty(R, C, dtype=x.dtype, device=x.device) if out is None else out
     check(lib().tt_affine_rows(ptr(x), ptr(scale), ptr(shift), ptr(out), _ll(R), _c(C), _c(x.stride(0)),
                                _c(out.stride(0)), _c(act), _c(dtype_code(x)), _st(x)), "tt_affine_rows")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.affine_rows(x, scale, shift, act, out)
     return out
 
 
@@ -414,7 +423,20 @@ def deform_im2col3x3(x, offsets, pad=1):
     check(lib().tt_deform_im2col3x3(ptr(x), ptr(offsets), ptr(cols), _c(N), _c(H), _c(W), _c(C),
                                     _c(offsets.shape[-1]), _c(pad), _c(dtype_code(x)), _st(x)),
           "tt_deform_im2col3x3")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.deform_im2col3x3(x, offsets, cols, pad)
     return cols
+
+
+def repeat_rows(t, times):
+    """t (R, C) -> (times * R, C), the rows repeated block-wise (torch's t.repeat(times, 1)); a copy the training tape
+    knows how to differentiate (the gradient is the sum over the repeats)."""
+    out = t.repeat(times, 1)
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.repeat_rows(t, out, times)
+    return out
 
 
 # ----------------------------------------------------------------------------- look module
@@ -577,6 +599,10 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, dil=1, x3=True, out=None, out_co
     else:
         assert (OH, OW) == (fh, fw), ((OH, OW), (fh, fw))
     wt = dgrad_weight(w)
+    if Cout % 4:        # the convolution wants 16-byte channel vectors: zero channels on both operands
+        cp = (Cout + 3) // 4 * 4
+        dy = torch.nn.functional.pad(dy, (0, cp - Cout))
+        wt = torch.nn.functional.pad(wt, (0, cp - Cout))
     pad_h, pad_w = dil * (KH - 1) - pad, dil * (KW - 1) - pad
     assert pad_h == pad_w and pad_h >= 0, "conv2d_dgrad: square kernels with pad <= dil*(K-1)"
     wx = weights.split_pairs_x3(wt) if (x3 and Cout % 32 == 0) else None
@@ -640,6 +666,33 @@ def bilinear_up2_bwd(dy, dx):
     assert dy.is_contiguous() and dx.is_contiguous() and tuple(dy.shape) == (N, 2 * H, 2 * W, C)
     check(lib().tt_bilinear_up2_bwd(ptr(dy), ptr(dx), _c(N), _c(H), _c(W), _c(C), _st(dy)), "tt_bilinear_up2_bwd")
     return dx
+
+
+def channel_gate_bwd(x, gate, dy, dx, dgate):
+    """dx += dy * sigmoid(gate), dgate += sigmoid'(gate) * sum_hw dy * x  (all f32, x / dy / dx [N,H,W,C] contiguous)."""
+    require_cuda(x, gate, dy, dx, dgate)
+    N, H, W, C = x.shape
+    assert x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous() and gate.is_contiguous() and dgate.is_contiguous()
+    check(lib().tt_channel_gate_bwd(ptr(x), ptr(gate), ptr(dy), ptr(dx), ptr(dgate), _c(N), _c(H * W), _c(C), _st(x)),
+          "tt_channel_gate_bwd")
+
+
+def spatial_mean_bwd(dpool, dx, C, coff=0):
+    """dx[n, :, :, coff:coff+C] += dpool[n] / (H*W)."""
+    require_cuda(dpool, dx)
+    N, H, W, Cs = dx.shape
+    assert dpool.is_contiguous() and dx.is_contiguous() and tuple(dpool.shape) == (N, C)
+    check(lib().tt_spatial_mean_bwd(ptr(dpool), ptr(dx), _c(N), _c(H * W), _c(C), _c(Cs), _c(coff), _st(dx)),
+          "tt_spatial_mean_bwd")
+
+
+def deform_im2col3x3_bwd(x, offsets, gcols, gx, goff, pad=1):
+    """gx += , goff += backward of deform_im2col3x3 (f32; gx through atomics)."""
+    require_cuda(x, offsets, gcols, gx, goff)
+    N, H, W, C = x.shape
+    assert all(t.is_contiguous() and t.dtype == torch.float32 for t in (x, offsets, gcols, gx, goff))
+    check(lib().tt_deform_im2col3x3_bwd(ptr(x), ptr(offsets), ptr(gcols), ptr(gx), ptr(goff), _c(N), _c(H), _c(W), _c(C),
+                                        _c(offsets.shape[-1]), _c(pad), _st(x)), "tt_deform_im2col3x3_bwd")
 
 
 def upsample_nearest_add_bwd(ddst, dsrc):
