@@ -465,6 +465,12 @@ int tt_channel_gate_bwd(const float* x, const float* gate, const float* dy, floa
                         void* stream);
 /* backward of tt_spatial_pool mode 0 (mean): dx[n][p][coff + c] += dpool[n][c] / HW */
 int tt_spatial_mean_bwd(const float* dpool, float* dx, int N, int HW, int C, int cstride, int coff, void* stream);
+/* backward of tt_lift_splat_fwd (f32, rot_flip = 0): grad_out is the [B][Y][X][out_cstride] BEV gradient (channel window at
+ * out_coff); grad_context [B*ncam][fH][fW][C] and grad_depth_logits [B*ncam][fH][fW][D] are accumulated (softmax included) */
+int tt_lift_splat_bwd(int batch_size, int num_cams, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y,
+                      int num_voxel_z, const float* depth_logits, const float* context, const int32_t* geom_xyz,
+                      const float* grad_out, int out_cstride, int out_coff, float* grad_depth_logits, float* grad_context,
+                      void* stream);
 /* backward of tt_deform_im2col3x3: gx += (f32 atomics), goffsets[pix][2 tap (+1)] += the sampling-position gradients */
 int tt_deform_im2col3x3_bwd(const float* x, const float* offsets, const float* gcols, float* gx, float* goffsets, int N,
                             int H, int W, int C, int off_cstride, int pad, void* stream);

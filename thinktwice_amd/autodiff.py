@@ -117,7 +117,7 @@ class Tape:
 
     # ---- recorders (called from ops.* while the tape is active)
     def conv(self, x, w, y, stride, pad, dil, scale, shift, act, in_coff, cin, out_coff, res1, res1_coff, res2, res2_coff,
-             pixel_shuffle2, in_cstride, shift_n=None, shift_n_mod=1):
+             pixel_shuffle2, in_cstride, shift_n=None, shift_n_mod=1, stop_grad=False):
         meta = CONV_META.get(id(w))
         if meta is None or in_cstride is not None:
             raise NotImplementedError("tape: convolution form without a backward yet (unnamed weight or row-run stem)")
@@ -172,6 +172,8 @@ class Tape:
             elif meta.bias is not None:
                 self.add_param_grad(meta.name + ".bias", dshift)
             # input: conv of dconv with the rotated weights, accumulated into x's gradient window
+            if stop_grad:           # the reference detaches this input (lss.py:589 seg_output.detach())
+                return
             gx = self.grad(x)
             if KH == KW:
                 ops.conv2d_dgrad(dconv, w, (H, W_), stride, pad, dil, x3=self.x3, out=gx, out_coff=in_coff)
@@ -247,6 +249,13 @@ class Tape:
         self._keep += [x, offsets, cols]
         self.nodes.append(lambda: ops.deform_im2col3x3_bwd(x, offsets, self.grad(cols).contiguous(), self.grad(x),
                                                            self.grad(offsets), pad))
+
+    def lift_splat(self, depth_logits, context, geom, voxel_num, B, ncam, out, out_coff, rot_flip):
+        if rot_flip:
+            raise NotImplementedError("tape: lift-splat with the fused rot90/flip output")
+        self._keep += [depth_logits, context, geom, out]
+        self.nodes.append(lambda: ops.lift_splat_bwd(depth_logits, context, geom, voxel_num, B, ncam, self.grad(out),
+                                                     out_coff, self.grad(depth_logits), self.grad(context)))
 
     def bilinear_up2(self, x, y):
         self._keep += [x, y]

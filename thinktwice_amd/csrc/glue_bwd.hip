@@ -191,6 +191,74 @@ __global__ __launch_bounds__(256) void deform_im2col_bwd_kernel(const float* __r
     }
 }
 
+// Lift-splat (softmax over the depth bins (x) context, scattered into the BEV cells; lss.py:583-632 + the voxel pooling
+// op) backward, fused like the forward: for pixel (image, h, w) with probabilities p_d = softmax(logits)_d and the cell
+// c(d) of its d-th frustum point,
+//   dctx[c]    = sum_d p_d * gbev[cell(d)][c]
+//   dp_d       = sum_c ctx[c] * gbev[cell(d)][c]
+//   dlogits_d  = p_d * (dp_d - sum_d' p_d' dp_d')            (softmax)
+// One wave per pixel; lanes hold 4 channels each (C <= 256), the per-bin dot products are wave reductions.  Every output is
+// written by exactly one wave: deterministic, and dctx / dlogits are ACCUMULATED into the gradient buffers.
+__global__ __launch_bounds__(256) void lift_splat_bwd_kernel(int B, int ncam, int D, int fH, int fW, int C, int X, int Y, int Z,
+                                                             const float* __restrict__ logits, const float* __restrict__ ctx,
+                                                             const int32_t* __restrict__ geom, const float* __restrict__ gbev,
+                                                             int g_cstride, int g_coff, float* __restrict__ dlogits,
+                                                             float* __restrict__ dctx) {
+    __shared__ float prob[4][128], dprob[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long npix = (long long)B * ncam * fH * fW;
+    const long long per_cam = (long long)D * fH * fW;
+    for (long long pix = (long long)blockIdx.x * 4 + wave; pix < npix; pix += (long long)gridDim.x * 4) {
+        const int w = (int)(pix % fW), h = (int)((pix / fW) % fH);
+        const long long bc = pix / ((long long)fH * fW);
+        const int b = (int)(bc / ncam);
+        const float* lg = logits + pix * D;
+        const float l0 = (lane < D) ? lg[lane] : -INFINITY, l1 = (lane + 64 < D) ? lg[lane + 64] : -INFINITY;
+        float m = fmaxf(l0, l1);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const float e0 = (lane < D) ? expf(l0 - m) : 0.f, e1 = (lane + 64 < D) ? expf(l1 - m) : 0.f;
+        float ssum = e0 + e1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
+        const float inv = 1.f / ssum;
+        if (lane < D) prob[wave][lane] = e0 * inv;
+        if (lane + 64 < D) prob[wave][lane + 64] = e1 * inv;
+        const float4 cv = (lane * 4 < C) ? *reinterpret_cast<const float4*>(ctx + pix * C + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int32_t* g = geom + bc * per_cam * 3;
+        for (int d = 0; d < D; ++d) {
+            const int32_t* q = g + ((long long)d * fH * fW + (long long)h * fW + w) * 3;
+            const int x = q[0], y = q[1], z = q[2];
+            float dot = 0.f;
+            if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {          // wave-uniform
+                const float* row = gbev + (((long long)b * Y + y) * X + x) * g_cstride + g_coff;
+                const float4 gv = (lane * 4 < C) ? *reinterpret_cast<const float4*>(row + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float p = prob[wave][d];
+                acc.x += p * gv.x; acc.y += p * gv.y; acc.z += p * gv.z; acc.w += p * gv.w;
+                dot = cv.x * gv.x + cv.y * gv.y + cv.z * gv.z + cv.w * gv.w;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+            }
+            if (lane == 0) dprob[wave][d] = dot;
+        }
+        if (lane * 4 < C) {
+            float4* dc = reinterpret_cast<float4*>(dctx + pix * C + lane * 4);
+            float4 t = *dc;
+            t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
+            *dc = t;
+        }
+        // softmax backward over the D bins
+        const float p0 = (lane < D) ? prob[wave][lane] : 0.f, p1 = (lane + 64 < D) ? prob[wave][lane + 64] : 0.f;
+        const float q0 = (lane < D) ? dprob[wave][lane] : 0.f, q1 = (lane + 64 < D) ? dprob[wave][lane + 64] : 0.f;
+        float s = p0 * q0 + p1 * q1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane < D) dlogits[pix * D + lane] += p0 * (q0 - s);
+        if (lane + 64 < D) dlogits[pix * D + lane + 64] += p1 * (q1 - s);
+    }
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -244,4 +312,21 @@ extern "C" int tt_deform_im2col3x3_bwd(const float* x, const float* offsets, con
     hipLaunchKernelGGL(deform_im2col_bwd_kernel, dim3(bwd_grid((long long)N * H * W * 9 * 64)), dim3(256), 0,
                        (hipStream_t)stream, x, offsets, gcols, gx, goffsets, N, H, W, C, off_cstride, pad);
     return check_launch("tt_deform_im2col3x3_bwd");
+}
+
+extern "C" int tt_lift_splat_bwd(int batch_size, int num_cams, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y,
+                                 int num_voxel_z, const float* depth_logits, const float* context, const int32_t* geom_xyz,
+                                 const float* grad_out, int out_cstride, int out_coff, float* grad_depth_logits,
+                                 float* grad_context, void* stream) {
+    TT_REQUIRE(depth_logits && context && geom_xyz && grad_out && grad_depth_logits && grad_context,
+               "tt_lift_splat_bwd: null pointer");
+    TT_REQUIRE(D <= 128 && C % 4 == 0 && C <= 256 && out_cstride % 4 == 0 && out_coff % 4 == 0,
+               "tt_lift_splat_bwd: D <= 128, C <= 256, 16-byte channel windows");
+    const long long npix = (long long)batch_size * num_cams * fH * fW;
+    long long blocks = (npix + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(lift_splat_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, batch_size, num_cams,
+                       D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z, depth_logits, context, geom_xyz, grad_out,
+                       out_cstride, out_coff, grad_depth_logits, grad_context);
+    return check_launch("tt_lift_splat_bwd");
 }

@@ -329,8 +329,8 @@ class LSS:
         # keep FPN maps of the key sweep before the UNet overwrites nothing of them (offset slices)
         seg = self._seg_net(bufs)
         f = seg
-        for cv in self.seg2feat[:-1]:
-            f = cv(f)
+        for i, cv in enumerate(self.seg2feat[:-1]):
+            f = cv(f, stop_grad=(i == 0))          # lss.py:589: the seg logits enter this branch detached
         self.seg2feat[-1](f, out=merge_in, out_coff=256)
         ctx = self.merge(merge_in, out_dtype=torch.float32)
         geom = self.geometry(consts["gm"], B, N)
@@ -340,7 +340,7 @@ class LSS:
         BN = B * N
         for s in range(T):
             ops.lift_splat(depth[s * BN:(s + 1) * BN], ctx[s * BN:(s + 1) * BN], geom, (vx, vy, vz), B, N,
-                           out=bev_cat, out_coff=s * OC)
+                           out=bev_cat, out_coff=s * OC, record=(s == 0))     # lss.py:711: older sweeps carry no grad
         if prev_bev is not None:
             assert T_all == 2 and tuple(prev_bev.shape) == (B, vy, vx, OC), prev_bev.shape
             bev_cat[..., OC:2 * OC].copy_(prev_bev)

@@ -42,7 +42,7 @@ def frustum_voxel_index(frustum, mats, voxel_lo, voxel_size, batch_size, num_cam
 
 
 def lift_splat(depth_logits, context, geom_xyz, voxel_num, batch_size, num_cams, out=None,
-               out_coff=0, rot_flip=False):
+               out_coff=0, rot_flip=False, record=True):
     """depth_logits [B*ncam,fH,fW,D], context [B*ncam,fH,fW,C] (channel-last, f32 or bf16),
     geom_xyz int32 [B, ncam*D*fH*fW, 3] -> out f32 [B, Y, X, Ctot] (accumulated into `out`)."""
     require_cuda(depth_logits, context, geom_xyz)
@@ -59,7 +59,24 @@ def lift_splat(depth_logits, context, geom_xyz, voxel_num, batch_size, num_cams,
                                  _c(out.shape[-1]), _c(out_coff), _c(1 if rot_flip else 0),
                                  cur_stream(context.device))
     check(rc, "tt_lift_splat_fwd")
+    if record:
+        from . import autodiff
+        if autodiff.TAPE is not None:
+            autodiff.TAPE.lift_splat(depth_logits, context, geom_xyz, (vx, vy, vz), batch_size, num_cams, out, out_coff,
+                                     rot_flip)
     return out
+
+
+def lift_splat_bwd(depth_logits, context, geom_xyz, voxel_num, batch_size, num_cams, gout, out_coff, gdepth, gctx):
+    """gdepth += , gctx += backward of lift_splat (f32; gout: the BEV gradient buffer [B, Y, X, Ctot])."""
+    require_cuda(depth_logits, context, geom_xyz, gout, gdepth, gctx)
+    BN, fH, fW, D = depth_logits.shape
+    C = context.shape[-1]
+    vx, vy, vz = voxel_num
+    assert all(t.is_contiguous() and t.dtype == torch.float32 for t in (depth_logits, context, gout, gdepth, gctx))
+    check(lib().tt_lift_splat_bwd(_c(batch_size), _c(num_cams), _c(D), _c(fH), _c(fW), _c(C), _c(vx), _c(vy), _c(vz),
+                                  ptr(depth_logits), ptr(context), ptr(geom_xyz), ptr(gout), _c(gout.shape[-1]),
+                                  _c(out_coff), ptr(gdepth), ptr(gctx), cur_stream(context.device)), "tt_lift_splat_bwd")
 
 
 # ----------------------------------------------------------------------------- conv / linear
@@ -156,7 +173,7 @@ def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None
 def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=None, res1_coff=0,
            res2=None, res2_coff=0, out=None, out_coff=0, in_coff=0, cin=None, pixel_shuffle2=False,
            shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None, splitk_ws=None,
-           in_cstride=None, w_x3=None, _no_tape=False):
+           in_cstride=None, w_x3=None, _no_tape=False, stop_grad=False):
     """Channel-last implicit-GEMM convolution on MFMA (tt_conv2d_fwd).
 
     x   [N,H,W,Cs]  (f32 or bf16); channels [in_coff, in_coff+cin) are convolved
@@ -227,7 +244,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
         from . import autodiff
         if autodiff.TAPE is not None:
             autodiff.TAPE.conv(x, w, out, stride, pad, dil, scale, shift, act, in_coff, cin, out_coff, res1, res1_coff,
-                               res2, res2_coff, pixel_shuffle2, in_cstride, shift_n, shift_n_mod)
+                               res2, res2_coff, pixel_shuffle2, in_cstride, shift_n, shift_n_mod, stop_grad)
     return out
 
 
