@@ -452,7 +452,20 @@ int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff, const flo
                          int res2_coff, const float* scale, const float* shift, long long M, int C, int act, float* dconv,
                          int dconv_cstride, int dconv_coff, float* dres, int dres_cstride, int dres_coff, float* dres2,
                          int dres2_cstride, int dres2_coff, int dres_accumulate, float* dscale, float* dshift,
-                         int accumulate, void* workspace, long long workspace_bytes, void* stream);
+                         int accumulate, const int* m_dev_or_null, void* workspace, long long workspace_bytes,
+                         void* stream);
+/* Sparse (rulebook) convolution backward.  Weight gradient dw[co][0][t][ci] (+)= sum_m dy[m][co] * x[nbr[m][t]][ci] over the
+ * live rows m < *m_dev (f32 MFMA, deterministic).  The input gradient is the forward gathered GEMM itself on a transposed
+ * rulebook: for a submanifold layer the rulebook is its own transpose under tap reversal; for a strided layer
+ * tt_sp_inverse_rulebook builds inv[j][t] = m  <=>  nbr[m][t] = j  (inv pre-filled with -1).  tt_sp_from_dense is the
+ * backward of tt_sp_to_dense (gathers the dense gradient back to the rows, accumulating). */
+long long tt_gather_conv_wgrad_workspace_bytes(long long M, int Cout, int Cin, int cin_pad, int taps);
+int tt_gather_conv_wgrad(const float* x, int x_cstride, int Cin, const int* nbr, const int* m_dev, long long M, int taps,
+                         const float* dy, int dy_cstride, int Cout, int cin_pad, int accumulate, float* dw, void* workspace,
+                         long long workspace_bytes, void* stream);
+int tt_sp_inverse_rulebook(const int* nbr, const int* m_dev, long long M, int taps, int* inv_prefilled_minus1, void* stream);
+int tt_sp_from_dense(const float* gdense, const int* coords, const int* num_rows, long long max_rows, int C, int D, int H,
+                     int W, float* grows, void* stream);
 /* backward of tt_maxpool3x3s2 (F.max_pool2d(x,3,2,1)): dx[n][ih][iw][c] += sum of dy over the <= 4 windows whose FIRST
  * maximum (scan order kh, kw, as torch) is this pixel; gather form, no atomics */
 int tt_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);

@@ -45,6 +45,8 @@ class ConvMeta:
                 full = torch.zeros(self.full_shape, dtype=torch.float32, device=dw.device)
                 tape.param_grads[self.name + ".weight"] = full
             full[:, self.lo:self.lo + self.cin] += g.permute(0, 3, 1, 2)
+        elif self.kind == "spconv":        # prepared [Cout][1][kD*kH*kW][Cin_p] -> spconv's (Cout, kD, kH, kW, Cin)
+            tape.add_param_grad(self.name + ".weight", g[:, 0].reshape(self.full_shape).contiguous())
         elif self.kind == "dcn_group":
             full = tape.param_grads.get(self.name + ".weight")
             if full is None:
@@ -190,23 +192,27 @@ class Tape:
     def _deconv2x2(self, meta, x, w, y, shift, act, in_coff, cin, out_coff, scale, res1, res2):
         """ConvTranspose2d(k=2, s=2) = 1x1 GEMM to 4*Cout channels + pixel shuffle (layers.deconv2x2_from_sd): the
         gradient is un-shuffled (a layout copy) and the layer is differentiated as the 1x1 convolution it is."""
-        if scale is not None or res1 is not None or res2 is not None or act != 0:
-            raise NotImplementedError("tape: transposed convolution with BatchNorm / residual / activation")
+        if res1 is not None or res2 is not None:
+            raise NotImplementedError("tape: transposed convolution with a residual input")
         C4 = w.shape[0]
         Cout = C4 // 4
         self._keep += [x, y]
 
         def bwd():
             N, H, W_, _ = x.shape
-            gy = self.grad(y)[..., out_coff:out_coff + Cout]                         # [N, 2H, 2W, Cout] window
-            dconv = gy.reshape(N, H, 2, W_, 2, Cout).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W_, C4).contiguous()
-            _, _, _, dshift = ops.conv_epilogue_bwd(dconv, dconv, None, None, 0, C=C4)
+            # the epilogue (per real output channel: folded BN affine or bias, activation) in the shuffled layout
+            gs, _, dscale, dshift = ops.conv_epilogue_bwd(self.grad(y), y, scale, shift, act, C=Cout, dy_coff=out_coff,
+                                                          y_coff=out_coff)
+            dconv = gs.view(N, H, 2, W_, 2, Cout).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W_, C4).contiguous()
             dw = ops.conv2d_wgrad(x, dconv, 1, 1, 1, 0, 1, cin=cin, in_coff=in_coff, cin_pad=w.shape[-1])
             # prepared rows are (dh*2+dw)*Cout + co; the reference weight is [Cin, Cout, 2, 2]
             self.add_param_grad(meta.name + ".weight",
                                 dw[:, 0, 0, :meta.cin].reshape(2, 2, Cout, meta.cin).permute(3, 2, 0, 1).contiguous())
-            if meta.bias is not None:
-                self.add_param_grad(meta.name + ".bias", dshift.view(4, Cout).sum(0))
+            if meta.bn is not None:
+                self.add_param_grad(meta.bn + ".weight", (dscale - meta.mean * dshift) / meta.sigma)
+                self.add_param_grad(meta.bn + ".bias", dshift)
+            elif meta.bias is not None:
+                self.add_param_grad(meta.name + ".bias", dshift)
             ops.conv2d_dgrad(dconv, w, (H, W_), 1, 0, 1, x3=self.x3, out=self.grad(x), out_coff=in_coff)
 
         self.nodes.append(bwd)
@@ -249,6 +255,41 @@ class Tape:
         self._keep += [x, offsets, cols]
         self.nodes.append(lambda: ops.deform_im2col3x3_bwd(x, offsets, self.grad(cols).contiguous(), self.grad(x),
                                                            self.grad(offsets), pad))
+
+    def gather_conv(self, feats, nbr, m_dev, w, scale, shift, act, res, out, in_rows):
+        """Sparse convolution (rulebook GEMM) + BatchNorm1d + residual + ReLU.  `in_rows`: None for a submanifold layer
+        (input rows == output rows), else (device row count, allocated rows) of the INPUT level of a strided layer."""
+        meta = CONV_META.get(id(w))
+        if meta is None:
+            raise NotImplementedError("tape: sparse convolution with an unregistered weight")
+        Cout, _, taps, cin_p = w.shape
+        self._keep += [feats, nbr, m_dev, res, out]
+
+        def bwd():
+            gy = self.grad(out)
+            g1 = None if res is None else self.grad(res)
+            dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, out, scale, shift, act, res, None, C=Cout, dres1=g1,
+                                                             m_dev=m_dev)
+            dw = ops.gather_conv_wgrad(feats, nbr, m_dev, dconv, taps, cin_pad=cin_p)
+            meta.place_weight_grad(self, dw)
+            self.add_param_grad(meta.bn + ".weight", (dscale - meta.mean * dshift) / meta.sigma)
+            self.add_param_grad(meta.bn + ".bias", dshift)
+            # input rows: the same gathered GEMM on the transposed rulebook, accumulated into the input's gradient
+            gx = self.grad(feats)
+            if in_rows is None:     # submanifold: nbr[m][t] = j  <=>  nbr[j][taps - 1 - t] = m
+                wt = w.flip(2).permute(3, 1, 2, 0).contiguous()
+                ops.gather_conv(dconv, nbr, m_dev, wt, res=gx, out=gx, _no_tape=True)
+            else:
+                rows_dev, rows_max = in_rows
+                inv = ops.sp_inverse_rulebook(nbr, m_dev, rows_max)
+                wt = w.permute(3, 1, 2, 0).contiguous()
+                ops.gather_conv(dconv, inv, rows_dev, wt, res=gx, out=gx, _no_tape=True)
+
+        self.nodes.append(bwd)
+
+    def sp_to_dense(self, x, coords, rows, max_rows, dims, dense):
+        self._keep += [x, coords, rows, dense]
+        self.nodes.append(lambda: ops.sp_from_dense(self.grad(dense), coords, rows, max_rows, dims, self.grad(x)))
 
     def lift_splat(self, depth_logits, context, geom, voxel_num, B, ncam, out, out_coff, rot_flip):
         if rot_flip:

@@ -131,6 +131,114 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
     dw[i] = v;
 }
 
+// Weight gradient of the gathered (sparse) convolution  y[m] = sum_t W_t x[nbr[m][t]]  (spconv SubMConv3d / SparseConv3d
+// as tt_conv2d_fwd runs them: rulebook rows, -1 = no input):  dW[co][t][ci] = sum_m dconv[m][co] * x[nbr[m][t]][ci].
+// Same structure as conv_wgrad_kernel: the pixel pair of an MFMA step is two consecutive output rows, whose input rows come
+// from the rulebook (one index load per lane half and step, then the same coalesced 128 B channel segments).
+struct GatherWgradArgs {
+    const float* x; const float* dy; const int* nbr; const int* m_dev; float* ws;
+    long long M;
+    int Cin, x_cstride, Cout, dy_cstride, taps, cin_p, ci_tiles;
+    long long pairs_per_split;
+};
+
+__global__ __launch_bounds__(256) void gather_wgrad_kernel(const GatherWgradArgs a) {
+    __shared__ float red[3][64 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, k = lane >> 5;
+    int t = blockIdx.x;
+    const int tap = t % a.taps;
+    t /= a.taps;
+    const int ci0 = (t % a.ci_tiles) * 64, co0 = (t / a.ci_tiles) * 64;
+    const long long Mlive = a.m_dev ? min(a.M, (long long)*a.m_dev) : a.M;
+    const long long npairs = (Mlive + 1) >> 1;
+    const long long p_begin = (long long)blockIdx.y * a.pairs_per_split;
+    const long long p_end = min(npairs, p_begin + a.pairs_per_split);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const bool co_ok[2] = {co0 + c < a.Cout, co0 + 32 + c < a.Cout};
+    const bool ci_ok[2] = {ci0 + c < a.Cin, ci0 + 32 + c < a.Cin};
+    for (long long p0 = p_begin + (long long)wave * kWgUnroll; p0 < p_end; p0 += 4 * kWgUnroll) {
+        float av[kWgUnroll][2], bv[kWgUnroll][2];
+#pragma unroll
+        for (int u = 0; u < kWgUnroll; ++u) {
+            const long long m = 2 * (p0 + u) + k;
+            const bool m_ok = (p0 + u) < p_end && m < Mlive;
+            const int j = m_ok ? a.nbr[m * a.taps + tap] : -1;
+            const float* dp = a.dy + (m_ok ? m : 0) * a.dy_cstride + co0 + c;
+            const float* xp = a.x + (long long)(j >= 0 ? j : 0) * a.x_cstride + ci0 + c;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                av[u][b] = (m_ok && co_ok[b]) ? dp[32 * b] : 0.f;
+                bv[u][b] = (j >= 0 && ci_ok[b]) ? xp[32 * b] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kWgUnroll; ++u)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * k;
+                    red[wave - 1][row * 64 + 32 * j + c] = acc[i][j][e];
+                }
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    float* ws = a.ws + (long long)blockIdx.y * a.Cout * a.taps * a.cin_p;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * k;
+                const int col = 32 * j + c;
+                float v = acc[i][j][e];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += red[w][row * 64 + col];
+                if (co0 + row < a.Cout && ci0 + col < a.cin_p)
+                    ws[((long long)(co0 + row) * a.taps + tap) * a.cin_p + ci0 + col] = (ci0 + col < a.Cin) ? v : 0.f;
+            }
+}
+
+// Transposed rulebook of a strided sparse convolution: inv[j][t] = the output row m with nbr[m][t] == j (at most one: the
+// output coordinate is determined by the input coordinate and the tap), -1 otherwise.  `inv` must be pre-filled with -1.
+__global__ __launch_bounds__(256) void sp_inverse_rulebook_kernel(const int* __restrict__ nbr, const int* __restrict__ m_dev,
+                                                                  long long M, int taps, int* __restrict__ inv) {
+    const long long Mlive = min(M, (long long)*m_dev);
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Mlive * taps) return;
+    const int j = nbr[i];
+    if (j >= 0) inv[(long long)j * taps + (int)(i % taps)] = (int)(i / taps);
+}
+
+// backward of sp_to_dense: grows[r][c] += gdense[b][y][x][c * D + z] for the live rows
+__global__ __launch_bounds__(256) void sp_from_dense_kernel(const float* __restrict__ gdense, const int* __restrict__ coords,
+                                                            const int* __restrict__ rows_n, long long max_rows, int C, int D,
+                                                            int H, int W, float* __restrict__ grows) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long r = t / C;
+    const int c = (int)(t % C);
+    if (r >= *rows_n || r >= max_rows) return;
+    const int b = coords[r * 4], z = coords[r * 4 + 1], y = coords[r * 4 + 2], x = coords[r * 4 + 3];
+    grows[r * C + c] += gdense[(((long long)b * H + y) * W + x) * ((long long)C * D) + (long long)c * D + z];
+}
+
 // Backward of the fused conv epilogue  y = act(scale[c] * conv + shift[c] + res1 + res2)  (folded BatchNorm affine /
 // bias, residual adds, activation; conv_common.h's forward epilogue).  From dy and the SAVED OUTPUT y:
 //   g      = dy * act'(pre)           act' from y: ReLU y > 0; sigmoid y (1 - y); none 1 (GELU / softplus need pre: refused)
@@ -146,6 +254,7 @@ struct EpiBwdArgs {
     const float* dy; const float* y; const float* res1; const float* res2;
     const float* scale; const float* shift;
     float* dconv; float* dres; float* dres2; float* partial;     // partial: [kEpiBlocks][2][C]
+    const int* m_dev;      // sparse layers: device count of live rows (rows beyond it are not touched), or null
     long long M;
     int C, dy_cstride, dy_coff, y_cstride, y_coff, r1_cstride, r1_coff, r2_cstride, r2_coff;
     int dconv_cstride, dconv_coff, dres_cstride, dres_coff, dres2_cstride, dres2_coff, dres_accumulate, act;
@@ -157,8 +266,9 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
     // thread (ty, tx): channel tx, tx + TX, ...; rows ty, ty + TY, ... of this workgroup's row range
     const int TX = a.C < 256 ? a.C : 256, TY = 256 / TX;
     const int tx = tid % TX, ty = tid / TX;
+    const long long Mlive = a.m_dev ? min(a.M, (long long)*a.m_dev) : a.M;
     const long long rows_per = (a.M + gridDim.x - 1) / gridDim.x;
-    const long long r0 = (long long)blockIdx.x * rows_per, r1 = min(a.M, r0 + rows_per);
+    const long long r0 = (long long)blockIdx.x * rows_per, r1 = min(Mlive, r0 + rows_per);
     for (int c0 = 0; c0 < a.C; c0 += TX) {             // uniform trip count: the loop body holds barriers
         const int c = c0 + tx;
         const bool c_ok = c < a.C;
@@ -275,8 +385,8 @@ extern "C" int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff
                                     int res2_coff, const float* scale, const float* shift, long long M, int C, int act,
                                     float* dconv, int dconv_cstride, int dconv_coff, float* dres, int dres_cstride,
                                     int dres_coff, float* dres2, int dres2_cstride, int dres2_coff, int dres_accumulate,
-                                    float* dscale, float* dshift, int accumulate, void* workspace,
-                                    long long workspace_bytes, void* stream) {
+                                    float* dscale, float* dshift, int accumulate, const int* m_dev_or_null,
+                                    void* workspace, long long workspace_bytes, void* stream) {
     TT_REQUIRE(dy && y && dconv && workspace && M > 0 && C > 0, "tt_conv_epilogue_bwd: bad argument");
     TT_REQUIRE(act == TT_ACT_NONE || act == TT_ACT_RELU || act == TT_ACT_SIGMOID,
                "tt_conv_epilogue_bwd: activation %d needs the pre-activation, which the forward does not keep", act);
@@ -288,7 +398,7 @@ extern "C" int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff
     a.r1_cstride = res1_cstride; a.r1_coff = res1_coff; a.r2_cstride = res2_cstride; a.r2_coff = res2_coff;
     a.dconv_cstride = dconv_cstride; a.dconv_coff = dconv_coff; a.dres_cstride = dres_cstride; a.dres_coff = dres_coff;
     a.dres2 = dres2; a.dres2_cstride = dres2_cstride; a.dres2_coff = dres2_coff; a.dres_accumulate = dres_accumulate;
-    a.act = act;
+    a.act = act; a.m_dev = m_dev_or_null;
     const int blocks = (int)(M < kEpiBlocks ? M : kEpiBlocks);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
@@ -296,4 +406,51 @@ extern "C" int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff
         hipLaunchKernelGGL(conv_epilogue_bwd_finish_kernel, dim3((unsigned)div_up(C, 256)), dim3(256), 0, st,
                            (const float*)workspace, blocks, C, accumulate, dscale, dshift);
     return check_launch("tt_conv_epilogue_bwd");
+}
+
+extern "C" long long tt_gather_conv_wgrad_workspace_bytes(long long M, int Cout, int Cin, int cin_pad, int taps) {
+    const long long tiles = (long long)div_up(Cout, 64) * div_up(cin_pad, 64) * taps;
+    long long s = (4LL * kNumCU + tiles - 1) / tiles;
+    if (s > (M + 63) / 64) s = (M + 63) / 64;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    return s * Cout * taps * cin_pad * 4;
+}
+
+extern "C" int tt_gather_conv_wgrad(const float* x, int x_cstride, int Cin, const int* nbr, const int* m_dev, long long M,
+                                    int taps, const float* dy, int dy_cstride, int Cout, int cin_pad, int accumulate,
+                                    float* dw, void* workspace, long long workspace_bytes, void* stream) {
+    TT_REQUIRE(x && nbr && dy && dw && workspace && M > 0 && taps > 0 && Cin > 0 && Cout > 0 && cin_pad >= Cin,
+               "tt_gather_conv_wgrad: bad argument");
+    const long long need = tt_gather_conv_wgrad_workspace_bytes(M, Cout, Cin, cin_pad, taps);
+    TT_REQUIRE(workspace_bytes >= need, "tt_gather_conv_wgrad: workspace too small");
+    const long long n = (long long)Cout * taps * cin_pad;
+    const int splits = (int)(need / (n * 4));
+    GatherWgradArgs a;
+    a.x = x; a.dy = dy; a.nbr = nbr; a.m_dev = m_dev; a.ws = (float*)workspace;
+    a.M = M; a.Cin = Cin; a.x_cstride = x_cstride; a.Cout = Cout; a.dy_cstride = dy_cstride; a.taps = taps;
+    a.cin_p = cin_pad; a.ci_tiles = div_up(cin_pad, 64);
+    a.pairs_per_split = div_up(div_up(M, 2), (long long)splits);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gather_wgrad_kernel, dim3((unsigned)(div_up(Cout, 64) * a.ci_tiles * taps), (unsigned)splits), dim3(256),
+                       0, st, a);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, st, (const float*)workspace, n,
+                       splits, accumulate, dw);
+    return check_launch("tt_gather_conv_wgrad");
+}
+
+extern "C" int tt_sp_inverse_rulebook(const int* nbr, const int* m_dev, long long M, int taps, int* inv_prefilled_minus1,
+                                      void* stream) {
+    TT_REQUIRE(nbr && m_dev && inv_prefilled_minus1 && M > 0 && taps > 0, "tt_sp_inverse_rulebook: bad argument");
+    hipLaunchKernelGGL(sp_inverse_rulebook_kernel, dim3((unsigned)div_up(M * taps, 256)), dim3(256), 0, (hipStream_t)stream,
+                       nbr, m_dev, M, taps, inv_prefilled_minus1);
+    return check_launch("tt_sp_inverse_rulebook");
+}
+
+extern "C" int tt_sp_from_dense(const float* gdense, const int* coords, const int* num_rows, long long max_rows, int C, int D,
+                                int H, int W, float* grows, void* stream) {
+    TT_REQUIRE(gdense && coords && num_rows && grows && max_rows > 0 && C > 0, "tt_sp_from_dense: bad argument");
+    hipLaunchKernelGGL(sp_from_dense_kernel, dim3((unsigned)div_up(max_rows * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       gdense, coords, num_rows, max_rows, C, D, H, W, grows);
+    return check_launch("tt_sp_from_dense");
 }

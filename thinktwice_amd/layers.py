@@ -82,10 +82,11 @@ def deconv2x2_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, act="none"):
     """nn.ConvTranspose2d(k=2, s=2) -> 1x1 GEMM to 4*Cout + pixel shuffle in the epilogue."""
     wq = weights.prep_deconv2x2_weight(sd[name + ".weight"].to(device), dtype)
     bias = sd.get(name + ".bias")
-    if bn is None:
-        from . import autodiff
-        autodiff.CONV_META[id(wq)] = autodiff.ConvMeta(name, sd[name + ".weight"].shape[0], None, None, None,
-                                                        _dev(bias, device))
+    from . import autodiff
+    autodiff.CONV_META[id(wq)] = autodiff.ConvMeta(
+        name, sd[name + ".weight"].shape[0], bn,
+        None if bn is None else _dev(sd[bn + ".running_mean"], device),
+        None if bn is None else torch.sqrt(_dev(sd[bn + ".running_var"], device) + eps), _dev(bias, device))
     if bn is not None:
         scale, shift = weights.fold_bn(sd[bn + ".weight"], sd[bn + ".bias"], sd[bn + ".running_mean"],
                                        sd[bn + ".running_var"], eps, bias)

@@ -85,11 +85,13 @@ def _bn1d(sd, p, dev, eps=1e-3):
     return s.to(dev).contiguous(), t.to(dev).contiguous()
 
 
-def _sp_conv(feats, nbr, level, w, bn, res=None, relu=True, plan=None):
+def _sp_conv(feats, nbr, level, w, bn, res=None, relu=True, plan=None, in_level=None):
     """SubMConv3d / SparseConv3d + BN1d (+ residual) + ReLU as ONE gathered MFMA GEMM (with the rulebook's tile plan:
-    rows sorted by tap mask, each 256-row tile multiplies only the taps that exist in it)."""
+    rows sorted by tap mask, each 256-row tile multiplies only the taps that exist in it).  `in_level`: the input level of
+    a strided layer (the training tape transposes its rulebook)."""
     return ops.gather_conv(feats, nbr, level.rows, w[0], scale=bn[0], shift=bn[1], res=res,
-                           act=_lib.ACT_RELU if relu else _lib.ACT_NONE, w_x3=w[1], plan=plan)
+                           act=_lib.ACT_RELU if relu else _lib.ACT_NONE, w_x3=w[1], plan=plan,
+                           in_rows=None if in_level is None else (in_level.rows, in_level.max_rows))
 
 
 @MIDDLE_ENCODERS.register_module()
@@ -111,8 +113,18 @@ class SparseEncoder_fp32:
         dev = self.device
         def _sp_w(t, d):
             return _sp_weight(t, d, self.wdtype)
-        self.w_in = _sp_w(sd[p + ".conv_input.0.weight"], dev)
-        self.bn_in = _bn1d(sd, p + ".conv_input.1", dev)
+
+        def _layer(conv, bnn):
+            """prepared weight + folded BN of one sparse layer, registered for the training tape"""
+            wt = sd[conv + ".weight"]
+            w = _sp_w(wt, dev)
+            b = _bn1d(sd, bnn, dev)
+            from . import autodiff
+            autodiff.CONV_META[id(w[0])] = autodiff.ConvMeta(
+                conv, wt.shape[-1], bnn, sd[bnn + ".running_mean"].float().to(dev),
+                torch.sqrt(sd[bnn + ".running_var"].float().to(dev) + 1e-3), None, kind="spconv", full_shape=tuple(wt.shape))
+            return w, b
+        self.w_in, self.bn_in = _layer(p + ".conv_input.0", p + ".conv_input.1")
         self.stages = []
         n = len(self.encoder_channels)
         for i, blocks in enumerate(self.encoder_channels):
@@ -122,13 +134,11 @@ class SparseEncoder_fp32:
                 if j == len(blocks) - 1 and i != n - 1:
                     pd = self.encoder_paddings[i][j]
                     pd = [pd] * 3 if isinstance(pd, int) else list(pd)
-                    st.append(("down", _sp_w(sd[r + ".0.weight"], dev), _bn1d(sd, r + ".1", dev), pd))
+                    st.append(("down", *_layer(r + ".0", r + ".1"), pd))
                 else:
-                    st.append(("block", _sp_w(sd[r + ".conv1.weight"], dev), _bn1d(sd, r + ".bn1", dev),
-                               _sp_w(sd[r + ".conv2.weight"], dev), _bn1d(sd, r + ".bn2", dev)))
+                    st.append(("block", *_layer(r + ".conv1", r + ".bn1"), *_layer(r + ".conv2", r + ".bn2")))
             self.stages.append(st)
-        self.w_out = _sp_w(sd[p + ".conv_out.0.weight"], dev)
-        self.bn_out = _bn1d(sd, p + ".conv_out.1", dev)
+        self.w_out, self.bn_out = _layer(p + ".conv_out.0", p + ".conv_out.1")
         return self
 
     def _down(self, feats, lvl, w, bn, kernel, stride, pad, batch):
@@ -156,7 +166,7 @@ class SparseEncoder_fp32:
         check(lib().tt_sp_rulebook(ptr(coords), ptr(rows), _ll(max_out), g, lvl.dims_c, ptr(lvl.volume()), ptr(nbr), st),
               "tt_sp_rulebook")
         plan = ops.sp_tile_plan(nbr, rows) if _TILE_PLAN else None
-        return _sp_conv(feats, nbr, new, w, bn, plan=plan), new
+        return _sp_conv(feats, nbr, new, w, bn, plan=plan, in_level=lvl), new
 
     def forward(self, voxel_features, coors, num_rows, max_rows, batch_size):
         """-> dense channel-last (B, H, W, C*D) f32 (== spatial_features.view(N, C*D, H, W))."""
@@ -178,12 +188,7 @@ class SparseEncoder_fp32:
                     _, w, bn, pd = item
                     x, lvl = self._down(x, lvl, w, bn, (3, 3, 3), (2, 2, 2), pd, batch_size)
         x, lvl = self._down(x, lvl, self.w_out, self.bn_out, (3, 1, 1), (2, 1, 1), (0, 0, 0), batch_size)
-        D, H, W = lvl.dims
-        C = x.shape[1]
-        dense = torch.zeros(batch_size, H, W, C * D, dtype=x.dtype, device=dev)
-        check(lib().tt_sp_to_dense(ptr(x), ptr(lvl.coords), ptr(lvl.rows), _ll(lvl.max_rows), _c(C), lvl.dims_c,
-                                   ptr(dense), _c(ops.dtype_code(x)), ops.cur_stream(dev)), "tt_sp_to_dense")
-        return dense
+        return ops.sp_to_dense(x, lvl.coords, lvl.rows, lvl.max_rows, lvl.dims, batch_size)
 
 
 @BACKBONES.register_module()

@@ -132,14 +132,17 @@ def sp_tile_plan(nbr, m_dev):
     return perm, mask
 
 
-def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None, out_dtype=None, w_x3=None, plan=None):
+def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None, out_dtype=None, w_x3=None, plan=None,
+                out=None, in_rows=None, _no_tape=False):
     """Sparse convolution as a gathered GEMM on MFMA: feats [R_in, C] rows, nbr int32 [M, taps]
     (rulebook, -1 = no input), m_dev device int (live output rows), w [Cout,1,taps,C] -> [M, Cout]."""
     require_cuda(feats, nbr, w)
     M, taps = nbr.shape
     Cout, _, KW, Cin = w.shape
     assert KW == taps and feats.shape[1] == Cin and feats.is_contiguous() and nbr.is_contiguous()
-    out = torch.empty(M, Cout, dtype=out_dtype or feats.dtype, device=feats.device)
+    if out is None:
+        out = torch.empty(M, Cout, dtype=out_dtype or feats.dtype, device=feats.device)
+    assert tuple(out.shape) == (M, Cout) and out.is_contiguous()
     d = _ConvDesc()
     d.in_ = feats.data_ptr(); d.N = M; d.H = 1; d.W = 1; d.Cin = Cin; d.in_cstride = Cin; d.in_coff = 0
     d.in_nstride = 0
@@ -167,7 +170,58 @@ def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None
             esz, osz = feats.element_size(), out.element_size()
             CONV_BYTES.append((Cin * esz + Cout * osz + (Cout * esz if res is not None else 0) + KW * 4,
                                w.numel() * w.element_size()))
+    if not _no_tape:
+        from . import autodiff
+        if autodiff.TAPE is not None:
+            autodiff.TAPE.gather_conv(feats, nbr, m_dev, w, scale, shift, act, res, out, in_rows)
     return out
+
+
+def gather_conv_wgrad(feats, nbr, m_dev, dy, taps, cin_pad=None):
+    """Weight gradient of gather_conv: feats [R_in, Cin] f32, nbr int32 [M, taps], dy [M, Cout] f32 -> [Cout,1,taps,cin_pad]."""
+    require_cuda(feats, nbr, dy)
+    M, Cout = dy.shape
+    Cin = feats.shape[1]
+    cin_pad = cin_pad or Cin
+    out = torch.empty(Cout, 1, taps, cin_pad, dtype=torch.float32, device=dy.device)
+    L = lib()
+    L.tt_gather_conv_wgrad_workspace_bytes.restype = ctypes.c_longlong
+    nb = int(L.tt_gather_conv_wgrad_workspace_bytes(_ll(M), _c(Cout), _c(Cin), _c(cin_pad), _c(taps)))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dy.device)
+    assert feats.is_contiguous() and dy.is_contiguous() and nbr.is_contiguous() and feats.dtype == torch.float32
+    check(L.tt_gather_conv_wgrad(ptr(feats), _c(Cin), _c(Cin), ptr(nbr), ptr(m_dev), _ll(M), _c(taps), ptr(dy), _c(Cout),
+                                 _c(Cout), _c(cin_pad), _c(0), ptr(out), ptr(ws), _ll(nb), _st(dy)), "tt_gather_conv_wgrad")
+    return out
+
+
+def sp_inverse_rulebook(nbr, m_dev, rows_in):
+    """inv int32 [rows_in, taps]: inv[j][t] = m with nbr[m][t] == j, else -1 (transposed rulebook of a strided sparse conv)."""
+    M, taps = nbr.shape
+    inv = torch.full((rows_in, taps), -1, dtype=torch.int32, device=nbr.device)
+    check(lib().tt_sp_inverse_rulebook(ptr(nbr), ptr(m_dev), _ll(M), _c(taps), ptr(inv), _st(nbr)), "tt_sp_inverse_rulebook")
+    return inv
+
+
+def sp_to_dense(x, coords, rows, max_rows, dims, batch_size):
+    """rows [R, C] at coords (b, z, y, x) -> dense channel-last (B, H, W, C*D) (== spatial_features.view(N, C*D, H, W))."""
+    D, H, W = dims
+    C = x.shape[1]
+    dense = torch.zeros(batch_size, H, W, C * D, dtype=x.dtype, device=x.device)
+    dc = (ctypes.c_int * 3)(*dims)
+    check(lib().tt_sp_to_dense(ptr(x), ptr(coords), ptr(rows), _ll(max_rows), _c(C), dc, ptr(dense), _c(dtype_code(x)),
+                               cur_stream(x.device)), "tt_sp_to_dense")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.sp_to_dense(x, coords, rows, max_rows, dims, dense)
+    return dense
+
+
+def sp_from_dense(gdense, coords, rows, max_rows, dims, grows):
+    """grows += the dense gradient gathered back to the rows (backward of sp_to_dense)."""
+    D, H, W = dims
+    C = grows.shape[1]
+    check(lib().tt_sp_from_dense(ptr(gdense), ptr(coords), ptr(rows), _ll(max_rows), _c(C), _c(D), _c(H), _c(W),
+                                 ptr(grows), cur_stream(grows.device)), "tt_sp_from_dense")
 
 
 def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=None, res1_coff=0,
@@ -631,7 +685,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, dil=1, x3=True, out=None, out_co
 
 def conv_epilogue_bwd(dy, y, scale=None, shift=None, act=0, res1=None, res2=None, want_dres=False, dscale=None, dshift=None,
                       accumulate=False, C=None, dy_coff=0, y_coff=0, res1_coff=0, res2_coff=0, dres1=None, dres1_coff=0,
-                      dres2=None, dres2_coff=0, dres_accumulate=True):
+                      dres2=None, dres2_coff=0, dres_accumulate=True, m_dev=None):
     """Backward of conv2d's fused epilogue (tt_conv_epilogue_bwd): dy / y / res* [..., Cs] f32 channel-last views of the
     same M rows (row stride = last dim) -> (dconv [M, C] dense f32, dres, dscale [C], dshift [C]).  `dres1` / `dres2`:
     gradient buffers of the residual inputs, g is added to (or, dres_accumulate=False, written over) their channel
@@ -663,7 +717,7 @@ def conv_epilogue_bwd(dy, y, scale=None, shift=None, act=0, res1=None, res2=None
                                  ptr(scale), ptr(shift), _ll(M), _c(C), _c(act), ptr(dconv), _c(C), _c(0),
                                  ptr(dres1), _c(cs(dres1)), _c(dres1_coff), ptr(dres2), _c(cs(dres2)), _c(dres2_coff),
                                  _c(1 if dres_accumulate else 0), ptr(dscale if scale is not None else None), ptr(dshift),
-                                 _c(1 if accumulate else 0), ptr(ws), _ll(nb), _st(y)), "tt_conv_epilogue_bwd")
+                                 _c(1 if accumulate else 0), ptr(m_dev), ptr(ws), _ll(nb), _st(y)), "tt_conv_epilogue_bwd")
     return dconv, dres, (dscale if scale is not None else None), dshift
 
 
