@@ -473,9 +473,12 @@ int tt_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H
 int tt_upsample_nearest_add_bwd(const float* ddst, float* dsrc, int N, int H, int W, int C, int h, int w, void* stream);
 /* backward of tt_bilinear_up2 (x2, align_corners=True): dx [N][H][W][C] += weights^T dy [N][2H][2W][C] */
 int tt_bilinear_up2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
-/* backward of tt_channel_gate (sigmoid gate, no residual, no output activation): dx += dy * s, dgate[n][c] += s(1-s) sum dy*x */
+/* backward of tt_channel_gate (sigmoid gate): dx += g * s, dgate[n][c] += s(1-s) sum g*x, with g = dy, or -- when the
+ * forward was out = relu(x*s + res), pass the saved out -- g = dy * [out > 0] and dres += g (optional) */
 int tt_channel_gate_bwd(const float* x, const float* gate, const float* dy, float* dx, float* dgate, int N, int HW, int C,
-                        void* stream);
+                        const float* out_relu_or_null, float* dres_or_null, void* stream);
+/* backward of tt_spatial_pool mode 1 (0.5 mean + 0.5 amax, ties share the amax gradient evenly); x dense [N][HW][C] */
+int tt_spatial_meanmax_bwd(const float* x, const float* dpool, float* dx, int N, int HW, int C, void* stream);
 /* backward of tt_spatial_pool mode 0 (mean): dx[n][p][coff + c] += dpool[n][c] / HW */
 int tt_spatial_mean_bwd(const float* dpool, float* dx, int N, int HW, int C, int cstride, int coff, void* stream);
 /* backward of tt_lift_splat_fwd (f32, rot_flip = 0): grad_out is the [B][Y][X][out_cstride] BEV gradient (channel window at

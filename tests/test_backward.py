@@ -277,3 +277,52 @@ def test_lidar_encoder_backward_matches_oracle_autograd():
     # folded), so ReLU masks differ on more elements than in the camera trunk: 5e-4 .. 1.1e-3 relative L2 observed
     bad = {k: e for k, e in worst.items() if e[0] > 3e-3 or e[1] > 2e-2}
     assert len(worst) > 100 and not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:10]
+
+
+def test_fusion_neck_and_flatten_backward_matches_oracle_autograd():
+    """BEV fusion neck + SEBasicBlocks (mean/amax pooling, gated residual) + flatten tail (EDF:213-235, utils.py:84-121) under
+    the tape, with upstream gradients on everything the losses touch: flat, the 32x21x21 map and the three coarser maps;
+    parameter gradients AND the gradients handed back to the camera / LiDAR BEV inputs against oracle autograd."""
+    from oracle import model_ref as M
+    from thinktwice_amd import autodiff, config, params
+    from thinktwice_amd.fusion import BEVFusion
+    B = 2
+    cfg = config.model_config()
+    sd = params.init_params(cfg, seed=4, parts=("fusion",))
+    names = [k for k in sd if k.split(".")[0] in ("conv_cam", "conv_lidar", "conv_fusion", "_256_to_32", "MLP21", "MLP10",
+                                                     "MLP4", "MLP2", "conv21_10", "conv10_4", "conv4_2", "output_fc")]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names
+              if sd[k].is_floating_point() and sd[k].dim() > 0 and not k.endswith(("running_mean", "running_var"))}
+    sdr = dict(sd)
+    sdr.update(leaves)
+    g = torch.Generator().manual_seed(14)
+    cam = torch.randn(B, 256, 21, 21, generator=g).requires_grad_(True)
+    lid = torch.randn(B, 512, 84, 84, generator=g).abs().requires_grad_(True)
+    flat, f21, mids = M.fusion(sdr, cam, lid)
+    outs = [flat, f21] + mids[3:]
+    R = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * r).sum() for o, r in zip(outs, R)).backward()
+
+    fus = BEVFusion(sd, "cuda")
+    cl = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()   # noqa: E731
+    camq, lidq = cl(cam), cl(lid)
+    with autodiff.Tape(x3=False) as tape:
+        hflat, hf21, hmids = fus(camq, lidq)
+        tape.seed(hflat, R[0])
+        for t, r in zip([hf21] + hmids[3:], R[1:]):
+            tape.seed(t, r.permute(0, 2, 3, 1))
+        tape.backward()
+    torch.cuda.synchronize()
+    assert float((hflat.cpu() - flat.detach()).abs().max() / flat.detach().abs().max()) < 1e-4
+    worst = {}
+    for k, v in leaves.items():
+        assert k in tape.param_grads, k
+        got = tape.param_grads[k].cpu()
+        assert got.shape == v.grad.shape, (k, got.shape, v.grad.shape)
+        worst[k] = float((got - v.grad).norm() / v.grad.norm().clamp_min(1e-20))
+    for name, t, ref in (("d cam_bev", camq, cam), ("d lidar_bev", lidq, lid)):
+        got = tape.grad(t).permute(0, 3, 1, 2).cpu()
+        worst[name] = float((got - ref.grad).norm() / ref.grad.norm())
+    print("fusion backward: tensors", len(worst), "worst L2 rel", max(worst.values()))
+    bad = {k: e for k, e in worst.items() if e > 1e-3}
+    assert len(worst) > 50 and not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]

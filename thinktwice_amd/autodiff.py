@@ -39,6 +39,10 @@ class ConvMeta:
             tape.add_param_grad(self.name + ".weight", g.permute(0, 3, 1, 2).contiguous())
         elif self.kind == "linear":
             tape.add_param_grad(self.name + ".weight", g[:, 0, 0, :].contiguous())
+        elif self.kind == "linear_hwc":    # Linear over a flattened (C, H*W) map whose columns were permuted to (H*W, C)
+            o = g.shape[0]
+            tape.add_param_grad(self.name + ".weight",
+                                g[:, 0, 0, :].reshape(o, self.lo, -1).permute(0, 2, 1).reshape(o, -1).contiguous())
         elif self.kind == "cin_slice":
             full = tape.param_grads.get(self.name + ".weight")
             if full is None:
@@ -228,24 +232,34 @@ class Tape:
             R, C = x.shape
             go = self.grad(out)
             # y = scale * x + shift on the first C columns: the conv-epilogue backward with conv := x
-            _, _, dscale, dshift = ops.conv_epilogue_bwd(go, out, scale, shift, 0, C=C)
+            dconv, _, dscale, dshift = ops.conv_epilogue_bwd(go, out, scale, shift, 0, C=C)
             self.add_param_grad(name + ".weight", (dscale - mean * dshift) / sigma)
-            self.add_param_grad(name + ".bias", dshift)      # (x is an input of the model: no gradient needed)
+            self.add_param_grad(name + ".bias", dshift)
+            self.grad(x).add_(dconv)
 
         self.nodes.append(bwd)
 
     def channel_gate(self, x, gate, res, out, gate_act, out_act):
         from . import _lib
-        if res is not None or out_act != 0 or gate_act != _lib.ACT_SIGMOID:
-            raise NotImplementedError("tape: channel gate with residual / output activation")
-        self._keep += [x, gate, out]
-        self.nodes.append(lambda: ops.channel_gate_bwd(x, gate, self.grad(out).contiguous(), self.grad(x), self.grad(gate)))
+        plain = res is None and out_act == _lib.ACT_NONE
+        se_block = res is not None and out_act == _lib.ACT_RELU      # SEBasicBlock: relu(x * sigmoid(g) + shortcut)
+        if gate_act != _lib.ACT_SIGMOID or not (plain or se_block):
+            raise NotImplementedError("tape: this channel-gate form has no backward yet")
+        self._keep += [x, gate, out, res]
+        if plain:
+            self.nodes.append(lambda: ops.channel_gate_bwd(x, gate, self.grad(out).contiguous(), self.grad(x),
+                                                           self.grad(gate)))
+        else:
+            self.nodes.append(lambda: ops.channel_gate_bwd(x, gate, self.grad(out).contiguous(), self.grad(x),
+                                                           self.grad(gate), out_relu=out, dres=self.grad(res)))
 
     def spatial_pool(self, x, out, mode, C, coff):
-        if mode != 0:
-            raise NotImplementedError("tape: (mean + max) / 2 pooling")
         self._keep += [x, out]
-        self.nodes.append(lambda: ops.spatial_mean_bwd(self.grad(out).contiguous(), self.grad(x), C, coff))
+        if mode == 0:
+            self.nodes.append(lambda: ops.spatial_mean_bwd(self.grad(out).contiguous(), self.grad(x), C, coff))
+        else:
+            assert coff == 0 and C == x.shape[-1], "tape: (mean + amax) / 2 pooling over a channel window"
+            self.nodes.append(lambda: ops.spatial_meanmax_bwd(x, self.grad(out).contiguous(), self.grad(x)))
 
     def repeat_rows(self, t, out, times):
         self._keep += [t, out]

@@ -105,9 +105,12 @@ __global__ __launch_bounds__(256) void bilinear_up2_ac_bwd_kernel(const float* _
 
 // out = x * sigmoid(gate[n][c])  (SELayer, lss.py:158) backward:  dx += dy * s,  dgate[n][c] += s (1 - s) sum_hw dy * x.
 // One workgroup per (image, 64-channel slab): 4 pixel partitions x 64 channels, the partitions added through LDS.
+// With `out` (the saved output) the forward was  out = relu(x * s + res): dy is masked by out > 0 first, and `dres` (optional)
+// receives the masked gradient of the residual input.
 __global__ __launch_bounds__(256) void channel_gate_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gate,
                                                                const float* __restrict__ dy, float* __restrict__ dx,
-                                                               float* __restrict__ dgate, int HW, int C) {
+                                                               float* __restrict__ dgate, int HW, int C,
+                                                               const float* __restrict__ out, float* __restrict__ dres) {
     __shared__ float red[4][64];
     const int n = blockIdx.y, cl = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -116,15 +119,45 @@ __global__ __launch_bounds__(256) void channel_gate_bwd_kernel(const float* __re
         s = 1.f / (1.f + expf(-gate[(long long)n * C + c]));
         const long long base = (long long)n * HW * C + c;
         for (int p = part; p < HW; p += 4) {
-            const float g = dy[base + (long long)p * C];
+            float g = dy[base + (long long)p * C];
+            if (out && !(out[base + (long long)p * C] > 0.f)) g = 0.f;
             acc += g * x[base + (long long)p * C];
             dx[base + (long long)p * C] += g * s;
+            if (dres) dres[base + (long long)p * C] += g;
         }
     }
     red[part][cl] = acc;
     __syncthreads();
     if (part == 0 && c < C)
         dgate[(long long)n * C + c] += s * (1.f - s) * (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+// SEModule pooling 0.5 * mean + 0.5 * amax (code/utils.py:91-92) backward: the mean half spreads dpool / HW, the amax half
+// goes to the maxima of the (image, channel) plane -- split EVENLY among ties, as torch.amax does (post-ReLU planes that are
+// all zero have HW ties).  One workgroup per (image, 64-channel slab).
+__global__ __launch_bounds__(256) void spatial_meanmax_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dpool,
+                                                                  float* __restrict__ dx, int HW, int C) {
+    __shared__ float red[4][64];
+    __shared__ float cnt[4][64];
+    const int n = blockIdx.y, cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long long base = (long long)n * HW * C + c;
+    float m = -INFINITY;
+    if (c < C)
+        for (int p = part; p < HW; p += 4) m = fmaxf(m, x[base + (long long)p * C]);
+    red[part][cl] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0][cl], red[1][cl]), fmaxf(red[2][cl], red[3][cl]));
+    float k = 0.f;
+    if (c < C)
+        for (int p = part; p < HW; p += 4) k += (x[base + (long long)p * C] == m) ? 1.f : 0.f;
+    cnt[part][cl] = k;
+    __syncthreads();
+    k = cnt[0][cl] + cnt[1][cl] + cnt[2][cl] + cnt[3][cl];
+    if (c >= C) return;
+    const float g = dpool[(long long)n * C + c];
+    const float gm = 0.5f * g / (float)HW, gx = 0.5f * g / k;
+    for (int p = part; p < HW; p += 4) dx[base + (long long)p * C] += gm + ((x[base + (long long)p * C] == m) ? gx : 0.f);
 }
 
 // mean over the pixels of an image (AdaptiveAvgPool2d(1)) backward: dx[n][p][coff + c] += dpool[n][c] / HW
@@ -292,11 +325,18 @@ extern "C" int tt_bilinear_up2_bwd(const float* dy, float* dx, int N, int H, int
 }
 
 extern "C" int tt_channel_gate_bwd(const float* x, const float* gate, const float* dy, float* dx, float* dgate, int N, int HW,
-                                   int C, void* stream) {
+                                   int C, const float* out_relu_or_null, float* dres_or_null, void* stream) {
     TT_REQUIRE(x && gate && dy && dx && dgate && N > 0 && HW > 0 && C > 0, "tt_channel_gate_bwd: bad argument");
     hipLaunchKernelGGL(channel_gate_bwd_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)N), dim3(256), 0, (hipStream_t)stream,
-                       x, gate, dy, dx, dgate, HW, C);
+                       x, gate, dy, dx, dgate, HW, C, out_relu_or_null, dres_or_null);
     return check_launch("tt_channel_gate_bwd");
+}
+
+extern "C" int tt_spatial_meanmax_bwd(const float* x, const float* dpool, float* dx, int N, int HW, int C, void* stream) {
+    TT_REQUIRE(x && dpool && dx && N > 0 && HW > 0 && C > 0, "tt_spatial_meanmax_bwd: bad argument");
+    hipLaunchKernelGGL(spatial_meanmax_bwd_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)N), dim3(256), 0,
+                       (hipStream_t)stream, x, dpool, dx, HW, C);
+    return check_launch("tt_spatial_meanmax_bwd");
 }
 
 extern "C" int tt_spatial_mean_bwd(const float* dpool, float* dx, int N, int HW, int C, int cstride, int coff, void* stream) {

@@ -739,13 +739,23 @@ def bilinear_up2_bwd(dy, dx):
     return dx
 
 
-def channel_gate_bwd(x, gate, dy, dx, dgate):
-    """dx += dy * sigmoid(gate), dgate += sigmoid'(gate) * sum_hw dy * x  (all f32, x / dy / dx [N,H,W,C] contiguous)."""
+def channel_gate_bwd(x, gate, dy, dx, dgate, out_relu=None, dres=None):
+    """dx += g * sigmoid(gate), dgate += sigmoid'(gate) * sum_hw g * x, g = dy (or dy * [out_relu > 0], then dres += g);
+    all f32, x / dy / dx [N,H,W,C] contiguous."""
     require_cuda(x, gate, dy, dx, dgate)
     N, H, W, C = x.shape
     assert x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous() and gate.is_contiguous() and dgate.is_contiguous()
-    check(lib().tt_channel_gate_bwd(ptr(x), ptr(gate), ptr(dy), ptr(dx), ptr(dgate), _c(N), _c(H * W), _c(C), _st(x)),
-          "tt_channel_gate_bwd")
+    check(lib().tt_channel_gate_bwd(ptr(x), ptr(gate), ptr(dy), ptr(dx), ptr(dgate), _c(N), _c(H * W), _c(C),
+                                    ptr(out_relu), ptr(dres), _st(x)), "tt_channel_gate_bwd")
+
+
+def spatial_meanmax_bwd(x, dpool, dx):
+    """dx += backward of spatial_pool(x, 1) (0.5 mean + 0.5 amax); x / dx [N,H,W,C] contiguous f32, dpool [N,C]."""
+    require_cuda(x, dpool, dx)
+    N, H, W, C = x.shape
+    assert x.is_contiguous() and dx.is_contiguous() and dpool.is_contiguous()
+    check(lib().tt_spatial_meanmax_bwd(ptr(x), ptr(dpool), ptr(dx), _c(N), _c(H * W), _c(C), _st(x)),
+          "tt_spatial_meanmax_bwd")
 
 
 def spatial_mean_bwd(dpool, dx, C, coff=0):
