@@ -481,6 +481,15 @@ int tt_channel_gate_bwd(const float* x, const float* gate, const float* dy, floa
 int tt_spatial_meanmax_bwd(const float* x, const float* dpool, float* dx, int N, int HW, int C, void* stream);
 /* backward of tt_spatial_pool mode 0 (mean): dx[n][p][coff + c] += dpool[n][c] / HW */
 int tt_spatial_mean_bwd(const float* dpool, float* dx, int N, int HW, int C, int cstride, int coff, void* stream);
+/* backward of tt_ew (same ops and row-strided channel windows): gv = dout * act'(saved out); da / db / dg (each optional)
+ * are accumulated.  Activations: none, ReLU, sigmoid, softplus (from the saved output). */
+int tt_ew_bwd(int op, int act, long long R, int C, const float* a, int a_stride, int a_coff, const float* b, int b_stride,
+              int b_coff, const float* g, int g_stride, int g_coff, const float* out, int o_stride, int o_coff,
+              const float* dout, int d_stride, int d_coff, float* da, int da_stride, int da_coff, float* db, int db_stride,
+              int db_coff, float* dg, int dg_stride, int dg_coff, void* stream);
+/* backward of tt_broadcast_rows: dv[n][c] += sum_p dout[n][p][coff + c] */
+int tt_broadcast_rows_bwd(const float* dout, float* dv, int N, int HW, int C, int cstride, int coff, int v_stride,
+                          void* stream);
 /* backward of tt_lift_splat_fwd (f32, rot_flip = 0): grad_out is the [B][Y][X][out_cstride] BEV gradient (channel window at
  * out_coff); grad_context [B*ncam][fH][fW][C] and grad_depth_logits [B*ncam][fH][fW][D] are accumulated (softmax included) */
 int tt_lift_splat_bwd(int batch_size, int num_cams, int D, int fH, int fW, int C, int num_voxel_x, int num_voxel_y,

@@ -136,7 +136,8 @@ class Tape:
             raise NotImplementedError("tape: per-image shift together with residual inputs")
 
         def bwd():
-            gy = self.grad(y)
+            # (views with an image stride -- e.g. one time step of a (B, T, H, W, C) buffer -- are read through dense copies)
+            gy, yd, xd = self.grad(y).contiguous(), y.contiguous(), x.contiguous()
             M = y.numel() // y.shape[-1]
             N, H, W_, _ = x.shape
             OH, OW = y.shape[1:3]
@@ -146,27 +147,27 @@ class Tape:
                 # y overwrote res1: its old value is gone (so is dscale; such layers carry a bias only) and the gradient
                 # w.r.t. it is g itself, written over gy in place
                 assert scale is None and res2 is None, "in-place residual output: bias-only epilogue"
-                dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, y, None, shift, act, None, None, C=Cout,
+                dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, yd, None, shift, act, None, None, C=Cout,
                                                                  dy_coff=out_coff, y_coff=out_coff, dres1=gy,
                                                                  dres1_coff=out_coff, dres_accumulate=False)
             elif shift_n is not None:
                 # y = act(scale * conv + shift + shift_n[image]): the kernel's dscale = sum g * (pre - shift) / scale already
                 # holds the shift_n term; d(shift_n)[image] = sum over the image's pixels of g
                 gdense = torch.empty(M, Cout, dtype=torch.float32, device=y.device)
-                dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, y, scale, shift, act, None, None, C=Cout,
+                dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, yd, scale, shift, act, None, None, C=Cout,
                                                                  dy_coff=out_coff, y_coff=out_coff, dres1=gdense,
                                                                  dres_accumulate=False)
                 imgs = shift_n.shape[0]
                 assert shift_n_mod == imgs == N, "tape: one shift row per image"
                 self.grad(shift_n).add_(ops.spatial_pool(gdense.view(N, OH, OW, Cout), 0), alpha=float(OH * OW))
             else:
-                dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, y, scale, shift, act, res1, res2, C=Cout,
+                dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, yd, scale, shift, act, res1, res2, C=Cout,
                                                                  dy_coff=out_coff, y_coff=out_coff, res1_coff=res1_coff,
                                                                  res2_coff=res2_coff, dres1=g1, dres1_coff=res1_coff,
                                                                  dres2=g2, dres2_coff=res2_coff)
             dconv = dconv.view(N, OH, OW, Cout)
             # parameters
-            dw = ops.conv2d_wgrad(x, dconv, KH, KW, stride, pad, dil, cin=cin, in_coff=in_coff, cin_pad=cin_p)
+            dw = ops.conv2d_wgrad(xd, dconv, KH, KW, stride, pad, dil, cin=cin, in_coff=in_coff, cin_pad=cin_p)
             meta.place_weight_grad(self, dw)
             if meta.bn is not None:
                 # scale = gamma / sigma, shift = beta + (bias - mean) * gamma / sigma
@@ -181,8 +182,10 @@ class Tape:
             if stop_grad:           # the reference detaches this input (lss.py:589 seg_output.detach())
                 return
             gx = self.grad(x)
-            if KH == KW:
+            if KH == KW and gx.is_contiguous():
                 ops.conv2d_dgrad(dconv, w, (H, W_), stride, pad, dil, x3=self.x3, out=gx, out_coff=in_coff)
+            elif KH == KW:
+                gx[..., in_coff:in_coff + cin] += ops.conv2d_dgrad(dconv, w, (H, W_), stride, pad, dil, x3=self.x3)
             else:
                 # 1 x KW kernel over a 1 x KW "image" (the grouped deformable-conv GEMM over im2col columns): one 1x1
                 # input-gradient GEMM per tap, written to that tap's pixel of the column gradient
@@ -221,8 +224,24 @@ class Tape:
 
         self.nodes.append(bwd)
 
+    def ew(self, op, act, R, C, a2, a_coff, b2, b_coff, g2, g_coff, o2, out_coff):
+        self._keep += [a2, b2, g2, o2]
+
+        def bwd():
+            gr = lambda t: None if t is None else self.grad(t)       # noqa: E731
+            ops.ew_bwd(op, act, R, C, a2, a_coff, b2, b_coff, g2, g_coff, o2, out_coff, self.grad(o2), gr(a2), gr(b2),
+                       gr(g2))
+
+        self.nodes.append(bwd)
+
+    def broadcast_rows(self, v, out, out_coff):
+        self._keep += [v, out]
+        self.nodes.append(lambda: ops.broadcast_rows_bwd(self.grad(out), self.grad(v), out_coff))
+
     def affine_rows(self, x, scale, shift, act, out):
         meta = AFFINE_META.get(id(scale))
+        if meta is None and act == 0 and x.untyped_storage().data_ptr() not in self.grads:
+            return      # a constant rescaling of a model input (speed / 12): nothing to differentiate
         if meta is None or act != 0:
             raise NotImplementedError("tape: affine_rows without a registered BatchNorm / with an activation")
         name, mean, sigma = meta

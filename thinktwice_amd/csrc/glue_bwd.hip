@@ -224,6 +224,53 @@ __global__ __launch_bounds__(256) void deform_im2col_bwd_kernel(const float* __r
     }
 }
 
+// tt_ew backward: out = act(v), v = a + b | (1 - b) a | (1 - g) a + g b | a  (ops 0..3).  gv = dout * act'(.) from the saved
+// output (none / ReLU / sigmoid / softplus; GELU needs the pre-activation and is refused); every requested input gradient is
+// accumulated in its own row-strided channel window.
+struct EwBwdArgs {
+    const float* a; const float* b; const float* g; const float* out; const float* dout;
+    float* da; float* db; float* dg;
+    long long R;
+    int C, as, aco, bs, bco, gs, gco, os, oco, ds, dco, das, daco, dbs, dbco, dgs, dgco, op, act;
+};
+
+__global__ __launch_bounds__(256) void ew_bwd_kernel(const EwBwdArgs p) {
+    const long long total = p.R * p.C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % p.C);
+        const long long r = i / p.C;
+        float gv = p.dout[r * p.ds + p.dco + c];
+        if (p.act != TT_ACT_NONE) {
+            const float o = p.out[r * p.os + p.oco + c];
+            if (p.act == TT_ACT_RELU) gv = o > 0.f ? gv : 0.f;
+            else if (p.act == TT_ACT_SIGMOID) gv *= o * (1.f - o);
+            else gv *= 1.f - expf(-o);                           // softplus: sigmoid(pre) = 1 - exp(-out)
+        }
+        const float av = p.a[r * p.as + p.aco + c];
+        const float bv = p.b ? p.b[r * p.bs + p.bco + c] : 0.f;
+        const float gg = p.g ? p.g[r * p.gs + p.gco + c] : 0.f;
+        float ga, gb = 0.f, gd = 0.f;
+        if (p.op == 0) { ga = gv; gb = gv; }
+        else if (p.op == 1) { ga = (1.f - bv) * gv; gb = -av * gv; }
+        else if (p.op == 2) { ga = (1.f - gg) * gv; gb = gg * gv; gd = (bv - av) * gv; }
+        else ga = gv;
+        if (p.da) p.da[r * p.das + p.daco + c] += ga;
+        if (p.db) p.db[r * p.dbs + p.dbco + c] += gb;
+        if (p.dg) p.dg[r * p.dgs + p.dgco + c] += gd;
+    }
+}
+
+// tt_broadcast_rows backward: dv[n][c] += sum over the HW pixels of image n of dout[n][p][coff + c]
+__global__ __launch_bounds__(256) void broadcast_rows_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dv, int N,
+                                                                 int HW, int C, int cstride, int coff, int v_stride) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i % C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += dout[((long long)n * HW + p) * cstride + coff + c];
+    dv[(long long)n * v_stride + c] += s;
+}
+
 // Lift-splat (softmax over the depth bins (x) context, scattered into the BEV cells; lss.py:583-632 + the voxel pooling
 // op) backward, fused like the forward: for pixel (image, h, w) with probabilities p_d = softmax(logits)_d and the cell
 // c(d) of its d-th frustum point,
@@ -369,4 +416,30 @@ extern "C" int tt_lift_splat_bwd(int batch_size, int num_cams, int D, int fH, in
                        D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z, depth_logits, context, geom_xyz, grad_out,
                        out_cstride, out_coff, grad_depth_logits, grad_context);
     return check_launch("tt_lift_splat_bwd");
+}
+
+extern "C" int tt_ew_bwd(int op, int act, long long R, int C, const float* a, int a_stride, int a_coff, const float* b,
+                         int b_stride, int b_coff, const float* g, int g_stride, int g_coff, const float* out, int o_stride,
+                         int o_coff, const float* dout, int d_stride, int d_coff, float* da, int da_stride, int da_coff,
+                         float* db, int db_stride, int db_coff, float* dg, int dg_stride, int dg_coff, void* stream) {
+    TT_REQUIRE(a && dout && R > 0 && C > 0 && op >= 0 && op <= 3, "tt_ew_bwd: bad argument");
+    TT_REQUIRE(act == TT_ACT_NONE || ((act == TT_ACT_RELU || act == TT_ACT_SIGMOID || act == TT_ACT_SOFTPLUS) && out),
+               "tt_ew_bwd: activation %d needs the pre-activation (or the saved output is missing)", act);
+    TT_REQUIRE(op == 3 || b, "tt_ew_bwd: op %d needs b", op);
+    TT_REQUIRE(op != 2 || g, "tt_ew_bwd: op 2 needs g");
+    EwBwdArgs p;
+    p.a = a; p.b = b; p.g = g; p.out = out; p.dout = dout; p.da = da; p.db = db; p.dg = dg;
+    p.R = R; p.C = C; p.as = a_stride; p.aco = a_coff; p.bs = b_stride; p.bco = b_coff; p.gs = g_stride; p.gco = g_coff;
+    p.os = o_stride; p.oco = o_coff; p.ds = d_stride; p.dco = d_coff; p.das = da_stride; p.daco = da_coff;
+    p.dbs = db_stride; p.dbco = db_coff; p.dgs = dg_stride; p.dgco = dg_coff; p.op = op; p.act = act;
+    hipLaunchKernelGGL(ew_bwd_kernel, dim3(bwd_grid(R * C)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("tt_ew_bwd");
+}
+
+extern "C" int tt_broadcast_rows_bwd(const float* dout, float* dv, int N, int HW, int C, int cstride, int coff, int v_stride,
+                                     void* stream) {
+    TT_REQUIRE(dout && dv && N > 0 && HW > 0 && C > 0, "tt_broadcast_rows_bwd: bad argument");
+    hipLaunchKernelGGL(broadcast_rows_bwd_kernel, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout,
+                       dv, N, HW, C, cstride, coff, v_stride);
+    return check_launch("tt_broadcast_rows_bwd");
 }

@@ -54,9 +54,13 @@ class _GRU:
         """inp6 (B,4,6) f32; state (B,H,W,32); fut (B,4,H,W,32) output buffer."""
         B, H, W, _ = state.shape
         dev = state.device
+        from . import autodiff
         xs = torch.zeros(B, H, W, 40, dtype=F32, device=dev)      # [x 6 | state 32 | pad 2]
         xr = torch.zeros(B, H, W, 40, dtype=F32, device=dev)
         for t in range(4):
+            if autodiff.TAPE is not None and t > 0:
+                # the training tape keeps every step's conv inputs: no reuse of the two staging buffers across steps
+                xs, xr = torch.zeros_like(xs), torch.zeros_like(xr)
             x_t = inp6[:, t]                                       # (B,6) row-strided view
             ops.broadcast_rows(x_t, xs, out_coff=0)
             ops.broadcast_rows(x_t, xr, out_coff=0)

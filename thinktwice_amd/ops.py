@@ -439,6 +439,9 @@ def broadcast_rows(v, out, out_coff=0):
     _, H, W, Ct = out.shape
     check(lib().tt_broadcast_rows(ptr(v), ptr(out), _c(N), _c(H * W), _c(C), _c(v.stride(0)), _c(Ct),
                                   _c(out_coff), _c(dtype_code(out)), _st(out)), "tt_broadcast_rows")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.broadcast_rows(v, out, out_coff)
     return out
 
 
@@ -457,7 +460,20 @@ def ew(op, a, b=None, g=None, out=None, C=None, a_coff=0, b_coff=0, g_coff=0, ou
                       _c(0 if b2 is None else b2.stride(0)), _c(b_coff), _c(0 if g2 is None else g2.stride(0)),
                       _c(g_coff), _c(o2.stride(0)), _c(out_coff), _c(op), _c(act), _c(dtype_code(a)), _st(a)),
           "tt_ew")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.ew(op, act, R, C, a2, a_coff, b2, b_coff, g2, g_coff, o2, out_coff)
     return out
+
+
+def ew_bwd(op, act, R, C, a2, a_coff, b2, b_coff, g2, g_coff, o2, out_coff, dout, da, db, dg):
+    """Backward of `ew` on the same 2-D row views (d* are the gradient views of a2 / b2 / g2 / o2, or None)."""
+    def st(t):
+        return 0 if t is None else t.stride(0)
+    check(lib().tt_ew_bwd(_c(op), _c(act), _ll(R), _c(C), ptr(a2), _c(st(a2)), _c(a_coff), ptr(b2), _c(st(b2)), _c(b_coff),
+                          ptr(g2), _c(st(g2)), _c(g_coff), ptr(o2), _c(st(o2)), _c(out_coff), ptr(dout), _c(st(dout)),
+                          _c(out_coff), ptr(da), _c(st(da)), _c(a_coff), ptr(db), _c(st(db)), _c(b_coff), ptr(dg),
+                          _c(st(dg)), _c(g_coff), _st(a2)), "tt_ew_bwd")
 
 
 def concat_rows(out, pieces, coff=0):
@@ -774,6 +790,14 @@ def deform_im2col3x3_bwd(x, offsets, gcols, gx, goff, pad=1):
     assert all(t.is_contiguous() and t.dtype == torch.float32 for t in (x, offsets, gcols, gx, goff))
     check(lib().tt_deform_im2col3x3_bwd(ptr(x), ptr(offsets), ptr(gcols), ptr(gx), ptr(goff), _c(N), _c(H), _c(W), _c(C),
                                         _c(offsets.shape[-1]), _c(pad), _st(x)), "tt_deform_im2col3x3_bwd")
+
+
+def broadcast_rows_bwd(dout, dv, out_coff):
+    """dv (N, C) (row-strided) += per-image sums of dout (N,H,W,Ct)[..., out_coff:out_coff+C]."""
+    N, C = dv.shape
+    _, H, W, Ct = dout.shape
+    check(lib().tt_broadcast_rows_bwd(ptr(dout), ptr(dv), _c(N), _c(H * W), _c(C), _c(Ct), _c(out_coff), _c(dv.stride(0)),
+                                      _st(dout)), "tt_broadcast_rows_bwd")
 
 
 def upsample_nearest_add_bwd(ddst, dsrc):

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_backward.py -m gpu -q -x -s -k "fusion" 2>&1 | tail -25
+timeout 900 python -m pytest tests/test_backward.py -m gpu -q -x -s -k "gru" 2>&1 | tail -25
