@@ -452,8 +452,10 @@ int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff, const flo
                          int res2_coff, const float* scale, const float* shift, long long M, int C, int act, float* dconv,
                          int dconv_cstride, int dconv_coff, float* dres, int dres_cstride, int dres_coff, float* dres2,
                          int dres2_cstride, int dres2_coff, int dres_accumulate, float* dscale, float* dshift,
-                         int accumulate, const int* m_dev_or_null, void* workspace, long long workspace_bytes,
-                         void* stream);
+                         int accumulate, const int* m_dev_or_null, const float* pre_or_null, void* workspace,
+                         long long workspace_bytes, void* stream);
+/* (pre_or_null: dense [M][C] pre-activation scale*conv + shift + res1 + res2, recomputed by running the layer once more
+ *  without its activation -- required for GELU / softplus, whose derivative cannot be read off the output) */
 /* Sparse (rulebook) convolution backward.  Weight gradient dw[co][0][t][ci] (+)= sum_m dy[m][co] * x[nbr[m][t]][ci] over the
  * live rows m < *m_dev (f32 MFMA, deterministic).  The input gradient is the forward gathered GEMM itself on a transposed
  * rulebook: for a submanifold layer the rulebook is its own transpose under tap reversal; for a strided layer
@@ -487,6 +489,14 @@ int tt_ew_bwd(int op, int act, long long R, int C, const float* a, int a_stride,
               int b_coff, const float* g, int g_stride, int g_coff, const float* out, int o_stride, int o_coff,
               const float* dout, int d_stride, int d_coff, float* da, int da_stride, int da_coff, float* db, int db_stride,
               int db_coff, float* dg, int dg_stride, int dg_coff, void* stream);
+/* backward of tt_layernorm_rows: dx += , dgamma += , dbeta +=  (deterministic; workspace tt_layernorm_rows_bwd_workspace_bytes) */
+long long tt_layernorm_rows_bwd_workspace_bytes(long long R, int D);
+int tt_layernorm_rows_bwd(const float* x, const float* gamma, const float* dout, float* dx, float* dgamma, float* dbeta,
+                          long long R, int D, int x_stride, int dout_stride, int dx_stride, float eps, void* workspace,
+                          long long workspace_bytes, void* stream);
+/* backward of one piece of tt_concat_rows: dsrc[(r / div) % mod or r / div][c] += dout[r][coff + c] summed over r */
+int tt_concat_piece_bwd(const float* dout, int out_stride, int coff, long long R, int C, int div, int mod, float* dsrc,
+                        int src_stride, int src_rows, void* stream);
 /* backward of tt_broadcast_rows: dv[n][c] += sum_p dout[n][p][coff + c] */
 int tt_broadcast_rows_bwd(const float* dout, float* dv, int N, int HW, int C, int cstride, int coff, int v_stride,
                           void* stream);

@@ -171,18 +171,24 @@ def test_depth_loss_backward_through_depthnet_and_trunk_matches_oracle_autograd(
 # level, and the handful of pre-activations that close to 0 get a different ReLU mask.  On the 2x4 .. 4x8-pixel maps of this
 # test one flipped pixel is percents of one channel's sum (checked: every kernel involved is exact to 1e-6 on these shapes,
 # tools/small_map_conv_check.py, and the same trunk with 2 images instead of 8 agrees to 3e-6 throughout).
-# (the op-level and sub-network tests above hold 1e-6..4e-6; this test checks the wiring of the whole encoder, and its bounds
-# are set by the mask flips: 4.5e-4 .. 4e-3 relative L2 observed over repeated runs -- the forward's f32 atomics make the
-# set of flipped pixels vary -- on maps of 8 .. 32 pixels)
-@pytest.mark.parametrize("mode,tol", [("f32", 3e-3), ("f32x3", 1e-2)])
-def test_whole_camera_encoder_backward_matches_oracle_autograd(mode, tol):
+# (the op-level and sub-network tests above hold 1e-6..4e-6; this test checks the wiring of the whole encoder.  With the
+# atomic split-K off the forward is run-to-run identical and so are these numbers: exact f32 4.5e-4 relative L2 (worst element
+# 2.2e-3); bf16x3 1.1e-2 on the seg-to-feature parameters, whose ReLUs see the 12 segmentation logits with the forward's
+# ~1e-5 error -- a hundred times more masks within rounding of 0 than in f32 -- on 16 x 32-pixel and smaller maps.  Bounds:
+# about 3x those.)
+@pytest.mark.parametrize("mode,tol", [("f32", 1.5e-3), ("f32x3", 3e-2)])
+def test_whole_camera_encoder_backward_matches_oracle_autograd(mode, tol, monkeypatch):
     """LSS.forward under the tape, two sweeps x four cameras: BEV (synthetic upstream gradient), focal segmentation loss and
     depth BCE together; every parameter of `img_encoder` against loss.backward() through oracle.lss_forward -- including the
     reference's gradient stops (older sweeps under no_grad lss.py:711, seg logits detached into seg-to-feature lss.py:589)."""
     from oracle import model_ref as M, train_ref as TR
     from thinktwice_amd import autodiff, config, params, synth
+    from thinktwice_amd import ops
     from thinktwice_amd.losses import LossReducer
     from thinktwice_amd.lss import LSS
+    # the cross-workgroup split-K of the small-M long-K layers adds with f32 atomics: without it the forward, and with it
+    # the set of ReLU masks that differ from the CPU forward, is the same in every run
+    monkeypatch.setattr(ops, "_AUTO_SPLITK", False)
     hw, B = (64, 128), 1
     cfg = config.model_config(final_dim=hw)
     sd = params.init_params(cfg, seed=8, parts=("img_encoder",))
@@ -227,7 +233,7 @@ def test_whole_camera_encoder_backward_matches_oracle_autograd(mode, tol):
     assert not missing, missing[:10]
     print("camera encoder backward: params", len(worst), "worst L2 rel", max(e[0] for e in worst.values()),
           "worst element rel", max(e[1] for e in worst.values()))
-    bad = {k: e for k, e in worst.items() if e[0] > tol or e[1] > 5 * tol}
+    bad = {k: e for k, e in worst.items() if e[0] > tol or e[1] > 6 * tol}
     assert len(worst) > 280 and not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:10]
 
 
@@ -372,3 +378,63 @@ def test_spatial_gru_backward_matches_oracle_autograd():
     print("GRU backward: tensors", len(worst), "worst L2 rel", max(worst.values()))
     bad = {k: e for k, e in worst.items() if e > 1e-3}
     assert len(worst) >= 18 and not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+
+
+def test_mlp_building_blocks_backward_match_autograd():
+    """The decoder's row-batched building blocks under the tape: concat with broadcast / modulo row mappings -> LayerNorm ->
+    Linear+GELU -> Linear (+ residual) -> softplus, and the rot90(flip) copy; parameter and input gradients vs torch autograd."""
+    import torch.nn.functional as F
+    from thinktwice_amd import _lib, autodiff, layers, ops
+    g = torch.Generator().manual_seed(21)
+    B = 3
+    fflat = torch.randn(B * 4, 64, generator=g, requires_grad=True)
+    look = torch.randn(B, 32, generator=g, requires_grad=True)
+    temporal = torch.randn(4, 16, generator=g, requires_grad=True)
+    sd = {"ln.weight": torch.rand(112, generator=g) + 0.5, "ln.bias": torch.randn(112, generator=g) * 0.1,
+          "l1.weight": torch.randn(96, 112, generator=g) * 0.1, "l1.bias": torch.randn(96, generator=g) * 0.1,
+          "l2.weight": torch.randn(64, 96, generator=g) * 0.1, "l2.bias": torch.randn(64, generator=g) * 0.1}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    # ---- torch reference
+    hin = torch.cat([fflat.view(B, 4, 64), look.unsqueeze(1).expand(B, 4, 32), temporal.unsqueeze(0).expand(B, 4, 16)], -1)
+    hin = hin.reshape(B * 4, 112)
+    hn = F.layer_norm(hin, (112,), leaves["ln.weight"], leaves["ln.bias"])
+    h = F.gelu(F.linear(hn, leaves["l1.weight"], leaves["l1.bias"]))
+    y = F.linear(h, leaves["l2.weight"], leaves["l2.bias"]) + fflat
+    z = F.softplus(y)
+    R = torch.randn(z.shape, generator=g)
+    (z * R).sum().backward()
+    # ---- HIP
+    l1 = layers.linear_from_sd(sd, "l1", "cuda", act="gelu")
+    l2 = layers.linear_from_sd(sd, "l2", "cuda")
+    gam, bet = sd["ln.weight"].cuda(), sd["ln.bias"].cuda()
+    autodiff.LN_META[id(gam)] = ("ln.weight", "ln.bias")
+    ff, lk, tp = fflat.detach().cuda(), look.detach().cuda(), temporal.detach().cuda()
+    with autodiff.Tape(x3=False) as tape:
+        hin_d = torch.empty(B * 4, 112, device="cuda")
+        ops.concat_rows(hin_d, [(ff, 64, 1, 0), (lk, 32, 4, 0), (tp, 16, 1, 4)])
+        hn_d = ops.layernorm_rows(hin_d, gam, bet)
+        y_d = layers.unrows(l2(l1(layers.rows(hn_d)), res1=layers.rows(ff)))
+        z_d = ops.ew(3, y_d, act=_lib.ACT_SOFTPLUS)
+        tape.seed(z_d, R)
+        tape.backward()
+    torch.cuda.synchronize()
+    assert float((z_d.cpu() - z.detach()).abs().max()) < 1e-5
+    errs = {k: float((tape.param_grads[k].cpu() - v.grad).norm() / v.grad.norm()) for k, v in leaves.items()}
+    for name, t, ref in (("d fflat", ff, fflat), ("d look", lk, look), ("d temporal", tp, temporal)):
+        errs[name] = float((tape.grad(t).cpu() - ref.grad).norm() / ref.grad.norm())
+    print("mlp blocks backward:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) < 2e-5, errs
+    # rot90(flip) copy
+    x = torch.randn(2, 21, 21, 8, generator=g)
+    Rr = torch.randn(2, 21, 21, 8, generator=g)
+    xd = x.cuda()
+    with autodiff.Tape() as tape:
+        out = torch.empty(2, 21, 21, 8, device="cuda")
+        ops.copy_nhwc(xd, out, rot_flip=True)
+        tape.seed(out, Rr)
+        tape.backward()
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yr = torch.rot90(torch.flip(xr, dims=[2]), 1, dims=[2, 3])
+    assert float((out.permute(0, 3, 1, 2).cpu() - yr.detach()).abs().max()) == 0.0
+    (yr * Rr.permute(0, 3, 1, 2)).sum().backward()
+    assert float((tape.grad(xd).permute(0, 3, 1, 2).cpu() - xr.grad).abs().max()) == 0.0

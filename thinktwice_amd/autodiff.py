@@ -63,6 +63,7 @@ class ConvMeta:
 
 
 AFFINE_META = {}        # id(scale tensor) -> (bn name, mean, sigma), filled by layers.bn_affine
+LN_META = {}            # id(gamma tensor) -> (weight name, bias name) of a LayerNorm
 
 
 CONV_META = {}          # id(weight tensor) -> ConvMeta, filled by layers.conv_from_sd
@@ -161,10 +162,15 @@ class Tape:
                 assert shift_n_mod == imgs == N, "tape: one shift row per image"
                 self.grad(shift_n).add_(ops.spatial_pool(gdense.view(N, OH, OW, Cout), 0), alpha=float(OH * OW))
             else:
+                pre = None
+                if act not in (0, 1, 2):        # GELU / softplus: the derivative needs the pre-activation -> run the layer
+                    pre = ops.conv2d(xd, w, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift, act=0,   # once more
+                                     in_coff=in_coff, cin=cin, res1=res1, res1_coff=res1_coff, res2=res2,
+                                     res2_coff=res2_coff, _no_tape=True)
                 dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, yd, scale, shift, act, res1, res2, C=Cout,
                                                                  dy_coff=out_coff, y_coff=out_coff, res1_coff=res1_coff,
                                                                  res2_coff=res2_coff, dres1=g1, dres1_coff=res1_coff,
-                                                                 dres2=g2, dres2_coff=res2_coff)
+                                                                 dres2=g2, dres2_coff=res2_coff, pre=pre)
             dconv = dconv.view(N, OH, OW, Cout)
             # parameters
             dw = ops.conv2d_wgrad(xd, dconv, KH, KW, stride, pad, dil, cin=cin, in_coff=in_coff, cin_pad=cin_p)
@@ -221,6 +227,47 @@ class Tape:
             elif meta.bias is not None:
                 self.add_param_grad(meta.name + ".bias", dshift)
             ops.conv2d_dgrad(dconv, w, (H, W_), 1, 0, 1, x3=self.x3, out=self.grad(x), out_coff=in_coff)
+
+        self.nodes.append(bwd)
+
+    def layernorm_rows(self, x, gamma, beta, out, D, eps):
+        names = LN_META.get(id(gamma))
+        if names is None:
+            raise NotImplementedError("tape: LayerNorm with unregistered parameters")
+        self._keep += [x, out]
+
+        def bwd():
+            dg = torch.zeros(D, dtype=torch.float32, device=x.device)
+            db = torch.zeros(D, dtype=torch.float32, device=x.device)
+            ops.layernorm_rows_bwd(x, gamma, self.grad(out), self.grad(x), dg, db, D, eps)
+            self.add_param_grad(names[0], dg)
+            self.add_param_grad(names[1], db)
+
+        self.nodes.append(bwd)
+
+    def concat_rows(self, o2, pieces, coff):
+        self._keep += [o2] + [p[0] for p in pieces]
+
+        def bwd():
+            go = self.grad(o2)
+            c = coff
+            for src, C, div, mod in pieces:
+                if src is not None:
+                    s2 = src.reshape(-1, src.shape[-1])
+                    assert s2.data_ptr() == src.data_ptr()
+                    ops.concat_piece_bwd(go, c, C, div, mod, self.grad(s2))
+                c += C
+
+        self.nodes.append(bwd)
+
+    def copy_nhwc(self, x, out, C, in_coff, out_coff, rot_flip):
+        self._keep += [x, out]
+
+        def bwd():
+            g = self.grad(out)[..., out_coff:out_coff + C]
+            if rot_flip:        # out = rot90(flip(x, H), 1, (H, W))  (EDF:241,246)  =>  x-grad = flip(rot90(g, -1), H)
+                g = torch.flip(torch.rot90(g, -1, (1, 2)), dims=[1])
+            self.grad(x)[..., in_coff:in_coff + C] += g
 
         self.nodes.append(bwd)
 

@@ -255,6 +255,7 @@ struct EpiBwdArgs {
     const float* scale; const float* shift;
     float* dconv; float* dres; float* dres2; float* partial;     // partial: [kEpiBlocks][2][C]
     const int* m_dev;      // sparse layers: device count of live rows (rows beyond it are not touched), or null
+    const float* pre;      // optional dense [M][C] pre-activation (scale*conv + shift + res): any activation
     long long M;
     int C, dy_cstride, dy_coff, y_cstride, y_coff, r1_cstride, r1_coff, r2_cstride, r2_coff;
     int dconv_cstride, dconv_coff, dres_cstride, dres_coff, dres2_cstride, dres2_coff, dres_accumulate, act;
@@ -279,7 +280,17 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
                 const float yv = a.y[m * a.y_cstride + a.y_coff + c];
                 float g = a.dy[m * a.dy_cstride + a.dy_coff + c];
                 float pre = yv;
-                if (a.act == TT_ACT_RELU) {
+                if (a.pre) {            // activation derivative from the recomputed pre-activation
+                    pre = a.pre[m * a.C + c];
+                    if (a.act == TT_ACT_RELU) g = pre > 0.f ? g : 0.f;
+                    else if (a.act == TT_ACT_SIGMOID) g *= yv * (1.f - yv);
+                    else if (a.act == TT_ACT_GELU)
+                        g *= 0.5f * (1.f + erff(pre * 0.70710678118654752440f)) +
+                             pre * 0.39894228040143267794f * expf(-0.5f * pre * pre);
+                    else if (a.act == TT_ACT_SOFTPLUS) g *= pre > 20.f ? 1.f : 1.f / (1.f + expf(-pre));
+                    else if (a.act == TT_ACT_SOFTPLUS_CLAMP)
+                        g *= yv > 1e-3f ? (pre > 20.f ? 1.f : 1.f / (1.f + expf(-pre))) : 0.f;
+                } else if (a.act == TT_ACT_RELU) {
                     g = yv > 0.f ? g : 0.f;
                 } else if (a.act == TT_ACT_SIGMOID) {
                     g *= yv * (1.f - yv);
@@ -386,10 +397,10 @@ extern "C" int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff
                                     float* dconv, int dconv_cstride, int dconv_coff, float* dres, int dres_cstride,
                                     int dres_coff, float* dres2, int dres2_cstride, int dres2_coff, int dres_accumulate,
                                     float* dscale, float* dshift, int accumulate, const int* m_dev_or_null,
-                                    void* workspace, long long workspace_bytes, void* stream) {
+                                    const float* pre_or_null, void* workspace, long long workspace_bytes, void* stream) {
     TT_REQUIRE(dy && y && dconv && workspace && M > 0 && C > 0, "tt_conv_epilogue_bwd: bad argument");
-    TT_REQUIRE(act == TT_ACT_NONE || act == TT_ACT_RELU || act == TT_ACT_SIGMOID,
-               "tt_conv_epilogue_bwd: activation %d needs the pre-activation, which the forward does not keep", act);
+    TT_REQUIRE(pre_or_null || act == TT_ACT_NONE || act == TT_ACT_RELU || act == TT_ACT_SIGMOID,
+               "tt_conv_epilogue_bwd: activation %d needs the pre-activation (pass the recomputed scale*conv+shift+res)", act);
     TT_REQUIRE(workspace_bytes >= tt_conv_epilogue_bwd_workspace_bytes(C), "tt_conv_epilogue_bwd: workspace too small");
     EpiBwdArgs a;
     a.dy = dy; a.y = y; a.res1 = res1; a.res2 = res2; a.scale = scale; a.shift = shift;
@@ -398,7 +409,7 @@ extern "C" int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff
     a.r1_cstride = res1_cstride; a.r1_coff = res1_coff; a.r2_cstride = res2_cstride; a.r2_coff = res2_coff;
     a.dconv_cstride = dconv_cstride; a.dconv_coff = dconv_coff; a.dres_cstride = dres_cstride; a.dres_coff = dres_coff;
     a.dres2 = dres2; a.dres2_cstride = dres2_cstride; a.dres2_coff = dres2_coff; a.dres_accumulate = dres_accumulate;
-    a.act = act; a.m_dev = m_dev_or_null;
+    a.act = act; a.m_dev = m_dev_or_null; a.pre = pre_or_null;
     const int blocks = (int)(M < kEpiBlocks ? M : kEpiBlocks);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);

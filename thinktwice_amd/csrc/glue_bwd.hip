@@ -260,6 +260,90 @@ __global__ __launch_bounds__(256) void ew_bwd_kernel(const EwBwdArgs p) {
     }
 }
 
+// LayerNorm over the first D columns of each row (tt_layernorm_rows) backward, one wave per row:
+//   xh = (x - mean) * rstd,  dx += rstd * (g*gamma - mean_D(g*gamma) - xh * mean_D(g*gamma*xh)),
+//   dgamma[i] += sum_rows g * xh,  dbeta[i] += sum_rows g   (per-workgroup partials [blocks][2][D], added in order by the
+//   finish kernel: deterministic).
+__global__ __launch_bounds__(256) void layernorm_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ dout, float* __restrict__ dx,
+                                                                 float* __restrict__ partial, long long R, int D, int xs,
+                                                                 int os, int dxs, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* pg = partial + (long long)blockIdx.x * 2 * D;
+    for (int i = threadIdx.x; i < 2 * D; i += 256) pg[i] = 0.f;
+    __syncthreads();
+    // the 4 waves of the workgroup take rows blockIdx.x * 4 * RPW + ...; partial sums through global atomics WITHIN the block
+    // would be non-deterministic, so each wave walks the block's rows in turn instead: wave w handles column slice, all rows
+    const long long rows_per = (R + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * rows_per, r1 = min(R, r0 + rows_per);
+    for (long long row = r0; row < r1; ++row) {
+        const float* xr = x + row * xs;
+        const float* gr = dout + row * os;
+        // statistics (every wave recomputes them: rows are short)
+        float s = 0.f;
+        for (int i = lane; i < D; i += 64) s += xr[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)D;
+        float q = 0.f, a = 0.f, b = 0.f;
+        for (int i = lane; i < D; i += 64) {
+            const float d = xr[i] - mean;
+            q += d * d;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.f / sqrtf(q / (float)D + eps);
+        for (int i = lane; i < D; i += 64) {
+            const float gg = gr[i] * gamma[i], xh = (xr[i] - mean) * rstd;
+            a += gg;
+            b += gg * xh;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o);
+            b += __shfl_xor(b, o);
+        }
+        a /= (float)D;
+        b /= (float)D;
+        // wave w owns the columns i with (i / 64) % 4 == w: dx and the column sums are written by exactly one lane
+        for (int i = lane + 64 * wave; i < D; i += 256) {
+            const float xh = (xr[i] - mean) * rstd, g = gr[i];
+            dx[row * dxs + i] += rstd * (g * gamma[i] - a - xh * b);
+            pg[i] += g * xh;
+            pg[D + i] += g;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_rows_bwd_finish_kernel(const float* __restrict__ partial, int blocks, int D,
+                                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < blocks; ++k) {
+        a += partial[(long long)k * 2 * D + i];
+        b += partial[(long long)k * 2 * D + D + i];
+    }
+    dgamma[i] += a;
+    dbeta[i] += b;
+}
+
+// tt_concat_rows backward for ONE piece: dsrc[row][c] += sum over the output rows r that read it of dout[r][coff + c]
+// (row = (r / div) % mod, or r / div when mod == 0).  R is small (batch x 4 time steps): every thread walks the rows.
+__global__ __launch_bounds__(256) void concat_piece_bwd_kernel(const float* __restrict__ dout, int out_stride, int coff,
+                                                               long long R, int C, int div, int mod, float* __restrict__ dsrc,
+                                                               int src_stride, int src_rows) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= src_rows * C) return;
+    const int row = i / C, c = i % C;
+    float s = 0.f;
+    for (long long r = 0; r < R; ++r) {
+        const long long q = r / div;
+        if ((mod ? q % mod : q) == row) s += dout[r * out_stride + coff + c];
+    }
+    dsrc[(long long)row * src_stride + c] += s;
+}
+
 // tt_broadcast_rows backward: dv[n][c] += sum over the HW pixels of image n of dout[n][p][coff + c]
 __global__ __launch_bounds__(256) void broadcast_rows_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dv, int N,
                                                                  int HW, int C, int cstride, int coff, int v_stride) {
@@ -442,4 +526,31 @@ extern "C" int tt_broadcast_rows_bwd(const float* dout, float* dv, int N, int HW
     hipLaunchKernelGGL(broadcast_rows_bwd_kernel, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout,
                        dv, N, HW, C, cstride, coff, v_stride);
     return check_launch("tt_broadcast_rows_bwd");
+}
+
+extern "C" long long tt_layernorm_rows_bwd_workspace_bytes(long long R, int D) {
+    const long long blocks = R < 256 ? R : 256;
+    return blocks * 2 * D * 4;
+}
+
+extern "C" int tt_layernorm_rows_bwd(const float* x, const float* gamma, const float* dout, float* dx, float* dgamma,
+                                     float* dbeta, long long R, int D, int x_stride, int dout_stride, int dx_stride, float eps,
+                                     void* workspace, long long workspace_bytes, void* stream) {
+    TT_REQUIRE(x && gamma && dout && dx && dgamma && dbeta && workspace && R > 0 && D > 0, "tt_layernorm_rows_bwd: bad argument");
+    TT_REQUIRE(workspace_bytes >= tt_layernorm_rows_bwd_workspace_bytes(R, D), "tt_layernorm_rows_bwd: workspace too small");
+    const int blocks = (int)(R < 256 ? R : 256);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(layernorm_rows_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, dout, dx,
+                       (float*)workspace, R, D, x_stride, dout_stride, dx_stride, eps);
+    hipLaunchKernelGGL(layernorm_rows_bwd_finish_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st,
+                       (const float*)workspace, blocks, D, dgamma, dbeta);
+    return check_launch("tt_layernorm_rows_bwd");
+}
+
+extern "C" int tt_concat_piece_bwd(const float* dout, int out_stride, int coff, long long R, int C, int div, int mod,
+                                   float* dsrc, int src_stride, int src_rows, void* stream) {
+    TT_REQUIRE(dout && dsrc && R > 0 && C > 0 && div >= 1 && mod >= 0 && src_rows > 0, "tt_concat_piece_bwd: bad argument");
+    hipLaunchKernelGGL(concat_piece_bwd_kernel, dim3((unsigned)((src_rows * C + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, dout, out_stride, coff, R, C, div, mod, dsrc, src_stride, src_rows);
+    return check_launch("tt_concat_piece_bwd");
 }

@@ -421,7 +421,29 @@ def layernorm_rows(x, gamma, beta, eps=1e-5, out=None, D=None):
     out = torch.zeros(R, x.shape[1], dtype=x.dtype, device=x.device) if out is None else out
     check(lib().tt_layernorm_rows(ptr(x), ptr(gamma), ptr(beta), ptr(out), _ll(R), _c(D), _c(x.stride(0)),
                                   _c(out.stride(0)), _f(eps), _c(dtype_code(x)), _st(x)), "tt_layernorm_rows")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.layernorm_rows(x, gamma, beta, out, D, eps)
     return out
+
+
+def layernorm_rows_bwd(x, gamma, dout, dx, dgamma, dbeta, D, eps=1e-5):
+    """dx[:, :D] += , dgamma += , dbeta += backward of layernorm_rows (2-D row-strided f32 views)."""
+    R = x.shape[0]
+    L = lib()
+    L.tt_layernorm_rows_bwd_workspace_bytes.restype = ctypes.c_longlong
+    nb = int(L.tt_layernorm_rows_bwd_workspace_bytes(_ll(R), _c(D)))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    check(L.tt_layernorm_rows_bwd(ptr(x), ptr(gamma), ptr(dout), ptr(dx), ptr(dgamma), ptr(dbeta), _ll(R), _c(D),
+                                  _c(x.stride(0)), _c(dout.stride(0)), _c(dx.stride(0)), _f(eps), ptr(ws), _ll(nb), _st(x)),
+          "tt_layernorm_rows_bwd")
+
+
+def concat_piece_bwd(dout, coff, C, div, mod, dsrc):
+    """dsrc[:, :C] += the gradient of one concat_rows piece (dout / dsrc 2-D row-strided f32 views)."""
+    R = dout.shape[0]
+    check(lib().tt_concat_piece_bwd(ptr(dout), _c(dout.stride(0)), _c(coff), _ll(R), _c(C), _c(div), _c(mod), ptr(dsrc),
+                                    _c(dsrc.stride(0)), _c(dsrc.shape[0]), _st(dout)), "tt_concat_piece_bwd")
 
 
 def copy_nhwc(x, out, C=None, in_coff=0, out_coff=0, rot_flip=False):
@@ -430,6 +452,9 @@ def copy_nhwc(x, out, C=None, in_coff=0, out_coff=0, rot_flip=False):
     check(lib().tt_copy_nhwc(ptr(x), ptr(out), _c(N), _c(H), _c(W), _c(C), _c(Cs), _c(in_coff),
                              _c(out.shape[-1]), _c(out_coff), _c(1 if rot_flip else 0), _c(dtype_code(x)),
                              _c(dtype_code(out)), _st(x)), "tt_copy_nhwc")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.copy_nhwc(x, out, C, in_coff, out_coff, rot_flip)
     return out
 
 
@@ -499,6 +524,9 @@ def concat_rows(out, pieces, coff=0):
         c += C
     check(lib().tt_concat_rows(ptr(o2), _ll(o2.shape[0]), _c(o2.stride(0)), _c(n), srcs, strides, widths, coffs, divs,
                                mods, _st(out)), "tt_concat_rows")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.concat_rows(o2, pieces, coff)
     return out
 
 
@@ -701,7 +729,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, dil=1, x3=True, out=None, out_co
 
 def conv_epilogue_bwd(dy, y, scale=None, shift=None, act=0, res1=None, res2=None, want_dres=False, dscale=None, dshift=None,
                       accumulate=False, C=None, dy_coff=0, y_coff=0, res1_coff=0, res2_coff=0, dres1=None, dres1_coff=0,
-                      dres2=None, dres2_coff=0, dres_accumulate=True, m_dev=None):
+                      dres2=None, dres2_coff=0, dres_accumulate=True, m_dev=None, pre=None):
     """Backward of conv2d's fused epilogue (tt_conv_epilogue_bwd): dy / y / res* [..., Cs] f32 channel-last views of the
     same M rows (row stride = last dim) -> (dconv [M, C] dense f32, dres, dscale [C], dshift [C]).  `dres1` / `dres2`:
     gradient buffers of the residual inputs, g is added to (or, dres_accumulate=False, written over) their channel
@@ -733,7 +761,8 @@ def conv_epilogue_bwd(dy, y, scale=None, shift=None, act=0, res1=None, res2=None
                                  ptr(scale), ptr(shift), _ll(M), _c(C), _c(act), ptr(dconv), _c(C), _c(0),
                                  ptr(dres1), _c(cs(dres1)), _c(dres1_coff), ptr(dres2), _c(cs(dres2)), _c(dres2_coff),
                                  _c(1 if dres_accumulate else 0), ptr(dscale if scale is not None else None), ptr(dshift),
-                                 _c(1 if accumulate else 0), ptr(m_dev), ptr(ws), _ll(nb), _st(y)), "tt_conv_epilogue_bwd")
+                                 _c(1 if accumulate else 0), ptr(m_dev), ptr(pre), ptr(ws), _ll(nb), _st(y)),
+          "tt_conv_epilogue_bwd")
     return dconv, dres, (dscale if scale is not None else None), dshift
 
 
