@@ -728,7 +728,7 @@ static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0) {
     if (a.m_begin == 0)      // (the tail launch of a split keeps the main launch's label)
         snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_igemm_glds_kernel<%s, %d, %d, %d, %d, %d, %s, %s>%s",
                  sizeof(T) == 4 ? "float" : "16-bit", BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER ? "true" : "false",
-                 X3 ? (PP ? "true, true" : "true") : "false", m_tiles_limit > 0 ? " + tail" : "");
+                 X3 ? (PP ? "true, true" : "true, false") : "false, false", m_tiles_limit > 0 ? " + tail" : "");
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(WAVES_M * WAVES_N * 64), smem, st, a, zp,
                        tiles_m, tiles_n);
     return 1;
