@@ -489,6 +489,18 @@ int tt_ew_bwd(int op, int act, long long R, int C, const float* a, int a_stride,
               int b_coff, const float* g, int g_stride, int g_coff, const float* out, int o_stride, int o_coff,
               const float* dout, int d_stride, int d_coff, float* da, int da_stride, int da_coff, float* db, int db_stride,
               int db_coff, float* dg, int dg_stride, int dg_coff, void* stream);
+/* Backward of the look module's kernels (f32; scatters with atomics).  The waypoint / control inputs of a refinement layer
+ * are detached in the reference (thinktwice_decoder.py:429-430), so there is no gradient for them or the reference points.
+ * tt_look_gather_query_bwd: dout = gradient of the query rows; adds into the embeddings, the per-sample vectors and the four
+ * FPN-side maps.  tt_msda_sample_bwd: adds into the value tensor's channel window, the offsets [R][512] and the attention
+ * logits [R][256] (softmax included).  tt_sca_reduce_bwd: dx[bc][k] += dout[bc] / B for the slots the forward summed. */
+int tt_look_gather_query_bwd(int B, const int* query_of_slot, const float* ref_packed, const float* dout, int row_stride,
+                             float* dtemporal, float* dstatic, float* dmeas, float* dflat, float* const* dlevel_maps,
+                             const int* level_hw, void* stream);
+int tt_msda_sample_bwd(int B, const float* value, int value_cstride, int value_coff, const float* offsets,
+                       const float* logits, const float* ref_packed, const int* level_hw, const float* dout, float* dvalue,
+                       float* doffsets, float* dlogits, void* stream);
+int tt_sca_reduce_bwd(int B, const float* dout, const int* max_len, float* dx, void* stream);
 /* backward of tt_layernorm_rows: dx += , dgamma += , dbeta +=  (deterministic; workspace tt_layernorm_rows_bwd_workspace_bytes) */
 long long tt_layernorm_rows_bwd_workspace_bytes(long long R, int D);
 int tt_layernorm_rows_bwd(const float* x, const float* gamma, const float* dout, float* dx, float* dgamma, float* dbeta,

@@ -438,3 +438,169 @@ def test_mlp_building_blocks_backward_match_autograd():
     assert float((out.permute(0, 3, 1, 2).cpu() - yr.detach()).abs().max()) == 0.0
     (yr * Rr.permute(0, 3, 1, 2)).sum().backward()
     assert float((tape.grad(xd).permute(0, 3, 1, 2).cpu() - xr.grad).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_look_module_backward_matches_oracle_autograd(B):
+    """Camera look module of one refinement layer (thinktwice_decoder.py:154-187, multi_scale_deformable_attn_function.py:
+    279-344 and :197-277): FPN-side 1x1 projections -> query gather (embeddings, per-sample vectors, bilinear samples of the
+    four maps) -> LayerNorm / MLP -> offsets + softmax weights -> deformable sampling of the value projection (with the
+    camera / level embedding shift) -> FFN -> slot reduction -> output MLP.  Parameter gradients under the reference names
+    and the gradients w.r.t. the FPN features, the measurement vector and the flattened BEV vector vs oracle autograd."""
+    from oracle import model_ref as M
+    from tests.test_decoder import _inputs
+    from thinktwice_amd import autodiff, config, params, weights
+    from thinktwice_amd.decoder import ThinkTwiceDecoder
+    hw = (128, 256)
+    cfg = config.model_config(final_dim=hw)
+    sd = params.init_params(cfg, seed=3, parts=("decoder",))
+    _, _, fpn, batch, l2i, ida = _inputs(B, hw, seed=4)
+    g = torch.Generator().manual_seed(33)
+    wp = torch.cumsum(torch.randn(B, 4, 2, generator=g) + torch.tensor([2.0, 0.0]), 1)
+    ctrl_sp = torch.rand(B, 4, 4, generator=g) + 0.5
+    meas = torch.randn(B, 128, generator=g).requires_grad_(True)
+    flat = torch.randn(B, 256, generator=g).requires_grad_(True)
+    fpn = [f.clone().requires_grad_(True) for f in fpn]
+    p = "decoder.decoder_layers.0.look_module"
+    used = (p + ".cam_look_module.", "decoder.fpn_linear", "decoder.cams_embeds", "decoder.level_embeds",
+            "decoder.temporal_embedding", "decoder.static_embedding")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith(used)}
+    sdr = dict(sd)
+    sdr.update(leaves)
+    mlvl = [M.conv(sdr, f"decoder.fpn_linear{i}", fpn[i]) for i in range(4)]
+    shapes = [tuple(f.shape[2:]) for f in mlvl]
+    vals = []
+    for lvl, f in enumerate(mlvl):
+        v = f.view(B, 4, 256, -1).permute(0, 1, 3, 2)
+        vals.append(v + sdr["decoder.cams_embeds"].view(1, 4, 1, 256) + sdr["decoder.level_embeds"][lvl].view(1, 1, 1, 256))
+    value_in = torch.cat(vals, 2).reshape(B * 4, -1, 256)
+    ref, info = M.look_module(sdr, p, cfg, wp, ctrl_sp, meas, flat, l2i, ida, mlvl, value_in, shapes,
+                              sdr["decoder.temporal_embedding"], sdr["decoder.static_embedding"])
+    assert info["max_len"] > B, "the test needs queries that project into the cameras"
+    R = torch.randn(ref.shape, generator=g)
+    (ref * R).sum().backward()
+
+    dec = ThinkTwiceDecoder(config=cfg["cfg"], bev_h=21, bev_w=21).load_state_dict(sd)
+    assert dec.fused is None
+    lay = dec.layers[0]
+    fpn_d = [weights.to_channel_last(f.detach()).cuda() for f in fpn]
+    meas_d, flat_d = meas.detach().cuda(), flat.detach().cuda()
+    with autodiff.Tape(x3=False) as tape:
+        maps = [dec.fpn_linear[i](t) for i, t in enumerate(fpn_d)]
+        level_hw = [(m.shape[1], m.shape[2]) for m in maps]
+        S = sum(h * w for h, w in level_hw)
+        value = dec._project_values_train(lay, maps, B, S)
+        out, _ = dec._look(lay, B, wp.cuda(), ctrl_sp.cuda(), meas_d, flat_d, l2i.cuda().float().contiguous(),
+                           ida.cuda().float().contiguous(), maps, level_hw, S, (value, 0, None))
+        tape.seed(out, R)
+        tape.backward()
+    torch.cuda.synchronize()
+    assert float((out.cpu() - ref.detach()).abs().max() / ref.detach().abs().max()) < 1e-4
+    worst, unused = {}, []
+    for k, v in leaves.items():
+        if v.grad is None:
+            unused.append(k)
+            continue
+        got = tape.param_grads[k].cpu()
+        assert got.shape == v.grad.shape, (k, got.shape, v.grad.shape)
+        worst[k] = float((got - v.grad).norm() / v.grad.norm().clamp_min(1e-20))
+    for i in range(4):
+        worst[f"d fpn{i}"] = float((tape.grad(fpn_d[i]).permute(0, 3, 1, 2).cpu() - fpn[i].grad).norm() / fpn[i].grad.norm())
+    worst["d meas"] = float((tape.grad(meas_d).cpu() - meas.grad).norm() / meas.grad.norm())
+    worst["d flat"] = float((tape.grad(flat_d).cpu() - flat.grad).norm() / flat.grad.norm())
+    print("look module backward: tensors", len(worst), "unused", len(unused), "worst L2 rel", max(worst.values()))
+    bad = {k: e for k, e in worst.items() if e > 1e-3}
+    assert len(worst) >= 30 and not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+
+
+def test_decoder_backward_matches_oracle_autograd():
+    """The whole look-and-predict decoder (thinktwice_decoder.py:419-533): coarse heads, five refinement layers (conv-GRU
+    + shared flatten network, look module, merge MLP, offset heads, BEV / flattened-feature updates) chained through the
+    DETACHED previous outputs (DEC:429-430), and the teacher-forcing pass over the same layers.  Random cotangents on every
+    output the training losses read; parameter gradients under the reference names and the gradients handed back to the
+    encoder (flattened BEV vector, BEV map, measurement vector, FPN features) vs oracle autograd."""
+    from oracle import model_ref as M
+    from tests.test_decoder import _inputs
+    from thinktwice_amd import autodiff, config, params, synth, weights
+    from thinktwice_amd.decoder import ThinkTwiceDecoder
+    from thinktwice_amd.encoder_decoder import EncoderDecoder
+    from thinktwice_amd.fusion import BEVFusion
+    B, hw, Rn = 2, (128, 256), 5
+    cfg = config.model_config(final_dim=hw)
+    sd = params.init_params(cfg, seed=6, parts=("fusion", "decoder"))
+    _, _, fpn, batch, l2i, ida = _inputs(B, hw, seed=7)
+    tgt = synth.make_train_targets(B, img_hw=hw)
+    teacher = {k: tgt[k] for k in ("waypoints", "action_mu", "action_sigma", "future_action_mu", "future_action_sigma")}
+    g = torch.Generator().manual_seed(44)
+    flat = torch.randn(B, 256, generator=g).requires_grad_(True)
+    bev = (torch.randn(B, 32, 21, 21, generator=g) * 0.5).requires_grad_(True)
+    meas = torch.randn(B, 128, generator=g).abs().requires_grad_(True)
+    fpn = [f.clone().requires_grad_(True) for f in fpn]
+    tail = ("MLP10.", "MLP4.", "MLP2.", "conv21_10.", "conv10_4.", "conv4_2.", "output_fc.")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if (k.startswith("decoder.") or k.startswith(tail)) and v.is_floating_point() and v.dim() > 0
+              and not k.endswith(("running_mean", "running_var"))}
+    sdr = dict(sd)
+    sdr.update(leaves)
+    ref = M.decoder_forward(sdr, cfg, flat, bev, meas, l2i, ida, fpn, teacher=teacher)
+    ct_ref = torch.cat([torch.cat([ref["mu_branches"], ref["sigma_branches"]], -1).unsqueeze(2),
+                        torch.cat([ref["future_mu"], ref["future_sigma"]], -1)], 2)                 # (B, R+1, 4, 4)
+    fut_ref = ref["refine_future_BEV_feature"].transpose(1, 2).reshape(B, Rn, 4, 32, 21, 21)        # undo the DEC:481 re-view
+    pairs = [("pred_wp", ref["pred_wp"], None), ("ct", ct_ref, None), ("pred_speed", ref["pred_speed"], None),
+             ("pred_value_traj", ref["pred_value_traj"], None), ("pred_value_ctrl", ref["pred_value_ctrl"], None),
+             ("pred_features_traj", ref["pred_features_traj"], None), ("pred_features_ctrl", ref["pred_features_ctrl"], None),
+             ("refine_flattned_BEV_feature", ref["refine_flattned_BEV_feature"], None),
+             ("_refine_bev_cl", ref["refine_BEV_feature"], (0, 1, 3, 4, 2)), ("_refine_fut_cl", fut_ref, (0, 1, 2, 4, 5, 3)),
+             ("teacher_pred_wp_offset", ref["teacher_pred_wp_offset"], None),
+             ("teacher_pred_ctrl_offset_lis", ref["teacher_pred_ctrl_offset_lis"], None),
+             ("teacher_refine_flattned_BEV_feature", ref["teacher_refine_flattned_BEV_feature"], None),
+             ("_teacher_refine_bev_cl", ref["teacher_refine_BEV_feature"], (0, 1, 3, 4, 2)),
+             ("_teacher_fut_cl", ref["teacher_future_BEV_feature"], (0, 1, 2, 4, 5, 3))]
+    cot = {name: torch.randn(t.shape, generator=g) for name, t, _ in pairs}
+    sum((t * cot[name]).sum() for name, t, _ in pairs).backward()
+
+    dev = torch.device("cuda")
+    par = EncoderDecoder.__new__(EncoderDecoder)
+    par.device = dev
+    par.fusion = BEVFusion(sd, dev)
+    dec = ThinkTwiceDecoder(config=cfg["cfg"], bev_h=21, bev_w=21).load_state_dict(sd)
+    fpn_d = [weights.to_channel_last(f.detach()).cuda() for f in fpn]
+    flat_d, meas_d = flat.detach().cuda(), meas.detach().cuda()
+    bev_d = weights.to_channel_last(bev.detach()).cuda()
+    t_dev = {k: ([t.cuda() for t in v] if isinstance(v, list) else v.cuda()) for k, v in teacher.items()}
+    with autodiff.Tape(x3=False) as tape:
+        out = dec(flat_d, bev_d, meas_d, batch["target_point"], par, t_dev, [l2i, ida, [(f, 0, 256) for f in fpn_d], None],
+                  channel_last_out=True)
+        for name, t, perm in pairs:
+            c = cot[name] if perm is None else cot[name].permute(*perm)
+            if name == "ct":
+                tape.seed(out["mu_branches"], c[:, :, 0, :2])
+                tape.seed(out["sigma_branches"], c[:, :, 0, 2:])
+                tape.seed(out["future_mu"], c[:, :, 1:, :2])
+                tape.seed(out["future_sigma"], c[:, :, 1:, 2:])
+            else:
+                tape.seed(out[name], c)
+        tape.backward()
+    torch.cuda.synchronize()
+    for name, t, perm in pairs:
+        if name == "ct":
+            continue
+        got = out[name].cpu() if perm is None else out[name].cpu().permute(*[perm.index(i) for i in range(len(perm))])
+        assert float((got - t.detach()).abs().max() / t.detach().abs().max()) < 1e-4, name
+    worst, unused = {}, []
+    for k, v in leaves.items():
+        if v.grad is None:
+            unused.append(k)
+            continue
+        assert k in tape.param_grads, k
+        got = tape.param_grads[k].cpu()
+        assert got.shape == v.grad.shape, (k, got.shape, v.grad.shape)
+        worst[k] = float((got - v.grad).norm() / v.grad.norm().clamp_min(1e-20))
+    for i in range(4):
+        worst[f"d fpn{i}"] = float((tape.grad(fpn_d[i]).permute(0, 3, 1, 2).cpu() - fpn[i].grad).norm() / fpn[i].grad.norm())
+    worst["d meas"] = float((tape.grad(meas_d).cpu() - meas.grad).norm() / meas.grad.norm())
+    worst["d flat"] = float((tape.grad(flat_d).cpu() - flat.grad).norm() / flat.grad.norm())
+    worst["d bev"] = float((tape.grad(bev_d).permute(0, 3, 1, 2).cpu() - bev.grad).norm() / bev.grad.norm())
+    print("decoder backward: tensors", len(worst), "unused", len(unused), "worst L2 rel", max(worst.values()))
+    bad = {k: e for k, e in worst.items() if e > 2e-3}
+    assert len(worst) >= 300 and not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]

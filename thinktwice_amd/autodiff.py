@@ -67,6 +67,13 @@ LN_META = {}            # id(gamma tensor) -> (weight name, bias name) of a Laye
 
 
 CONV_META = {}          # id(weight tensor) -> ConvMeta, filled by layers.conv_from_sd
+PARAM_TENSORS = {}      # id(tensor) -> (state_dict name, tensor): parameters the ops read directly as activations-like inputs
+                        # (embeddings); their gradient buffers are moved to param_grads when backward() ends
+
+
+def register_param(t, name):
+    PARAM_TENSORS[id(t)] = (name, t)
+    return t
 
 
 class Tape:
@@ -119,6 +126,9 @@ class Tape:
                 fn()
         finally:
             TAPE = active
+        for name, t in PARAM_TENSORS.values():
+            if t.is_cuda and t.untyped_storage().data_ptr() in self.grads:
+                self.add_param_grad(name, self.grad(t).clone())
         self.nodes.clear()
         self._keep.clear()
 
@@ -159,8 +169,9 @@ class Tape:
                                                                  dy_coff=out_coff, y_coff=out_coff, dres1=gdense,
                                                                  dres_accumulate=False)
                 imgs = shift_n.shape[0]
-                assert shift_n_mod == imgs == N, "tape: one shift row per image"
-                self.grad(shift_n).add_(ops.spatial_pool(gdense.view(N, OH, OW, Cout), 0), alpha=float(OH * OW))
+                assert shift_n_mod == imgs and N % imgs == 0, "tape: image n reads shift row n % rows"
+                per_image = ops.spatial_pool(gdense.view(N, OH, OW, Cout), 0)
+                self.grad(shift_n).add_(per_image.view(N // imgs, imgs, Cout).sum(0), alpha=float(OH * OW))
             else:
                 pre = None
                 if act not in (0, 1, 2):        # GELU / softplus: the derivative needs the pre-activation -> run the layer
@@ -242,6 +253,61 @@ class Tape:
             ops.layernorm_rows_bwd(x, gamma, self.grad(out), self.grad(x), dg, db, D, eps)
             self.add_param_grad(names[0], dg)
             self.add_param_grad(names[1], db)
+
+        self.nodes.append(bwd)
+
+    # ---- look module (decoder): the waypoint / control inputs are detached by the reference (DEC:429-430)
+    def look_gather_query(self, qos, ref, out, temporal, static, meas, flat, maps, row_stride):
+        self._keep += [qos, ref, out, temporal, static, meas, flat] + list(maps)
+
+        def bwd():
+            B = meas.shape[0]
+            grads = [self.grad(m) for m in maps]
+            assert all(g.is_contiguous() for g in grads) and meas.is_contiguous() and flat.is_contiguous()
+            ops.look_gather_query_bwd(B, qos, ref, self.grad(out), row_stride, self.grad(temporal), self.grad(static),
+                                      self.grad(meas), self.grad(flat), grads)
+
+        self.nodes.append(bwd)
+
+    def msda_sample(self, value, offsets, logits, ref, level_hw, B, coff, out):
+        self._keep += [value, offsets, logits, ref, out]
+
+        def bwd():
+            gv, go, gl = self.grad(value), self.grad(offsets), self.grad(logits)
+            assert gv.is_contiguous() and go.is_contiguous() and gl.is_contiguous()
+            ops.msda_sample_bwd(B, value, coff, offsets, logits, ref, level_hw, self.grad(out), gv, go, gl)
+
+        self.nodes.append(bwd)
+
+    def sca_reduce(self, x, max_len, B, out):
+        self._keep += [x, max_len, out]
+
+        def bwd():
+            gx = self.grad(x)
+            assert gx.is_contiguous()
+            ops.sca_reduce_bwd(B, self.grad(out), max_len, gx)
+
+        self.nodes.append(bwd)
+
+    def value_shift(self, vshift, weight, weight_name, cams, cams_name, lvls, lvls_name):
+        """vshift[l] (cam, 256) = (cams + lvls[l]) @ W^T -- the embedding part of value_proj(feat + cam + level) (DEC:392-393).
+        Recorded BEFORE the projections that read it, so it runs after they have accumulated d(vshift)."""
+        self._keep += list(vshift)
+
+        def bwd():
+            dW = torch.zeros_like(weight)
+            dc = torch.zeros_like(cams)
+            dl = torch.zeros_like(lvls)
+            for l, vs in enumerate(vshift):
+                g = self.grad(vs)                                   # (cam, 256 out)
+                emb = cams.view(-1, 256) + lvls[l].view(1, 256)
+                dW += g.t() @ emb
+                de = g @ weight
+                dc += de.view_as(dc)
+                dl[l] += de.sum(0)
+            self.add_param_grad(weight_name, dW)
+            self.add_param_grad(cams_name, dc)
+            self.add_param_grad(lvls_name, dl)
 
         self.nodes.append(bwd)
 

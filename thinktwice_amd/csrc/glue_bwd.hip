@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void deform_im2col_bwd_kernel(const float* __r
 }
 
 // tt_ew backward: out = act(v), v = a + b | (1 - b) a | (1 - g) a + g b | a  (ops 0..3).  gv = dout * act'(.) from the saved
-// output (none / ReLU / sigmoid / softplus; GELU needs the pre-activation and is refused); every requested input gradient is
+// output (none / ReLU / sigmoid / softplus [clamped]; GELU needs the pre-activation and is refused); every requested input gradient is
 // accumulated in its own row-strided channel window.
 struct EwBwdArgs {
     const float* a; const float* b; const float* g; const float* out; const float* dout;
@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void ew_bwd_kernel(const EwBwdArgs p) {
             const float o = p.out[r * p.os + p.oco + c];
             if (p.act == TT_ACT_RELU) gv = o > 0.f ? gv : 0.f;
             else if (p.act == TT_ACT_SIGMOID) gv *= o * (1.f - o);
+            else if (p.act == TT_ACT_SOFTPLUS_CLAMP) gv = o > 1e-3f ? gv * (1.f - expf(-o)) : 0.f;   // clamped: no gradient
             else gv *= 1.f - expf(-o);                           // softplus: sigmoid(pre) = 1 - exp(-out)
         }
         const float av = p.a[r * p.as + p.aco + c];
@@ -507,7 +508,7 @@ extern "C" int tt_ew_bwd(int op, int act, long long R, int C, const float* a, in
                          int o_coff, const float* dout, int d_stride, int d_coff, float* da, int da_stride, int da_coff,
                          float* db, int db_stride, int db_coff, float* dg, int dg_stride, int dg_coff, void* stream) {
     TT_REQUIRE(a && dout && R > 0 && C > 0 && op >= 0 && op <= 3, "tt_ew_bwd: bad argument");
-    TT_REQUIRE(act == TT_ACT_NONE || ((act == TT_ACT_RELU || act == TT_ACT_SIGMOID || act == TT_ACT_SOFTPLUS) && out),
+    TT_REQUIRE(act == TT_ACT_NONE || ((act == TT_ACT_RELU || act == TT_ACT_SIGMOID || act == TT_ACT_SOFTPLUS || act == TT_ACT_SOFTPLUS_CLAMP) && out),
                "tt_ew_bwd: activation %d needs the pre-activation (or the saved output is missing)", act);
     TT_REQUIRE(op == 3 || b, "tt_ew_bwd: op %d needs b", op);
     TT_REQUIRE(op != 2 || g, "tt_ew_bwd: op 2 needs g");

@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from . import _lib, ops, weights
+from . import _lib, autodiff, ops, weights
 from .layers import conv_from_sd, conv_from_weight, linear_from_sd, rows, unrows
 from .registry import HEADS
 
@@ -54,7 +54,6 @@ class _GRU:
         """inp6 (B,4,6) f32; state (B,H,W,32); fut (B,4,H,W,32) output buffer."""
         B, H, W, _ = state.shape
         dev = state.device
-        from . import autodiff
         xs = torch.zeros(B, H, W, 40, dtype=F32, device=dev)      # [x 6 | state 32 | pad 2]
         xr = torch.zeros(B, H, W, 40, dtype=F32, device=dev)
         for t in range(4):
@@ -76,12 +75,18 @@ class _GRU:
         return fut
 
 
+def _layer_norm_params(sd, name, dev):
+    gamma = sd[name + ".weight"].to(dev, F32).contiguous()
+    beta = sd[name + ".bias"].to(dev, F32).contiguous()
+    autodiff.LN_META[id(gamma)] = (name + ".weight", name + ".bias")
+    return gamma, beta
+
+
 class _Layer:
     def __init__(self, sd, p, dev, dtype):
         self.gru = _GRU(sd, p + ".prediction_module.spatial_gru", dev)
         c = p + ".look_module.cam_look_module"
-        self.q_ln = (sd[c + ".query_linear.0.weight"].to(dev, F32).contiguous(),
-                     sd[c + ".query_linear.0.bias"].to(dev, F32).contiguous())
+        self.q_ln = _layer_norm_params(sd, c + ".query_linear.0", dev)
         self.q1 = linear_from_sd(sd, c + ".query_linear.1", dev, act="gelu", in_pad=1544)
         self.q3 = linear_from_sd(sd, c + ".query_linear.3", dev, act="gelu")
         d = c + ".deformable_attention"
@@ -90,14 +95,14 @@ class _Layer:
         self.vproj = linear_from_sd(sd, d + ".value_proj", dev, dtype=dtype)
         self.vproj_w = sd[d + ".value_proj.weight"].to(dev, F32)
         self.vproj_b = sd[d + ".value_proj.bias"].to(dev, F32)
-        self.ffn_ln = (sd[c + ".ffn.norm.weight"].to(dev, F32).contiguous(), sd[c + ".ffn.norm.bias"].to(dev, F32).contiguous())
+        self.vproj_name = d + ".value_proj.weight"
+        self.ffn_ln = _layer_norm_params(sd, c + ".ffn.norm", dev)
         self.ffn1 = linear_from_sd(sd, c + ".ffn.w_1", dev, act="gelu")
         self.ffn2 = linear_from_sd(sd, c + ".ffn.w_2", dev)
-        self.o_ln = (sd[c + ".output_proj.0.weight"].to(dev, F32).contiguous(),
-                     sd[c + ".output_proj.0.bias"].to(dev, F32).contiguous())
+        self.o_ln = _layer_norm_params(sd, c + ".output_proj.0", dev)
         self.o1 = linear_from_sd(sd, c + ".output_proj.1", dev, act="gelu")
         self.o3 = linear_from_sd(sd, c + ".output_proj.3", dev)
-        self.mlp_ln = (sd[p + ".mlp.0.weight"].to(dev, F32).contiguous(), sd[p + ".mlp.0.bias"].to(dev, F32).contiguous())
+        self.mlp_ln = _layer_norm_params(sd, p + ".mlp.0", dev)
         self.mlp1 = linear_from_sd(sd, p + ".mlp.1", dev, act="relu")
         self.mlp4 = linear_from_sd(sd, p + ".mlp.4", dev, act="relu")
         self.traj = _mlp(sd, p + ".traj_offset_module", (0, 2, 4), dev, in_pad=516)
@@ -134,10 +139,13 @@ class ThinkTwiceDecoder:
         self.dist_mu = _mlp(sd, p + ".dist_mu", (0, 2), dev)
         self.dist_sigma = _mlp(sd, p + ".dist_sigma", (0, 2), dev)
         self.fpn_linear = [conv_from_sd(sd, f"{p}.fpn_linear{i}", self.wdtype, dev) for i in range(4)]
-        self.temporal = sd[p + ".temporal_embedding"].to(dev, F32).contiguous()
-        self.static = sd[p + ".static_embedding"].to(dev, F32).contiguous()
+        self.prefix = p
+        self.temporal = autodiff.register_param(sd[p + ".temporal_embedding"].to(dev, F32).contiguous(),
+                                                p + ".temporal_embedding")
+        self.static = autodiff.register_param(sd[p + ".static_embedding"].to(dev, F32).contiguous(), p + ".static_embedding")
         cams = sd[p + ".cams_embeds"].to(dev, F32)
         lvls = sd[p + ".level_embeds"].to(dev, F32)
+        self.cams_embeds, self.level_embeds = cams, lvls
         self.layers = [_Layer(sd, f"{p}.decoder_layers.{L}", dev, self.wdtype) for L in range(self.refine_num)]
         # value_proj(feat + cam_embed + level_embed) = value_proj(feat) + per-(level, cam) shift  (DEC:392-393)
         for lay in self.layers:
@@ -175,6 +183,20 @@ class ThinkTwiceDecoder:
             start += hw
         return value
 
+    def _project_values_train(self, lay, mlvl, B, S):
+        """One refinement layer's value projection under the training tape: the layer's own value_proj (so its weight and
+        bias gradients land under the reference names) with the per-(level, camera) embedding shift as a recorded input."""
+        autodiff.TAPE.value_shift(lay.vshift, lay.vproj_w, lay.vproj_name, self.cams_embeds, self.prefix + ".cams_embeds",
+                                  self.level_embeds, self.prefix + ".level_embeds")
+        value = torch.empty(B * 4, S, 256, dtype=F32, device=mlvl[0].device)
+        start = 0
+        for l, m in enumerate(mlvl):
+            hw = m.shape[1] * m.shape[2]
+            lay.vproj(m, shift_n=lay.vshift[l], shift_n_mod=4,
+                      out=value[:, start:start + hw].unflatten(1, (m.shape[1], m.shape[2])), out_nstride=S * 256)
+            start += hw
+        return value
+
     def _look(self, lay, B, wp, ctrl_sp, meas, flat, lidar2img, ida_mat, mlvl, level_hw, S, values):
         ref, qos, count, max_len = ops.look_project_pack(wp, lidar2img, ida_mat, self.config["img_size"])
         qrows = ops.look_gather_query(qos, ref, wp, ctrl_sp, self.temporal, self.static, meas, flat, mlvl)
@@ -201,7 +223,8 @@ class ThinkTwiceDecoder:
         device; look_feature_metadata = [lidar2img (B,4,4,4), ida_mat (B,4,4,4), fpn (4 x (tensor, coff, C))
         channel-last, lidar feature (unused: the LiDAR look branch is zeroed, DEC:186)]."""
         flat, bev, meas = flattend_BEV_feat, BEV_feat, measurement_feat
-        if self.fused is not None:
+        taped = autodiff.TAPE is not None      # training: the layer-wise path (every op records its backward), one stream
+        if self.fused is not None and not taped:
             return self._forward_fused(flat, bev, meas, parent_module, teacher_forcing_data, look_feature_metadata,
                                        channel_last_out)
         B = flat.shape[0]
@@ -239,9 +262,13 @@ class ThinkTwiceDecoder:
         S = sum(h * w for h, w in level_hw)
 
         # all layers' value projections, on their own stream under the coarse heads / first GRU
-        fork = getattr(parent_module, "use_side_stream", True)
+        fork = getattr(parent_module, "use_side_stream", True) and not taped
+        fused_concat = _FUSED_CONCAT or taped   # (the broadcast pieces of the concats need the row-mapped backward)
         vready = None
-        if fork:
+        if taped:
+            value_all = None
+            train_values = [self._project_values_train(lay, mlvl, B, S) for lay in self.layers]
+        elif fork:
             main = torch.cuda.current_stream(dev)
             if self._vstream is None:
                 self._vstream = torch.cuda.Stream(dev)
@@ -267,7 +294,7 @@ class ThinkTwiceDecoder:
                 wp, ctrl = inputs_of(L)
                 sp = ops.ew(3, ctrl.view(B * 4, 4), act=_lib.ACT_SOFTPLUS).view(B, 4, 4)
                 inp6 = torch.empty(B, 4, 6, dtype=F32, device=dev)
-                if _FUSED_CONCAT:
+                if fused_concat:
                     ops.concat_rows(inp6.view(B * 4, 6), [(wp.view(B * 4, 2), 2, 1, 0), (sp.view(B * 4, 4), 4, 1, 0)])
                 else:
                     ops.ew(3, wp.view(B * 4, 2), out=inp6.view(B * 4, 6), C=2, out_coff=0)
@@ -277,7 +304,6 @@ class ThinkTwiceDecoder:
                 # branch (value projections, MSDA sampling, attention MLPs) only meet at the concat below: run the
                 # former on a second HIP stream.  Both are chains of microsecond-scale launches on a few CUs each, so
                 # they overlap almost perfectly (DEC:428-447 runs them back to back).
-                fork = getattr(parent_module, "use_side_stream", True)
                 if fork:
                     main = torch.cuda.current_stream(dev)
                     if self._branch is None:
@@ -291,14 +317,15 @@ class ThinkTwiceDecoder:
                 else:
                     lay.gru(inp6, cur_bev, fut)
                     fflat = parent_module.flatten_tail(fut.view(B * 4, H, W, 32))        # (B*4,256)
-                look, info = self._look(lay, B, wp, sp, meas, cur_flat, lidar2img, ida_mat, mlvl, level_hw, S,
-                                        (value_all, L, vready if (L == 0 and wait_values) else None))
+                values = (train_values[L], 0, None) if taped else \
+                    (value_all, L, vready if (L == 0 and wait_values) else None)
+                look, info = self._look(lay, B, wp, sp, meas, cur_flat, lidar2img, ida_mat, mlvl, level_hw, S, values)
                 if fork:
                     main.wait_stream(self._branch)
                     fflat.record_stream(main)
                 look_info.append(info)
                 # [future flat 256 | look 256 | zeros 256 (LiDAR look) | temporal 128 | meas 128]
-                if _FUSED_CONCAT:
+                if fused_concat:
                     hin = torch.empty(B * 4, 1024, dtype=F32, device=dev)
                     ops.concat_rows(hin, [(fflat, 256, 1, 0), (look, 256, 4, 0), (None, 256, 1, 0),
                                           (self.temporal, 128, 1, 4), (meas, 128, 4, 0)])
@@ -312,7 +339,7 @@ class ThinkTwiceDecoder:
                         ops.ew(3, self.temporal[t:t + 1].expand(B, 128), out=hv[:, t], C=128, out_coff=768)
                 hn = ops.layernorm_rows(hin, lay.mlp_ln[0], lay.mlp_ln[1])
                 h = unrows(lay.mlp4(lay.mlp1(rows(hn))))                                 # (B*4,512)
-                if _FUSED_CONCAT:
+                if fused_concat:
                     tin = torch.empty(B * 4, 516, dtype=F32, device=dev)
                     ops.concat_rows(tin, [(wp.view(B * 4, 2), 2, 1, 0), (h, 512, 1, 0), (None, 2, 1, 0)])
                 else:
@@ -321,7 +348,7 @@ class ThinkTwiceDecoder:
                     ops.ew(3, h, out=tin, C=512, out_coff=2)
                 d_wp = unrows(_run(lay.traj, rows(tin)))                                  # (B*4,2)
                 cin = torch.empty(B * 4, 516, dtype=F32, device=dev)
-                if _FUSED_CONCAT:
+                if fused_concat:
                     ops.concat_rows(cin, [(ctrl.view(B * 4, 4), 4, 1, 0), (h, 512, 1, 0)])
                 else:
                     ops.ew(3, ctrl.view(B * 4, 4), out=cin, C=4, out_coff=0)
@@ -349,7 +376,7 @@ class ThinkTwiceDecoder:
                 else:
                     new_bev = bev_update()
                 fin = torch.empty(B, 2304, dtype=F32, device=dev)
-                if _FUSED_CONCAT:
+                if fused_concat:
                     ops.concat_rows(fin, [(cur_flat, 256, 1, 0), (hb, 2048, 1, 0)])
                 else:
                     ops.ew(3, cur_flat, out=fin, C=256, out_coff=0)
@@ -363,7 +390,9 @@ class ThinkTwiceDecoder:
             return look_info
 
         def chained_inputs(L):
-            return wp_all[:, L].contiguous(), ctrl_all[:, L].contiguous()
+            # copies = the reference's .detach() of the previous layer's outputs (DEC:429-430): under the training tape no
+            # gradient flows back through them (.clone(): for B = 1 the slice is already contiguous)
+            return wp_all[:, L].clone(), ctrl_all[:, L].clone()
 
         def chained_emit(L, d_wp, d_ctrl, wp, ctrl):
             ops.ew(0, d_wp.view(B, 8), b=wp.view(B, 8), out=wp_all[:, L + 1].view(B, 8))

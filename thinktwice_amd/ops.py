@@ -580,7 +580,27 @@ def look_gather_query(qos, ref, wp, ctrl_sp, temporal, static, meas, flat, maps,
     check(lib().tt_look_gather_query(_c(B), ptr(qos), ptr(ref), ptr(wp), ptr(ctrl_sp), ptr(temporal), ptr(static),
                                      ptr(meas), ptr(flat), arr, hw, _c(dtype_code(maps[0])), ptr(out),
                                      _c(row_stride), _st(wp)), "tt_look_gather_query")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.look_gather_query(qos, ref, out, temporal, static, meas, flat, maps, row_stride)
     return out
+
+
+def look_gather_query_bwd(B, qos, ref, dout, row_stride, dtemporal, dstatic, dmeas, dflat, dmaps):
+    arr, hw = _level_args(dmaps)
+    check(lib().tt_look_gather_query_bwd(_c(B), ptr(qos), ptr(ref), ptr(dout), _c(row_stride), ptr(dtemporal), ptr(dstatic),
+                                         ptr(dmeas), ptr(dflat), arr, hw, _st(dout)), "tt_look_gather_query_bwd")
+
+
+def msda_sample_bwd(B, value, coff, offsets, logits, ref, level_hw, dout, dvalue, doffsets, dlogits):
+    hw = (ctypes.c_int * 8)(*[v for pair in level_hw for v in pair])
+    assert value.dtype == torch.float32
+    check(lib().tt_msda_sample_bwd(_c(B), ptr(value), _c(value.shape[-1]), _c(coff), ptr(offsets), ptr(logits), ptr(ref), hw,
+                                   ptr(dout), ptr(dvalue), ptr(doffsets), ptr(dlogits), _st(dout)), "tt_msda_sample_bwd")
+
+
+def sca_reduce_bwd(B, dout, max_len, dx):
+    check(lib().tt_sca_reduce_bwd(_c(B), ptr(dout), ptr(max_len), ptr(dx), _st(dout)), "tt_sca_reduce_bwd")
 
 
 def msda_sample(value, offsets, logits, ref, level_hw, B, coff=0):
@@ -590,12 +610,18 @@ def msda_sample(value, offsets, logits, ref, level_hw, B, coff=0):
     check(lib().tt_msda_sample_strided(_c(B), ptr(value), _c(dtype_code(value)), _c(value.shape[-1]), _c(coff),
                                        ptr(offsets), ptr(logits), ptr(ref), hw, ptr(out), _st(value)),
           "tt_msda_sample")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.msda_sample(value, offsets, logits, ref, level_hw, B, coff, out)
     return out
 
 
 def sca_reduce(x, max_len, B):
     out = torch.empty(B, 1024, dtype=torch.float32, device=x.device)
     check(lib().tt_sca_reduce(_c(B), ptr(x), ptr(max_len), ptr(out), _st(x)), "tt_sca_reduce")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.sca_reduce(x, max_len, B, out)
     return out
 
 
