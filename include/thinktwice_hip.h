@@ -399,6 +399,13 @@ long long tt_loss_workspace_bytes(void);
  * torch.clamp(..., -5, 5) of DEC:51-52 is clamp_max = 5); reduce == 0: out[i] = scale * l_i (reduction='none'). */
 int tt_loss_smooth_l1(const float* pred, const float* target, long long n_outer, int repeat, long long inner,
                       float clamp_max, float scale, int reduce, float* out, void* workspace, void* stream);
+/* gradients of the two mean-reduced decoder terms w.r.t. the prediction, dense in the prediction's layout (written, not
+ * accumulated): dpred = d[scale * mean(...)]/dpred.  tt_loss_smooth_l1_bwd: zero where the clamp is active. */
+int tt_loss_smooth_l1_bwd(const float* pred, const float* target, long long n_outer, int repeat, long long inner,
+                          float clamp_max, float scale, float* dpred, void* stream);
+int tt_loss_beta_kl_bwd(const float* target_alpha, const float* target_beta, const float* pred_alpha,
+                        const float* pred_beta, long long n_outer, int repeat, long long inner, float scale,
+                        float* dpred_alpha, float* dpred_beta, void* stream);
 /* out[0] = scale * mean KL(Beta(target_alpha, target_beta) || Beta(pred_alpha, pred_beta)), target [n_outer][inner]
  * broadcast over pred [n_outer][repeat][inner] (torch.distributions.kl_divergence, DEC:553-556, 571-573) */
 int tt_loss_beta_kl(const float* target_alpha, const float* target_beta, const float* pred_alpha,

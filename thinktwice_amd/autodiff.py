@@ -71,6 +71,25 @@ PARAM_TENSORS = {}      # id(tensor) -> (state_dict name, tensor): parameters th
                         # (embeddings); their gradient buffers are moved to param_grads when backward() ends
 
 
+def clear_metas():
+    """Forget every registered parameter mapping (before the model's operands are re-prepared from new master weights)."""
+    for d in (CONV_META, AFFINE_META, LN_META, PARAM_TENSORS):
+        d.clear()
+
+
+class paused:
+    """`with autodiff.paused():` -- ops inside are not recorded (input plumbing, detached sub-graphs)."""
+
+    def __enter__(self):
+        global TAPE
+        self.saved, TAPE = TAPE, None
+
+    def __exit__(self, *exc):
+        global TAPE
+        TAPE = self.saved
+        return False
+
+
 def register_param(t, name):
     PARAM_TENSORS[id(t)] = (name, t)
     return t

@@ -315,6 +315,43 @@ __global__ __launch_bounds__(kLossThreads) void loss_depth_bce_bwd_kernel(const 
     }
 }
 
+// ---- gradients of the mean-reduced terms w.r.t. the prediction (dense, same layout as `pred`): elementwise, no reduction
+// d/dpred [weight * mean(min(sl1(pred - t), clamp_max))] = weight/total * clip(d, -1, 1), zero where the clamp is active
+__global__ __launch_bounds__(kLossThreads) void loss_smooth_l1_bwd_kernel(const float* __restrict__ pred,
+                                                                          const float* __restrict__ target, long long total,
+                                                                          long long rep_inner, long long inner,
+                                                                          float clamp_max, float weight,
+                                                                          float* __restrict__ dpred) {
+    for (long long i = (long long)blockIdx.x * kLossThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kLossThreads) {
+        float t = 0.f;
+        if (target) {
+            const long long n = i / rep_inner, e = i % inner;
+            t = target[n * inner + e];
+        }
+        const float d = pred[i] - t;
+        float g = fminf(fmaxf(d, -1.f), 1.f);
+        if (clamp_max > 0.f && smooth_l1(d) > clamp_max) g = 0.f;
+        dpred[i] = g * weight;
+    }
+}
+
+// d KL(p || q) / d q_alpha = psi(q_alpha) - psi(q_alpha + q_beta) - psi(p_alpha) + psi(p_alpha + p_beta)   (same with beta)
+__global__ __launch_bounds__(kLossThreads) void loss_beta_kl_bwd_kernel(const float* __restrict__ p_alpha,
+                                                                        const float* __restrict__ p_beta,
+                                                                        const float* __restrict__ q_alpha,
+                                                                        const float* __restrict__ q_beta, long long total,
+                                                                        long long rep_inner, long long inner, float weight,
+                                                                        float* __restrict__ dq_alpha,
+                                                                        float* __restrict__ dq_beta) {
+    for (long long i = (long long)blockIdx.x * kLossThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kLossThreads) {
+        const long long n = i / rep_inner, e = i % inner;
+        const double pa = p_alpha[n * inner + e], pb = p_beta[n * inner + e], qa = q_alpha[i], qb = q_beta[i];
+        const double common = digamma_pos(pa + pb) - digamma_pos(qa + qb);
+        dq_alpha[i] = (float)((digamma_pos(qa) - digamma_pos(pa) + common) * (double)weight);
+        dq_beta[i] = (float)((digamma_pos(qb) - digamma_pos(pb) + common) * (double)weight);
+    }
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -397,4 +434,25 @@ extern "C" int tt_loss_depth_bce(const float* logits_cl, int row_stride, int D, 
     hipLaunchKernelGGL(loss_depth_bce_kernel, dim3(loss_grid(total)), dim3(kLossThreads), 0, (hipStream_t)stream,
                        logits_cl, row_stride, D, gt_depth, BN, H, W, factor, d_lo, d_step, out, (LossWs*)workspace);
     return check_launch("tt_loss_depth_bce");
+}
+
+extern "C" int tt_loss_smooth_l1_bwd(const float* pred, const float* target, long long n_outer, int repeat, long long inner,
+                                     float clamp_max, float scale, float* dpred, void* stream) {
+    TT_REQUIRE(pred && dpred && n_outer > 0 && repeat > 0 && inner > 0, "tt_loss_smooth_l1_bwd: bad argument");
+    const long long total = n_outer * repeat * inner;
+    hipLaunchKernelGGL(loss_smooth_l1_bwd_kernel, dim3(loss_grid(total)), dim3(kLossThreads), 0, (hipStream_t)stream, pred,
+                       target, total, (long long)repeat * inner, inner, clamp_max, (float)((double)scale / (double)total), dpred);
+    return check_launch("tt_loss_smooth_l1_bwd");
+}
+
+extern "C" int tt_loss_beta_kl_bwd(const float* target_alpha, const float* target_beta, const float* pred_alpha,
+                                   const float* pred_beta, long long n_outer, int repeat, long long inner, float scale,
+                                   float* dpred_alpha, float* dpred_beta, void* stream) {
+    TT_REQUIRE(target_alpha && target_beta && pred_alpha && pred_beta && dpred_alpha && dpred_beta && n_outer > 0 &&
+                   repeat > 0 && inner > 0, "tt_loss_beta_kl_bwd: bad argument");
+    const long long total = n_outer * repeat * inner;
+    hipLaunchKernelGGL(loss_beta_kl_bwd_kernel, dim3(loss_grid(total)), dim3(kLossThreads), 0, (hipStream_t)stream,
+                       target_alpha, target_beta, pred_alpha, pred_beta, total, (long long)repeat * inner, inner,
+                       (float)((double)scale / (double)total), dpred_alpha, dpred_beta);
+    return check_launch("tt_loss_beta_kl_bwd");
 }

@@ -6,7 +6,7 @@ package's registry.  Every tensor op runs on the gfx950 kernels behind include/t
 """
 import torch
 
-from . import _lib, control, ops
+from . import _lib, autodiff, control, ops
 from .fusion import BEVFusion
 from .layers import linear_from_sd, rows, unrows
 from .registry import DETECTORS, build_backbone, build_head
@@ -133,7 +133,7 @@ class EncoderDecoder(torch.nn.Module):
         # stream so its many small launches fill the tail of the big camera convolutions.
         main = torch.cuda.current_stream(self.device)
         pts = points[:, -1].to(self.device)
-        if not self.use_side_stream:
+        if not self.use_side_stream or autodiff.TAPE is not None:      # (the training tape records on one stream)
             lidar = self.lidar_encoder(pts, channel_last=True, rot_flip=True)          # EDF:244-246
             cam = self.img_encoder(img.to(self.device), img_metas, channel_last=True, consts=consts,
                                prev_bev=prev_bev)
@@ -180,24 +180,39 @@ class EncoderDecoder(torch.nn.Module):
         """EncoderDecoder.forward_train (encoder_decoder_framework.py:147-191): the forward with the decoder's
         teacher-forcing pass, then every loss term as a device reduction (thinktwice_amd/losses.py, csrc/losses.hip).
         BatchNorm layers use their running statistics -- what the reference computes under model.eval() and what a
-        frozen-BN fine-tune runs (golden F10); batch-statistics BN and the backward pass are not implemented
-        (SURVEY 8f-4), so the returned losses carry no autograd graph."""
+        frozen-BN fine-tune runs (golden F10 / F13); batch-statistics BN is not implemented.  The returned device scalars
+        carry no torch autograd graph: inside `with autodiff.Tape()` the forward ops and the loss terms record their
+        backward on the tape (trainer.Trainer.step runs it)."""
         from . import losses as LS
         if self._loss_red is None:
             self._loss_red = LS.LossReducer(self.device)
         red = self._loss_red
+        tape = autodiff.TAPE
         teacher = {k: batch[k] for k in LS.TEACHER_KEYS}
         teacher = {k: ([t.to(self.device) for t in v] if isinstance(v, (list, tuple)) else v.to(self.device))
                    for k, v in teacher.items()}
-        pred = self.forward_inference(batch, teacher=teacher)
-        mids = [None if m is None else ops.nhwc_to_nchw(m) for m in pred["_mid_bev_cl"]]
-        out = LS.decoder_loss(red, self.config, batch, pred, mids)
+        # Under the training tape (thinktwice_amd/trainer.py) every term reads the forward's own channel-last tensors and
+        # records the gradient of its mean w.r.t. them; the terms are elementwise means, so the values do not change.
+        pred = self.forward_inference(batch, teacher=teacher, channel_last_out=tape is not None)
+        if tape is None:
+            mids = [None if m is None else ops.nhwc_to_nchw(m) for m in pred["_mid_bev_cl"]]
+            out = LS.decoder_loss(red, self.config, batch, pred, mids)
+        else:
+            out = LS.decoder_loss(red, self.config, batch, pred, pred["_mid_bev_cl"], channel_last=True)
         if self.use_seg:                                                      # EDF:172-176
-            out["seg_loss"] = red.seg_focal(pred["_seg_cl"].float().contiguous(), batch["seg"], num_classes=12,
-                                            factor=self.seg_downsample_factor)
+            seg = pred["_seg_cl"].float().contiguous()
+            out["seg_loss"] = red.seg_focal(seg, batch["seg"], num_classes=12, factor=self.seg_downsample_factor)
+            if tape is not None:
+                assert seg.data_ptr() == pred["_seg_cl"].data_ptr(), "training runs on f32 activation storage"
+                tape.nodes.append(lambda: tape.grad(seg).add_(
+                    red.seg_focal_bwd(seg, batch["seg"], num_classes=12, factor=self.seg_downsample_factor)))
         if self.use_depth:                                                    # EDF:179-190
-            out["depth_loss"] = red.depth_bce(pred["_depth_cl"].float().contiguous(), batch["depth"], self.d_bound,
-                                              self.downsample_factor)
+            dep = pred["_depth_cl"].float().contiguous()
+            out["depth_loss"] = red.depth_bce(dep, batch["depth"], self.d_bound, self.downsample_factor)
+            if tape is not None:
+                assert dep.data_ptr() == pred["_depth_cl"].data_ptr(), "training runs on f32 activation storage"
+                tape.nodes.append(lambda: tape.grad(dep).add_(
+                    red.depth_bce_bwd(dep, batch["depth"], self.d_bound, self.downsample_factor)))
         return out
 
     def _parse_losses(self, losses):
@@ -206,7 +221,8 @@ class EncoderDecoder(torch.nn.Module):
 
     def train_step(self, data, optimizer=None):
         """encoder_decoder_framework.py:140-145: dict(loss, log_vars, num_samples).  `optimizer` is unused, as in the
-        reference (the mmcv OptimizerHook steps it); here there is no backward to step on yet."""
+        reference (the mmcv OptimizerHook calls loss.backward() and steps it); the backward + all-reduce + AdamW half of
+        the iteration is trainer.Trainer.step, which calls this inside its tape."""
         loss, log_vars = self._parse_losses(self.forward_train(data))
         return dict(loss=loss, log_vars=log_vars, num_samples=data["img"].shape[0])
 

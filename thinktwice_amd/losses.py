@@ -11,7 +11,7 @@ from collections import OrderedDict
 
 import torch
 
-from . import ops
+from . import autodiff, ops
 from ._lib import check, cur_stream, lib, ptr, require_cuda
 
 F32 = torch.float32
@@ -40,6 +40,7 @@ class LossReducer:
 
     def smooth_l1(self, pred, target=None, clamp_max=0.0, scale=1.0, reduce=True):
         """pred (N, [R,] ...) vs target (N, ...) broadcast over R (None: zeros)."""
+        pred_in = pred
         pred = self._f(pred)
         require_cuda(pred)
         N = pred.shape[0]
@@ -54,10 +55,20 @@ class LossReducer:
         check(lib().tt_loss_smooth_l1(ptr(pred), ptr(target), _ll(N), _c(rep), _ll(inner), _f(clamp_max), _f(scale),
                                       _c(1 if reduce else 0), ptr(out), ptr(self.ws), cur_stream(self.device)),
               "tt_loss_smooth_l1")
+        tape = autodiff.TAPE
+        if tape is not None:
+            # the term enters the total as its MEAN with weight 1 (parse_losses; an unreduced term is averaged there)
+            def bwd():
+                d = torch.empty_like(pred)
+                check(lib().tt_loss_smooth_l1_bwd(ptr(pred), ptr(target), _ll(N), _c(rep), _ll(inner), _f(clamp_max),
+                                                  _f(scale), ptr(d), cur_stream(self.device)), "tt_loss_smooth_l1_bwd")
+                tape.grad(pred_in).add_(d.view(pred_in.shape))
+            tape.nodes.append(bwd)
         return out[0] if reduce else out
 
     def beta_kl(self, t_alpha, t_beta, p_alpha, p_beta, scale=1.0):
         """mean KL(Beta(target) || Beta(pred)); target (N, ...) broadcast over pred (N, R, ...)."""
+        pa_in, pb_in = p_alpha, p_beta
         t_alpha, t_beta, p_alpha, p_beta = (self._f(t) for t in (t_alpha, t_beta, p_alpha, p_beta))
         N = p_alpha.shape[0]
         inner = t_alpha.numel() // N
@@ -66,6 +77,16 @@ class LossReducer:
         out = self._out()
         check(lib().tt_loss_beta_kl(ptr(t_alpha), ptr(t_beta), ptr(p_alpha), ptr(p_beta), _ll(N), _c(rep), _ll(inner),
                                     _f(scale), ptr(out), ptr(self.ws), cur_stream(self.device)), "tt_loss_beta_kl")
+        tape = autodiff.TAPE
+        if tape is not None:
+            def bwd():
+                da, db = torch.empty_like(p_alpha), torch.empty_like(p_beta)
+                check(lib().tt_loss_beta_kl_bwd(ptr(t_alpha), ptr(t_beta), ptr(p_alpha), ptr(p_beta), _ll(N), _c(rep),
+                                                _ll(inner), _f(scale), ptr(da), ptr(db), cur_stream(self.device)),
+                      "tt_loss_beta_kl_bwd")
+                tape.grad(pa_in).add_(da.view(pa_in.shape))
+                tape.grad(pb_in).add_(db.view(pb_in.shape))
+            tape.nodes.append(bwd)
         return out[0]
 
     def l1_cols(self, pred, target, pred_beta=None, target_beta=None):
@@ -131,11 +152,23 @@ class LossReducer:
         return d
 
 
-def decoder_loss(red, c, batch, pred, mid_bev):
+def decoder_loss(red, c, batch, pred, mid_bev, channel_last=False):
     """ThinkTwiceDecoder.loss DEC:536-619.  `pred`: forward_inference(batch, teacher=...) outputs in the reference's
     layouts (channel_last_out=False); `mid_bev[2..5]`: the encoder's 32x21x21 ... 256x2x2 maps, NCHW; `c`: the model's
-    train_cfg (value_weight, features_weight)."""
+    train_cfg (value_weight, features_weight).  `channel_last`: the BEV-map terms read the forward's own channel-last
+    tensors (`pred` from channel_last_out=True, `mid_bev` channel-last) against targets permuted to match -- the terms are
+    elementwise means, so the values are the same, and under the training tape the gradients land on the tensors the
+    forward produced."""
     dev = red.device
+
+    def cl(t, nd=4):        # target (..., C, H, W) -> (..., H, W, C)
+        if not channel_last:
+            return t
+        t = t.to(dev, F32)
+        return t.permute(*range(t.dim() - 3), t.dim() - 2, t.dim() - 1, t.dim() - 3).contiguous()
+
+    k_rbev, k_tfut, k_trbev = (("_refine_bev_cl", "_teacher_fut_cl", "_teacher_refine_bev_cl") if channel_last else
+                               ("refine_BEV_feature", "teacher_future_BEV_feature", "teacher_refine_BEV_feature"))
     L = OrderedDict()
     gt_speed = batch["speed"].to(dev, F32).view(-1, 1) * (1.0 / 12.0)
     gt_value = batch["value"].to(dev, F32).view(-1, 1)
@@ -157,18 +190,17 @@ def decoder_loss(red, c, batch, pred, mid_bev):
     L["future_action_loss"] = red.beta_kl(fmu, fsg, pred["future_mu"], pred["future_sigma"], ACTION_W * 0.25)
     L["wp_loss"] = red.smooth_l1(pred["pred_wp"], gt_wp, scale=WP_W)
     for i in DISTIL_INDEX:
-        L[f"BEV_feature_loss{i}"] = red.smooth_l1(mid_bev[i], batch["grid_feature"][i], clamp_max=5.0, scale=DISTIL_W[i])
-    g2 = batch["grid_feature"][2]
-    L["refine_BEV_feature_loss2"] = red.smooth_l1(pred["refine_BEV_feature"], g2, clamp_max=5.0, scale=DISTIL_W[2])
+        L[f"BEV_feature_loss{i}"] = red.smooth_l1(mid_bev[i], cl(batch["grid_feature"][i]), clamp_max=5.0,
+                                                  scale=DISTIL_W[i])
+    g2 = cl(batch["grid_feature"][2])
+    L["refine_BEV_feature_loss2"] = red.smooth_l1(pred[k_rbev], g2, clamp_max=5.0, scale=DISTIL_W[2])
     L["refine_flattened_feature_loss"] = red.smooth_l1(pred["refine_flattned_BEV_feature"], gt_feat, clamp_max=5.0,
                                                        scale=c["features_weight"] * 0.1)
     L["teacher_wp_loss"] = red.smooth_l1(pred["teacher_pred_wp_offset"])
     L["teacher_action_loss"] = red.smooth_l1(pred["teacher_pred_ctrl_offset_lis"])
-    gfut = torch.stack([g[2].to(dev, F32) for g in batch["future_grid_feature"]], 1)               # (N, T, C, W, H)
-    L["teacher_future_BEV_feature_loss2"] = red.smooth_l1(pred["teacher_future_BEV_feature"], gfut, clamp_max=5.0,
-                                                          scale=DISTIL_W[2])
-    L["teacher_refine_BEV_feature_loss2"] = red.smooth_l1(pred["teacher_refine_BEV_feature"], g2, clamp_max=5.0,
-                                                          scale=DISTIL_W[2])
+    gfut = cl(torch.stack([g[2].to(dev, F32) for g in batch["future_grid_feature"]], 1))           # (N, T, C, W, H)
+    L["teacher_future_BEV_feature_loss2"] = red.smooth_l1(pred[k_tfut], gfut, clamp_max=5.0, scale=DISTIL_W[2])
+    L["teacher_refine_BEV_feature_loss2"] = red.smooth_l1(pred[k_trbev], g2, clamp_max=5.0, scale=DISTIL_W[2])
     L["teacher_refine_flattened_feature_loss"] = red.smooth_l1(pred["teacher_refine_flattned_BEV_feature"], gt_feat,
                                                                clamp_max=5.0, scale=c["features_weight"])
     return L

@@ -1,0 +1,90 @@
+"""One data-parallel training iteration (reference: mmcv EpochBasedRunner.run_iter -> model.train_step
+(encoder_decoder_framework.py:140-145) + OptimizerHook (loss.backward(), grad clip, AdamW.step; configs/thinktwice.py:282-290)
+under MMDistributedDataParallel (apis/mmdet_train.py:67-74)).
+
+    forward_train on the HIP forward  ->  reverse sweep of the tape (thinktwice_amd/autodiff.py: hand-written backward kernels,
+    gradients under the reference's state_dict names)  ->  ONE all-reduce of the flat gradient buffer (grad_sync.py, RCCL)
+    ->  global-norm clip + AdamW on the flat buffers (optim.py, two launches)  ->  operands re-prepared from the master weights.
+
+The master parameters are f32 views of one flat buffer (288 GB of HBM: master weights, Adam moments, the flat gradient and the
+kernels' operand formats all stay resident).  BatchNorm runs on its running statistics (frozen-BN fine-tuning, what golden F10 /
+F13 pin); its affine parameters train, its statistics are not updated.  Parameters the loss never reaches (the reference's 90
+dead ones) keep zero gradients, as under DDP's find_unused_parameters.
+"""
+import torch
+
+from . import autodiff
+from .grad_sync import FlatGradBuffer
+from .losses import parse_losses
+from .optim import FlatAdamW
+
+
+# registered buffers of the reference modules (BatchNorm statistics; the LSS frustum / voxel grid constants, lss.py:470-476)
+_BUFFERS = ("running_mean", "running_var", "num_batches_tracked", "voxel_size", "voxel_coord", "voxel_num", "frustum")
+
+
+def _trainable(name, t):
+    return torch.is_tensor(t) and t.is_floating_point() and t.dim() > 0 and not name.endswith(_BUFFERS)
+
+
+class Trainer:
+    def __init__(self, model, state_dict, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7, max_grad_norm=100.0,
+                 x3=None):
+        """`model`: an EncoderDecoder (dtype torch.float32 or "f32x3"); `state_dict`: reference-format weights.  `x3`: input
+        gradients of the convolutions through the bf16x3 kernel (default: when the model's forward uses it)."""
+        dev = model.device
+        self.model = model
+        self.x3 = (model.dtype != torch.float32) if x3 is None else x3
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items() if k != "_metadata"}
+        self.names = [k for k, v in sd.items() if _trainable(k, v)]
+        self._trainable = set(self.names)
+        total = sum(sd[k].numel() for k in self.names)
+        self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
+        self.sd = {}
+        off = 0
+        for k, v in sd.items():
+            if k in self._trainable:
+                view = self.flat_param[off:off + v.numel()].view(v.shape)
+                view.copy_(v.to(dev, torch.float32))
+                self.sd[k] = view.requires_grad_(True)          # a leaf whose .grad FlatGradBuffer points into its buffer
+                off += v.numel()
+            else:
+                self.sd[k] = v
+        self.grads = FlatGradBuffer([self.sd[k] for k in self.names])
+        self.opt = FlatAdamW(self.flat_param, self.grads.flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                             max_grad_norm=max_grad_norm)
+        self.param_grads = None
+        self._prepare()
+
+    def _prepare(self):
+        """(Re)build the kernels' operand formats (folded BatchNorm affines, channel-last / pair-split weights) from the
+        master weights, through the same host-side load path a checkpoint takes (one 0.5 GB device-to-host copy per
+        iteration; preparing the operands on the device straight from the flat buffer is the obvious next step)."""
+        autodiff.clear_metas()
+        with torch.no_grad():
+            self.model.load_state_dict({k: (v.detach().cpu() if k in self._trainable else v) for k, v in self.sd.items()})
+
+    def backward(self, batch):
+        """Forward + losses + reverse sweep: fills the flat gradient buffer (no collective, no update).  Returns
+        dict(loss, log_vars, num_samples) of train_step."""
+        self.grads.zero_()
+        with autodiff.Tape(x3=self.x3) as tape:
+            out = self.model.train_step(batch, None)
+            tape.backward()
+        self.param_grads = tape.param_grads
+        unknown = [k for k in tape.param_grads if k not in self.sd]
+        assert not unknown, f"gradients for names outside the state_dict: {unknown[:5]}"
+        for k, g in tape.param_grads.items():
+            self.sd[k].grad.copy_(g.reshape(self.sd[k].shape))
+        return out
+
+    def step(self, batch, lr=None):
+        """One iteration; adds `grad_norm` (device tensor [norm, clip factor]) to train_step's dict."""
+        out = self.backward(batch)
+        self.grads.all_reduce_mean()
+        out["grad_norm"] = self.opt.step(lr)
+        self._prepare()
+        return out
+
+    def state_dict(self):
+        return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in self.sd.items()}
