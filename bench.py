@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- ThinkTwice per-frame forward path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload forward|voxel_pool] [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--workload forward|voxel_pool|train_step] [--batch B]
 
 One "step" = one pass of the hot path over one batch of B synthetic frames per GPU
 (4 cams x 2 sweeps x 448x896 + LiDAR).  Prints ONE JSON line (rank 0).  For N>1 the driver
@@ -139,6 +139,9 @@ def make_workload(name, batch, device):
     if name == "forward":
         from thinktwice_amd import bench_forward
         return bench_forward.ForwardWorkload(batch, device)
+    if name == "train_step":
+        from thinktwice_amd import bench_train
+        return bench_train.TrainStepWorkload(batch, device)
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -217,6 +220,9 @@ def main():
             line.update(extra())
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = wl.cpu_baseline()
+        if name == "train_step":
+            line["unit"] = "samples/s"
+            line["config"]["parallelism"] = f"data parallel x{world}: one all-reduce of the flat gradient buffer per iteration"
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1,0 +1,90 @@
+"""bench.py --workload train_step: one data-parallel training iteration (trainer.Trainer.step) at the thinktwice.py
+configuration -- forward_train, the tape's reverse sweep, ONE all-reduce of the flat gradient buffer over RCCL (world > 1),
+global-norm clip + AdamW, operand re-preparation.  Frozen-BatchNorm fine-tuning mode (running statistics), synthetic batch and
+targets, random-init weights.  Not the BASELINE.json metric (that is the inference forward): an auxiliary line for SURVEY 8f-4."""
+import os
+import time
+
+import torch
+
+from . import model as tm
+from . import ops, params, synth
+from .bench_forward import MFMA_PEAK_TF, TORCH_DTYPE
+
+
+class TrainStepWorkload:
+    metric = "training samples/sec (forward_train + backward + all-reduce + clip/AdamW, thinktwice.py cfg, frozen BN)"
+
+    def __init__(self, batch, device, dtype=None):
+        from .trainer import Trainer
+        dtype = dtype or os.environ.get("TT_BENCH_DTYPE", "bf16x3")
+        assert dtype in ("f32", "bf16x3"), "training runs on f32 activation storage"
+        self.dtype, self.B = dtype, batch
+        self.name = (f"train_step thinktwice.py cfg: {batch} samples x (2 sweeps x 4 cams x 448x896 + 65536-pt LiDAR), "
+                     f"23 loss terms incl. the teacher-forcing pass, 878 live / 968 parameters")
+        self.precision_note = ("f32 storage; forward and input-gradient convolutions in bf16x3, weight gradients on the "
+                               "exact-f32 MFMA" if dtype == "bf16x3" else "f32 everywhere (exact-f32 MFMA)")
+        self.launch_note = "eager launches, one stream"
+        self.model, self.cfg = tm.build_thinktwice(dtype=TORCH_DTYPE[dtype], device=str(device))
+        sd = params.init_params(self.cfg, seed=0)
+        self.trainer = Trainer(self.model, sd)
+        del sd
+        rank = int(os.environ.get("RANK", "0"))
+        self.batch = tm.batch_to_device(synth.make_batch(batch, seed=1234 + rank * batch), device)
+        self.batch.update(synth.make_train_targets(batch))
+        self.last = None
+
+    def step(self):
+        self.last = self.trainer.step(self.batch)
+        return self.last
+
+    def frames_per_step(self):
+        return self.B
+
+    def roofline(self):
+        """All convolution-shaped launches of one iteration (forward, GELU recomputes, input gradients, weight gradients):
+        algorithmic FLOPs / summed launch durations, HIP events on the launch stream."""
+        torch.cuda.synchronize()
+        ops.CONV_PROFILE, ops.CONV_BYTES, ops.CONV_KERNELS = [], None, None
+        t0 = time.perf_counter()
+        self.trainer.backward(self.batch)
+        torch.cuda.synchronize()
+        t_bwd = time.perf_counter() - t0
+        rec, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+        dense = [r for r in rec if len(r) == 4]
+        flops = sum(r[0] for r in dense)
+        ms = sum(r[1].elapsed_time(r[2]) for r in dense)
+        wg = [r for r in dense if r[3].startswith("wgrad")]
+        wg_ms = sum(r[1].elapsed_time(r[2]) for r in wg)
+        # phases of one iteration, each bracketed by a device synchronise
+        ph = {}
+        t0 = time.perf_counter()
+        self.trainer.grads.all_reduce_mean()
+        torch.cuda.synchronize()
+        ph["all_reduce_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        self.trainer.opt.step()
+        torch.cuda.synchronize()
+        ph["clip_adamw_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        self.trainer._prepare()
+        torch.cuda.synchronize()
+        ph["prepare_operands_ms"] = (time.perf_counter() - t0) * 1e3
+        ph["forward_backward_ms_profiled"] = t_bwd * 1e3
+        self._phases = {k: round(v, 2) for k, v in ph.items()}
+        self._phases["loss"] = float(self.last["loss"]) if self.last is not None else None
+        self._phases["peak_memory_gb"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+        peak = MFMA_PEAK_TF[self.dtype]
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": None, "kernel": "all dense conv / linear launches of one iteration (sparse gathered GEMMs excluded)",
+                "launches": len(dense), "kernel_ms": round(ms, 2), "gflop": round(flops / 1e9, 1),
+                "wgrad": {"launches": len(wg), "ms": round(wg_ms, 2),
+                          "tflops": round(sum(r[0] for r in wg) / max(wg_ms * 1e-3, 1e-9) / 1e12, 1),
+                          "note": "exact-f32 MFMA (peak 157.3 TFLOP/s)"}}
+
+    def extra(self):
+        return {"train_step_phases": getattr(self, "_phases", None)}
+
+    def cpu_baseline(self):
+        return None

@@ -708,9 +708,20 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, dil=1, cin=None, in_coff=0, cou
     L.tt_conv2d_wgrad_workspace_bytes.restype = ctypes.c_longlong
     nb = int(L.tt_conv2d_wgrad_workspace_bytes(_c(N), _c(OH), _c(cout), _c(cin), _c(cin_pad), _c(kh), _c(kw)))
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    if CONV_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(L.tt_conv2d_wgrad(ptr(x), _c(N), _c(H), _c(W), _c(cin), _c(Cs), _c(in_coff), ptr(dy), _c(OH), _c(OW), _c(cout),
                             _c(Cd), _c(dy_coff), _c(kh), _c(kw), _c(stride), _c(pad), _c(dil), _c(cin_pad),
                             _c(1 if accumulate else 0), ptr(out), ptr(ws), _ll(nb), _st(x)), "tt_conv2d_wgrad")
+    if CONV_PROFILE is not None:
+        e1.record()
+        CONV_PROFILE.append((2.0 * N * OH * OW * cout * kh * kw * cin, e0, e1,
+                             f"wgrad M={N * OH * OW} N={cout} K={kh * kw * cin} k{kh}x{kw}s{stride}"))
+        if CONV_KERNELS is not None:
+            CONV_KERNELS.append("conv_wgrad_kernel")
+        if CONV_BYTES is not None:
+            CONV_BYTES.append((x.numel() + dy.numel() + out.numel()) * 4)
     return out
 
 
