@@ -609,5 +609,5 @@ def test_decoder_backward_matches_oracle_autograd(monkeypatch):
     w_tail = max(e for k, e in worst.items() if k.startswith(tail))
     rest = sorted(((k, e) for k, e in worst.items() if not k.startswith(tail)), key=lambda kv: -kv[1])
     print("  flatten network worst", w_tail, "| other tensors worst 5:", rest[:5])
-    bad = {k: e for k, e in worst.items() if e > (3e-2 if k.startswith(tail) else 3e-3)}
+    bad = {k: e for k, e in worst.items() if e > 2e-3}           # measured worst: 3.0e-4
     assert len(worst) >= 400 and not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]

@@ -82,3 +82,54 @@ def test_training_step_updates_parameters_and_reduces_the_loss():
     # the re-prepared model runs inference with the updated weights
     pred = m.forward_inference(batch)
     assert torch.isfinite(pred["pred_wp"]).all()
+
+
+def _rank_step(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from thinktwice_amd import model as tm, params, synth
+        from thinktwice_amd.trainer import Trainer
+        hw = (128, 256)
+        m, cfg = tm.build_thinktwice(final_dim=hw, dtype="f32x3")
+        tr = Trainer(m, params.init_params(cfg, seed=0), lr=1e-4)
+        batch = synth.make_batch(1, img_hw=hw, num_points=4096, seed=100 + rank)      # every rank its own sample
+        batch.update(synth.make_train_targets(1, img_hw=hw, seed=200 + rank))
+        out = tr.backward(batch)
+        local = tr.grads.flat[::997].cpu()
+        tr.grads.all_reduce_mean()
+        reduced = tr.grads.flat[::997].cpu()
+        tr.opt.step()
+        torch.cuda.synchronize()
+        # (numpy arrays: plain pickles -- torch tensors would travel as shared-memory handles of a process that may be gone)
+        q.put((rank, float(out["loss"]), out["log_vars"]["loss"], local.numpy(), reduced.numpy(),
+               tr.flat_param[::997].cpu().numpy(), float(tr.flat_param.double().sum())))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_step_gloo():
+    """The data-parallel iteration with world_size 2 (both ranks on this box's one GPU, gloo instead of RCCL): every rank
+    runs forward_train + backward on ITS sample, the flat gradient buffer is all-reduced to the mean once, and the AdamW
+    step leaves bit-identical parameters on both ranks (apis/mmdet_train.py:67-79: MMDistributedDataParallel)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rank_step, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, loss0, logged0, g0, red0, p0, sum0), (_, loss1, logged1, g1, red1, p1, sum1) = got
+    assert abs(loss0 - loss1) > 1e-3                                   # different samples
+    assert abs(logged0 - 0.5 * (loss0 + loss1)) < 1e-4 * abs(logged0)  # _parse_losses logs the all-reduced mean (EDF:431-437)
+    assert logged0 == logged1
+    assert float(np.abs(g0 - g1).max()) > 0
+    want = 0.5 * g0 + 0.5 * g1
+    assert np.array_equal(red0, red1) and float(np.abs(red0 - want).max()) <= 1e-6 * float(np.abs(want).max())
+    assert np.array_equal(p0, p1) and sum0 == sum1

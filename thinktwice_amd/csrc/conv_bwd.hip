@@ -27,6 +27,7 @@ struct WgradArgs {
     int OH, OW, Cout, dy_cstride, dy_coff;
     int KH, KW, stride, pad, dil, cin_p;
     int ci_tiles, rows_per_split;
+    int xcd_tiles;         // > 0: number of real tiles of an XCD-remapped grid (see the kernel); 0: identity mapping
 };
 
 constexpr int kWgUnroll = 4;       // pixel pairs in flight per wave (each: 2 + 2 dword loads, 4 MFMAs)
@@ -37,6 +38,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int c = lane & 31, k = lane >> 5;                 // channel within a 32-block, pixel of the pair
     const int taps = a.KH * a.KW;
     int t = blockIdx.x;
+    if (a.xcd_tiles) {      // workgroup i runs on XCD i % 8: give every XCD a contiguous run of tiles, so that the taps of one
+        t = (t & 7) * (gridDim.x >> 3) + (t >> 3);      // (co, ci) tile -- which read the same dy rows and shifted x rows --
+        if (t >= a.xcd_tiles) return;                   // share that XCD's L2 (the grid is padded to a multiple of 8)
+    }
     const int tap = t % taps;
     t /= taps;
     const int ci0 = (t % a.ci_tiles) * 64, co0 = (t / a.ci_tiles) * 64;
@@ -140,6 +145,7 @@ struct GatherWgradArgs {
     long long M;
     int Cin, x_cstride, Cout, dy_cstride, taps, cin_p, ci_tiles;
     long long pairs_per_split;
+    int xcd_tiles;
 };
 
 __global__ __launch_bounds__(256) void gather_wgrad_kernel(const GatherWgradArgs a) {
@@ -147,13 +153,19 @@ __global__ __launch_bounds__(256) void gather_wgrad_kernel(const GatherWgradArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, k = lane >> 5;
     int t = blockIdx.x;
+    if (a.xcd_tiles) {      // XCD-contiguous tile order, as in conv_wgrad_kernel
+        t = (t & 7) * (gridDim.x >> 3) + (t >> 3);
+        if (t >= a.xcd_tiles) return;
+    }
     const int tap = t % a.taps;
     t /= a.taps;
     const int ci0 = (t % a.ci_tiles) * 64, co0 = (t / a.ci_tiles) * 64;
     const long long Mlive = a.m_dev ? min(a.M, (long long)*a.m_dev) : a.M;
     const long long npairs = (Mlive + 1) >> 1;
-    const long long p_begin = (long long)blockIdx.y * a.pairs_per_split;
-    const long long p_end = min(npairs, p_begin + a.pairs_per_split);
+    // the LIVE rows (device count) are divided over the splits -- not the capacity M, which would leave most splits idle
+    const long long pps = (npairs + gridDim.y - 1) / gridDim.y;
+    const long long p_begin = (long long)blockIdx.y * pps;
+    const long long p_end = min(npairs, p_begin + pps);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -329,18 +341,45 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
     }
 }
 
+// per-channel sums of the workgroups' partials [blocks][2][C], in a fixed order (deterministic): 16 channels per workgroup,
+// 16 thread groups each walk every 16th partial row, then the 16 group sums are added in index order
 __global__ __launch_bounds__(256) void conv_epilogue_bwd_finish_kernel(const float* __restrict__ partial, int blocks, int C,
                                                                        int accumulate, float* __restrict__ dscale,
                                                                        float* __restrict__ dshift) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sh[2][16][17];
+    const int cx = threadIdx.x & 15, by = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     float g = 0.f, gx = 0.f;
-    for (int b = 0; b < blocks; ++b) {
-        g += partial[((long long)b * 2 + 0) * C + c];
-        gx += partial[((long long)b * 2 + 1) * C + c];
+    if (c < C)
+        for (int b = by; b < blocks; b += 16) {
+            g += partial[((long long)b * 2 + 0) * C + c];
+            gx += partial[((long long)b * 2 + 1) * C + c];
+        }
+    sh[0][by][cx] = g;
+    sh[1][by][cx] = gx;
+    __syncthreads();
+    if (by == 0 && c < C) {
+        g = 0.f;
+        gx = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            g += sh[0][k][cx];
+            gx += sh[1][k][cx];
+        }
+        if (dshift) dshift[c] = (accumulate ? dshift[c] : 0.f) + g;
+        if (dscale) dscale[c] = (accumulate ? dscale[c] : 0.f) + gx;
     }
-    if (dshift) dshift[c] = (accumulate ? dshift[c] : 0.f) + g;
-    if (dscale) dscale[c] = (accumulate ? dscale[c] : 0.f) + gx;
+}
+
+// TT_WGRAD_XCD=1: XCD-contiguous workgroup -> tile order.  Measured (MI355X, 3x3 layers of the camera trunk at batch 8): no gain
+// where the grid is large (256 -> 256: 65.0 vs 63.8 TF/s) and a loss where it is small (64 -> 64: 36.3 vs 55.1 TF/s; a
+// training iteration 1701 vs 1368 ms), so the default is the identity mapping.
+static bool wgrad_xcd_remap() {
+    static const bool on = [] {
+        const char* e = getenv("TT_WGRAD_XCD");
+        return e && e[0] == '1';
+    }();
+    return on;
 }
 
 static int wgrad_splits(int N, int OH, int Cout, int Cin, int taps) {
@@ -382,7 +421,9 @@ extern "C" int tt_conv2d_wgrad(const float* x, int N, int H, int W, int Cin, int
     a.rows_per_split = div_up(N * OH, splits);
     hipStream_t st = (hipStream_t)stream;
     const unsigned tiles = (unsigned)(div_up(Cout, 64) * a.ci_tiles * taps);
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, st, a);
+    const bool remap = wgrad_xcd_remap() && taps > 1;
+    a.xcd_tiles = remap ? (int)tiles : 0;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(remap ? (tiles + 7u) / 8u * 8u : tiles, (unsigned)splits), dim3(256), 0, st, a);
     const long long n = (long long)Cout * taps * cin_pad;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, st, (const float*)workspace, n,
                        splits, accumulate, dw);
@@ -414,7 +455,7 @@ extern "C" int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
     if (dscale || dshift)
-        hipLaunchKernelGGL(conv_epilogue_bwd_finish_kernel, dim3((unsigned)div_up(C, 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(conv_epilogue_bwd_finish_kernel, dim3((unsigned)div_up(C, 16)), dim3(256), 0, st,
                            (const float*)workspace, blocks, C, accumulate, dscale, dshift);
     return check_launch("tt_conv_epilogue_bwd");
 }
@@ -443,8 +484,10 @@ extern "C" int tt_gather_conv_wgrad(const float* x, int x_cstride, int Cin, cons
     a.cin_p = cin_pad; a.ci_tiles = div_up(cin_pad, 64);
     a.pairs_per_split = div_up(div_up(M, 2), (long long)splits);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gather_wgrad_kernel, dim3((unsigned)(div_up(Cout, 64) * a.ci_tiles * taps), (unsigned)splits), dim3(256),
-                       0, st, a);
+    const unsigned tiles = (unsigned)(div_up(Cout, 64) * a.ci_tiles * taps);
+    const bool remap = wgrad_xcd_remap() && taps > 1;
+    a.xcd_tiles = remap ? (int)tiles : 0;
+    hipLaunchKernelGGL(gather_wgrad_kernel, dim3(remap ? (tiles + 7u) / 8u * 8u : tiles, (unsigned)splits), dim3(256), 0, st, a);
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, st, (const float*)workspace, n,
                        splits, accumulate, dw);
     return check_launch("tt_gather_conv_wgrad");

@@ -140,9 +140,12 @@ class ThinkTwiceDecoder:
         self.dist_sigma = _mlp(sd, p + ".dist_sigma", (0, 2), dev)
         self.fpn_linear = [conv_from_sd(sd, f"{p}.fpn_linear{i}", self.wdtype, dev) for i in range(4)]
         self.prefix = p
-        self.temporal = autodiff.register_param(sd[p + ".temporal_embedding"].to(dev, F32).contiguous(),
+        # (own copies: the training tape sizes their gradient buffers by storage, and a checkpoint tensor may be a view of
+        # something much larger -- the trainer's flat master buffer)
+        self.temporal = autodiff.register_param(sd[p + ".temporal_embedding"].to(dev, F32).clone().contiguous(),
                                                 p + ".temporal_embedding")
-        self.static = autodiff.register_param(sd[p + ".static_embedding"].to(dev, F32).contiguous(), p + ".static_embedding")
+        self.static = autodiff.register_param(sd[p + ".static_embedding"].to(dev, F32).clone().contiguous(),
+                                              p + ".static_embedding")
         cams = sd[p + ".cams_embeds"].to(dev, F32)
         lvls = sd[p + ".level_embeds"].to(dev, F32)
         self.cams_embeds, self.level_embeds = cams, lvls

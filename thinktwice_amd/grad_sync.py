@@ -51,6 +51,12 @@ class FlatGradBuffer:
             return None
         world = dist.get_world_size(group)
         self.flat.div_(world)      # pre-scale: the sum of pre-scaled f32 terms equals the mean without a second pass
+        if self.flat.is_cuda and dist.get_backend(group) == "gloo":
+            # test rigs only (several ranks on one GPU, no RCCL): stage through the host
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            self.flat.copy_(host)
+            return None
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
     def clip_grad_norm_(self, max_norm):

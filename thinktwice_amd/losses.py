@@ -224,6 +224,8 @@ def parse_losses(losses):
     for name, value in log_vars.items():
         if dist.is_available() and dist.is_initialized():
             value = value.detach().clone()
+            if value.is_cuda and dist.get_backend() == "gloo":        # test rigs without RCCL
+                value = value.cpu()
             dist.all_reduce(value.div_(dist.get_world_size()))
         log_vars[name] = value.item()
     return loss, log_vars

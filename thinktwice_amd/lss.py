@@ -71,7 +71,7 @@ class _ResNet50:
                            act=self.stem.act, in_cstride=self.cin_pad, out_hw=((Hp - 6) // 2, (Wp - 8) // 2),
                            w_x3=self.stem_rr_x3)
         else:
-            y = self.stem(x)
+            y = self.stem(x, stop_grad=True)      # (training tape: the image is a leaf without a gradient)
         x = ops.maxpool3x3s2(y)
         outs = []
         for stage in self.blocks:

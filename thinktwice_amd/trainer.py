@@ -54,14 +54,33 @@ class Trainer:
         self.opt = FlatAdamW(self.flat_param, self.grads.flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                              max_grad_norm=max_grad_norm)
         self.param_grads = None
+        import os
+        self._prepare_on_device = os.environ.get("TT_TRAIN_PREPARE", "device") != "host"
+        self._dev_buffers = None
         self._prepare()
 
     def _prepare(self):
         """(Re)build the kernels' operand formats (folded BatchNorm affines, channel-last / pair-split weights) from the
-        master weights, through the same host-side load path a checkpoint takes (one 0.5 GB device-to-host copy per
-        iteration; preparing the operands on the device straight from the flat buffer is the obvious next step)."""
+        master weights.  Device path: the load code runs on views of the flat master buffer (BatchNorm statistics moved to
+        the device once), so nothing crosses PCIe.  TT_TRAIN_PREPARE=host takes the route a checkpoint takes instead (one
+        0.5 GB device-to-host copy + host-side preparation per iteration); it is also the fallback if the load code meets
+        a host-only operation on a device tensor."""
         autodiff.clear_metas()
         with torch.no_grad():
+            if self._prepare_on_device:
+                if self._dev_buffers is None:
+                    self._dev_buffers = {k: v.to(self.flat_param.device) for k, v in self.sd.items()
+                                         if torch.is_tensor(v) and k.endswith(("running_mean", "running_var"))}
+                try:
+                    self.model.load_state_dict({k: (v.detach() if k in self._trainable else self._dev_buffers.get(k, v))
+                                                for k, v in self.sd.items()})
+                    return
+                except (RuntimeError, TypeError) as e:
+                    import sys
+                    print(f"[trainer] device-side operand preparation failed ({type(e).__name__}: {e}); "
+                          f"using the host path", file=sys.stderr, flush=True)
+                    self._prepare_on_device = False
+                    autodiff.clear_metas()
             self.model.load_state_dict({k: (v.detach().cpu() if k in self._trainable else v) for k, v in self.sd.items()})
 
     def backward(self, batch):
