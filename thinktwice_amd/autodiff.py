@@ -9,11 +9,10 @@ gradient windows.  Parameter gradients are collected under the reference's state
 (`tape.param_grads["img_encoder.img_backbone.layer1.0.conv1.weight"]` is [Cout, Cin, KH, KW]), which is what the gradient
 golden F13 (tests/golden/gen_golden.py) is keyed by.
 
-Covered so far: convolution with its fused epilogue (folded eval-mode BatchNorm affine or bias, ReLU / sigmoid / none, up to
-two residual inputs, in-place residual outputs), the 2x2/2 transposed convolution, 3x3/2 max-pooling, the in-place nearest-
-upsample-add of the PAFPN top-down path, the x2 bilinear upsampling -- i.e. the ResNet-50 + PAFPN camera trunk and the UNet
-segmentation head, end to end from the focal segmentation loss (losses.LossReducer.seg_focal_bwd).  Ops without a
-recorder contribute no gradient yet (the remaining branches of the model).
+Every op of `EncoderDecoder.forward_train` has a recorder (both encoders, the fusion neck, the decoder with its look module
+and teacher-forcing pass, and -- in losses.py -- the loss terms); a form without one raises NotImplementedError instead of
+silently dropping a gradient.  trainer.Trainer drives the tape; tests/test_backward.py checks every sub-network against torch
+autograd through the oracle and tests/test_train_step.py the whole model against the reference's own gradients (golden F13).
 """
 import torch
 

@@ -7,7 +7,8 @@ Same state_dict keys and the same output dict (keys/shapes of SURVEY 8a A22).  A
 done on the device (no host sync inside the 5-layer loop); dead branches of the reference
 (LiDAR look features zeroed at DEC:186, PredictionModule.ffn discarded at DEC:44-46) are not
 computed -- their parameters are accepted and ignored.  With `teacher_forcing_data` the decoder also runs the
-teacher-forcing pass of the training step (DEC:491-533); losses and backward are not part of this build.
+teacher-forcing pass of the training step (DEC:491-533).  Inside `autodiff.Tape` the layer-wise path runs on one stream
+and every op records its backward (trainer.py); the losses are thinktwice_amd/losses.py.
 """
 import os
 
