@@ -10,8 +10,9 @@ gradient windows.  Parameter gradients are collected under the reference's state
 golden F13 (tests/golden/gen_golden.py) is keyed by.
 
 Every op of `EncoderDecoder.forward_train` has a recorder (both encoders, the fusion neck, the decoder with its look module
-and teacher-forcing pass, and -- in losses.py -- the loss terms); a form without one raises NotImplementedError instead of
-silently dropping a gradient.  trainer.Trainer drives the tape; tests/test_backward.py checks every sub-network against torch
+and teacher-forcing pass, and -- in losses.py -- the loss terms).  The recorders raise NotImplementedError for operand forms
+they do not differentiate (row-run stem, unregistered weights, ...); the fused inference-only kernels (decoder_fused.py, the
+*_ln look kernels) and the NCHW output conversions have no recorder and are not used by the taped forward.  trainer.Trainer drives the tape; tests/test_backward.py checks every sub-network against torch
 autograd through the oracle and tests/test_train_step.py the whole model against the reference's own gradients (golden F13).
 """
 import torch
