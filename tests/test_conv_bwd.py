@@ -17,6 +17,12 @@ CASES = [
     (4, 40, 48, 3, 64, 7, 2, 3, 1),        # stem: Cin = 3 (padded to 4 in the weight layout)
     (1, 21, 21, 256, 256, 3, 1, 1, 1),     # BEV-level layer: few pixels, many channels
     (8, 64, 96, 64, 64, 3, 1, 1, 1),       # many rows: split partial sums
+    (2, 16, 21, 160, 200, 3, 1, 1, 1),     # wide (128-channel) wave tiles with channel tails on both sides, odd width
+    (2, 14, 14, 512, 96, 1, 1, 0, 1),      # wide on the input side only
+    (3, 18, 16, 48, 320, 3, 2, 1, 1),      # wide on the output side only, stride 2
+    (2, 24, 31, 32, 12, 3, 1, 1, 1),       # 32-channel wave tiles on both sides (segmentation head), Cout tail, odd width
+    (2, 12, 16, 24, 256, 1, 1, 0, 1),      # narrow input, wide output
+    (2, 12, 16, 200, 20, 3, 1, 1, 1),      # wide input, narrow output
 ]
 
 

@@ -56,6 +56,14 @@ class TrainStepWorkload:
         ms = sum(r[1].elapsed_time(r[2]) for r in dense)
         wg = [r for r in dense if r[3].startswith("wgrad")]
         wg_ms = sum(r[1].elapsed_time(r[2]) for r in wg)
+        agg = {}
+        for r in wg:
+            a = agg.setdefault(r[3], [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += r[1].elapsed_time(r[2])
+            a[2] += r[0]
+        self._wgrad_top = [{"shape": k, "calls": v[0], "ms": round(v[1], 2), "tf": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
+                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]]
         # phases of one iteration, each bracketed by a device synchronise
         ph = {}
         t0 = time.perf_counter()
@@ -84,7 +92,7 @@ class TrainStepWorkload:
                           "note": "exact-f32 MFMA (peak 157.3 TFLOP/s)"}}
 
     def extra(self):
-        return {"train_step_phases": getattr(self, "_phases", None)}
+        return {"train_step_phases": getattr(self, "_phases", None), "wgrad_top_shapes": getattr(self, "_wgrad_top", None)}
 
     def cpu_baseline(self):
         return None

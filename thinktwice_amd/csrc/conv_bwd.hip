@@ -30,6 +30,12 @@ struct WgradArgs {
     int xcd_tiles;         // > 0: number of real tiles of an XCD-remapped grid (see the kernel); 0: identity mapping
 };
 
+// v if ok else 0, as a MULTIPLY on an always-executed load of a clamped (valid, finite) element: a select or a bit mask is
+// folded back into select(ok, load, 0), which the code generator turns into a divergent branch around the load with a wait
+// inside -- serialising the loads of a group.  Used by the wide kernel, whose software pipeline needs its loads in flight under
+// the MFMAs (measured on the 64 x 64 kernel: the conditional loads are FASTER there, 55 vs 36 TF/s, so it keeps them)
+__device__ __forceinline__ float masked(float v, bool ok) { return v * (ok ? 1.f : 0.f); }
+
 constexpr int kWgUnroll = 4;       // pixel pairs in flight per wave (each: 2 + 2 dword loads, 4 MFMAs)
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
@@ -126,14 +132,127 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             }
 }
 
-// dw[i] = (accumulate ? dw[i] : 0) + sum over splits (in order) of ws[s][i]
+// Wide variant for layers with >= 128 channels on a side: every WAVE owns a (32 BI) x (32 BJ) tile of dW[.][tap][.] (up to
+// 128 x 128 = 256 accumulator registers) over its share of the rows, so a pixel pair costs BI + BJ dword loads per BI * BJ
+// MFMAs (0.5 per MFMA at 4 x 4, against 1.0 in the 64 x 64 kernel above: that kernel is bound by its operand loads, not by the
+// f32 MFMA pipe).  No cross-wave reduction in the workgroup: each wave stores its partial tile as its own split slice
+// (blockIdx.y * 4 + wave) and the ordered reduce kernel adds them -- still deterministic.
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void conv_wgrad_wide_kernel(const WgradArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, k = lane >> 5;
+    const int taps = a.KH * a.KW;
+    int t = blockIdx.x;
+    const int tap = t % taps;
+    t /= taps;
+    const int ci0 = (t % a.ci_tiles) * (32 * BJ), co0 = (t / a.ci_tiles) * (32 * BI);
+    const int kh = tap / a.KW, kw = tap % a.KW;
+    const int rows = a.N * a.OH;
+    const int r_begin = blockIdx.y * a.rows_per_split;
+    const int r_end = min(rows, r_begin + a.rows_per_split);
+
+    f32x16 acc[BI][BJ];
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bool co_ok[BI], ci_ok[BJ];
+    int cco[BI], cci[BJ];                                    // clamped channels: unconditional loads, masked afterwards
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        co_ok[i] = co0 + 32 * i + c < a.Cout;
+        cco[i] = min(co0 + 32 * i + c, a.Cout - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        ci_ok[j] = ci0 + 32 * j + c < a.Cin;
+        cci[j] = min(ci0 + 32 * j + c, a.Cin - 1);
+    }
+    const int npairs = (a.OW + 1) >> 1;
+    // pixel pairs in flight (each: BI + BJ loads, BI * BJ MFMAs): more of them where a pair is little MFMA work
+    constexpr int U = BI * BJ >= 8 ? 2 : (BI * BJ >= 4 ? 4 : 8);
+    for (int r = r_begin + wave; r < r_end; r += 4) {
+        const int n = r / a.OH, oh = r - n * a.OH;
+        const int ih = oh * a.stride - a.pad + kh * a.dil;
+        if (ih < 0 || ih >= a.H) continue;
+        const float* dyrow = a.dy + ((long long)r * a.OW) * a.dy_cstride + a.dy_coff;
+        const float* xrow = a.x + (((long long)n * a.H + ih) * a.W) * a.x_cstride + a.x_coff;
+        // software pipeline: the operands of the next U pairs are in flight while the MFMAs of the current ones run (one wave
+        // per SIMD at this accumulator size: nothing else hides the load latency)
+        auto load_pairs = [&](int p0, float (&av)[U][BI], float (&bv)[U][BJ]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ow = 2 * (p0 + u) + k;
+                const int iw = ow * a.stride - a.pad + kw * a.dil;
+                const bool m_ok = ow < a.OW;
+                const bool x_ok = m_ok && iw >= 0 && iw < a.W;
+                const float* dp = dyrow + (long long)(m_ok ? ow : 0) * a.dy_cstride;
+                const float* xp = xrow + (long long)(x_ok ? iw : 0) * a.x_cstride;
+#pragma unroll
+                for (int i = 0; i < BI; ++i) {
+                    av[u][i] = masked(dp[cco[i]], m_ok && co_ok[i]);
+                }
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) {
+                    bv[u][j] = masked(xp[cci[j]], x_ok && ci_ok[j]);
+                }
+            }
+        };
+        float av[U][BI], bv[U][BJ], an[U][BI], bn[U][BJ];
+        load_pairs(0, av, bv);
+        for (int p0 = 0; p0 < npairs; p0 += U) {
+            load_pairs(p0 + U, an, bn);                      // (past the row: every pair is masked to zero operands)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < BI; ++i)
+#pragma unroll
+                    for (int j = 0; j < BJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int i = 0; i < BI; ++i) av[u][i] = an[u][i];
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) bv[u][j] = bn[u][j];
+            }
+        }
+    }
+    float* ws = a.ws + ((long long)blockIdx.y * 4 + wave) * a.Cout * taps * a.cin_p;
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * k;
+                const int col = 32 * j + c;
+                if (co0 + row < a.Cout && ci0 + col < a.cin_p)
+                    ws[((long long)(co0 + row) * taps + tap) * a.cin_p + ci0 + col] = (ci0 + col < a.Cin) ? acc[i][j][e] : 0.f;
+            }
+}
+
+// dw[i] = (accumulate ? dw[i] : 0) + sum over the partial slices ws[s][i], in a FIXED order: 32 elements per workgroup, eight
+// thread groups walk every 8th slice, then the eight group sums are added in index order (deterministic; with up to a few
+// thousand slices of a small tile a single serial loop per element was the slowest part of the launch)
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ ws, long long n, int splits,
                                                                 int accumulate, float* __restrict__ dw) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float v = accumulate ? dw[i] : 0.f;
-    for (int s = 0; s < splits; ++s) v += ws[(long long)s * n + i];
-    dw[i] = v;
+    __shared__ float sh[8][33];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + e;
+    float v = 0.f;
+    if (i < n)
+        for (int s = g; s < splits; s += 8) v += ws[(long long)s * n + i];
+    sh[g][e] = v;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        v = accumulate ? dw[i] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += sh[k][e];
+        dw[i] = v;
+    }
 }
 
 // Weight gradient of the gathered (sparse) convolution  y[m] = sum_t W_t x[nbr[m][t]]  (spconv SubMConv3d / SparseConv3d
@@ -382,9 +501,25 @@ static bool wgrad_xcd_remap() {
     return on;
 }
 
+// tile of one wave in 32-channel blocks per side: 4 (128 channels) where the side has >= 128, 1 where it has <= 32 (the
+// segmentation / depth heads, the stem's 3 input channels: a 64-wide tile would multiply mostly zeros), else 2.  2 x 2 is the
+// 64 x 64 workgroup-tile kernel, everything else the per-wave-tile kernel.  TT_WGRAD_WIDE=0: always 2 x 2.
+static void wgrad_blocks(int Cout, int Cin, int* bi, int* bj) {
+    static const bool wide = [] {
+        const char* e = getenv("TT_WGRAD_WIDE");
+        return !(e && e[0] == '0');
+    }();
+    *bi = !wide ? 2 : (Cout >= 128 ? 4 : (Cout <= 32 ? 1 : 2));
+    *bj = !wide ? 2 : (Cin >= 128 ? 4 : (Cin <= 32 ? 1 : 2));
+}
+
 static int wgrad_splits(int N, int OH, int Cout, int Cin, int taps) {
-    const long long tiles = (long long)div_up(Cout, 64) * div_up(Cin, 64) * taps;
-    long long s = (4LL * kNumCU + tiles - 1) / tiles;        // aim at >= 4 workgroups per CU
+    int bi, bj;
+    wgrad_blocks(Cout, Cin, &bi, &bj);
+    const long long tiles = (long long)div_up(Cout, 32 * bi) * div_up(Cin, 32 * bj) * taps;
+    // aim at >= 4 workgroups per CU, 2 for the 128-wide wave tiles (one wave per SIMD each, and every split costs four
+    // partial slices)
+    long long s = ((bi * bj >= 8 ? 2LL : 4LL) * kNumCU + tiles - 1) / tiles;
     const int rows = N * OH;
     if (s > rows / 4) s = rows / 4;                          // every wave of a workgroup gets at least one row
     if (s < 1) s = 1;
@@ -392,12 +527,19 @@ static int wgrad_splits(int N, int OH, int Cout, int Cin, int taps) {
     return (int)s;
 }
 
+// partial-sum slices in the workspace: one per split, x 4 in the wide kernel (one per wave)
+static int wgrad_slices(int N, int OH, int Cout, int Cin, int taps) {
+    int bi, bj;
+    wgrad_blocks(Cout, Cin, &bi, &bj);
+    return wgrad_splits(N, OH, Cout, Cin, taps) * ((bi == 2 && bj == 2) ? 1 : 4);
+}
+
 }  // namespace tt
 
 using namespace tt;
 
 extern "C" long long tt_conv2d_wgrad_workspace_bytes(int N, int OH, int Cout, int Cin, int cin_pad, int KH, int KW) {
-    return (long long)wgrad_splits(N, OH, Cout, Cin, KH * KW) * Cout * KH * KW * cin_pad * 4;
+    return (long long)wgrad_slices(N, OH, Cout, Cin, KH * KW) * Cout * KH * KW * cin_pad * 4;
 }
 
 extern "C" int tt_conv2d_wgrad(const float* x, int N, int H, int W, int Cin, int x_cstride, int x_coff, const float* dy,
@@ -417,16 +559,32 @@ extern "C" int tt_conv2d_wgrad(const float* x, int N, int H, int W, int Cin, int
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_cstride = x_cstride; a.x_coff = x_coff;
     a.OH = OH; a.OW = OW; a.Cout = Cout; a.dy_cstride = dy_cstride; a.dy_coff = dy_coff;
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil; a.cin_p = cin_pad;
-    a.ci_tiles = div_up(cin_pad, 64);
+    int bi, bj;
+    wgrad_blocks(Cout, Cin, &bi, &bj);
+    a.ci_tiles = div_up(cin_pad, 32 * bj);
     a.rows_per_split = div_up(N * OH, splits);
     hipStream_t st = (hipStream_t)stream;
-    const unsigned tiles = (unsigned)(div_up(Cout, 64) * a.ci_tiles * taps);
-    const bool remap = wgrad_xcd_remap() && taps > 1;
-    a.xcd_tiles = remap ? (int)tiles : 0;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(remap ? (tiles + 7u) / 8u * 8u : tiles, (unsigned)splits), dim3(256), 0, st, a);
+    const unsigned tiles = (unsigned)(div_up(Cout, 32 * bi) * a.ci_tiles * taps);
+    int slices = splits;
+    if (bi == 2 && bj == 2) {
+        const bool remap = wgrad_xcd_remap() && taps > 1;
+        a.xcd_tiles = remap ? (int)tiles : 0;
+        hipLaunchKernelGGL(conv_wgrad_kernel, dim3(remap ? (tiles + 7u) / 8u * 8u : tiles, (unsigned)splits), dim3(256), 0, st, a);
+    } else {
+        a.xcd_tiles = 0;
+        slices = splits * 4;
+        const dim3 grid(tiles, (unsigned)splits);
+        switch (bi * 8 + bj) {
+#define TT_WG(BI_, BJ_) \
+    case BI_ * 8 + BJ_: hipLaunchKernelGGL((conv_wgrad_wide_kernel<BI_, BJ_>), grid, dim3(256), 0, st, a); break;
+            TT_WG(4, 4) TT_WG(4, 2) TT_WG(2, 4) TT_WG(4, 1) TT_WG(1, 4) TT_WG(2, 1) TT_WG(1, 2) TT_WG(1, 1)
+#undef TT_WG
+            default: TT_REQUIRE(false, "tt_conv2d_wgrad: no kernel for wave tile %d x %d", bi, bj);
+        }
+    }
     const long long n = (long long)Cout * taps * cin_pad;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, st, (const float*)workspace, n,
-                       splits, accumulate, dw);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)div_up(n, 32)), dim3(256), 0, st, (const float*)workspace, n,
+                       slices, accumulate, dw);
     return check_launch("tt_conv2d_wgrad");
 }
 
@@ -488,7 +646,7 @@ extern "C" int tt_gather_conv_wgrad(const float* x, int x_cstride, int Cin, cons
     const bool remap = wgrad_xcd_remap() && taps > 1;
     a.xcd_tiles = remap ? (int)tiles : 0;
     hipLaunchKernelGGL(gather_wgrad_kernel, dim3(remap ? (tiles + 7u) / 8u * 8u : tiles, (unsigned)splits), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)div_up(n, 256)), dim3(256), 0, st, (const float*)workspace, n,
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)div_up(n, 32)), dim3(256), 0, st, (const float*)workspace, n,
                        splits, accumulate, dw);
     return check_launch("tt_gather_conv_wgrad");
 }
