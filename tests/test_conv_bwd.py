@@ -140,3 +140,28 @@ def test_conv_bn_relu_residual_layer_backward():
     assert rel(dx.permute(0, 3, 1, 2), x.grad) < 2e-4
     assert rel(dres.view(N, H, W, Cout).permute(0, 3, 1, 2), res.grad) < 1e-6
     assert rel(dgamma, gamma.grad) < 1e-4 and rel(dshift, beta.grad) < 3e-5
+
+
+@pytest.mark.parametrize("Cin,Cout", [(16, 16), (32, 64), (64, 64), (128, 128), (48, 160), (130, 24)])
+def test_gather_conv_wgrad_matches_dense_sum(Cin, Cout):
+    """tt_gather_conv_wgrad: dW[co][t][ci] = sum over the LIVE rows m of dy[m][co] * x[nbr[m][t]][ci] (nbr = -1: no input) for
+    every wave-tile form of the kernel (32 / 64 / 128 channels a side), a ragged live-row count and empty taps."""
+    from thinktwice_amd import ops
+    g = torch.Generator().manual_seed(Cin * 31 + Cout)
+    R_in, M, live, taps = 700, 1500, 1237, 27
+    x = torch.randn(R_in, Cin, generator=g)
+    dy = torch.randn(M, Cout, generator=g)
+    nbr = torch.randint(0, R_in, (M, taps), generator=g, dtype=torch.int32)
+    nbr[torch.rand(M, taps, generator=g) < 0.6] = -1
+    nbr[:, 5] = -1                                            # a tap no row uses
+    xg = torch.where((nbr >= 0).unsqueeze(-1), x[nbr.clamp_min(0).long()], torch.zeros(()))   # (M, taps, Cin)
+    ref = torch.einsum("mo,mti->oti", dy[:live].double(), xg[:live].double()).float()
+    cin_pad = (Cin + 3) // 4 * 4
+    m_dev = torch.tensor([live], dtype=torch.int32, device="cuda")
+    got = ops.gather_conv_wgrad(x.cuda(), nbr.cuda(), m_dev, dy.cuda(), taps, cin_pad=cin_pad).cpu()
+    assert got.shape == (Cout, 1, taps, cin_pad)
+    assert float(got[..., Cin:].abs().max()) == 0.0 if cin_pad > Cin else True
+    err = float((got[:, 0, :, :Cin] - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
+    again = ops.gather_conv_wgrad(x.cuda(), nbr.cuda(), m_dev, dy.cuda(), taps, cin_pad=cin_pad).cpu()
+    assert torch.equal(got, again)                            # ordered partial sums: bit-reproducible

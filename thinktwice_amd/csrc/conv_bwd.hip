@@ -460,6 +460,80 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
     }
 }
 
+// Per-wave-tile form of gather_wgrad_kernel (see conv_wgrad_wide_kernel): 32 channels a side for the 16 / 32-channel levels of
+// the sparse encoder (a 64-wide tile multiplies mostly zeros there), 128 for its 128-channel levels.  Every wave walks its
+// share of the live row pairs and stores its partial tile as its own slice (blockIdx.y * 4 + wave) of the ordered reduction.
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void gather_wgrad_wide_kernel(const GatherWgradArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, k = lane >> 5;
+    int t = blockIdx.x;
+    const int tap = t % a.taps;
+    t /= a.taps;
+    const int ci0 = (t % a.ci_tiles) * (32 * BJ), co0 = (t / a.ci_tiles) * (32 * BI);
+    const long long Mlive = a.m_dev ? min(a.M, (long long)*a.m_dev) : a.M;
+    const long long npairs = (Mlive + 1) >> 1;
+    const long long pps = (npairs + gridDim.y - 1) / gridDim.y;
+    const long long p_begin = (long long)blockIdx.y * pps;
+    const long long p_end = min(npairs, p_begin + pps);
+    f32x16 acc[BI][BJ];
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bool co_ok[BI], ci_ok[BJ];
+    int cco[BI], cci[BJ];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        co_ok[i] = co0 + 32 * i + c < a.Cout;
+        cco[i] = min(co0 + 32 * i + c, a.Cout - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        ci_ok[j] = ci0 + 32 * j + c < a.Cin;
+        cci[j] = min(ci0 + 32 * j + c, a.Cin - 1);
+    }
+    constexpr int U = BI * BJ >= 8 ? 2 : 4;                  // row pairs in flight per wave
+    for (long long p0 = p_begin + (long long)wave * U; p0 < p_end; p0 += 4 * U) {
+        float av[U][BI], bv[U][BJ];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long m = 2 * (p0 + u) + k;
+            const bool m_ok = (p0 + u) < p_end && m < Mlive;
+            const long long mc = m_ok ? m : 0;
+            const int jr = a.nbr[mc * a.taps + tap];
+            const bool x_ok = m_ok && jr >= 0;
+            const float* dp = a.dy + mc * a.dy_cstride;
+            const float* xp = a.x + (long long)(x_ok ? jr : 0) * a.x_cstride;
+#pragma unroll
+            for (int i = 0; i < BI; ++i) av[u][i] = masked(dp[cco[i]], m_ok && co_ok[i]);
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) bv[u][j] = masked(xp[cci[j]], x_ok && ci_ok[j]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+#pragma unroll
+                for (int j = 0; j < BJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+    }
+    float* ws = a.ws + ((long long)blockIdx.y * 4 + wave) * a.Cout * a.taps * a.cin_p;
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * k;
+                const int col = 32 * j + c;
+                if (co0 + row < a.Cout && ci0 + col < a.cin_p)
+                    ws[((long long)(co0 + row) * a.taps + tap) * a.cin_p + ci0 + col] = (ci0 + col < a.Cin) ? acc[i][j][e] : 0.f;
+            }
+}
+
 // per-channel sums of the workgroups' partials [blocks][2][C], in a fixed order (deterministic): 16 channels per workgroup,
 // 16 thread groups each walk every 16th partial row, then the 16 group sums are added in index order
 __global__ __launch_bounds__(256) void conv_epilogue_bwd_finish_kernel(const float* __restrict__ partial, int blocks, int C,
@@ -618,13 +692,23 @@ extern "C" int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff
     return check_launch("tt_conv_epilogue_bwd");
 }
 
-extern "C" long long tt_gather_conv_wgrad_workspace_bytes(long long M, int Cout, int Cin, int cin_pad, int taps) {
-    const long long tiles = (long long)div_up(Cout, 64) * div_up(cin_pad, 64) * taps;
-    long long s = (4LL * kNumCU + tiles - 1) / tiles;
+// splits of the live rows (and, in the per-wave-tile kernel, four partial slices per split)
+static int gather_wgrad_splits(long long M, int Cout, int Cin, int cin_pad, int taps, int* slices) {
+    int bi, bj;
+    wgrad_blocks(Cout, Cin, &bi, &bj);
+    const long long tiles = (long long)div_up(Cout, 32 * bi) * div_up(cin_pad, 32 * bj) * taps;
+    long long s = ((bi * bj >= 8 ? 2LL : 4LL) * kNumCU + tiles - 1) / tiles;
     if (s > (M + 63) / 64) s = (M + 63) / 64;
     if (s < 1) s = 1;
     if (s > 1024) s = 1024;
-    return s * Cout * taps * cin_pad * 4;
+    *slices = (int)s * ((bi == 2 && bj == 2) ? 1 : 4);
+    return (int)s;
+}
+
+extern "C" long long tt_gather_conv_wgrad_workspace_bytes(long long M, int Cout, int Cin, int cin_pad, int taps) {
+    int slices;
+    gather_wgrad_splits(M, Cout, Cin, cin_pad, taps, &slices);
+    return (long long)slices * Cout * taps * cin_pad * 4;
 }
 
 extern "C" int tt_gather_conv_wgrad(const float* x, int x_cstride, int Cin, const int* nbr, const int* m_dev, long long M,
@@ -635,19 +719,33 @@ extern "C" int tt_gather_conv_wgrad(const float* x, int x_cstride, int Cin, cons
     const long long need = tt_gather_conv_wgrad_workspace_bytes(M, Cout, Cin, cin_pad, taps);
     TT_REQUIRE(workspace_bytes >= need, "tt_gather_conv_wgrad: workspace too small");
     const long long n = (long long)Cout * taps * cin_pad;
-    const int splits = (int)(need / (n * 4));
+    int slices, bi, bj;
+    const int splits = gather_wgrad_splits(M, Cout, Cin, cin_pad, taps, &slices);
+    wgrad_blocks(Cout, Cin, &bi, &bj);
     GatherWgradArgs a;
     a.x = x; a.dy = dy; a.nbr = nbr; a.m_dev = m_dev; a.ws = (float*)workspace;
     a.M = M; a.Cin = Cin; a.x_cstride = x_cstride; a.Cout = Cout; a.dy_cstride = dy_cstride; a.taps = taps;
-    a.cin_p = cin_pad; a.ci_tiles = div_up(cin_pad, 64);
+    a.cin_p = cin_pad; a.ci_tiles = div_up(cin_pad, 32 * bj);
     a.pairs_per_split = div_up(div_up(M, 2), (long long)splits);
     hipStream_t st = (hipStream_t)stream;
-    const unsigned tiles = (unsigned)(div_up(Cout, 64) * a.ci_tiles * taps);
-    const bool remap = wgrad_xcd_remap() && taps > 1;
-    a.xcd_tiles = remap ? (int)tiles : 0;
-    hipLaunchKernelGGL(gather_wgrad_kernel, dim3(remap ? (tiles + 7u) / 8u * 8u : tiles, (unsigned)splits), dim3(256), 0, st, a);
+    const unsigned tiles = (unsigned)(div_up(Cout, 32 * bi) * a.ci_tiles * taps);
+    if (bi == 2 && bj == 2) {
+        const bool remap = wgrad_xcd_remap() && taps > 1;
+        a.xcd_tiles = remap ? (int)tiles : 0;
+        hipLaunchKernelGGL(gather_wgrad_kernel, dim3(remap ? (tiles + 7u) / 8u * 8u : tiles, (unsigned)splits), dim3(256), 0, st, a);
+    } else {
+        a.xcd_tiles = 0;
+        const dim3 grid(tiles, (unsigned)splits);
+        switch (bi * 8 + bj) {
+#define TT_GW(BI_, BJ_) \
+    case BI_ * 8 + BJ_: hipLaunchKernelGGL((gather_wgrad_wide_kernel<BI_, BJ_>), grid, dim3(256), 0, st, a); break;
+            TT_GW(4, 4) TT_GW(4, 2) TT_GW(2, 4) TT_GW(4, 1) TT_GW(1, 4) TT_GW(2, 1) TT_GW(1, 2) TT_GW(1, 1)
+#undef TT_GW
+            default: TT_REQUIRE(false, "tt_gather_conv_wgrad: no kernel for wave tile %d x %d", bi, bj);
+        }
+    }
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)div_up(n, 32)), dim3(256), 0, st, (const float*)workspace, n,
-                       splits, accumulate, dw);
+                       slices, accumulate, dw);
     return check_launch("tt_gather_conv_wgrad");
 }
 
