@@ -192,6 +192,8 @@ def main():
     from thinktwice_amd.bench_harness import run_timed
     res = run_timed(wl, args.steps, args.warmup, dist=dist, sync=torch.cuda.synchronize, device=device)
     dt = res["seconds"]
+    if hasattr(wl, "collect"):      # report data that takes collectives to produce: on every rank
+        wl.collect()
 
     if rank == 0:
         frames = wl.frames_per_step() * args.steps * world

@@ -41,9 +41,10 @@ class TrainStepWorkload:
     def frames_per_step(self):
         return self.B
 
-    def roofline(self):
-        """All convolution-shaped launches of one iteration (forward, GELU recomputes, input gradients, weight gradients):
-        algorithmic FLOPs / summed launch durations, HIP events on the launch stream."""
+    def collect(self):
+        """Runs on EVERY rank after the timed steps (the profiled iteration issues the step's collectives): all
+        convolution-shaped launches of one iteration (forward, GELU recomputes, input gradients, weight gradients) --
+        algorithmic FLOPs / summed launch durations, HIP events on the launch stream -- and the phases of the iteration."""
         torch.cuda.synchronize()
         ops.CONV_PROFILE, ops.CONV_BYTES, ops.CONV_KERNELS = [], None, None
         t0 = time.perf_counter()
@@ -84,12 +85,16 @@ class TrainStepWorkload:
         self._phases["peak_memory_gb"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
         peak = MFMA_PEAK_TF[self.dtype]
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": None, "kernel": "all dense conv / linear launches of one iteration (sparse gathered GEMMs excluded)",
-                "launches": len(dense), "kernel_ms": round(ms, 2), "gflop": round(flops / 1e9, 1),
-                "wgrad": {"launches": len(wg), "ms": round(wg_ms, 2),
-                          "tflops": round(sum(r[0] for r in wg) / max(wg_ms * 1e-3, 1e-9) / 1e12, 1),
-                          "note": "exact-f32 MFMA (peak 157.3 TFLOP/s)"}}
+        self._roofline = {
+            "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": None, "kernel": "all dense conv / linear launches of one iteration (sparse gathered GEMMs excluded)",
+            "launches": len(dense), "kernel_ms": round(ms, 2), "gflop": round(flops / 1e9, 1),
+            "wgrad": {"launches": len(wg), "ms": round(wg_ms, 2),
+                      "tflops": round(sum(r[0] for r in wg) / max(wg_ms * 1e-3, 1e-9) / 1e12, 1),
+                      "note": "exact-f32 MFMA (peak 157.3 TFLOP/s)"}}
+
+    def roofline(self):
+        return self._roofline
 
     def extra(self):
         return {"train_step_phases": getattr(self, "_phases", None), "wgrad_top_shapes": getattr(self, "_wgrad_top", None)}
