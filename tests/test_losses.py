@@ -78,3 +78,47 @@ def test_seg_focal_and_depth_bce_match_oracle(BN, H, W):
     # no foreground cell at all: sum / max(1, 0) = 0
     got0 = red.depth_bce(logits.permute(0, 2, 3, 1).contiguous().cuda(), torch.zeros_like(dep), d_bound, 16)
     assert float(got0) == 0.0 and float(TR.depth_loss(logits, torch.zeros_like(dep), d_bound, 16)) == 0.0
+
+
+def test_smooth_l1_and_beta_kl_gradients_match_autograd():
+    """The gradient half of the two decoder loss forms (tt_loss_smooth_l1_bwd, tt_loss_beta_kl_bwd) as the training tape
+    records them: d[mean-reduced term]/d(prediction) with a broadcast target, the clamp (zero gradient where it is active),
+    the unreduced (B, 1) form that `_parse_losses` averages, and predictions that are strided VIEWS of a larger tensor
+    (mu / sigma columns of the stacked control tensor)."""
+    from torch.distributions import Beta, kl_divergence
+    from thinktwice_amd import autodiff
+    g = torch.Generator().manual_seed(11)
+    red = _red()
+    # smooth-L1: broadcast over the refinement dimension, residuals on both sides of 1 and of the clamp
+    x = (torch.randn(4, 5, 3, 7, generator=g) * 4.0).requires_grad_(True)
+    t = torch.randn(4, 3, 7, generator=g)
+    want = (torch.clamp(F.smooth_l1_loss(x, t.unsqueeze(1).expand_as(x), reduction="none"), max=5.0).mean() * 0.25)
+    want.backward()
+    xd = x.detach().cuda()
+    with autodiff.Tape() as tape:
+        got = red.smooth_l1(xd, t, clamp_max=5.0, scale=0.25)
+        tape.backward()
+    assert abs(float(got) - float(want)) < 1e-6 * abs(float(want))
+    assert float((tape.grad(xd).cpu() - x.grad).abs().max()) < 1e-7
+    assert int((x.grad == 0).sum()) > 0                       # the clamp was active somewhere
+    # unreduced form: (B, 1) values, averaged by parse_losses
+    v = torch.randn(6, 1, generator=g, requires_grad=True)
+    tv = torch.randn(6, 1, generator=g)
+    (F.smooth_l1_loss(v, tv, reduction="none") * 0.001).mean().backward()
+    vd = v.detach().cuda()
+    with autodiff.Tape() as tape:
+        red.smooth_l1(vd, tv, scale=0.001, reduce=False)
+        tape.backward()
+    assert float((tape.grad(vd).cpu() - v.grad).abs().max()) < 1e-9
+    # Beta KL on strided views: ct (B, R, 4, 4) -> mu = ct[:, :, 0, :2], sigma = ct[:, :, 0, 2:]
+    ct = (torch.rand(3, 6, 4, 4, generator=g) * 4.0 + 0.05).requires_grad_(True)
+    ta = torch.rand(3, 2, generator=g) * 3.0 + 0.1
+    tb = torch.rand(3, 2, generator=g) * 3.0 + 0.1
+    (kl_divergence(Beta(ta.unsqueeze(1), tb.unsqueeze(1)), Beta(ct[:, :, 0, :2], ct[:, :, 0, 2:])).mean() * 15.0).backward()
+    cd = ct.detach().cuda()
+    with autodiff.Tape() as tape:
+        red.beta_kl(ta, tb, cd[:, :, 0, :2], cd[:, :, 0, 2:], 15.0)
+        tape.backward()
+    err = float((tape.grad(cd).cpu() - ct.grad).abs().max() / ct.grad.abs().max())
+    assert err < 1e-5, err
+    assert float(tape.grad(cd)[:, :, 1:].abs().max()) == 0.0  # nothing outside the two views
