@@ -11,11 +11,13 @@ kernels' operand formats all stay resident).  BatchNorm runs on its running stat
 F13 pin); its affine parameters train, its statistics are not updated.  Parameters the loss never reaches (the reference's 90
 dead ones) keep zero gradients, as under DDP's find_unused_parameters.
 """
+import os
+import sys
+
 import torch
 
 from . import autodiff
 from .grad_sync import FlatGradBuffer
-from .losses import parse_losses
 from .optim import FlatAdamW
 
 
@@ -54,7 +56,6 @@ class Trainer:
         self.opt = FlatAdamW(self.flat_param, self.grads.flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                              max_grad_norm=max_grad_norm)
         self.param_grads = None
-        import os
         self._prepare_on_device = os.environ.get("TT_TRAIN_PREPARE", "device") != "host"
         self._dev_buffers = None
         self._prepare()
@@ -76,7 +77,6 @@ class Trainer:
                                                 for k, v in self.sd.items()})
                     return
                 except (RuntimeError, TypeError) as e:
-                    import sys
                     print(f"[trainer] device-side operand preparation failed ({type(e).__name__}: {e}); "
                           f"using the host path", file=sys.stderr, flush=True)
                     self._prepare_on_device = False
@@ -106,4 +106,5 @@ class Trainer:
         return out
 
     def state_dict(self):
-        return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in self.sd.items()}
+        """Reference-format weights (own copies: the master tensors are views of one flat buffer)."""
+        return {k: (v.detach().clone() if k in self._trainable else v) for k, v in self.sd.items()}
