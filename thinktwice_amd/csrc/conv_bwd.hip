@@ -407,12 +407,11 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
         const float sc = (c_ok && a.scale) ? a.scale[c] : 1.f, sh = (c_ok && a.shift) ? a.shift[c] : 0.f;
         float s_g = 0.f, s_gx = 0.f;
         if (ty < TY && c_ok) {
-            for (long long m = r0 + ty; m < r1; m += TY) {
-                const float yv = a.y[m * a.y_cstride + a.y_coff + c];
-                float g = a.dy[m * a.dy_cstride + a.dy_coff + c];
+            // one element: activation derivative, per-channel sums (in row order), the gradient stores
+            auto element = [&](long long m, float yv, float g, float pre_in, float r) {
                 float pre = yv;
                 if (a.pre) {            // activation derivative from the recomputed pre-activation
-                    pre = a.pre[m * a.C + c];
+                    pre = pre_in;
                     if (a.act == TT_ACT_RELU) g = pre > 0.f ? g : 0.f;
                     else if (a.act == TT_ACT_SIGMOID) g *= yv * (1.f - yv);
                     else if (a.act == TT_ACT_GELU)
@@ -427,9 +426,6 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
                     g *= yv * (1.f - yv);
                     pre = logf(yv / (1.f - yv));
                 }
-                float r = 0.f;
-                if (a.res1) r += a.res1[m * a.r1_cstride + a.r1_coff + c];
-                if (a.res2) r += a.res2[m * a.r2_cstride + a.r2_coff + c];
                 s_g += g;
                 if (a.scale) s_gx += g * ((pre - sh - r) / sc);   // (needs the pre-add residual values: see the header)
                 a.dconv[m * a.dconv_cstride + a.dconv_coff + c] = g * sc;
@@ -441,6 +437,30 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
                     float* d = a.dres2 + m * a.dres2_cstride + a.dres2_coff + c;
                     *d = a.dres_accumulate ? *d + g : g;
                 }
+            };
+            auto fetch = [&](long long m, float& yv, float& g, float& pre_in, float& r) {
+                yv = a.y[m * a.y_cstride + a.y_coff + c];
+                g = a.dy[m * a.dy_cstride + a.dy_coff + c];
+                pre_in = a.pre ? a.pre[m * a.C + c] : 0.f;
+                r = 0.f;
+                if (a.res1) r += a.res1[m * a.r1_cstride + a.r1_coff + c];
+                if (a.res2) r += a.res2[m * a.r2_cstride + a.r2_coff + c];
+            };
+            // four rows per trip with all their loads issued before the first use (a thread walks up to thousands of rows:
+            // one row at a time leaves the loop bound by load latency); the elements are still consumed in row order, so
+            // the sums are the same as a one-row loop's
+            long long m = r0 + ty;
+            for (; m + 3LL * TY < r1; m += 4LL * TY) {
+                float yv[4], g[4], pv[4], rv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fetch(m + (long long)u * TY, yv[u], g[u], pv[u], rv[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) element(m + (long long)u * TY, yv[u], g[u], pv[u], rv[u]);
+            }
+            for (; m < r1; m += TY) {
+                float yv, g, pv, rv;
+                fetch(m, yv, g, pv, rv);
+                element(m, yv, g, pv, rv);
             }
         }
         // add the TY row lanes of this channel (fixed order)
