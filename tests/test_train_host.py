@@ -1,0 +1,99 @@
+"""Host logic of the training iteration that needs no GPU: the tape's storage-mirrored gradient buffers, the mapping of
+prepared-weight gradients back to the reference's parameter layouts, the trainable / buffer split of a state_dict and
+`_parse_losses`."""
+import os
+
+import numpy as np
+import torch
+
+from thinktwice_amd import autodiff
+
+
+def test_tape_gradient_buffers_mirror_the_activation_storage():
+    buf = torch.zeros(4, 6)
+    window = buf[:, 2:5]                                   # a channel-offset "concat" window of a wider buffer
+    first_rows = buf[:2]                                   # a t[:n] view
+    with autodiff.Tape() as tape:
+        assert autodiff.TAPE is tape
+        tape.seed(window, torch.ones(4, 3))
+        tape.grad(first_rows).add_(2.0)
+        seen = []
+        tape.nodes.append(lambda: seen.append(("first", autodiff.TAPE)))
+        tape.nodes.append(lambda: seen.append(("second", autodiff.TAPE)))
+        with autodiff.paused():
+            assert autodiff.TAPE is None
+        assert autodiff.TAPE is tape
+        tape.backward()
+        assert autodiff.TAPE is tape
+    assert autodiff.TAPE is None
+    assert [s[0] for s in seen] == ["second", "first"] and all(s[1] is None for s in seen)   # reverse order, not recorded
+    want = torch.zeros(4, 6)
+    want[:, 2:5] += 1.0
+    want[:2] += 2.0
+    assert torch.equal(tape.grad(buf), want)               # both views addressed the same gradient memory
+    assert tape.grad(window).data_ptr() == tape.grad(buf)[:, 2:5].data_ptr()
+    tape.add_param_grad("w", torch.ones(3))
+    tape.add_param_grad("w", torch.ones(3))
+    assert torch.equal(tape.param_grads["w"], torch.full((3,), 2.0))
+
+
+def test_prepared_weight_gradients_return_in_the_reference_layouts():
+    """ConvMeta.place_weight_grad: prepared operands are [Cout][KH][KW][cin_pad]; the reference stores Conv2d as
+    [Cout, Cin, KH, KW], Linear as [Cout, Cin], spconv as (Cout, kD, kH, kW, Cin), and some prepared convs are channel
+    slices / row groups of a wider reference weight."""
+    g = torch.Generator().manual_seed(0)
+    tape = autodiff.Tape()
+    ref = torch.randn(5, 3, 3, 3, generator=g)                                     # a Conv2d weight gradient
+    prepared = torch.zeros(5, 3, 3, 4)
+    prepared[..., :3] = ref.permute(0, 2, 3, 1)
+    prepared[..., 3] = 99.0                                                        # channel padding: must be dropped
+    autodiff.ConvMeta("a.conv", 3).place_weight_grad(tape, prepared)
+    assert torch.equal(tape.param_grads["a.conv.weight"], ref)
+    lin = torch.randn(7, 10, generator=g)
+    autodiff.ConvMeta("a.fc", 10, kind="linear").place_weight_grad(tape, lin.view(7, 1, 1, 10))
+    assert torch.equal(tape.param_grads["a.fc.weight"], lin)
+    # Linear over a flattened (C=4, HW=6) map whose prepared columns run (HW, C)
+    ref_hwc = torch.randn(7, 24, generator=g)                                      # reference columns run (C, HW)
+    prep = ref_hwc.view(7, 4, 6).permute(0, 2, 1).reshape(7, 1, 1, 24)
+    autodiff.ConvMeta("a.flat", 24, kind="linear_hwc", lo=6).place_weight_grad(tape, prep)      # lo = HW
+    assert torch.equal(tape.param_grads["a.flat.weight"], ref_hwc)
+    # two input-channel slices of one wider conv weight accumulate into the full gradient
+    full = torch.randn(5, 8, 1, 1, generator=g)
+    for lo, n in ((0, 5), (5, 3)):
+        autodiff.ConvMeta("a.wide", n, kind="cin_slice", full_shape=(5, 8, 1, 1), lo=lo).place_weight_grad(
+            tape, full[:, lo:lo + n].permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(tape.param_grads["a.wide.weight"], full)
+    sp = torch.randn(6, 3, 3, 3, 4, generator=g)                                   # spconv (Cout, kD, kH, kW, Cin)
+    autodiff.ConvMeta("a.sp", 4, kind="spconv", full_shape=tuple(sp.shape)).place_weight_grad(tape, sp.reshape(6, 1, 27, 4))
+    assert torch.equal(tape.param_grads["a.sp.weight"], sp)
+    dcn = torch.randn(8, 2, 3, 3, generator=g)                                     # grouped deformable conv: 4 rows per group
+    for r0 in (0, 4):
+        grp = dcn[r0:r0 + 4].permute(0, 2, 3, 1).reshape(4, 1, 9, 2)
+        autodiff.ConvMeta("a.dcn", 2, kind="dcn_group", full_shape=(8, 2, 3, 3), lo=r0).place_weight_grad(tape, grp)
+    assert torch.equal(tape.param_grads["a.dcn.weight"], dcn)
+
+
+def test_trainable_split_matches_the_reference_gradient_golden():
+    """trainer._trainable keeps exactly the reference's nn.Parameters: the 878 live + 90 dead names of golden F13 (whose
+    backward ran on the instantiated reference modules), none of the registered buffers."""
+    from thinktwice_amd import config, params
+    from thinktwice_amd.trainer import _trainable
+    here = os.path.dirname(__file__)
+    pack = np.load(os.path.join(here, "golden", "f13_train_gradients_b2.npz"))
+    spec = params.param_spec(config.model_config())        # name -> (shape, kind) of the full state_dict
+    fake = {k: torch.zeros(shp if kind != "bn_nbt" else (), dtype=torch.int64 if kind in ("bn_nbt", "buf_voxel_num")
+                           else torch.float32) for k, (shp, kind) in spec.items()}
+    got = sorted(k for k, v in fake.items() if _trainable(k, v))
+    want = sorted([str(n) for n in pack["names"]] + [str(n) for n in pack["dead"]])
+    assert len(want) == 968 and got == want
+
+
+def test_parse_losses_single_process():
+    from thinktwice_amd.losses import parse_losses
+    losses = {"wp_loss": torch.tensor(1.0), "value_loss": torch.tensor([[0.5], [1.5]]),
+              "lateral_offset": torch.tensor(10.0), "aux": [torch.tensor(2.0), torch.tensor([4.0, 6.0])]}
+    loss, log_vars = parse_losses(losses)
+    assert abs(float(loss) - 2.0) < 1e-6                                           # wp_loss + mean(value_loss): 'loss' names only
+    assert list(log_vars) == ["wp_loss", "value_loss", "lateral_offset", "aux", "loss"]
+    assert log_vars["aux"] == 7.0 and log_vars["lateral_offset"] == 10.0 and abs(log_vars["loss"] - 2.0) < 1e-6
+    assert all(isinstance(v, float) for v in log_vars.values())
