@@ -92,14 +92,12 @@ class VoxelPoolWorkload:
 
     def roofline(self):
         torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b in self.kernel_ms]
-        ms = sorted(ms)[: max(1, len(ms) // 2)]   # launch+memset overhead sits in the upper half
-        avg = sum(ms) / len(ms)
+        ms = sorted(a.elapsed_time(b) for a, b in self.kernel_ms)
+        avg = ms[len(ms) // 2]                    # median launch (no best-half filter)
         ach = self.alg_bytes_per_launch / (avg * 1e-3) / 1e9
         comp = self.compulsory_bytes_per_launch / (avg * 1e-3) / 1e9
         pms = sorted(a.elapsed_time(b) for a, b in self.planned_ms)
-        pms = pms[: max(1, len(pms) // 2)]
-        pavg = sum(pms) / len(pms)
+        pavg = pms[len(pms) // 2]
         pcomp = (self.compulsory_bytes_per_launch - self.B * self.Np * 12 + self.in_range_rows * 4) / (pavg * 1e-3) / 1e9
         planned = {"kernel": "vp_planned_segments_kernel + vp_planned_cells_kernel", "avg_launch_ms": round(pavg, 4),
                    "achieved": round(pcomp, 1), "frac": round(pcomp / HBM_PEAK_GBS, 4), "unit": "GB/s",

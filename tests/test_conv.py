@@ -324,3 +324,64 @@ def test_row_run_stem_matches_conv7x7s2():
     assert err < 2e-2, err
     # the border must still be zero (the conversion writes the interior only)
     assert float(xp[:, :3].abs().max()) == 0 and float(xp[:, :, :3].abs().max()) == 0 and float(xp[:, :, W + 3:].abs().max()) == 0
+
+
+def _grid_rulebook(B, D, H, W, occ, stride, g):
+    """Rulebook of a 3x3x3 sparse conv on a random occupancy grid, rows in (b, z, y, x) cell order like
+    csrc/lidar.hip builds them.  stride 1: SubM (outputs = inputs, pad 1); stride 2: spconv SparseConv3d pad 1."""
+    vol = torch.rand(B, D, H, W, generator=g) < occ
+    idx = torch.full((B, D, H, W), -1, dtype=torch.int64)
+    idx[vol] = torch.arange(int(vol.sum()))
+    rows_in = int(vol.sum())
+    pad = F.pad(idx, (1, 1, 1, 1, 1, 1), value=-1)
+    if stride == 1:
+        oc = vol.nonzero()
+    else:
+        od = [(n + 2 - 3) // 2 + 1 for n in (D, H, W)]
+        hit = F.max_pool3d(F.pad(vol.float()[:, None], (1, 1, 1, 1, 1, 1)), 3, 2)[:, 0, :od[0], :od[1], :od[2]] > 0
+        oc = hit.nonzero()
+    b, z, y, x = oc.unbind(1)
+    taps = []
+    for kz in range(3):
+        for ky in range(3):
+            for kx in range(3):
+                taps.append(pad[b, z * stride + kz, y * stride + ky, x * stride + kx])
+    return torch.stack(taps, 1).to(torch.int32), rows_in
+
+
+@pytest.mark.parametrize("Cin,Cout,stride,occ,dims", [
+    (32, 32, 1, 0.10, (2, 10, 60, 60)),      # level-2 like: sparse lines
+    (64, 64, 1, 0.65, (2, 6, 40, 44)),       # level-3 like: near-dense
+    (128, 128, 1, 0.85, (3, 3, 30, 34)),     # level-4 like
+    (32, 64, 2, 0.10, (2, 11, 60, 60)),      # strided: every other input line
+    (64, 128, 2, 0.65, (2, 5, 44, 40)),
+    (64, 64, 1, 0.002, (1, 9, 420, 420)),    # isolated sites: most groups empty, centre tap only
+])
+def test_run_staged_sparse_conv_on_cell_ordered_rulebooks(Cin, Cout, stride, occ, dims):
+    """csrc/sp_conv_runs.hip (bf16x3, 27 taps, >= 32 channels): rulebooks with the locality of real levels (rows in cell
+    order), a live-row count below the allocation, garbage beyond it.  Reference: explicit gather + matmul in f32."""
+    from thinktwice_amd import ops, weights
+    g = torch.Generator().manual_seed(Cin + Cout + stride)
+    nbr, rows_in = _grid_rulebook(*dims, occ, stride, g)
+    live = nbr.shape[0]
+    M = live + 300
+    nbr_alloc = torch.randint(-5, 10 ** 6, (M, 27), generator=g, dtype=torch.int32)   # rows >= live: garbage
+    nbr_alloc[:live] = nbr
+    feats = torch.randn(rows_in, Cin, generator=g)
+    w = torch.randn(Cout, 1, 27, Cin, generator=g) * (27 * Cin) ** -0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.3
+    res = torch.randn(M, Cout, generator=g)
+    wd = w.cuda()
+    out = torch.full((M, Cout), 123.0, device="cuda")
+    ops.gather_conv(feats.cuda(), nbr_alloc.cuda(), torch.tensor([live], dtype=torch.int32).cuda(), wd,
+                    scale=scale.cuda(), shift=shift.cuda(), act=1, res=res.cuda(), w_x3=weights.split_pairs_x3(wd), out=out)
+    torch.cuda.synchronize()
+    if live >= 2048:
+        assert ops._last_conv_kernel().startswith("sp_conv_runs_kernel"), ops._last_conv_kernel()
+    gathered = torch.where((nbr >= 0).unsqueeze(-1), feats[nbr.clamp_min(0).long()], torch.zeros(()))
+    ref = torch.relu(gathered.reshape(live, -1) @ w.reshape(Cout, -1).t() * scale + shift + res[:live])
+    got = out.cpu()
+    err = float((got[:live] - ref).abs().max() / ref.abs().max())
+    assert err < 1e-4, err
+    assert bool((got[live:] == 123.0).all())          # rows beyond the live count are not written

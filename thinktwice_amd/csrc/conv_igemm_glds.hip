@@ -87,8 +87,16 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    // XCD-aware remap (bijective for any grid size): hardware places block b on XCD b % 8
-    const int nblk = tiles_m * tiles_n;
+    int Mlim = p.M;
+    if (GATHER && p.m_dev) {           // sparse conv: live output rows are only known on the device
+        const int md = *p.m_dev;
+        Mlim = md < Mlim ? md : Mlim;
+    }
+    // XCD-aware remap (bijective for any grid size): hardware places block b on XCD b % 8.  Sparse launches cover the
+    // ALLOCATED rows: remap over the live row tiles only, or whole XCDs end up holding nothing but dead tiles
+    const int live_m = (GATHER && p.m_dev) ? (Mlim - p.m_begin + BM - 1) / BM : tiles_m;
+    const int nblk = (live_m < tiles_m ? (live_m > 0 ? live_m : 0) : tiles_m) * tiles_n;
+    if ((int)blockIdx.x >= nblk) return;               // block-uniform, before any barrier
     int L;
     {
         const int b = blockIdx.x, xcd = b & 7, q = nblk >> 3, r = nblk & 7;
@@ -96,11 +104,6 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     }
     const int tile_n = L % tiles_n, tile_m = L / tiles_n;
     const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
-    int Mlim = p.M;
-    if (GATHER && p.m_dev) {           // sparse conv: live output rows are only known on the device
-        const int md = *p.m_dev;
-        Mlim = md < Mlim ? md : Mlim;
-    }
     if (m0 >= Mlim) return;            // block-uniform, before any barrier
 
     const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
@@ -760,6 +763,7 @@ static int tail_split_rows(const ConvArgs& a) {
 // f32 path on the plain weights).
 int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
     if (a.gather) {
+        if (try_launch_sp_conv_runs(a, st)) return 1;      // 3x3x3 rulebooks with 32+ channels: run-staged kernel
         const bool cin_ok = a.Cin >= 16 && (a.Cin & (a.Cin - 1)) == 0;
         if (!cin_ok || a.M < 2048 || a.Cout < 16 || a.Cout > 128) return 0;
         if (a.Cout <= 32) return launch_glds<float, 32, 8, 1, 128, 2, true, true>(a, st);

@@ -85,13 +85,13 @@ def _bn1d(sd, p, dev, eps=1e-3):
     return s.to(dev).contiguous(), t.to(dev).contiguous()
 
 
-def _sp_conv(feats, nbr, level, w, bn, res=None, relu=True, plan=None, in_level=None):
+def _sp_conv(feats, nbr, level, w, bn, res=None, relu=True, plan=None, in_level=None, stride=1):
     """SubMConv3d / SparseConv3d + BN1d (+ residual) + ReLU as ONE gathered MFMA GEMM (with the rulebook's tile plan:
     rows sorted by tap mask, each 256-row tile multiplies only the taps that exist in it).  `in_level`: the input level of
     a strided layer (the training tape transposes its rulebook)."""
     return ops.gather_conv(feats, nbr, level.rows, w[0], scale=bn[0], shift=bn[1], res=res,
                            act=_lib.ACT_RELU if relu else _lib.ACT_NONE, w_x3=w[1], plan=plan,
-                           in_rows=None if in_level is None else (in_level.rows, in_level.max_rows))
+                           in_rows=None if in_level is None else (in_level.rows, in_level.max_rows), stride=stride)
 
 
 @MIDDLE_ENCODERS.register_module()
@@ -166,7 +166,7 @@ class SparseEncoder_fp32:
         check(lib().tt_sp_rulebook(ptr(coords), ptr(rows), _ll(max_out), g, lvl.dims_c, ptr(lvl.volume()), ptr(nbr), st),
               "tt_sp_rulebook")
         plan = ops.sp_tile_plan(nbr, rows) if _TILE_PLAN else None
-        return _sp_conv(feats, nbr, new, w, bn, plan=plan, in_level=lvl), new
+        return _sp_conv(feats, nbr, new, w, bn, plan=plan, in_level=lvl, stride=max(stride)), new
 
     def forward(self, voxel_features, coors, num_rows, max_rows, batch_size):
         """-> dense channel-last (B, H, W, C*D) f32 (== spatial_features.view(N, C*D, H, W))."""

@@ -133,9 +133,11 @@ def sp_tile_plan(nbr, m_dev):
 
 
 def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None, out_dtype=None, w_x3=None, plan=None,
-                out=None, in_rows=None, _no_tape=False):
+                out=None, in_rows=None, stride=1, _no_tape=False):
     """Sparse convolution as a gathered GEMM on MFMA: feats [R_in, C] rows, nbr int32 [M, taps]
-    (rulebook, -1 = no input), m_dev device int (live output rows), w [Cout,1,taps,C] -> [M, Cout]."""
+    (rulebook, -1 = no input), m_dev device int (live output rows), w [Cout,1,taps,C] -> [M, Cout].  `stride`: the spatial
+    stride of the sparse conv the rulebook came from (a dispatch hint: stride-1 rulebooks of cell-ordered rows take the
+    run-staged kernel, csrc/sp_conv_runs.hip; the arithmetic does not depend on it)."""
     require_cuda(feats, nbr, w)
     M, taps = nbr.shape
     Cout, _, KW, Cin = w.shape
@@ -146,7 +148,7 @@ def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None
     d = _ConvDesc()
     d.in_ = feats.data_ptr(); d.N = M; d.H = 1; d.W = 1; d.Cin = Cin; d.in_cstride = Cin; d.in_coff = 0
     d.in_nstride = 0
-    d.weight = w.data_ptr(); d.Cout = Cout; d.KH = 1; d.KW = KW; d.stride = 1; d.pad = 0; d.dil = 1
+    d.weight = w.data_ptr(); d.Cout = Cout; d.KH = 1; d.KW = KW; d.stride = stride; d.pad = 0; d.dil = 1
     d.out = out.data_ptr(); d.OH = 1; d.OW = 1; d.out_cstride = Cout; d.out_coff = 0; d.out_nstride = 0
     d.scale = _dp(scale); d.shift = _dp(shift)
     d.res1 = _dp(res); d.res1_cstride = 0 if res is None else res.shape[-1]
