@@ -536,6 +536,62 @@ int tt_deform_im2col3x3_bwd(const float* x, const float* offsets, const float* g
 int tt_lidar_merge_half_sweeps(const float* prev_xyzi, int n_prev, const float* now_xyzi, int n_now,
                                const float* rel_transform_3x4, float z_shift, float* out_xyzi, void* stream);
 
+/* ------------------------------------------------------------------------
+ * action post-processing of a closed-loop tick, on the device (one thread) or on the host.
+ * Replaces, in ONE call:
+ *   EncoderDecoder.process_action / _get_action_beta  (code/encoder_decoder_framework.py:268-304): Beta mode of the last
+ *       refinement stage's control branch -> (steer, throttle, brake)_ctrl;
+ *   EncoderDecoder.control_pid + PIDController.step   (encoder_decoder_framework.py:309-390, code/utils.py:7-29): waypoint
+ *       PID with its two n-entry error windows -> (steer, throttle, brake)_traj;
+ *   the agent's arbitration + stuck detector          (leaderboard/team_code/thinktwice_agent.py:463-509)
+ *       -> the final (steer, throttle, brake).
+ * The reference copies mu / sigma / waypoints to the host and does this in numpy; here the model outputs are read where
+ * they are and a tick needs exactly one small device->host copy (`out`).
+ *   cfg    : the reference's `cfg` scalars (configs/thinktwice.py:44-57) + stuck_threshold (thinktwice_agent.py: 800).
+ *   state  : caller-owned; zero-initialised == the reference's fresh deques ([0]*n) and stuck_detector = 0.
+ *   mu_last / sigma_last : 2 floats each = pred['mu_branches'][0, -1, :], pred['sigma_branches'][0, -1, :]
+ *   wp_last: 8 floats = pred['pred_wp'][0, -1, :, :] (4 waypoints x (x, y));  target_xy: 2 floats.
+ *   stuck_desired_speed <= 0: unused (the reference's default -1).
+ *   out    : TT_ACTION_OUT doubles, see the index names below.
+ * tt_action_post: mu/sigma/wp/state/out are DEVICE pointers, target/speed by value; asynchronous on `stream`.
+ * tt_action_post_host: every pointer is a HOST pointer; no GPU involved (same arithmetic, same source).
+ * ---------------------------------------------------------------------- */
+#define TT_PID_WINDOW_MAX 64
+typedef struct tt_action_cfg {
+    double turn_KP, turn_KI, turn_KD, speed_KP, speed_KI, speed_KD;
+    double brake_speed, brake_ratio, clip_delta, aim_dist, angle_thresh, dist_thresh;
+    int turn_n, speed_n, stuck_threshold, reserved;
+} tt_action_cfg;
+typedef struct tt_action_state {
+    double turn_window[TT_PID_WINDOW_MAX], speed_window[TT_PID_WINDOW_MAX];
+    int turn_head, speed_head;      /* ring position of the OLDEST entry (= where the next error is written) */
+    int stuck_detector, reserved;
+} tt_action_state;
+enum {
+    TT_ACT_STEER = 0, TT_ACT_THROTTLE, TT_ACT_BRAKE,                 /* the final control of the tick            */
+    TT_ACT_STEER_CTRL, TT_ACT_THROTTLE_CTRL, TT_ACT_BRAKE_CTRL,      /* process_action                           */
+    TT_ACT_STEER_TRAJ, TT_ACT_THROTTLE_TRAJ, TT_ACT_BRAKE_TRAJ,      /* control_pid (brake: 0 / 1)               */
+    TT_ACT_DESIRED_SPEED, TT_ACT_ANGLE, TT_ACT_ANGLE_LAST, TT_ACT_ANGLE_TARGET, TT_ACT_ANGLE_FINAL, TT_ACT_DELTA,
+    TT_ACT_AIM_X, TT_ACT_AIM_Y,                                      /* control_pid metadata                     */
+    TT_ACT_IS_TURN, TT_ACT_IS_STUCK, TT_ACT_STUCK_DETECTOR,          /* arbitration                              */
+    TT_ACTION_OUT = 24
+};
+int tt_action_post(const float* mu_last, const float* sigma_last, const float* wp_last, float speed, float target_x,
+                   float target_y, float stuck_desired_speed, const tt_action_cfg* cfg_host, tt_action_state* state,
+                   double* out, void* stream);
+int tt_action_post_host(const float* mu_last, const float* sigma_last, const float* wp_last, float speed, float target_x,
+                        float target_y, float stuck_desired_speed, const tt_action_cfg* cfg, tt_action_state* state,
+                        double* out);
+/* the three stages one by one on the host, for callers that keep the reference's call structure (process_action, then
+ * control_pid, then the agent's own arbitration): each fills its slots of `out` (the rest is zeroed) */
+int tt_action_ctrl_host(const float* mu_last, const float* sigma_last, double* out);
+int tt_action_pid_host(const float* wp_last, float speed, float target_x, float target_y, float stuck_desired_speed,
+                       const tt_action_cfg* cfg, tt_action_state* state, double* out);
+/* the arbitration stage alone (thinktwice_agent.py:463-509), for a host that already holds the two heads' controls:
+ * fills TT_ACT_STEER / THROTTLE / BRAKE / IS_TURN / IS_STUCK / STUCK_DETECTOR of `out`, updates state->stuck_detector */
+int tt_action_arbitrate_host(double steer_ctrl, double throttle_ctrl, double brake_ctrl, double throttle_traj,
+                             double brake_traj, float speed, const tt_action_cfg* cfg, tt_action_state* state, double* out);
+
 #ifdef __cplusplus
 }
 #endif

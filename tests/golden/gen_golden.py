@@ -474,8 +474,9 @@ def gen_f13():
 
 
 # ---------------------------------------------------------------------------
-# F15: pose matrices of the closed-loop agent (leaderboard/team_code/thinktwice_agent.py:47-92), produced by executing
-#      the reference's OWN function definitions (extracted with ast at generation time: importing the module needs carla)
+# F15: pose matrices (leaderboard/team_code/thinktwice_agent.py:47-92) and the brake / throttle arbitration + stuck detector
+#      (:463-509) of the closed-loop agent, produced by executing the reference's OWN definitions / statements (extracted
+#      with ast at generation time: importing the module needs carla)
 # ---------------------------------------------------------------------------
 def gen_f15():
     import ast
@@ -491,7 +492,55 @@ def gen_f15():
     poses = np.concatenate([rng.uniform(-200, 200, (24, 2)), rng.uniform(-2 * np.pi, 2 * np.pi, (24, 1))], 1)
     fwd = np.stack([ns["obtain_transform_matrix"](*p) for p in poses])
     inv = np.stack([ns["obtain_inv_transform_matrix"](*p) for p in poses])
-    _save("f15_agent_transforms.npz", poses=poses, fwd=fwd, inv=inv)
+
+    # --- the brake / throttle arbitration + stuck detector of a tick (thinktwice_agent.py:463-509).  It is not a function
+    # in the reference but a run of statements inside `run_step` (after the `control_pid` call, inside `with
+    # torch.no_grad()`); the statements are lifted out of the parsed tree unmodified and wrapped into a function whose
+    # arguments are the names they read.  carla.VehicleControl is a plain attribute bag here (carla is not installed).
+    def find_arbitration(tree):
+        for cls in [n for n in tree.body if isinstance(n, ast.ClassDef)]:
+            for fn in [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "run_step"]:
+                for w in [n for n in ast.walk(fn) if isinstance(n, ast.With)]:
+                    for i, st in enumerate(w.body):
+                        if isinstance(st, ast.Assign) and isinstance(st.targets[0], ast.Tuple) and \
+                                [getattr(e, "id", None) for e in st.targets[0].elts][:3] == ["steer_traj", "throttle_traj",
+                                                                                              "brake_traj"]:
+                            return w.body[i + 1:]
+        raise SystemExit("arbitration block not found in thinktwice_agent.py")
+    stmts = find_arbitration(tree)
+    argn = ["self", "steer_ctrl", "throttle_ctrl", "brake_ctrl", "throttle_traj", "brake_traj", "gt_velocity", "tick_data"]
+    fn = ast.FunctionDef(name="_arbitrate", args=ast.arguments(posonlyargs=[], args=[ast.arg(arg=a) for a in argn],
+                                                               kwonlyargs=[], kw_defaults=[], defaults=[]),
+                         body=list(stmts) + [ast.Return(value=ast.Name(id="control", ctx=ast.Load()))], decorator_list=[])
+    amod = ast.fix_missing_locations(ast.Module(body=[fn], type_ignores=[]))
+
+    class _Control:
+        steer = throttle = brake = 0.0
+
+    class _Carla:
+        VehicleControl = _Control
+    import contextlib
+    import io
+    import types
+    ans = {"np": np, "carla": _Carla, "torch": torch}
+    exec(compile(amod, path, "exec"), ans)
+    agent = types.SimpleNamespace(stuck_detector=0, stuck_threshold=40, step=0)
+    arng = np.random.default_rng(1515)
+    arb_in, arb_out = [], []
+    for t in range(400):
+        speed = 0.0 if 100 <= t < 200 else float(arng.uniform(0, 6))        # a long standstill trips the stuck detector
+        if t in (250, 251):
+            speed = 0.5                                                      # neither branch of the detector update
+        a = [float(arng.uniform(-0.3, 0.3)), float(arng.uniform(0, 1) * (arng.random() < 0.6)), float(arng.uniform(0, 1)),
+             float(arng.uniform(0, 0.75) * (arng.random() < 0.7)), float(arng.integers(0, 2)), speed]
+        agent.step = t
+        with contextlib.redirect_stdout(io.StringIO()):
+            c = ans["_arbitrate"](agent, a[0], a[1], a[2], a[3], a[4], torch.FloatTensor([speed]), {"speed": speed})
+        arb_in.append(a)
+        arb_out.append([float(c.steer), float(c.throttle), float(c.brake), float(agent.stuck_detector)])
+    assert max(o[3] for o in arb_out) > 40, "the scripted sequence must trip the stuck detector"
+    _save("f15_agent_transforms.npz", poses=poses, fwd=fwd, inv=inv, arb_in=np.asarray(arb_in), arb_out=np.asarray(arb_out),
+          arb_stuck_threshold=np.array([40]))
 
 
 FIXTURES = {"F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8, "F9": gen_f9, "F10": gen_f10, "F11": gen_f11,

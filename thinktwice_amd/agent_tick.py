@@ -3,7 +3,7 @@
 * `LidarSweepMerger`  -- the two 180-degree LiDAR half sweeps of consecutive ticks merged in the current ego frame
   (leaderboard/team_code/thinktwice_agent.py:340-352), on the device (tt_lidar_merge_half_sweeps);
 * `AgentController`   -- the brake / throttle arbitration between the control branch and the trajectory PID, the stuck
-  detector and the speed-dependent throttle cap (thinktwice_agent.py:463-509): host scalars, like the reference.
+  detector and the speed-dependent throttle cap (thinktwice_agent.py:463-509): a binding of tt_action_arbitrate_host.
 """
 import ctypes
 import math
@@ -68,32 +68,22 @@ class LidarSweepMerger:
 
 class AgentController:
     """Final control of a tick from the two heads (AGENT:463-509).  Inputs are what `process_action` (control branch)
-    and `control_pid` (last refinement stage's waypoints) return; state = the stuck counter."""
+    and `control_pid` (last refinement stage's waypoints) return; state = the stuck counter.  A binding: the arbitration
+    itself is `tt_action_arbitrate_host` (csrc/action_post.hip), the same source the one-call device entry
+    `tt_action_post` (`control.ActionPost.tick`) compiles."""
 
     def __init__(self, stuck_threshold=800):
-        self.stuck_detector = 0
+        from . import config, control
+        self._cfg = control.make_cfg(config.model_config()["cfg"], stuck_threshold)
+        self._state = control.ActionState()
         self.stuck_threshold = stuck_threshold
+
+    @property
+    def stuck_detector(self):
+        return int(self._state.stuck_detector)
 
     def step(self, steer_ctrl, throttle_ctrl, brake_ctrl, throttle_traj, brake_traj, speed):
         """-> (steer, throttle, brake, info).  `speed` in m/s (the measured velocity)."""
-        if brake_traj < 0.05:
-            brake_traj = 0.0
-        if throttle_traj > brake_traj:
-            brake_traj = 0.0
-        wants_accel = (throttle_traj > 0) or (throttle_ctrl > 0) or (brake_traj < 0.95) or (brake_ctrl < 0.95)
-        wants_brake = (brake_traj > 0.2) or (brake_ctrl > 0.2)
-        steer = steer_ctrl
-        is_turn = abs(steer) > 0.07
-        speed_threshold = 1.5 if is_turn else 3.5            # less stuck in turns / fewer red-light infractions
-        brake, throttle = (1.0, 0.0) if wants_brake else (0.0, 1.0)
-        is_stuck = self.stuck_detector > self.stuck_threshold
-        if is_stuck:                                         # crawl (TransFuser's rule)
-            brake, throttle = (0.0, 1.0) if wants_accel else (1.0, 0.0)
-        if float(speed) < 0.5:
-            self.stuck_detector += 1
-        elif float(speed) > 0.5:
-            self.stuck_detector = 0
-        max_throttle = 0.05 if float(speed) > speed_threshold else (0.4 if is_turn else 0.6)
-        throttle = float(np.clip(throttle, 0.0, max_throttle))
-        return float(steer), throttle, float(brake), {"is_turn": is_turn, "is_stuck": is_stuck,
-                                                      "stuck_detector": self.stuck_detector}
+        from . import control
+        return control.arbitrate(self._cfg, self._state, steer_ctrl, throttle_ctrl, brake_ctrl, throttle_traj, brake_traj,
+                                 speed)

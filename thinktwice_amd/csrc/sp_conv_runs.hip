@@ -165,14 +165,20 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     // per-lane constants of the DMA slots: instruction i covers stage rows 8i .. 8i+7, lane = (row, 16 B position)
     const int d_row = lane >> 3, d_pos = lane & 7;
+    // measurement knobs (TT_SP_DEBUG, tools only; 0 in the product): bit 4 = no activation DMA after the first stage,
+    // bit 5 = no weight DMA after the first stage, bit 6 = no MFMA phase
+    const bool dbg_no_a = (p.flags & 16) != 0, dbg_no_b = (p.flags & 32) != 0, dbg_no_mfma = (p.flags & 64) != 0;
+    bool first_issue = true;
     auto issue = [&](const Walk& w, int buf) {
+        const bool skip_a = dbg_no_a && !first_issue, skip_b = dbg_no_b && !first_issue;
+        first_issue = false;
         const unsigned sa = lds_base + (unsigned)buf * ABUF, sb = lds_base + 2u * ABUF + (unsigned)buf * BBUF;
         const int nrows = (w.hi - w.c) < S ? (w.hi - w.c) : S;
         const float* abase = in + p.in_coff + w.sl * 32;
 #pragma unroll
         for (int j = 0; j < NIA; ++j) {
             const int i = wave_s + NW * j;
-            if (i < NA_INSTR && 8 * i < nrows) {                       // wave-uniform
+            if (i < NA_INSTR && 8 * i < nrows && !skip_a) {            // wave-uniform
                 const int row = 8 * i + d_row;
                 int src = w.c + row;
                 src = src < w.hi ? src : w.hi - 1;                     // rows past the range: any valid line (never read)
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
 #pragma unroll
         for (int j = 0; j < NIB; ++j) {
             const int i = wave_s + NW * j;
-            if (i < NB_INSTR) {
+            if (i < NB_INSTR && !skip_b) {
                 const int r = 8 * i + d_row;                           // r = t * BN + n
                 const int t = r / BN, n = r - t * BN;
                 const float* sp = bbase + (long long)n * p.K + t * p.Cin + ((d_pos ^ ((n >> 1) & 7)) << 2);
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
         for (int t = 0; t < kG; ++t) {
             const int s = ent_cur[t] - wc.c;
             const bool ok = ent_cur[t] >= 0 && (unsigned)s < (unsigned)nrows;
-            if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;   // no row of this wave has the tap in this chunk
+            if (__builtin_amdgcn_ballot_w64(ok) == 0ull || dbg_no_mfma) continue;   // no row of this wave has the tap in this chunk
             const unsigned ar = ok ? (unsigned)s : (unsigned)S;
             const unsigned a_off = sa + ar * kRowB, a_swz = (ar >> 1) & 7;
 #pragma unroll
@@ -325,6 +331,8 @@ static int launch_sp_runs(ConvArgs& a, hipStream_t st) {
     a.splits = 1;
     a.ws = nullptr;
     a.m_begin = 0;
+    static const int dbg = [] { const char* e = getenv("TT_SP_DEBUG"); return e ? atoi(e) : 0; }();
+    a.flags = (a.flags & 15) | (dbg << 4);
     snprintf(g_conv_kernel, sizeof(g_conv_kernel), "sp_conv_runs_kernel<%d, %d, %d>", NCB, WR, WC);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles_m), dim3(NW * 64), smem, st, a, tiles_m);
     return 1;

@@ -53,7 +53,13 @@ class EncoderDecoder(torch.nn.Module):
             self.turn_controller = control.PIDController(c["turn_KP"], c["turn_KI"], c["turn_KD"], c["turn_n"])
             self.speed_controller = control.PIDController(c["speed_KP"], c["speed_KI"], c["speed_KD"], c["speed_n"])
 
-    # closed-loop post-processing (host scalar math, thinktwice_agent.py:458-461)
+    # closed-loop post-processing (thinktwice_agent.py:458-509).  `action_post()` is the one-call device path
+    # (tt_action_post: control branch + waypoint PID + arbitration on the output tensors where they are, one D2H copy);
+    # process_action / control_pid keep the reference's call structure on the host entries of the same C source.
+    def action_post(self, stuck_threshold=800):
+        """-> control.ActionPost bound to this model's cfg and device (create once per route, `.tick(pred, speed, target)`)."""
+        return control.ActionPost(self.config, stuck_threshold, device=self.device)
+
     def process_action(self, pred, command, speed, target_point):
         return control.process_action(pred, command, speed, target_point)
 
