@@ -1,0 +1,304 @@
+// Train-mode BatchNorm (batch statistics) over channel-last rows, forward and backward.
+//
+// Reference: every nn.BatchNorm2d / BatchNorm1d of the model under `model.train()` -- the reference trains with
+// norm_eval=False and SyncBN=True (configs/thinktwice.py:39,146; apis/mmdet_train.py:86-87 converts them to
+// torch.nn.SyncBatchNorm), i.e.  y = gamma * (z - mean_B) / sqrt(var_B + eps) + beta  with the biased variance of the
+// (global) batch, running statistics updated with `momentum` and the unbiased variance.  The eval-mode path folds BatchNorm
+// into the conv epilogue (csrc/conv_common.h); in train mode the convolution writes its raw output z (bias included) and
+// these kernels do the rest:
+//   tt_bn_stats       per-channel sum / sum of squares / row count, per row GROUP (the camera trunk runs its T sweeps as
+//                     one batch of T equal image groups, each normalised with its own statistics like the reference's
+//                     per-sweep passes, lss.py:690-717); f64 accumulation, per-workgroup partials added in index order
+//   (host)            SyncBN: ONE all-reduce of the [groups][2C + 2] statistics block (thinktwice_amd/ops.py)
+//   tt_bn_finalize    mean / invstd / folded scale + shift per group, running-statistics update
+//   tt_bn_apply       y = act(z * scale + shift + res1 + res2) into a channel window of the consumer's buffer
+//   tt_bn_bwd_reduce  g = dy * act'(y) (written over dy), residual gradients, per-channel sum g and sum g * xhat
+//   (host)            SyncBN: one all-reduce of the [groups][2C] sums
+//   tt_bn_bwd_apply   dz = scale * (g - sum_g / n - xhat * sum_gxhat / n)
+// dgamma = sum g * xhat and dbeta = sum g are the LOCAL sums (the gradient all-reduce averages them like DDP does).
+#include "tt_common.h"
+
+namespace tt {
+
+constexpr int kBnBlocks = 128;     // workgroups per row group in the reductions
+
+struct BnRows {
+    long long M;          // allocated rows
+    const int* m_dev;     // sparse layers: device count of live rows (groups == 1), else null
+    int C, groups;
+};
+
+__device__ __forceinline__ void group_range(const BnRows& r, int g, int blk, long long& r0, long long& r1) {
+    const long long Mlive = r.m_dev ? min(r.M, (long long)*r.m_dev) : r.M;
+    const long long per_group = r.m_dev ? Mlive : r.M / r.groups;
+    const long long g0 = (long long)g * per_group;
+    const long long rows_per = (per_group + kBnBlocks - 1) / kBnBlocks;
+    r0 = g0 + (long long)blk * rows_per;
+    r1 = min(g0 + per_group, r0 + rows_per);
+}
+
+// partial[(g * kBnBlocks + blk) * 2 * C + {0, C} + c]
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, int z_cstride, int z_coff, BnRows r,
+                                                       double* __restrict__ partial) {
+    __shared__ double red[2][256];
+    const int tid = threadIdx.x, g = blockIdx.y, blk = blockIdx.x;
+    const int TX = r.C < 256 ? r.C : 256, TY = 256 / TX;
+    const int tx = tid % TX, ty = tid / TX;
+    long long r0, r1;
+    group_range(r, g, blk, r0, r1);
+    for (int c0 = 0; c0 < r.C; c0 += TX) {
+        const int c = c0 + tx;
+        double s = 0.0, ss = 0.0;
+        if (ty < TY && c < r.C) {
+            long long m = r0 + ty;
+            for (; m + 3LL * TY < r1; m += 4LL * TY) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = z[(m + (long long)u * TY) * z_cstride + z_coff + c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s += (double)v[u]; ss += (double)v[u] * (double)v[u]; }
+            }
+            for (; m < r1; m += TY) {
+                const float v = z[m * z_cstride + z_coff + c];
+                s += (double)v;
+                ss += (double)v * (double)v;
+            }
+        }
+        __syncthreads();
+        red[0][tid] = s;
+        red[1][tid] = ss;
+        __syncthreads();
+        if (ty == 0 && c < r.C) {
+            double t0 = 0.0, t1 = 0.0;
+            for (int q = 0; q < TY; ++q) { t0 += red[0][q * TX + tx]; t1 += red[1][q * TX + tx]; }
+            double* p = partial + ((long long)g * kBnBlocks + blk) * 2 * r.C;
+            p[c] = t0;
+            p[r.C + c] = t1;
+        }
+    }
+}
+
+// out[g][0..C) = sum of partial[.][0], out[g][C..2C) = sum of partial[.][1] (index order); with `count`: out[g][2C] = rows
+__global__ void bn_finish_kernel(const double* __restrict__ partial, BnRows r, int out_stride, int with_count,
+                                 double* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (c < 2 * r.C) {
+        const int which = c / r.C, cc = c % r.C;
+        double s = 0.0;
+        for (int b = 0; b < kBnBlocks; ++b) s += partial[((long long)g * kBnBlocks + b) * 2 * r.C + which * r.C + cc];
+        out[(long long)g * out_stride + c] = s;
+    }
+    if (with_count && c == 0) {
+        const long long Mlive = r.m_dev ? min(r.M, (long long)*r.m_dev) : r.M;
+        out[(long long)g * out_stride + 2 * r.C] = (double)(r.m_dev ? Mlive : r.M / r.groups);
+        out[(long long)g * out_stride + 2 * r.C + 1] = 0.0;
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, int groups, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean, float* __restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int stride = 2 * C + 2;
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+    // group groups-1 is the OLDEST sweep (sweep-major image order, key sweep first): the reference runs the sweeps oldest
+    // first, so its running statistics see the groups in that order
+    for (int g = groups - 1; g >= 0; --g) {
+        const double n = stats[(long long)g * stride + 2 * C];
+        const double mu = n > 0 ? stats[(long long)g * stride + c] / n : 0.0;
+        double var = n > 0 ? stats[(long long)g * stride + C + c] / n - mu * mu : 0.0;
+        var = var > 0.0 ? var : 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = (gamma ? gamma[c] : 1.f) * is;
+        scale[g * C + c] = sc;
+        shift[g * C + c] = (beta ? beta[c] : 0.f) - (float)mu * sc;
+        mean[g * C + c] = (float)mu;
+        invstd[g * C + c] = is;
+        if (n > 0) {
+            rm = (1.f - momentum) * rm + momentum * (float)mu;
+            rv = (1.f - momentum) * rv + momentum * (float)(n > 1 ? var * n / (n - 1.0) : var);
+        }
+    }
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
+}
+
+struct BnApplyArgs {
+    const float* z; const float* scale; const float* shift; const float* res1; const float* res2; float* out;
+    BnRows r;
+    int z_cstride, z_coff, r1_cstride, r1_coff, r2_cstride, r2_coff, out_cstride, out_coff, act;
+};
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
+    const long long Mlive = a.r.m_dev ? min(a.r.M, (long long)*a.r.m_dev) : a.r.M;
+    const long long per_group = a.r.m_dev ? (Mlive > 0 ? Mlive : 1) : a.r.M / a.r.groups;
+    const long long total = Mlive * a.r.C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / a.r.C;
+        const int c = (int)(i - m * a.r.C);
+        const int g = (int)(m / per_group);
+        float v = a.z[m * a.z_cstride + a.z_coff + c] * a.scale[g * a.r.C + c] + a.shift[g * a.r.C + c];
+        if (a.res1) v += a.res1[m * a.r1_cstride + a.r1_coff + c];
+        if (a.res2) v += a.res2[m * a.r2_cstride + a.r2_coff + c];
+        if (a.act == TT_ACT_RELU) v = v > 0.f ? v : 0.f;
+        a.out[m * a.out_cstride + a.out_coff + c] = v;
+    }
+}
+
+struct BnBwdArgs {
+    float* dy; const float* y; const float* z; const float* mean; const float* invstd;
+    float* dres1; float* dres2; double* partial;
+    BnRows r;
+    int dy_cstride, dy_coff, y_cstride, y_coff, z_cstride, z_coff, d1_cstride, d1_coff, d2_cstride, d2_coff, act;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
+    __shared__ double red[2][256];
+    const int tid = threadIdx.x, g = blockIdx.y, blk = blockIdx.x;
+    const int C = a.r.C;
+    const int TX = C < 256 ? C : 256, TY = 256 / TX;
+    const int tx = tid % TX, ty = tid / TX;
+    long long r0, r1;
+    group_range(a.r, g, blk, r0, r1);
+    for (int c0 = 0; c0 < C; c0 += TX) {
+        const int c = c0 + tx;
+        double s = 0.0, sx = 0.0;
+        if (ty < TY && c < C) {
+            const float mu = a.mean[g * C + c], is = a.invstd[g * C + c];
+            for (long long m = r0 + ty; m < r1; m += TY) {
+                float gv = a.dy[m * a.dy_cstride + a.dy_coff + c];
+                if (a.act == TT_ACT_RELU && !(a.y[m * a.y_cstride + a.y_coff + c] > 0.f)) gv = 0.f;
+                a.dy[m * a.dy_cstride + a.dy_coff + c] = gv;
+                if (a.dres1) a.dres1[m * a.d1_cstride + a.d1_coff + c] += gv;
+                if (a.dres2) a.dres2[m * a.d2_cstride + a.d2_coff + c] += gv;
+                const float xh = (a.z[m * a.z_cstride + a.z_coff + c] - mu) * is;
+                s += (double)gv;
+                sx += (double)gv * (double)xh;
+            }
+        }
+        __syncthreads();
+        red[0][tid] = s;
+        red[1][tid] = sx;
+        __syncthreads();
+        if (ty == 0 && c < C) {
+            double t0 = 0.0, t1 = 0.0;
+            for (int q = 0; q < TY; ++q) { t0 += red[0][q * TX + tx]; t1 += red[1][q * TX + tx]; }
+            double* p = a.partial + ((long long)g * kBnBlocks + blk) * 2 * C;
+            p[c] = t0;
+            p[C + c] = t1;
+        }
+    }
+}
+
+struct BnBwdApplyArgs {
+    const float* g; const float* z; const float* scale; const float* mean; const float* invstd;
+    const double* sums;    // [groups][2C] (global under SyncBN)
+    const double* stats;   // [groups][2C + 2]: the forward's statistics block, [2C] = (global) row count
+    float* dz;
+    BnRows r;
+    int g_cstride, g_coff, z_cstride, z_coff, dz_cstride, dz_coff;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
+    const int C = a.r.C;
+    const long long Mlive = a.r.m_dev ? min(a.r.M, (long long)*a.r.m_dev) : a.r.M;
+    const long long per_group = a.r.m_dev ? (Mlive > 0 ? Mlive : 1) : a.r.M / a.r.groups;
+    const long long total = Mlive * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / C;
+        const int c = (int)(i - m * C);
+        const int g = (int)(m / per_group);
+        const double n = a.stats[(long long)g * (2 * C + 2) + 2 * C];
+        const float inv_n = n > 0 ? (float)(1.0 / n) : 0.f;
+        const float sg = (float)a.sums[(long long)g * 2 * C + c] * inv_n, sgx = (float)a.sums[(long long)g * 2 * C + C + c] * inv_n;
+        const float xh = (a.z[m * a.z_cstride + a.z_coff + c] - a.mean[g * C + c]) * a.invstd[g * C + c];
+        const float gv = a.g[m * a.g_cstride + a.g_coff + c];
+        a.dz[m * a.dz_cstride + a.dz_coff + c] = a.scale[g * C + c] * (gv - sg - xh * sgx);
+    }
+}
+
+static int check_rows(long long M, int C, int groups, const int* m_dev, const char* who) {
+    TT_REQUIRE(M > 0 && C > 0 && groups >= 1, "%s: bad sizes (M=%lld C=%d groups=%d)", who, M, C, groups);
+    TT_REQUIRE(!m_dev || groups == 1, "%s: a device row count goes with one group", who);
+    TT_REQUIRE(m_dev || M % groups == 0, "%s: %lld rows do not split into %d equal groups", who, M, groups);
+    return 0;
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" long long tt_bn_workspace_bytes(int C, int groups) {
+    return (long long)groups * kBnBlocks * 2 * C * (long long)sizeof(double);
+}
+
+extern "C" int tt_bn_stats(const float* z, long long M, int C, int z_cstride, int z_coff, const int* m_dev, int groups,
+                           double* stats, void* workspace, long long workspace_bytes, void* stream) {
+    TT_REQUIRE(z && stats && workspace, "tt_bn_stats: null");
+    if (int rc = check_rows(M, C, groups, m_dev, "tt_bn_stats")) return rc;
+    TT_REQUIRE(workspace_bytes >= tt_bn_workspace_bytes(C, groups), "tt_bn_stats: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    BnRows r{M, m_dev, C, groups};
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(kBnBlocks, groups), dim3(256), 0, st, z, z_cstride, z_coff, r, (double*)workspace);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(div_up(2 * C, 256), groups), dim3(256), 0, st, (const double*)workspace, r,
+                       2 * C + 2, 1, stats);
+    return check_launch("tt_bn_stats");
+}
+
+extern "C" int tt_bn_finalize(const double* stats, int C, int groups, const float* gamma, const float* beta, float eps,
+                              float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
+                              float* invstd, void* stream) {
+    TT_REQUIRE(stats && scale && shift && mean && invstd && C > 0 && groups >= 1, "tt_bn_finalize: null / bad sizes");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(div_up(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, C, groups, gamma,
+                       beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
+    return check_launch("tt_bn_finalize");
+}
+
+extern "C" int tt_bn_apply(const float* z, long long M, int C, int z_cstride, int z_coff, const int* m_dev, int groups,
+                           const float* scale, const float* shift, const float* res1, int r1_cstride, int r1_coff,
+                           const float* res2, int r2_cstride, int r2_coff, int act, float* out, int out_cstride, int out_coff,
+                           void* stream) {
+    TT_REQUIRE(z && scale && shift && out, "tt_bn_apply: null");
+    if (int rc = check_rows(M, C, groups, m_dev, "tt_bn_apply")) return rc;
+    TT_REQUIRE(act == TT_ACT_NONE || act == TT_ACT_RELU, "tt_bn_apply: activation %d after a train-mode BatchNorm", act);
+    BnApplyArgs a{z, scale, shift, res1, res2, out, BnRows{M, m_dev, C, groups}, z_cstride, z_coff, r1_cstride, r1_coff,
+                  r2_cstride, r2_coff, out_cstride, out_coff, act};
+    const long long total = M * C;
+    const int blocks = (int)min((long long)kNumCU * 16, (total + 255) / 256);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("tt_bn_apply");
+}
+
+extern "C" int tt_bn_bwd_reduce(float* dy, int dy_cstride, int dy_coff, const float* y, int y_cstride, int y_coff,
+                                const float* z, int z_cstride, int z_coff, long long M, int C, const int* m_dev, int groups,
+                                const float* mean, const float* invstd, int act, float* dres1, int d1_cstride, int d1_coff,
+                                float* dres2, int d2_cstride, int d2_coff, double* sums, void* workspace,
+                                long long workspace_bytes, void* stream) {
+    TT_REQUIRE(dy && y && z && mean && invstd && sums && workspace, "tt_bn_bwd_reduce: null");
+    if (int rc = check_rows(M, C, groups, m_dev, "tt_bn_bwd_reduce")) return rc;
+    TT_REQUIRE(act == TT_ACT_NONE || act == TT_ACT_RELU, "tt_bn_bwd_reduce: activation %d", act);
+    TT_REQUIRE(workspace_bytes >= tt_bn_workspace_bytes(C, groups), "tt_bn_bwd_reduce: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    BnBwdArgs a{dy, y, z, mean, invstd, dres1, dres2, (double*)workspace, BnRows{M, m_dev, C, groups}, dy_cstride, dy_coff,
+                y_cstride, y_coff, z_cstride, z_coff, d1_cstride, d1_coff, d2_cstride, d2_coff, act};
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(kBnBlocks, groups), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(div_up(2 * C, 256), groups), dim3(256), 0, st, (const double*)workspace, a.r,
+                       2 * C, 0, sums);
+    return check_launch("tt_bn_bwd_reduce");
+}
+
+extern "C" int tt_bn_bwd_apply(const float* g, int g_cstride, int g_coff, const float* z, int z_cstride, int z_coff,
+                               long long M, int C, const int* m_dev, int groups, const double* sums, const double* stats,
+                               const float* scale, const float* mean, const float* invstd, float* dz, int dz_cstride,
+                               int dz_coff, void* stream) {
+    TT_REQUIRE(g && z && sums && stats && scale && mean && invstd && dz, "tt_bn_bwd_apply: null");
+    if (int rc = check_rows(M, C, groups, m_dev, "tt_bn_bwd_apply")) return rc;
+    BnBwdApplyArgs a{g, z, scale, mean, invstd, sums, stats, dz, BnRows{M, m_dev, C, groups}, g_cstride, g_coff, z_cstride,
+                     z_coff, dz_cstride, dz_coff};
+    const long long total = M * C;
+    const int blocks = (int)min((long long)kNumCU * 16, (total + 255) / 256);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("tt_bn_bwd_apply");
+}

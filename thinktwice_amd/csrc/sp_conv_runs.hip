@@ -53,8 +53,9 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
     static_assert(S % 8 == 0, "stage rows");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int* s_rng = reinterpret_cast<int*>(smem + 2 * ABUF + 2 * BBUF);   // [0..8] lo, [16..24] hi
-    int* s_ent = s_rng + 32;                                           // the tile's rulebook rows [TM][27]
+    constexpr int ENT_INSTR = (TM * kG * kNG * 4 + 1023) / 1024;       // 1 KiB DMA pieces of the tile's rulebook block
+    int* s_ent = reinterpret_cast<int*>(smem + 2 * ABUF + 2 * BBUF);   // the tile's rulebook rows [TM][27]
+    int* s_rng = s_ent + ENT_INSTR * 256;                              // [0..8] lo, [16..24] hi
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WC, wn = wave % WC;
@@ -82,49 +83,86 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
     const int KV = p.KW;                        // 27
     const int nsl = p.Cin >> 5;                 // 32-channel slices
 
-    // ---- prologue: zero rows, the input-row range of every (dz, dy) group of this tile
+    // ---- prologue: zero rows, the tile's rulebook block, the input-row range of every (dz, dy) group of this tile
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    {
+        // the tile's rulebook block is contiguous (TM x 27 dwords): DMA it into LDS in 1 KiB pieces (the first version
+        // copied it with a load -> wait -> ds_write loop, 14 serialised L2 round trips = ~14 us per tile).  Rows beyond
+        // the live count hold garbage and are masked where they are read; the source is clamped to the allocation.
+        const char* src = reinterpret_cast<const char*>(p.gather + (long long)m0 * KV);
+        const long long avail = ((long long)p.M - m0) * KV * 4 - 16;            // last readable 16 B chunk of the allocation
+        const unsigned se = lds_base + 2u * ABUF + 2u * BBUF;
+#pragma unroll
+        for (int j = 0; j < (ENT_INSTR + NW - 1) / NW; ++j) {
+            const int i = wave_s + NW * j;
+            if (i < ENT_INSTR) {
+                long long off = (long long)i * 1024 + lane * 16;
+                off = off < avail ? off : avail;
+                __builtin_amdgcn_global_load_lds(src + off, (lds_ptr_t)(uintptr_t)(se + (unsigned)i * 1024u), 16, 0, 0);
+            }
+        }
+    }
     if (tid < 16) *reinterpret_cast<uint4*>(smem + (tid >> 3) * ABUF + S * kRowB + (tid & 7) * 16) = uint4{0, 0, 0, 0};
     if (tid < 32) s_rng[tid] = (tid < 16) ? INT_MAX : -1;
-    // the tile's rulebook block is contiguous: coalesced copy into LDS (-1 beyond the live rows); the main loop then
-    // has no global loads besides the DMA (a compiler-tracked load next to `global_load_lds` gets an immediate
-    // `s_waitcnt vmcnt(0)`, measured in the ISA of the first version)
-    {
-        const int* src = p.gather + (long long)m0 * KV;
-        const int live = (Mlim - m0 < TM ? Mlim - m0 : TM) * KV;
-        for (int i = tid; i < TM * KV; i += NT) s_ent[i] = i < live ? src[i] : -1;
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    {
+    if (wave * 64 < TM) {
         int lo[kNG], hi[kNG];
+        const bool live_row = tid < TM && m0 + tid < Mlim;
+        const int* e = s_ent + tid * KV;           // stride 27 dwords: conflict-free
 #pragma unroll
-        for (int g = 0; g < kNG; ++g) { lo[g] = INT_MAX; hi[g] = -1; }
-        if (tid < TM) {
-            const int* e = s_ent + tid * KV;       // stride 27 dwords: conflict-free
+        for (int g = 0; g < kNG; ++g) {
+            lo[g] = INT_MAX;
+            hi[g] = -1;
 #pragma unroll
-            for (int g = 0; g < kNG; ++g)
-#pragma unroll
-                for (int t = 0; t < kG; ++t) {
-                    const int v = e[g * kG + t];
-                    if (v >= 0) {
-                        lo[g] = v < lo[g] ? v : lo[g];
-                        hi[g] = v + 1 > hi[g] ? v + 1 : hi[g];
-                    }
-                }
-        }
-        if (wave * 64 < TM) {
-#pragma unroll
-            for (int g = 0; g < kNG; ++g) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const int a = __shfl_xor(lo[g], off), b = __shfl_xor(hi[g], off);
-                    lo[g] = a < lo[g] ? a : lo[g];
-                    hi[g] = b > hi[g] ? b : hi[g];
-                }
-                if (lane == 0) {
-                    atomicMin(&s_rng[g], lo[g]);
-                    atomicMax(&s_rng[16 + g], hi[g]);
+            for (int t = 0; t < kG; ++t) {
+                const int v = live_row ? e[g * kG + t] : -1;
+                if (v >= 0) {
+                    lo[g] = v < lo[g] ? v : lo[g];
+                    hi[g] = v + 1 > hi[g] ? v + 1 : hi[g];
                 }
             }
+        }
+        // wave min / max of the 18 values: DPP inside 16-lane rows (xor 1, xor 2, half-row mirror, row mirror), then two
+        // cross-row exchanges issued for all values at once
+        auto dpp_step = [&](auto ctrl) {
+            constexpr int C = decltype(ctrl)::value;
+#pragma unroll
+            for (int g = 0; g < kNG; ++g) {
+                const int a = __builtin_amdgcn_update_dpp(0, lo[g], C, 0xF, 0xF, false);
+                const int b = __builtin_amdgcn_update_dpp(0, hi[g], C, 0xF, 0xF, false);
+                lo[g] = a < lo[g] ? a : lo[g];
+                hi[g] = b > hi[g] ? b : hi[g];
+            }
+        };
+        dpp_step(std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
+        dpp_step(std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
+        dpp_step(std::integral_constant<int, 0x141>{});    // row_half_mirror
+        dpp_step(std::integral_constant<int, 0x140>{});    // row_mirror
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            int a[kNG], b[kNG];
+#pragma unroll
+            for (int g = 0; g < kNG; ++g) {
+                a[g] = __shfl_xor(lo[g], off);
+                b[g] = __shfl_xor(hi[g], off);
+            }
+#pragma unroll
+            for (int g = 0; g < kNG; ++g) {
+                lo[g] = a[g] < lo[g] ? a[g] : lo[g];
+                hi[g] = b[g] > hi[g] ? b[g] : hi[g];
+            }
+        }
+        if (lane < kNG) {
+            int l = lo[0], h = hi[0];
+#pragma unroll
+            for (int g = 1; g < kNG; ++g) {
+                l = lane == g ? lo[g] : l;
+                h = lane == g ? hi[g] : h;
+            }
+            atomicMin(&s_rng[lane], l);
+            atomicMax(&s_rng[16 + lane], h);
         }
     }
     __syncthreads();
@@ -161,53 +199,70 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
         }
     };
 
-    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     // per-lane constants of the DMA slots: instruction i covers stage rows 8i .. 8i+7, lane = (row, 16 B position)
     const int d_row = lane >> 3, d_pos = lane & 7;
     // measurement knobs (TT_SP_DEBUG, tools only; 0 in the product): bit 4 = no activation DMA after the first stage,
     // bit 5 = no weight DMA after the first stage, bit 6 = no MFMA phase
     const bool dbg_no_a = (p.flags & 16) != 0, dbg_no_b = (p.flags & 32) != 0, dbg_no_mfma = (p.flags & 64) != 0;
+    // bit 7 = no operand split (raw bits as bf16), bit 8 = every lane reads the zero row (no gather bank conflicts)
+    const bool dbg_no_split = (p.flags & 128) != 0, dbg_zero_a = (p.flags & 256) != 0;
     bool first_issue = true;
+    // Address diet: everything about a DMA slot that does not change from stage to stage is a per-lane 32-bit element
+    // offset computed once (weights: row n, tap t, swizzled chunk; activations: swizzled chunk); per stage a slot costs a
+    // clamp + one 24-bit multiply (activations) and one 64-bit add onto a wave-uniform base.  (The first version redid
+    // the 64-bit row * stride arithmetic per slot per stage: ~350 instructions between the barrier and the first MFMA.)
+    int a_chunk[NIA], a_row[NIA], b_off[NIB];
+#pragma unroll
+    for (int j = 0; j < NIA; ++j) {
+        const int row = 8 * (wave + NW * j) + d_row;
+        a_row[j] = row;
+        a_chunk[j] = (d_pos ^ ((row >> 1) & 7)) << 2;
+    }
+#pragma unroll
+    for (int j = 0; j < NIB; ++j) {
+        const int r = 8 * (wave + NW * j) + d_row;                 // r = t * BN + n
+        const int t = r / BN, n = r - t * BN;
+        b_off[j] = n * p.K + t * p.Cin + ((d_pos ^ ((n >> 1) & 7)) << 2);     // < 2^31 elements: Cout * K floats
+    }
     auto issue = [&](const Walk& w, int buf) {
         const bool skip_a = dbg_no_a && !first_issue, skip_b = dbg_no_b && !first_issue;
         first_issue = false;
         const unsigned sa = lds_base + (unsigned)buf * ABUF, sb = lds_base + 2u * ABUF + (unsigned)buf * BBUF;
         const int nrows = (w.hi - w.c) < S ? (w.hi - w.c) : S;
-        const float* abase = in + p.in_coff + w.sl * 32;
+        const float* abase = in + p.in_coff + w.sl * 32 + (long long)w.c * p.in_cstride;      // wave-uniform
 #pragma unroll
         for (int j = 0; j < NIA; ++j) {
             const int i = wave_s + NW * j;
             if (i < NA_INSTR && 8 * i < nrows && !skip_a) {            // wave-uniform
-                const int row = 8 * i + d_row;
-                int src = w.c + row;
-                src = src < w.hi ? src : w.hi - 1;                     // rows past the range: any valid line (never read)
-                const float* sp = abase + (long long)src * p.in_cstride + ((d_pos ^ ((row >> 1) & 7)) << 2);
+                // rows past the range: the last valid line (never read).  row * stride < 2^24 * 2^7 fits 32 bits
+                const int row = a_row[j] < nrows ? a_row[j] : nrows - 1;
+                const float* sp = abase + (unsigned)(__umul24((unsigned)row, (unsigned)p.in_cstride) + (unsigned)a_chunk[j]);
                 __builtin_amdgcn_global_load_lds(sp, (lds_ptr_t)(uintptr_t)(sa + (unsigned)i * 1024u), 16, 0, 0);
             }
         }
-        const float* bbase = wgt + (long long)(w.g * kG) * p.Cin + w.sl * 32;
+        const float* bbase = wgt + (long long)(w.g * kG) * p.Cin + w.sl * 32;                  // wave-uniform
 #pragma unroll
         for (int j = 0; j < NIB; ++j) {
             const int i = wave_s + NW * j;
-            if (i < NB_INSTR && !skip_b) {
-                const int r = 8 * i + d_row;                           // r = t * BN + n
-                const int t = r / BN, n = r - t * BN;
-                const float* sp = bbase + (long long)n * p.K + t * p.Cin + ((d_pos ^ ((n >> 1) & 7)) << 2);
-                __builtin_amdgcn_global_load_lds(sp, (lds_ptr_t)(uintptr_t)(sb + (unsigned)i * 1024u), 16, 0, 0);
-            }
+            if (i < NB_INSTR && !skip_b)
+                __builtin_amdgcn_global_load_lds(bbase + (unsigned)b_off[j], (lds_ptr_t)(uintptr_t)(sb + (unsigned)i * 1024u),
+                                                 16, 0, 0);
         }
     };
     // rulebook entries of this lane's output row for the three taps of group g (asm LDS reads, see `rng`)
     const unsigned ent_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)s_ent +
                               4u * (unsigned)((wm * 32 + (lane & 31)) * KV);
+    const bool row_live = m0 + wm * 32 + (lane & 31) < Mlim;
     auto load_ent = [&](int g, int (&e)[kG]) {
 #pragma unroll
         for (int t = 0; t < kG; ++t)
             asm volatile("ds_read_b32 %0, %1" : "=v"(e[t]) : "v"(ent_base + 4u * (unsigned)(g * kG + t)) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int t = 0; t < kG; ++t) asm volatile("" : "+v"(e[t]));
+        for (int t = 0; t < kG; ++t) {
+            asm volatile("" : "+v"(e[t]));
+            e[t] = row_live ? e[t] : -1;            // rows beyond the live count: garbage in the rulebook
+        }
     };
 
     f32x16 acc[NCB];
@@ -255,26 +310,45 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
         // ---- compute stage (wc.g, wc.c, wc.sl) from buffer `buf`
         const unsigned sa = lds_base + (unsigned)buf * ABUF, sb = lds_base + 2u * ABUF + (unsigned)buf * BBUF;
         const int nrows = (wc.hi - wc.c) < S ? (wc.hi - wc.c) : S;
+        unsigned a_off[kG], a_swz[kG];
+        bool any = false;
 #pragma unroll
         for (int t = 0; t < kG; ++t) {
             const int s = ent_cur[t] - wc.c;
             const bool ok = ent_cur[t] >= 0 && (unsigned)s < (unsigned)nrows;
-            if (__builtin_amdgcn_ballot_w64(ok) == 0ull || dbg_no_mfma) continue;   // no row of this wave has the tap in this chunk
-            const unsigned ar = ok ? (unsigned)s : (unsigned)S;
-            const unsigned a_off = sa + ar * kRowB, a_swz = (ar >> 1) & 7;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const unsigned a0 = a_off + (((4u * ks + 2u * kb) ^ a_swz) << 4);
-                const u32x4 ra0 = lds_read(a0), ra1 = lds_read(a0 ^ 16u);
-                u32x4 bh[NCB], bl[NCB];
+            any = any || ok;
+            const unsigned ar = (ok && !dbg_zero_a) ? (unsigned)s : (unsigned)S;   // absent (or in another chunk): the zero row
+            a_off[t] = sa + ar * kRowB;
+            a_swz[t] = (ar >> 1) & 7;
+        }
+        // no row of this wave has a neighbour of this group in this chunk (chunked ranges, isolated sites): nothing to add
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull && !dbg_no_mfma) {
+            // 6 sub-steps (tap, k-step); the LDS reads of sub-step i+1 are in flight under the split + MFMAs of sub-step i
+            u32x4 ra[2][2], rbh[2][NCB], rbl[2][NCB];
+            auto reads = [&](int i, int slot) {
+                const int t = i >> 1, ks = i & 1;
+                const unsigned a0 = a_off[t] + (((4u * ks + 2u * kb) ^ a_swz[t]) << 4);
+                ra[slot][0] = lds_read(a0);
+                ra[slot][1] = lds_read(a0 ^ 16u);
 #pragma unroll
                 for (int j = 0; j < NCB; ++j) {
                     const unsigned b0 = sb + (unsigned)t * (BN * kRowB) + fb_row[j] + (((4u * ks + kb) ^ fb_swz[j]) << 4);
-                    bh[j] = lds_read(b0);
-                    bl[j] = lds_read(b0 ^ 32u);
+                    rbh[slot][j] = lds_read(b0);
+                    rbl[slot][j] = lds_read(b0 ^ 32u);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                u32x4 r0 = ra0, r1 = ra1;
+            };
+            reads(0, 0);
+#pragma unroll
+            for (int i = 0; i < 2 * kG; ++i) {
+                const int cur = i & 1;
+                if (i + 1 < 2 * kG) {
+                    reads(i + 1, cur ^ 1);
+                    if constexpr (NCB == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                u32x4 r0 = ra[cur][0], r1 = ra[cur][1];
                 asm volatile("" : "+v"(r0));
                 asm volatile("" : "+v"(r1));
                 const float x[8] = {__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z),
@@ -288,9 +362,16 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
                     const float q1 = x[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
                     l[e] = pack_bf16x2(q0, q1);
                 }
-                const uint4 ah = uint4{h[0], h[1], h[2], h[3]}, al = uint4{l[0], l[1], l[2], l[3]};
+                uint4 ah = uint4{h[0], h[1], h[2], h[3]}, al = uint4{l[0], l[1], l[2], l[3]};
+                if (dbg_no_split) {
+                    ah = __builtin_bit_cast(uint4, r0);
+                    al = __builtin_bit_cast(uint4, r1);
+                }
+                u32x4 bh[NCB], bl[NCB];
 #pragma unroll
                 for (int j = 0; j < NCB; ++j) {
+                    bh[j] = rbh[cur][j];
+                    bl[j] = rbl[cur][j];
                     asm volatile("" : "+v"(bh[j]));
                     asm volatile("" : "+v"(bl[j]));
                 }
@@ -317,7 +398,8 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
 template <int NCB, int WR, int WC>
 static int launch_sp_runs(ConvArgs& a, hipStream_t st) {
     constexpr int TM = WR * 32, BN = WC * NCB * 32, S = TM + 32, NW = WR * WC;
-    size_t smem = (size_t)2 * (S + 8) * kRowB + (size_t)2 * kG * BN * kRowB + 128 + (size_t)TM * kG * kNG * 4;
+    size_t smem = (size_t)2 * (S + 8) * kRowB + (size_t)2 * kG * BN * kRowB + 128 +
+                  (size_t)((TM * kG * kNG * 4 + 1023) / 1024) * 1024;
     const size_t epi = (size_t)NW * 32 * (NCB * 32 + 4) * 4;
     if (smem < epi) smem = epi;
     auto kern = sp_conv_runs_kernel<NCB, WR, WC>;
