@@ -459,10 +459,13 @@ int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff, const flo
                          int res2_coff, const float* scale, const float* shift, long long M, int C, int act, float* dconv,
                          int dconv_cstride, int dconv_coff, float* dres, int dres_cstride, int dres_coff, float* dres2,
                          int dres2_cstride, int dres2_coff, int dres_accumulate, float* dscale, float* dshift,
-                         int accumulate, const int* m_dev_or_null, const float* pre_or_null, void* workspace,
-                         long long workspace_bytes, void* stream);
+                         int accumulate, const int* m_dev_or_null, const float* pre_or_null, const float* conv_raw_or_null,
+                         void* workspace, long long workspace_bytes, void* stream);
 /* (pre_or_null: dense [M][C] pre-activation scale*conv + shift + res1 + res2, recomputed by running the layer once more
- *  without its activation -- required for GELU / softplus, whose derivative cannot be read off the output) */
+ *  without its activation -- required for GELU / softplus, whose derivative cannot be read off the output.
+ *  conv_raw_or_null: dense [M][C] raw convolution output, recomputed likewise without scale / shift: dscale = sum g * conv
+ *  is then exact; without it conv is reconstructed as (pre - shift - res) / scale, which loses everything when a BatchNorm
+ *  gamma is (near) zero -- zero_init_residual, pruned channels -- or a sigmoid saturates; a zero scale contributes 0) */
 /* Sparse (rulebook) convolution backward.  Weight gradient dw[co][0][t][ci] (+)= sum_m dy[m][co] * x[nbr[m][t]][ci] over the
  * live rows m < *m_dev (f32 MFMA, deterministic).  The input gradient is the forward gathered GEMM itself on a transposed
  * rulebook: for a submanifold layer the rulebook is its own transpose under tap reversal; for a strided layer
@@ -535,6 +538,44 @@ int tt_deform_im2col3x3_bwd(const float* x, const float* offsets, const float* g
  * = [transformed prev | now] with z += z_shift (2.5). */
 int tt_lidar_merge_half_sweeps(const float* prev_xyzi, int n_prev, const float* now_xyzi, int n_now,
                                const float* rel_transform_3x4, float z_shift, float* out_xyzi, void* stream);
+
+/* ------------------------------------------------------------------------
+ * train-mode BatchNorm (batch statistics) over channel-last rows -- what every nn.BatchNorm2d / BatchNorm1d
+ * (torch.nn.SyncBatchNorm under configs/thinktwice.py:39 SyncBN=True, apis/mmdet_train.py:86-87) computes under
+ * model.train() (norm_eval=False, configs/thinktwice.py:146).  The convolution in front writes its raw output z (bias in);
+ * `groups` equal row groups are normalised with their own statistics (the camera trunk's T sweeps run as one batch here,
+ * one pass per sweep in the reference, lss.py:690-717); m_dev != NULL: sparse rows, live count on the device, groups == 1.
+ *   stats  : double [groups][2C + 2] = per-channel sum | sum of squares | row count | 0 -- the block a SyncBN all-reduce
+ *            (SUM) runs over, between tt_bn_stats and tt_bn_finalize
+ *   scale / shift / mean / invstd : float [groups][C]; running_mean / running_var (nullable) are updated like torch does
+ *            (momentum, unbiased variance), group 0 (the key sweep) first, like lss.py:689-714
+ *   tt_bn_apply      out[m][out_coff + c] = act(z * scale + shift + res1 + res2), act in {TT_ACT_NONE, TT_ACT_RELU}
+ *   tt_bn_bwd_reduce dy := dy * act'(y) in place, dres += it, sums = double [groups][2C] = sum g | sum g * xhat (LOCAL;
+ *            dgamma / dbeta are these; under SyncBN they are all-reduced before tt_bn_bwd_apply)
+ *   tt_bn_bwd_apply  dz = scale * (g - sum_g / n - xhat * sum_gxhat / n), n = stats[g][2C]
+ * ---------------------------------------------------------------------- */
+long long tt_bn_workspace_bytes(int C, int groups);
+int tt_bn_stats(const float* z, long long M, int C, int z_cstride, int z_coff, const int* m_dev, int groups, double* stats,
+                void* workspace, long long workspace_bytes, void* stream);
+int tt_bn_finalize(const double* stats, int C, int groups, const float* gamma, const float* beta, float eps, float momentum,
+                   float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd,
+                   void* stream);
+int tt_bn_apply(const float* z, long long M, int C, int z_cstride, int z_coff, const int* m_dev, int groups,
+                const float* scale, const float* shift, const float* res1, int r1_cstride, int r1_coff, const float* res2,
+                int r2_cstride, int r2_coff, int act, float* out, int out_cstride, int out_coff, void* stream);
+int tt_bn_bwd_reduce(float* dy, int dy_cstride, int dy_coff, const float* y, int y_cstride, int y_coff, const float* z,
+                     int z_cstride, int z_coff, long long M, int C, const int* m_dev, int groups, const float* mean,
+                     const float* invstd, int act, float* dres1, int d1_cstride, int d1_coff, float* dres2, int d2_cstride,
+                     int d2_coff, double* sums, void* workspace, long long workspace_bytes, void* stream);
+int tt_bn_bwd_apply(const float* g, int g_cstride, int g_coff, const float* z, int z_cstride, int z_coff, long long M, int C,
+                    const int* m_dev, int groups, const double* sums, const double* stats, const float* scale,
+                    const float* mean, const float* invstd, float* dz, int dz_cstride, int dz_coff, void* stream);
+/* nn.Dropout(p) of the DepthNet ASPP (lss.py:91,110) in train mode: keep-mask from a counter-based generator (seed, element
+ * index -> splitmix64), out = x * mask / (1 - p); `mask` (uint8 [n], nullable) receives the keep bits for the backward, or --
+ * mask_in != NULL -- supplies them (parity tests replay the reference's torch mask). */
+int tt_dropout_fwd(const float* x, float* out, long long n, float p, unsigned long long seed, const uint8_t* mask_in,
+                   uint8_t* mask_out, void* stream);
+int tt_dropout_bwd(const float* dout, const uint8_t* mask, float* dx, long long n, float p, void* stream);
 
 /* ------------------------------------------------------------------------
  * action post-processing of a closed-loop tick, on the device (one thread) or on the host.

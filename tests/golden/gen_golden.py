@@ -422,7 +422,19 @@ def _grad_leaves(sd):
             for k, v in sd.items()}
 
 
+def gen_f16():
+    """F16: F13 under model.train() -- the reference's TRAINING semantics (batch-statistics BatchNorm everywhere, each
+    sweep through the camera trunk on its own; live ASPP Dropout(0.5) drawing from torch's global RNG, seeded right before
+    each forward): total loss, every loss term and the gradient of the total loss w.r.t. every parameter, reference autograd
+    vs autograd through the oracle restatement in train mode."""
+    _gen_gradients("f16_train_gradients_trainmode_b2.npz", train=True)
+
+
 def gen_f13():
+    _gen_gradients("f13_train_gradients_b2.npz", train=False)
+
+
+def _gen_gradients(fname, train):
     """F13: BACKWARD of the training step.  The reference's own autograd graph (its custom VoxelPooling Function,
     the detach() / no_grad placements of lss.py:589,711 and thinktwice_decoder.py:429-430, `_parse_losses`) against
     autograd through the oracle restatement, model.eval(), B=2 128x256: gradient of the total loss w.r.t. every
@@ -435,19 +447,29 @@ def gen_f13():
     sd = params.init_params(cfg, seed=seed)
     batch = synth.make_batch(B, img_hw=hw, num_points=npts)
     batch.update(synth.make_train_targets(B, img_hw=hw))
+    import contextlib
+    rng = 20240607
     sd_ref = _grad_leaves(sd)                      # leaves for the third-party stand-ins (they read `sd` directly)
     model = build_reference_model(cfg, sd_ref)
-    losses = model.forward_train(batch)
-    loss_ref, _ = model._parse_losses(losses)
-    loss_ref.backward()
+    mode = TR.train_mode if train else contextlib.nullcontext
+    if train:
+        model.train()
+    with mode():                                   # (the third-party stand-ins call the oracle blocks: same switch)
+        torch.manual_seed(rng)
+        losses = model.forward_train(batch)
+        loss_ref, _ = model._parse_losses(losses)
+        loss_ref.backward()
+    model.eval()
     own = dict(model.named_parameters())
     sd_ora = _grad_leaves(sd)
-    lo, _ = TR.forward_train(sd_ora, cfg, batch)
-    loss_ora = TR.total_loss(lo)
-    loss_ora.backward()
+    with mode():
+        torch.manual_seed(rng)
+        lo, _ = TR.forward_train(sd_ora, cfg, batch)
+        loss_ora = TR.total_loss(lo)
+        loss_ora.backward()
     print(f"total loss reference {float(loss_ref):.6f} oracle {float(loss_ora):.6f}")
     g = torch.Generator().manual_seed(5)
-    names, norms, samples, idxs, dead, worst = [], [], [], [], [], 0.0
+    names, norms, samples, idxs, dead, worst, noise = [], [], [], [], [], 0.0, []
     for k, v in sd_ora.items():
         if not (torch.is_tensor(v) and v.requires_grad):
             continue
@@ -458,9 +480,16 @@ def gen_f13():
             dead.append(k)
             continue
         e = float((gr - go).norm() / gr.norm().clamp_min(1e-20))
-        worst = max(worst, e)
-        if e > 1e-4:
-            print(f"  {k:70s} |g| {float(gr.norm()):.3e} rel err {e:.2e}")
+        if train and e > 1e-3 and k.endswith(".bias") and float(gr.norm()) < 2e-3:
+            # a conv bias in front of a batch-statistics BatchNorm: its gradient is analytically ZERO (the mean subtraction
+            # removes it); what autograd returns is rounding noise of the two reduction terms, different in every
+            # implementation.  Recorded by name; the tests bound its magnitude instead of comparing values.
+            noise.append(k)
+            print(f"  {k:70s} |g| {float(gr.norm()):.3e} (analytically zero: noise)")
+        else:
+            worst = max(worst, e)
+            if e > 1e-4:
+                print(f"  {k:70s} |g| {float(gr.norm()):.3e} rel err {e:.2e}")
         idx = torch.randint(0, gr.numel(), (8,), generator=g)
         names.append(k)
         norms.append(float(gr.norm()))
@@ -468,9 +497,14 @@ def gen_f13():
         samples.append(gr.reshape(-1)[idx].numpy())
     print(f"{len(names)} parameters with gradient, {len(dead)} without, worst relative gradient error {worst:.2e}")
     assert worst < 1e-3, worst
-    _save("f13_train_gradients_b2.npz", names=np.array(names), norms=np.array(norms), idx=np.stack(idxs),
+    extra = {}
+    if train:       # the loss terms too (F11 holds them for the no-grad forward; here from the run the gradients belong to)
+        extra = {"loss__" + k: v.detach().float().numpy() for k, v in losses.items()}
+        extra["rng"] = np.array([rng])
+        extra["noise"] = np.array(noise)
+    _save(fname, names=np.array(names), norms=np.array(norms), idx=np.stack(idxs),
           samples=np.stack(samples), dead=np.array(dead), total_loss=np.array([float(loss_ref)]),
-          meta=np.array([B, hw[0], hw[1], npts, seed]), oracle_vs_reference_worst_rel_err=np.array([worst]))
+          meta=np.array([B, hw[0], hw[1], npts, seed]), oracle_vs_reference_worst_rel_err=np.array([worst]), **extra)
 
 
 # ---------------------------------------------------------------------------
@@ -544,7 +578,7 @@ def gen_f15():
 
 
 FIXTURES = {"F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8, "F9": gen_f9, "F10": gen_f10, "F11": gen_f11,
-            "F13": gen_f13, "F14": gen_f14, "F15": gen_f15}
+            "F13": gen_f13, "F14": gen_f14, "F15": gen_f15, "F16": gen_f16}
 
 
 def main():

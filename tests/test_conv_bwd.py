@@ -165,3 +165,46 @@ def test_gather_conv_wgrad_matches_dense_sum(Cin, Cout):
     assert err < 1e-5, err
     again = ops.gather_conv_wgrad(x.cuda(), nbr.cuda(), m_dev, dy.cuda(), taps, cin_pad=cin_pad).cpu()
     assert torch.equal(got, again)                            # ordered partial sums: bit-reproducible
+
+
+def test_frozen_bn_layer_backward_with_zero_and_tiny_gamma_channels():
+    """a folded BatchNorm channel with gamma == 0 (mmdet zero_init_residual, pruned channels) or gamma ~ 1e-8
+    must not turn dgamma into NaN / garbage.  The taped layer recomputes the raw convolution for such layers
+    (autodiff.refresh_small_scale_flags) and the kernel sums g * conv directly; without the flag a zero scale contributes
+    0 instead of 0/0."""
+    from thinktwice_amd import autodiff, layers, ops, weights
+    g = torch.Generator().manual_seed(21)
+    N, H, W, Cin, Cout = 2, 12, 16, 32, 64
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (Cin * 9) ** -0.5).requires_grad_(True)
+    gamma = torch.rand(Cout, generator=g) + 0.5
+    gamma[3], gamma[10], gamma[40] = 0.0, 1e-8, -1e-9
+    gamma.requires_grad_(True)
+    beta = (torch.randn(Cout, generator=g) * 0.2).requires_grad_(True)
+    mean, var = torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5
+    y = torch.relu(F.batch_norm(F.conv2d(x, w, None, 1, 1), mean, var, gamma, beta, False, 0.0, 1e-5))
+    R = torch.randn(N, Cout, H, W, generator=g)
+    (y * R).sum().backward()
+    sd = {"l.weight": w.detach(), "l_bn.weight": gamma.detach(), "l_bn.bias": beta.detach(), "l_bn.running_mean": mean,
+          "l_bn.running_var": var}
+    autodiff.clear_metas()
+    conv = layers.conv_from_sd(sd, "l", torch.float32, torch.device("cuda"), bn="l_bn", pad=1, act="relu")
+    assert autodiff.refresh_small_scale_flags() == 1
+    xq = weights.to_channel_last(x, torch.float32).cuda()
+    for flagged in (True, False):
+        autodiff.CONV_META[id(conv.w)].small_scale = flagged
+        with autodiff.Tape(x3=False) as tape:
+            out = conv(xq)
+            tape.seed(out, R.permute(0, 2, 3, 1))
+            tape.backward()
+        torch.cuda.synchronize()
+        dg, db = tape.param_grads["l_bn.weight"].cpu(), tape.param_grads["l_bn.bias"].cpu()
+        assert torch.isfinite(dg).all() and torch.isfinite(db).all() and torch.isfinite(tape.param_grads["l.weight"]).all()
+        assert float((db - beta.grad).abs().max()) < 3e-5 * float(beta.grad.abs().max())
+        if flagged:         # exact everywhere, the degenerate channels included
+            assert float((dg - gamma.grad).abs().max()) < 1e-4 * float(gamma.grad.abs().max())
+        else:               # ordinary channels exact, degenerate ones finite (their information is not in the saved output)
+            ok = torch.ones(Cout, dtype=torch.bool)
+            ok[[3, 10, 40]] = False
+            assert float((dg - gamma.grad)[ok].abs().max()) < 1e-4 * float(gamma.grad.abs().max())
+    autodiff.clear_metas()

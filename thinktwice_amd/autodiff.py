@@ -32,6 +32,9 @@ class ConvMeta:
     def __init__(self, name, cin, bn=None, mean=None, sigma=None, bias=None, kind="conv", full_shape=None, lo=0):
         self.name, self.cin, self.bn, self.mean, self.sigma, self.bias = name, cin, bn, mean, sigma, bias
         self.kind, self.full_shape, self.lo = kind, full_shape, lo
+        # the folded scale has (near-)zero entries (BatchNorm gamma ~ 0: zero_init_residual, pruned channels): dscale must
+        # come from a recomputed raw convolution, not from dividing the saved output by the scale (refresh_small_scale_flags)
+        self.scale_ref, self.small_scale = None, False
 
     def place_weight_grad(self, tape, dw):
         g = dw[..., :self.cin]
@@ -69,6 +72,18 @@ LN_META = {}            # id(gamma tensor) -> (weight name, bias name) of a Laye
 CONV_META = {}          # id(weight tensor) -> ConvMeta, filled by layers.conv_from_sd
 PARAM_TENSORS = {}      # id(tensor) -> (state_dict name, tensor): parameters the ops read directly as activations-like inputs
                         # (embeddings); their gradient buffers are moved to param_grads when backward() ends
+
+
+def refresh_small_scale_flags(threshold=1e-4):
+    """One pass over the registered layers' folded scales (ONE host sync): flag those with |scale| < threshold * max|scale| in
+    some channel.  trainer.Trainer calls it after (re)preparing the operands in frozen-BN mode."""
+    metas = [m for m in CONV_META.values() if m.scale_ref is not None]
+    if not metas:
+        return 0
+    ratios = torch.stack([m.scale_ref.abs().min() / m.scale_ref.abs().max().clamp_min(1e-30) for m in metas]).cpu()
+    for m, r in zip(metas, ratios.tolist()):
+        m.small_scale = not (r >= threshold)          # (NaN compares false -> flagged)
+    return sum(m.small_scale for m in metas)
 
 
 def clear_metas():
@@ -153,12 +168,14 @@ class Tape:
 
     # ---- recorders (called from ops.* while the tape is active)
     def conv(self, x, w, y, stride, pad, dil, scale, shift, act, in_coff, cin, out_coff, res1, res1_coff, res2, res2_coff,
-             pixel_shuffle2, in_cstride, shift_n=None, shift_n_mod=1, stop_grad=False):
+             pixel_shuffle2, in_cstride, shift_n=None, shift_n_mod=1, stop_grad=False, bn_raw=False):
+        """`bn_raw`: the train-mode form of a BatchNorm'd layer -- this launch wrote the raw convolution (+ bias) and
+        ops.batchnorm_train, recorded on its own, owns the BatchNorm parameters."""
         meta = CONV_META.get(id(w))
         if meta is None or in_cstride is not None:
             raise NotImplementedError("tape: convolution form without a backward yet (unnamed weight or row-run stem)")
         if pixel_shuffle2:
-            return self._deconv2x2(meta, x, w, y, shift, act, in_coff, cin, out_coff, scale, res1, res2)
+            return self._deconv2x2(meta, x, w, y, shift, act, in_coff, cin, out_coff, scale, res1, res2, bn_raw)
         Cout, KH, KW, cin_p = w.shape
         self._keep += [x, y, res1, res2, shift_n]
         inplace1 = res1 is not None and res1.data_ptr() == y.data_ptr() and res1_coff == out_coff
@@ -192,7 +209,11 @@ class Tape:
                 per_image = ops.spatial_pool(gdense.view(N, OH, OW, Cout), 0)
                 self.grad(shift_n).add_(per_image.view(N // imgs, imgs, Cout).sum(0), alpha=float(OH * OW))
             else:
-                pre = None
+                pre = zraw = None
+                if scale is not None and (meta.small_scale or act == 2):
+                    # BatchNorm gamma ~ 0 in some channel / a sigmoid epilogue: dscale from the raw convolution itself
+                    zraw = ops.conv2d(xd, w, stride=stride, pad=pad, dil=dil, act=0, in_coff=in_coff, cin=cin,
+                                      out_dtype=torch.float32, _no_tape=True)
                 if act not in (0, 1, 2):        # GELU / softplus: the derivative needs the pre-activation -> run the layer
                     pre = ops.conv2d(xd, w, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift, act=0,   # once more
                                      in_coff=in_coff, cin=cin, res1=res1, res1_coff=res1_coff, res2=res2,
@@ -200,12 +221,15 @@ class Tape:
                 dconv, _, dscale, dshift = ops.conv_epilogue_bwd(gy, yd, scale, shift, act, res1, res2, C=Cout,
                                                                  dy_coff=out_coff, y_coff=out_coff, res1_coff=res1_coff,
                                                                  res2_coff=res2_coff, dres1=g1, dres1_coff=res1_coff,
-                                                                 dres2=g2, dres2_coff=res2_coff, pre=pre)
+                                                                 dres2=g2, dres2_coff=res2_coff, pre=pre, conv_raw=zraw)
             dconv = dconv.view(N, OH, OW, Cout)
             # parameters
             dw = ops.conv2d_wgrad(xd, dconv, KH, KW, stride, pad, dil, cin=cin, in_coff=in_coff, cin_pad=cin_p)
             meta.place_weight_grad(self, dw)
-            if meta.bn is not None:
+            if bn_raw:
+                if meta.bias is not None and shift is not None:
+                    self.add_param_grad(meta.name + ".bias", dshift)
+            elif meta.bn is not None:
                 # scale = gamma / sigma, shift = beta + (bias - mean) * gamma / sigma
                 off = meta.mean if meta.bias is None else meta.mean - meta.bias
                 self.add_param_grad(meta.bn + ".weight", (dscale - off * dshift) / meta.sigma)
@@ -232,7 +256,7 @@ class Tape:
 
         self.nodes.append(bwd)
 
-    def _deconv2x2(self, meta, x, w, y, shift, act, in_coff, cin, out_coff, scale, res1, res2):
+    def _deconv2x2(self, meta, x, w, y, shift, act, in_coff, cin, out_coff, scale, res1, res2, bn_raw=False):
         """ConvTranspose2d(k=2, s=2) = 1x1 GEMM to 4*Cout channels + pixel shuffle (layers.deconv2x2_from_sd): the
         gradient is un-shuffled (a layout copy) and the layer is differentiated as the 1x1 convolution it is."""
         if res1 is not None or res2 is not None:
@@ -251,7 +275,10 @@ class Tape:
             # prepared rows are (dh*2+dw)*Cout + co; the reference weight is [Cin, Cout, 2, 2]
             self.add_param_grad(meta.name + ".weight",
                                 dw[:, 0, 0, :meta.cin].reshape(2, 2, Cout, meta.cin).permute(3, 2, 0, 1).contiguous())
-            if meta.bn is not None:
+            if bn_raw:
+                if meta.bias is not None and shift is not None:
+                    self.add_param_grad(meta.name + ".bias", dshift)
+            elif meta.bn is not None:
                 self.add_param_grad(meta.bn + ".weight", (dscale - meta.mean * dshift) / meta.sigma)
                 self.add_param_grad(meta.bn + ".bias", dshift)
             elif meta.bias is not None:
@@ -421,7 +448,7 @@ class Tape:
         self.nodes.append(lambda: ops.deform_im2col3x3_bwd(x, offsets, self.grad(cols).contiguous(), self.grad(x),
                                                            self.grad(offsets), pad))
 
-    def gather_conv(self, feats, nbr, m_dev, w, scale, shift, act, res, out, in_rows):
+    def gather_conv(self, feats, nbr, m_dev, w, scale, shift, act, res, out, in_rows, bn_raw=False):
         """Sparse convolution (rulebook GEMM) + BatchNorm1d + residual + ReLU.  `in_rows`: None for a submanifold layer
         (input rows == output rows), else (device row count, allocated rows) of the INPUT level of a strided layer."""
         meta = CONV_META.get(id(w))
@@ -437,8 +464,9 @@ class Tape:
                                                              m_dev=m_dev)
             dw = ops.gather_conv_wgrad(feats, nbr, m_dev, dconv, taps, cin_pad=cin_p)
             meta.place_weight_grad(self, dw)
-            self.add_param_grad(meta.bn + ".weight", (dscale - meta.mean * dshift) / meta.sigma)
-            self.add_param_grad(meta.bn + ".bias", dshift)
+            if not bn_raw:
+                self.add_param_grad(meta.bn + ".weight", (dscale - meta.mean * dshift) / meta.sigma)
+                self.add_param_grad(meta.bn + ".bias", dshift)
             # input rows: the same gathered GEMM on the transposed rulebook, accumulated into the input's gradient
             gx = self.grad(feats)
             if in_rows is None:     # submanifold: nbr[m][t] = j  <=>  nbr[j][taps - 1 - t] = m
@@ -451,6 +479,31 @@ class Tape:
                 ops.gather_conv(dconv, inv, rows_dev, wt, res=gx, out=gx, _no_tape=True)
 
         self.nodes.append(bwd)
+
+    def bn_train(self, z, out, out_coff, spec, act, res1, res1_coff, res2, res2_coff, m_dev, groups, stats, scale, mean, invstd):
+        """Train-mode BatchNorm (ops.batchnorm_train): batch-statistics backward with its two reduction terms; dgamma / dbeta
+        under the layer's state_dict names; under SyncBN the reductions are all-reduced inside ops.batchnorm_train_bwd."""
+        self._keep += [z, out, res1, res2, stats, scale, mean, invstd, m_dev]
+
+        def bwd():
+            gy = self.grad(out)
+            assert gy.is_contiguous(), "bn_train: the output's gradient buffer must be row-linear"
+            g1 = None if res1 is None else self.grad(res1)
+            g2 = None if res2 is None else self.grad(res2)
+            for g in (g1, g2):
+                assert g is None or g.is_contiguous()
+            dz = self.grad(z)
+            dgamma, dbeta = ops.batchnorm_train_bwd(gy, out_coff, out, out_coff, z, mean, invstd, scale, stats, act, g1,
+                                                    res1_coff, g2, res2_coff, dz, m_dev=m_dev, groups=groups)
+            if spec.gamma is not None:
+                self.add_param_grad(spec.name + ".weight", dgamma)
+                self.add_param_grad(spec.name + ".bias", dbeta)
+
+        self.nodes.append(bwd)
+
+    def dropout(self, x, out, mask, p):
+        self._keep += [x, out, mask]
+        self.nodes.append(lambda: ops.dropout_bwd(self.grad(out), mask, self.grad(x), p))
 
     def sp_to_dense(self, x, coords, rows, max_rows, dims, dense):
         self._keep += [x, coords, rows, dense]

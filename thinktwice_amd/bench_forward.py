@@ -188,19 +188,26 @@ class ForwardWorkload:
         rocprofv3 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command (counters cannot be read from inside
         the process): FETCH_SIZE x 2 (gfx950 16 B/lane correction, MI355X_MICROARCH.md) + WRITE_SIZE, in KB."""
         import json
+        from . import build
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles",
-                            f"r02_forward_{self.dtype}_pmc.json")
+                            f"r03_forward_{self.dtype}_pmc.json")
         if self.B != 8 or not os.path.exists(path):
             return None, "no PMC summary for this dtype / batch"
+        data = json.load(open(path))
+        stamp = data.get("_stamp", {})
+        if stamp.get("csrc_sha") != build.source_fingerprint():
+            return None, (f"profiles/{os.path.basename(path)} was collected from another build (source fingerprint "
+                          f"{stamp.get('csrc_sha')} != {build.source_fingerprint()}): counters are not quoted; re-run "
+                          "tools/pmc_profile.sh + tools/summarize_pmc.py")
         forwards = 4     # the profiled command: bench.py --steps 2 --warmup 1 (+1 roofline pass)
         rd = wr = 0.0
-        for name, c in json.load(open(path)).items():
-            if "conv_" in name or "igemm" in name or "splitk" in name:
+        for name, c in data.items():
+            if name != "_stamp" and ("conv_" in name or "igemm" in name or "splitk" in name):
                 rd += c.get("FETCH_SIZE", {}).get("sum", 0.0)
                 wr += c.get("WRITE_SIZE", {}).get("sum", 0.0)
         return int((2.0 * rd + wr) * 1024 / forwards), ("bytes per step over the same launches, from profiles/"
-                                                         f"r02_forward_{self.dtype}_pmc.json (separate --pmc passes, "
-                                                         "FETCH_SIZE x2 corrected)")
+                                                         f"{os.path.basename(path)} (separate --pmc passes, FETCH_SIZE x2 "
+                                                         f"corrected; build {stamp.get('csrc_sha')})")
 
     def extra(self):
         out = {}

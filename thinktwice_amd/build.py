@@ -41,6 +41,20 @@ def _compile(src, hdr_mtime, verbose):
     return obj
 
 
+def source_fingerprint():
+    """sha256 over the library's sources (csrc/*, include/thinktwice_hip.h): the identity of a build, available wherever the
+    tree is (the GPU box has no .git).  Profiles under profiles/ carry it (tools/summarize_pmc.py) and bench.py only quotes
+    counter data whose fingerprint matches the tree it runs from."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp", ".h"))]
+    files.append(os.path.join(HERE, "..", "include", "thinktwice_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(verbose=True, force=False):
     os.makedirs(OBJ, exist_ok=True)
     if force:

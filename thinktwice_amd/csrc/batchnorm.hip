@@ -103,9 +103,9 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, int 
     if (c >= C) return;
     const int stride = 2 * C + 2;
     float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
-    // group groups-1 is the OLDEST sweep (sweep-major image order, key sweep first): the reference runs the sweeps oldest
-    // first, so its running statistics see the groups in that order
-    for (int g = groups - 1; g >= 0; --g) {
+    // group 0 is the KEY sweep (sweep-major image order): the reference runs the key frame first, then the older sweeps
+    // (lss.py:689-714), so its running statistics see the groups in index order
+    for (int g = 0; g < groups; ++g) {
         const double n = stats[(long long)g * stride + 2 * C];
         const double mu = n > 0 ? stats[(long long)g * stride + c] / n : 0.0;
         double var = n > 0 ? stats[(long long)g * stride + C + c] / n - mu * mu : 0.0;
@@ -219,6 +219,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
     }
 }
 
+// nn.Dropout in train mode.  Keep decision: splitmix64(seed + element index) uniform in [0, 1) >= p
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, long long n, float p,
+                                   unsigned long long seed, const uint8_t* __restrict__ mask_in, uint8_t* __restrict__ mask_out) {
+    const float inv = 1.f / (1.f - p);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        bool keep;
+        if (mask_in) {
+            keep = mask_in[i] != 0;
+        } else {
+            unsigned long long zz = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+            zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull;
+            zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull;
+            zz ^= zz >> 31;
+            keep = (float)(zz >> 40) * (1.f / 16777216.f) >= p;
+        }
+        if (mask_out) mask_out[i] = keep ? 1 : 0;
+        out[i] = keep ? x[i] * inv : 0.f;
+    }
+}
+
+__global__ void dropout_bwd_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ mask, float* __restrict__ dx,
+                                   long long n, float p) {
+    const float inv = 1.f / (1.f - p);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dx[i] += mask[i] ? dout[i] * inv : 0.f;
+}
+
 static int check_rows(long long M, int C, int groups, const int* m_dev, const char* who) {
     TT_REQUIRE(M > 0 && C > 0 && groups >= 1, "%s: bad sizes (M=%lld C=%d groups=%d)", who, M, C, groups);
     TT_REQUIRE(!m_dev || groups == 1, "%s: a device row count goes with one group", who);
@@ -301,4 +328,20 @@ extern "C" int tt_bn_bwd_apply(const float* g, int g_cstride, int g_coff, const 
     const int blocks = (int)min((long long)kNumCU * 16, (total + 255) / 256);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("tt_bn_bwd_apply");
+}
+
+extern "C" int tt_dropout_fwd(const float* x, float* out, long long n, float p, unsigned long long seed,
+                              const uint8_t* mask_in, uint8_t* mask_out, void* stream) {
+    TT_REQUIRE(x && out && n > 0 && p >= 0.f && p < 1.f, "tt_dropout_fwd: null / bad p");
+    const int blocks = (int)min((long long)kNumCU * 16, (n + 255) / 256);
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, n, p, seed, mask_in,
+                       mask_out);
+    return check_launch("tt_dropout_fwd");
+}
+
+extern "C" int tt_dropout_bwd(const float* dout, const uint8_t* mask, float* dx, long long n, float p, void* stream) {
+    TT_REQUIRE(dout && mask && dx && n > 0 && p >= 0.f && p < 1.f, "tt_dropout_bwd: null / bad p");
+    const int blocks = (int)min((long long)kNumCU * 16, (n + 255) / 256);
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, mask, dx, n, p);
+    return check_launch("tt_dropout_bwd");
 }

@@ -388,6 +388,7 @@ struct EpiBwdArgs {
     float* dconv; float* dres; float* dres2; float* partial;     // partial: [kEpiBlocks][2][C]
     const int* m_dev;      // sparse layers: device count of live rows (rows beyond it are not touched), or null
     const float* pre;      // optional dense [M][C] pre-activation (scale*conv + shift + res): any activation
+    const float* zraw;     // optional dense [M][C] raw convolution output: dscale = sum g * zraw (no division by scale)
     long long M;
     int C, dy_cstride, dy_coff, y_cstride, y_coff, r1_cstride, r1_coff, r2_cstride, r2_coff;
     int dconv_cstride, dconv_coff, dres_cstride, dres_coff, dres2_cstride, dres2_coff, dres_accumulate, act;
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
         float s_g = 0.f, s_gx = 0.f;
         if (ty < TY && c_ok) {
             // one element: activation derivative, per-channel sums (in row order), the gradient stores
-            auto element = [&](long long m, float yv, float g, float pre_in, float r) {
+            auto element = [&](long long m, float yv, float g, float pre_in, float r, float zr) {
                 float pre = yv;
                 if (a.pre) {            // activation derivative from the recomputed pre-activation
                     pre = pre_in;
@@ -428,7 +429,11 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
                     pre = logf(yv / (1.f - yv));
                 }
                 s_g += g;
-                if (a.scale) s_gx += g * ((pre - sh - r) / sc);   // (needs the pre-add residual values: see the header)
+                // dscale: from the raw convolution output when the caller recomputed it (layers with a vanishing or zero
+                // BatchNorm gamma, sigmoid epilogues: the reconstruction below is 0/0 or inf there); else reconstructed from
+                // the saved output, a zero scale contributing nothing instead of NaN
+                if (a.zraw) s_gx += g * zr;
+                else if (a.scale) s_gx += (sc != 0.f && g != 0.f) ? g * ((pre - sh - r) / sc) : 0.f;
                 a.dconv[m * a.dconv_cstride + a.dconv_coff + c] = g * sc;
                 if (a.dres) {
                     float* d = a.dres + m * a.dres_cstride + a.dres_coff + c;
@@ -439,10 +444,11 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
                     *d = a.dres_accumulate ? *d + g : g;
                 }
             };
-            auto fetch = [&](long long m, float& yv, float& g, float& pre_in, float& r) {
+            auto fetch = [&](long long m, float& yv, float& g, float& pre_in, float& r, float& zr) {
                 yv = a.y[m * a.y_cstride + a.y_coff + c];
                 g = a.dy[m * a.dy_cstride + a.dy_coff + c];
                 pre_in = a.pre ? a.pre[m * a.C + c] : 0.f;
+                zr = a.zraw ? a.zraw[m * a.C + c] : 0.f;
                 r = 0.f;
                 if (a.res1) r += a.res1[m * a.r1_cstride + a.r1_coff + c];
                 if (a.res2) r += a.res2[m * a.r2_cstride + a.r2_coff + c];
@@ -452,16 +458,16 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
             // the sums are the same as a one-row loop's
             long long m = r0 + ty;
             for (; m + 3LL * TY < r1; m += 4LL * TY) {
-                float yv[4], g[4], pv[4], rv[4];
+                float yv[4], g[4], pv[4], rv[4], zv[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) fetch(m + (long long)u * TY, yv[u], g[u], pv[u], rv[u]);
+                for (int u = 0; u < 4; ++u) fetch(m + (long long)u * TY, yv[u], g[u], pv[u], rv[u], zv[u]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) element(m + (long long)u * TY, yv[u], g[u], pv[u], rv[u]);
+                for (int u = 0; u < 4; ++u) element(m + (long long)u * TY, yv[u], g[u], pv[u], rv[u], zv[u]);
             }
             for (; m < r1; m += TY) {
-                float yv, g, pv, rv;
-                fetch(m, yv, g, pv, rv);
-                element(m, yv, g, pv, rv);
+                float yv, g, pv, rv, zv;
+                fetch(m, yv, g, pv, rv, zv);
+                element(m, yv, g, pv, rv, zv);
             }
         }
         // add the TY row lanes of this channel (fixed order)
@@ -704,7 +710,8 @@ extern "C" int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff
                                     float* dconv, int dconv_cstride, int dconv_coff, float* dres, int dres_cstride,
                                     int dres_coff, float* dres2, int dres2_cstride, int dres2_coff, int dres_accumulate,
                                     float* dscale, float* dshift, int accumulate, const int* m_dev_or_null,
-                                    const float* pre_or_null, void* workspace, long long workspace_bytes, void* stream) {
+                                    const float* pre_or_null, const float* conv_raw_or_null, void* workspace,
+                                    long long workspace_bytes, void* stream) {
     TT_REQUIRE(dy && y && dconv && workspace && M > 0 && C > 0, "tt_conv_epilogue_bwd: bad argument");
     TT_REQUIRE(pre_or_null || act == TT_ACT_NONE || act == TT_ACT_RELU || act == TT_ACT_SIGMOID,
                "tt_conv_epilogue_bwd: activation %d needs the pre-activation (pass the recomputed scale*conv+shift+res)", act);
@@ -716,7 +723,7 @@ extern "C" int tt_conv_epilogue_bwd(const float* dy, int dy_cstride, int dy_coff
     a.r1_cstride = res1_cstride; a.r1_coff = res1_coff; a.r2_cstride = res2_cstride; a.r2_coff = res2_coff;
     a.dconv_cstride = dconv_cstride; a.dconv_coff = dconv_coff; a.dres_cstride = dres_cstride; a.dres_coff = dres_coff;
     a.dres2 = dres2; a.dres2_cstride = dres2_cstride; a.dres2_coff = dres2_coff; a.dres_accumulate = dres_accumulate;
-    a.act = act; a.m_dev = m_dev_or_null; a.pre = pre_or_null;
+    a.act = act; a.m_dev = m_dev_or_null; a.pre = pre_or_null; a.zraw = conv_raw_or_null;
     const int blocks = (int)(M < kEpiBlocks ? M : kEpiBlocks);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);

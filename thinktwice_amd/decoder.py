@@ -228,7 +228,8 @@ class ThinkTwiceDecoder:
         channel-last, lidar feature (unused: the LiDAR look branch is zeroed, DEC:186)]."""
         flat, bev, meas = flattend_BEV_feat, BEV_feat, measurement_feat
         taped = autodiff.TAPE is not None      # training: the layer-wise path (every op records its backward), one stream
-        if self.fused is not None and not taped:
+        from . import layers as _layers
+        if self.fused is not None and not taped and not _layers.BN_TRAIN:    # (the composite kernels fold eval-mode BN)
             return self._forward_fused(flat, bev, meas, parent_module, teacher_forcing_data, look_feature_metadata,
                                        channel_last_out)
         B = flat.shape[0]

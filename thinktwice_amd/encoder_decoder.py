@@ -73,6 +73,10 @@ class EncoderDecoder(torch.nn.Module):
         return self
 
     def train(self, mode=True):
+        """model.train(): `forward_train` / `train_step` then run the reference's TRAINING semantics -- batch-statistics
+        BatchNorm (SyncBN across ranks, configs/thinktwice.py:39; running statistics updated) and the live ASPP
+        Dropout(0.5) (lss.py:91).  model.eval() (the default) keeps running-statistics BatchNorm, which is also the
+        frozen-BN fine-tuning mode (`trainer.Trainer(frozen_bn=True)`).  `forward_inference` is eval-mode either way."""
         self.training = bool(mode)
         return self
 
@@ -185,10 +189,19 @@ class EncoderDecoder(torch.nn.Module):
     def forward_train(self, batch):
         """EncoderDecoder.forward_train (encoder_decoder_framework.py:147-191): the forward with the decoder's
         teacher-forcing pass, then every loss term as a device reduction (thinktwice_amd/losses.py, csrc/losses.hip).
-        BatchNorm layers use their running statistics -- what the reference computes under model.eval() and what a
-        frozen-BN fine-tune runs (golden F10 / F13); batch-statistics BN is not implemented.  The returned device scalars
+        Under model.eval() BatchNorm layers use their running statistics (golden F10 / F13: what the reference computes under
+        model.eval(), and the frozen-BN fine-tuning mode); under model.train() they normalise with batch statistics and the
+        ASPP dropout is live (golden F11 / F16: the reference under model.train()).  The returned device scalars
         carry no torch autograd graph: inside `with autodiff.Tape()` the forward ops and the loss terms record their
         backward on the tape (trainer.Trainer.step runs it)."""
+        from . import layers
+        saved, layers.BN_TRAIN = layers.BN_TRAIN, bool(self.training)
+        try:
+            return self._forward_train(batch)
+        finally:
+            layers.BN_TRAIN = saved
+
+    def _forward_train(self, batch):
         from . import losses as LS
         if self._loss_red is None:
             self._loss_red = LS.LossReducer(self.device)

@@ -52,7 +52,7 @@ class FlattenTail:
         f4 = self.m4(self.c10(f10))
         f2 = self.m2(self.c4(f4))
         h = unrows(self.fc0(f2.view(f2.shape[0], 1, 1, 1024)))
-        h = ops.affine_rows(h, self.bn[0], self.bn[1])
+        h = self.bn(h)                                   # BatchNorm1d (output_fc.2)
         flat = unrows(self.fc3(rows(h)))
         return (flat, [f10, f4, f2]) if want_mids else flat
 

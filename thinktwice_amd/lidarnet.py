@@ -79,19 +79,27 @@ def _sp_weight(w, dev, dtype):
     return (out, weights.split_pairs_x3(out) if dtype == weights.X3 else None)
 
 
-def _bn1d(sd, p, dev, eps=1e-3):
+def _bn1d(sd, p, dev, eps=1e-3, momentum=0.01):
+    """(folded eval scale, folded eval shift, train-mode spec) of a BatchNorm1d over sparse rows (mmdet3d SparseEncoder
+    norm_cfg: eps 1e-3, momentum 0.01)."""
     s = sd[p + ".weight"].float() / torch.sqrt(sd[p + ".running_var"].float() + eps)
     t = sd[p + ".bias"].float() - sd[p + ".running_mean"].float() * s
-    return s.to(dev).contiguous(), t.to(dev).contiguous()
+    from . import layers
+    return s.to(dev).contiguous(), t.to(dev).contiguous(), layers._bn_spec(sd, p, dev, eps, momentum)
 
 
 def _sp_conv(feats, nbr, level, w, bn, res=None, relu=True, plan=None, in_level=None, stride=1):
     """SubMConv3d / SparseConv3d + BN1d (+ residual) + ReLU as ONE gathered MFMA GEMM (with the rulebook's tile plan:
     rows sorted by tap mask, each 256-row tile multiplies only the taps that exist in it).  `in_level`: the input level of
     a strided layer (the training tape transposes its rulebook)."""
-    return ops.gather_conv(feats, nbr, level.rows, w[0], scale=bn[0], shift=bn[1], res=res,
-                           act=_lib.ACT_RELU if relu else _lib.ACT_NONE, w_x3=w[1], plan=plan,
-                           in_rows=None if in_level is None else (in_level.rows, in_level.max_rows), stride=stride)
+    from . import layers
+    in_rows = None if in_level is None else (in_level.rows, in_level.max_rows)
+    act = _lib.ACT_RELU if relu else _lib.ACT_NONE
+    if layers.BN_TRAIN:     # model.train(): raw rulebook GEMM, then batch statistics over the live rows
+        z = ops.gather_conv(feats, nbr, level.rows, w[0], w_x3=w[1], plan=plan, in_rows=in_rows, stride=stride, bn_raw=True)
+        return ops.batchnorm_train(z, bn[2], act, res1=res, m_dev=level.rows)
+    return ops.gather_conv(feats, nbr, level.rows, w[0], scale=bn[0], shift=bn[1], res=res, act=act, w_x3=w[1], plan=plan,
+                           in_rows=in_rows, stride=stride)
 
 
 @MIDDLE_ENCODERS.register_module()
@@ -209,14 +217,15 @@ class LidarNet:
         dev, p = self.device, prefix
         self.middle.load_state_dict(sd, p + ".pts_middle_encoder")
         eps = self.bb.get("bn_eps", 1e-3)
+        mom = 0.01                                   # norm_cfg momentum of SECOND / SECONDFPN (configs/thinktwice.py:183,190)
         self.blocks = []
         for b, (n, s) in enumerate(zip(self.bb["layer_nums"], self.bb["layer_strides"])):
             q = f"{p}.pts_backbone.blocks.{b}"
             self.blocks.append([conv_from_sd(sd, f"{q}.{3 * l}", self.wdtype, dev, bn=f"{q}.{3 * l + 1}", eps=eps,
-                                             stride=s if l == 0 else 1, pad=1, act="relu") for l in range(n + 1)])
+                                             stride=s if l == 0 else 1, pad=1, act="relu", bn_momentum=mom) for l in range(n + 1)])
         q = p + ".pts_neck.deblocks"
-        self.de0 = conv_from_sd(sd, q + ".0.0", self.wdtype, dev, bn=q + ".0.1", eps=eps, act="relu")
-        self.de1 = deconv2x2_from_sd(sd, q + ".1.0", self.wdtype, dev, bn=q + ".1.1", eps=eps, act="relu")
+        self.de0 = conv_from_sd(sd, q + ".0.0", self.wdtype, dev, bn=q + ".0.1", eps=eps, act="relu", bn_momentum=mom)
+        self.de1 = deconv2x2_from_sd(sd, q + ".1.0", self.wdtype, dev, bn=q + ".1.1", eps=eps, act="relu", bn_momentum=mom)
         return self
 
     def voxelize(self, pts):

@@ -219,7 +219,7 @@ class LSS:
         NI, h, w, _ = src.shape
         dev, dt = src.device, self.dtype
         m24 = torch.zeros(mlp_in.shape[0], 24, dtype=torch.float32, device=dev)
-        ops.affine_rows(mlp_in, self.bn22[0], self.bn22[1], out=m24)
+        self.bn22(mlp_in, out=m24)        # BatchNorm1d(22) of the camera-parameter vector (train mode: batch statistics)
         x = self.reduce(src)
         g_ctx = ops.repeat_rows(self._se_gate("context", m24), T)
         g_dep = ops.repeat_rows(self._se_gate("depth", m24), T)
@@ -233,8 +233,12 @@ class LSS:
         for i, br in enumerate(self.aspp):
             br(d, out=cat, out_coff=i * mid)
         x5 = self.aspp_gap(rows(ops.spatial_pool(d, 0)))                 # (NI,1,1,mid) f32
-        shift_n = unrows(self.aspp_gapw(x5)).contiguous()                # bn_scale * (W5 @ x5)
+        # eval: bn_scale * (W5 @ x5) joins the folded epilogue; train: the raw W5 @ x5 joins the raw conv in front of the BN
+        self.aspp_gapw.scale = None if layers.BN_TRAIN else self.aspp_out.scale
+        shift_n = unrows(self.aspp_gapw(x5)).contiguous()
         d = self.aspp_out(cat, shift_n=shift_n, shift_n_mod=NI)
+        if layers.BN_TRAIN:
+            d = ops.dropout(d, 0.5)                                      # ASPP nn.Dropout(0.5), lss.py:91,110
         off = self.dcn_off(d, out_dtype=torch.float32)
         cols = ops.deform_im2col3x3(d, off, pad=1)
         dd = torch.empty(NI, h, w, mid, dtype=dt, device=dev)
@@ -321,18 +325,21 @@ class LSS:
                     ops.check(ops.lib().tt_nchw_to_nhwc_pad(ops.ptr(src), ops.ptr(x[o:o + N]), N, C, H, W,
                                                             x.shape[-1], ops.dtype_code(x),
                                                             ops.cur_stream(img.device)), "tt_nchw_to_nhwc_pad")
-        bufs = self._trunk(x, bordered=border is not None)
-        fpn2_buf, fpn2_off, _ = self._fpn_views(bufs)[2]
-        src = self.neck_conv(fpn2_buf, in_coff=fpn2_off, cin=256)
-        mlp_in = consts["mlp_in"]
-        depth, merge_in = self._depth_net(src, mlp_in, T)
-        # keep FPN maps of the key sweep before the UNet overwrites nothing of them (offset slices)
-        seg = self._seg_net(bufs)
-        f = seg
-        for i, cv in enumerate(self.seg2feat[:-1]):
-            f = cv(f, stop_grad=(i == 0))          # lss.py:589: the seg logits enter this branch detached
-        self.seg2feat[-1](f, out=merge_in, out_coff=256)
-        ctx = self.merge(merge_in, out_dtype=torch.float32)
+        # train mode: the T sweeps are T equal image groups; every BatchNorm below normalises each with its own batch
+        # statistics, like the reference's one-pass-per-sweep loop (lss.py:690-717)
+        with layers.bn_groups(T):
+            bufs = self._trunk(x, bordered=border is not None)
+            fpn2_buf, fpn2_off, _ = self._fpn_views(bufs)[2]
+            src = self.neck_conv(fpn2_buf, in_coff=fpn2_off, cin=256)
+            mlp_in = consts["mlp_in"]
+            depth, merge_in = self._depth_net(src, mlp_in, T)
+            # keep FPN maps of the key sweep before the UNet overwrites nothing of them (offset slices)
+            seg = self._seg_net(bufs)
+            f = seg
+            for i, cv in enumerate(self.seg2feat[:-1]):
+                f = cv(f, stop_grad=(i == 0))          # lss.py:589: the seg logits enter this branch detached
+            self.seg2feat[-1](f, out=merge_in, out_coff=256)
+            ctx = self.merge(merge_in, out_dtype=torch.float32)
         geom = self.geometry(consts["gm"], B, N)
         vx, vy, vz = (int(v) for v in self.voxel_num)
         OC = self.output_channels

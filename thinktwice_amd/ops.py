@@ -133,7 +133,7 @@ def sp_tile_plan(nbr, m_dev):
 
 
 def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None, out_dtype=None, w_x3=None, plan=None,
-                out=None, in_rows=None, stride=1, _no_tape=False):
+                out=None, in_rows=None, stride=1, _no_tape=False, bn_raw=False):
     """Sparse convolution as a gathered GEMM on MFMA: feats [R_in, C] rows, nbr int32 [M, taps]
     (rulebook, -1 = no input), m_dev device int (live output rows), w [Cout,1,taps,C] -> [M, Cout].  `stride`: the spatial
     stride of the sparse conv the rulebook came from (a dispatch hint: stride-1 rulebooks of cell-ordered rows take the
@@ -175,7 +175,7 @@ def gather_conv(feats, nbr, m_dev, w, *, scale=None, shift=None, act=0, res=None
     if not _no_tape:
         from . import autodiff
         if autodiff.TAPE is not None:
-            autodiff.TAPE.gather_conv(feats, nbr, m_dev, w, scale, shift, act, res, out, in_rows)
+            autodiff.TAPE.gather_conv(feats, nbr, m_dev, w, scale, shift, act, res, out, in_rows, bn_raw)
     return out
 
 
@@ -229,7 +229,7 @@ def sp_from_dense(gdense, coords, rows, max_rows, dims, grows):
 def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=None, res1_coff=0,
            res2=None, res2_coff=0, out=None, out_coff=0, in_coff=0, cin=None, pixel_shuffle2=False,
            shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None, splitk_ws=None,
-           in_cstride=None, w_x3=None, _no_tape=False, stop_grad=False):
+           in_cstride=None, w_x3=None, _no_tape=False, stop_grad=False, bn_raw=False):
     """Channel-last implicit-GEMM convolution on MFMA (tt_conv2d_fwd).
 
     x   [N,H,W,Cs]  (f32 or bf16); channels [in_coff, in_coff+cin) are convolved
@@ -300,7 +300,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
         from . import autodiff
         if autodiff.TAPE is not None:
             autodiff.TAPE.conv(x, w, out, stride, pad, dil, scale, shift, act, in_coff, cin, out_coff, res1, res1_coff,
-                               res2, res2_coff, pixel_shuffle2, in_cstride, shift_n, shift_n_mod, stop_grad)
+                               res2, res2_coff, pixel_shuffle2, in_cstride, shift_n, shift_n_mod, stop_grad, bn_raw)
     return out
 
 
@@ -311,6 +311,134 @@ _f = ctypes.c_float
 
 def _st(t):
     return cur_stream(t.device)
+
+
+# ----------------------------------------------------------------------------- train-mode BatchNorm / dropout
+BN_SYNC = True          # SyncBN (configs/thinktwice.py:39): all-reduce the batch statistics when torch.distributed runs > 1 rank
+DROPOUT_MASKS = None    # tests: iterator of host uint8 keep-masks (the reference's torch masks) consumed by dropout()
+DROPOUT_SEED = [0x5EED, 0]    # [seed, calls so far]: the product's counter-based generator
+
+
+def _all_reduce_sum_(t):
+    """In-place SUM over the ranks (no-op on a single rank): the SyncBN statistic exchange."""
+    import torch.distributed as dist
+    if not (BN_SYNC and dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    if t.is_cuda and dist.get_backend() == "gloo":        # CPU test rigs: stage through the host
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+class BNSpec:
+    """One BatchNorm layer's tensors for the train-mode path (device f32): affine, running statistics (updated in place),
+    eps / momentum, and the state_dict prefix the parameter gradients are filed under."""
+
+    def __init__(self, name, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+        self.name, self.gamma, self.beta, self.running_mean, self.running_var = name, gamma, beta, running_mean, running_var
+        self.eps, self.momentum = float(eps), float(momentum)
+
+
+def _bn_ws(C, groups, dev):
+    L = lib()
+    L.tt_bn_workspace_bytes.restype = ctypes.c_longlong
+    nb = int(L.tt_bn_workspace_bytes(_c(C), _c(groups)))
+    return torch.empty(nb, dtype=torch.uint8, device=dev), nb
+
+
+def batchnorm_train(z, spec, act=0, res1=None, res1_coff=0, res2=None, res2_coff=0, out=None, out_coff=0, m_dev=None,
+                    groups=1, update_running=True):
+    """y = act(BN_batch(z) + res1 + res2): z [..., C] dense f32 rows (the raw conv output, bias included); out: row-linear
+    buffer [..., Ct] written at channel offset out_coff (allocated if None).  `groups` equal row groups get their own
+    statistics; m_dev: device count of live rows (sparse levels).  SyncBN: one all-reduce of the statistics block."""
+    require_cuda(z)
+    assert z.dtype == torch.float32 and z.is_contiguous()
+    C = z.shape[-1]
+    M = z.numel() // C
+    dev = z.device
+    if out is None:
+        out = torch.empty_like(z)
+    assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() // out.shape[-1] == M, (out.shape, z.shape)
+    for r in (res1, res2):
+        assert r is None or (r.is_contiguous() and r.dtype == torch.float32 and r.numel() // r.shape[-1] == M)
+    stats = torch.empty(groups, 2 * C + 2, dtype=torch.float64, device=dev)
+    ws, nb = _bn_ws(C, groups, dev)
+    st = _st(z)
+    L = lib()
+    check(L.tt_bn_stats(ptr(z), _ll(M), _c(C), _c(C), _c(0), ptr(m_dev), _c(groups), ptr(stats), ptr(ws), _ll(nb), st),
+          "tt_bn_stats")
+    _all_reduce_sum_(stats)
+    scale, shift, mean, invstd = (torch.empty(groups, C, dtype=torch.float32, device=dev) for _ in range(4))
+    check(L.tt_bn_finalize(ptr(stats), _c(C), _c(groups), ptr(spec.gamma), ptr(spec.beta), _f(spec.eps), _f(spec.momentum),
+                           ptr(spec.running_mean if update_running else None),
+                           ptr(spec.running_var if update_running else None), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                           st), "tt_bn_finalize")
+
+    def cs(t):
+        return 0 if t is None else t.shape[-1]
+    check(L.tt_bn_apply(ptr(z), _ll(M), _c(C), _c(C), _c(0), ptr(m_dev), _c(groups), ptr(scale), ptr(shift), ptr(res1),
+                        _c(cs(res1)), _c(res1_coff), ptr(res2), _c(cs(res2)), _c(res2_coff), _c(act), ptr(out),
+                        _c(out.shape[-1]), _c(out_coff), st), "tt_bn_apply")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.bn_train(z, out, out_coff, spec, act, res1, res1_coff, res2, res2_coff, m_dev, groups, stats, scale,
+                               mean, invstd)
+    return out
+
+
+def batchnorm_train_bwd(dy, dy_coff, y, y_coff, z, mean, invstd, scale, stats, act, dres1, dres1_coff, dres2, dres2_coff, dz,
+                        m_dev=None, groups=1):
+    """Backward of batchnorm_train: dy (the gradient buffer of `out`, its channel window is overwritten with g), -> dz
+    written, dres* accumulated; returns (dgamma [C], dbeta [C]) from the LOCAL sums."""
+    C = z.shape[-1]
+    M = z.numel() // C
+    dev = z.device
+    sums = torch.empty(groups, 2 * C, dtype=torch.float64, device=dev)
+    ws, nb = _bn_ws(C, groups, dev)
+    st = _st(z)
+    L = lib()
+
+    def cs(t):
+        return 0 if t is None else t.shape[-1]
+    check(L.tt_bn_bwd_reduce(ptr(dy), _c(dy.shape[-1]), _c(dy_coff), ptr(y), _c(y.shape[-1]), _c(y_coff), ptr(z), _c(C), _c(0),
+                             _ll(M), _c(C), ptr(m_dev), _c(groups), ptr(mean), ptr(invstd), _c(act), ptr(dres1), _c(cs(dres1)),
+                             _c(dres1_coff), ptr(dres2), _c(cs(dres2)), _c(dres2_coff), ptr(sums), ptr(ws), _ll(nb), st),
+          "tt_bn_bwd_reduce")
+    local = sums.sum(0).to(torch.float32)
+    _all_reduce_sum_(sums)
+    check(L.tt_bn_bwd_apply(ptr(dy), _c(dy.shape[-1]), _c(dy_coff), ptr(z), _c(C), _c(0), _ll(M), _c(C), ptr(m_dev), _c(groups),
+                            ptr(sums), ptr(stats), ptr(scale), ptr(mean), ptr(invstd), ptr(dz), _c(dz.shape[-1]), _c(0), st),
+          "tt_bn_bwd_apply")
+    return local[C:].contiguous(), local[:C].contiguous()
+
+
+def dropout(x, p=0.5):
+    """nn.Dropout(p) in train mode (lss.py:91,110).  Keep-mask from the counter-based device generator, or -- tests -- the next
+    host mask of DROPOUT_MASKS (the reference's own torch mask, in x's channel-last layout)."""
+    require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty_like(x)
+    mask = torch.empty(x.numel(), dtype=torch.uint8, device=x.device)
+    mask_in = None
+    if DROPOUT_MASKS is not None:
+        mask_in = next(DROPOUT_MASKS).to(device=x.device, dtype=torch.uint8).contiguous()
+        assert mask_in.numel() == x.numel()
+    DROPOUT_SEED[1] += 1
+    seed = (DROPOUT_SEED[0] * 0x100000001B3 + DROPOUT_SEED[1] * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    check(lib().tt_dropout_fwd(ptr(x), ptr(out), _ll(x.numel()), _f(p), ctypes.c_ulonglong(seed), ptr(mask_in), ptr(mask),
+                               _st(x)), "tt_dropout_fwd")
+    from . import autodiff
+    if autodiff.TAPE is not None:
+        autodiff.TAPE.dropout(x, out, mask, p)
+    return out
+
+
+def dropout_bwd(dout, mask, dx, p):
+    assert dout.is_contiguous() and dx.is_contiguous()
+    check(lib().tt_dropout_bwd(ptr(dout), ptr(mask), ptr(dx), _ll(dout.numel()), _f(p), _st(dout)), "tt_dropout_bwd")
 
 
 def nchw_to_nhwc_border(x, out, top, left):
@@ -768,7 +896,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, dil=1, x3=True, out=None, out_co
 
 def conv_epilogue_bwd(dy, y, scale=None, shift=None, act=0, res1=None, res2=None, want_dres=False, dscale=None, dshift=None,
                       accumulate=False, C=None, dy_coff=0, y_coff=0, res1_coff=0, res2_coff=0, dres1=None, dres1_coff=0,
-                      dres2=None, dres2_coff=0, dres_accumulate=True, m_dev=None, pre=None):
+                      dres2=None, dres2_coff=0, dres_accumulate=True, m_dev=None, pre=None, conv_raw=None):
     """Backward of conv2d's fused epilogue (tt_conv_epilogue_bwd): dy / y / res* [..., Cs] f32 channel-last views of the
     same M rows (row stride = last dim) -> (dconv [M, C] dense f32, dres, dscale [C], dshift [C]).  `dres1` / `dres2`:
     gradient buffers of the residual inputs, g is added to (or, dres_accumulate=False, written over) their channel
@@ -800,7 +928,7 @@ def conv_epilogue_bwd(dy, y, scale=None, shift=None, act=0, res1=None, res2=None
                                  ptr(scale), ptr(shift), _ll(M), _c(C), _c(act), ptr(dconv), _c(C), _c(0),
                                  ptr(dres1), _c(cs(dres1)), _c(dres1_coff), ptr(dres2), _c(cs(dres2)), _c(dres2_coff),
                                  _c(1 if dres_accumulate else 0), ptr(dscale if scale is not None else None), ptr(dshift),
-                                 _c(1 if accumulate else 0), ptr(m_dev), ptr(pre), ptr(ws), _ll(nb), _st(y)),
+                                 _c(1 if accumulate else 0), ptr(m_dev), ptr(pre), ptr(conv_raw), ptr(ws), _ll(nb), _st(y)),
           "tt_conv_epilogue_bwd")
     return dconv, dres, (dscale if scale is not None else None), dshift
 

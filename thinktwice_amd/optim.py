@@ -23,8 +23,20 @@ class FlatAdamW:
         self._ws = torch.empty(1024, dtype=torch.float32, device=flat_param.device)
         self.norm_scale = torch.zeros(2, dtype=torch.float32, device=flat_param.device)   # [||g||, clip factor]
 
-    def step(self, lr=None):
-        """One optimizer step; returns the (device) tensor [grad norm, clip factor] of this step."""
+    def state_dict(self):
+        """Adam moments + step count (what an mmcv checkpoint's `optimizer` entry carries for a resume)."""
+        return {"exp_avg": self.m.detach().clone().cpu(), "exp_avg_sq": self.v.detach().clone().cpu(), "step": self.steps,
+                "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["exp_avg"].to(self.m.device))
+        self.v.copy_(sd["exp_avg_sq"].to(self.v.device))
+        self.steps = int(sd["step"])
+
+    def step(self, lr=None, live_ranges=None):
+        """One optimizer step; returns the (device) tensor [grad norm, clip factor] of this step.  `live_ranges`: [(offset,
+        count)] element ranges to update -- torch's AdamW skips parameters whose .grad is None (the reference's 90 dead
+        ones: no weight decay, no moment update); the ranges of the others, merged, are what this step touches."""
         n = ctypes.c_longlong(self.p.numel())
         st = cur_stream(self.p.device)
         scale = None
@@ -33,8 +45,22 @@ class FlatAdamW:
                   "tt_grad_norm_clip")
             scale = ctypes.c_void_p(self.norm_scale.data_ptr() + 4)
         self.steps += 1
-        check(lib().tt_adamw_step(ptr(self.p), ptr(self.g), ptr(self.m), ptr(self.v), n,
-                                  _f(self.lr if lr is None else lr), _f(self.betas[0]), _f(self.betas[1]),
-                                  _f(self.eps), _f(self.wd), ctypes.c_int(self.steps),
-                                  scale if scale is not None else ctypes.c_void_p(0), st), "tt_adamw_step")
+        for off, cnt in (live_ranges if live_ranges is not None else [(0, self.p.numel())]):
+            at = lambda t: ctypes.c_void_p(t.data_ptr() + 4 * off)
+            check(lib().tt_adamw_step(at(self.p), at(self.g), at(self.m), at(self.v), ctypes.c_longlong(cnt),
+                                      _f(self.lr if lr is None else lr), _f(self.betas[0]), _f(self.betas[1]),
+                                      _f(self.eps), _f(self.wd), ctypes.c_int(self.steps),
+                                      scale if scale is not None else ctypes.c_void_p(0), st), "tt_adamw_step")
         return self.norm_scale
+
+
+def warmup_cosine_lr(base_lr, it, total_iters, warmup_iters=1000, warmup_ratio=1.0 / 3, min_lr_ratio=1e-3):
+    """Learning rate of iteration `it` (0-based) under the reference's lr_config (configs/thinktwice.py:289-294: mmcv
+    CosineAnnealingLrUpdaterHook, by iteration here, with linear warmup): cosine from base_lr to base_lr * min_lr_ratio over the
+    run; during the first `warmup_iters` iterations that value is scaled by 1 - (1 - it / warmup_iters) * (1 - warmup_ratio)."""
+    import math
+    target = base_lr * min_lr_ratio
+    lr = target + 0.5 * (base_lr - target) * (1.0 + math.cos(math.pi * min(it, total_iters) / max(1, total_iters)))
+    if it < warmup_iters:
+        lr *= 1.0 - (1.0 - it / warmup_iters) * (1.0 - warmup_ratio)
+    return lr

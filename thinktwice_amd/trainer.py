@@ -31,11 +31,16 @@ def _trainable(name, t):
 
 class Trainer:
     def __init__(self, model, state_dict, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7, max_grad_norm=100.0,
-                 x3=None):
+                 x3=None, frozen_bn=True):
         """`model`: an EncoderDecoder (dtype torch.float32 or "f32x3"); `state_dict`: reference-format weights.  `x3`: input
-        gradients of the convolutions through the bf16x3 kernel (default: when the model's forward uses it)."""
+        gradients of the convolutions through the bf16x3 kernel (default: when the model's forward uses it).
+        `frozen_bn=False`: the reference's training semantics (model.train(): batch-statistics BatchNorm with SyncBN across
+        the ranks, running statistics updated in `self.buffers`, live ASPP dropout; goldens F11 / F16).  `frozen_bn=True`:
+        BatchNorm on its running statistics (model.eval() arithmetic, goldens F10 / F13) -- fine-tuning with frozen
+        statistics; the BatchNorm affine parameters still train."""
         dev = model.device
         self.model = model
+        self.frozen_bn = bool(frozen_bn)
         self.x3 = (model.dtype != torch.float32) if x3 is None else x3
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items() if k != "_metadata"}
         self.names = [k for k, v in sd.items() if _trainable(k, v)]
@@ -57,7 +62,13 @@ class Trainer:
                              max_grad_norm=max_grad_norm)
         self.param_grads = None
         self._prepare_on_device = os.environ.get("TT_TRAIN_PREPARE", "device") != "host"
-        self._dev_buffers = None
+        # BatchNorm running statistics: device copies the prepared layers alias (train mode updates them in place)
+        self.buffers = {k: v.to(dev, torch.float32).contiguous() for k, v in self.sd.items()
+                        if torch.is_tensor(v) and k.endswith(("running_mean", "running_var"))}
+        self._dev_buffers = self.buffers
+        if not self.frozen_bn and not self._prepare_on_device:
+            raise ValueError("Trainer(frozen_bn=False) keeps the running statistics on the device: TT_TRAIN_PREPARE=host "
+                             "is a frozen-BN path")
         self._prepare()
 
     def _prepare(self):
@@ -69,12 +80,11 @@ class Trainer:
         autodiff.clear_metas()
         with torch.no_grad():
             if self._prepare_on_device:
-                if self._dev_buffers is None:
-                    self._dev_buffers = {k: v.to(self.flat_param.device) for k, v in self.sd.items()
-                                         if torch.is_tensor(v) and k.endswith(("running_mean", "running_var"))}
                 try:
                     self.model.load_state_dict({k: (v.detach() if k in self._trainable else self._dev_buffers.get(k, v))
                                                 for k, v in self.sd.items()})
+                    if self.frozen_bn:
+                        autodiff.refresh_small_scale_flags()
                     return
                 except (RuntimeError, TypeError) as e:
                     print(f"[trainer] device-side operand preparation failed ({type(e).__name__}: {e}); "
@@ -87,10 +97,27 @@ class Trainer:
         """Forward + losses + reverse sweep: fills the flat gradient buffer (no collective, no update).  Returns
         dict(loss, log_vars, num_samples) of train_step."""
         self.grads.zero_()
-        with autodiff.Tape(x3=self.x3) as tape:
-            out = self.model.train_step(batch, None)
-            tape.backward()
+        was_training = self.model.training
+        self.model.train(not self.frozen_bn)
+        try:
+            with autodiff.Tape(x3=self.x3) as tape:
+                out = self.model.train_step(batch, None)
+                tape.backward()
+        finally:
+            self.model.train(was_training)
         self.param_grads = tape.param_grads
+        # element ranges of the parameters that received a gradient (the others are skipped by the optimizer like torch's
+        # grad-is-None parameters): merged runs in flat-buffer order
+        runs, off = [], 0
+        for k in self.names:
+            n = self.sd[k].numel()
+            if k in tape.param_grads:
+                if runs and runs[-1][0] + runs[-1][1] == off:
+                    runs[-1][1] += n
+                else:
+                    runs.append([off, n])
+            off += n
+        self.live_ranges = [tuple(r) for r in runs]
         unknown = [k for k in tape.param_grads if k not in self.sd]
         assert not unknown, f"gradients for names outside the state_dict: {unknown[:5]}"
         for k, g in tape.param_grads.items():
@@ -101,10 +128,36 @@ class Trainer:
         """One iteration; adds `grad_norm` (device tensor [norm, clip factor]) to train_step's dict."""
         out = self.backward(batch)
         self.grads.all_reduce_mean()
-        out["grad_norm"] = self.opt.step(lr)
+        out["grad_norm"] = self.opt.step(lr, live_ranges=self.live_ranges)
+        if not bool(torch.isfinite(out["grad_norm"][0])):
+            raise FloatingPointError("Trainer.step: non-finite gradient norm (the update was NOT applied cleanly); "
+                                     "restore from the last checkpoint")
         self._prepare()
         return out
 
     def state_dict(self):
-        """Reference-format weights (own copies: the master tensors are views of one flat buffer)."""
-        return {k: (v.detach().clone() if k in self._trainable else v) for k, v in self.sd.items()}
+        """Reference-format weights (own copies: the master tensors are views of one flat buffer), BatchNorm running
+        statistics as they stand now."""
+        out = {}
+        for k, v in self.sd.items():
+            if k in self._trainable:
+                out[k] = v.detach().clone()
+            elif k in self.buffers:
+                out[k] = self.buffers[k].detach().clone().cpu()
+            else:
+                out[k] = v
+        return out
+
+    def checkpoint(self):
+        """What an mmcv checkpoint holds for a resume (configs/thinktwice.py:292 checkpoint_config): weights + optimizer."""
+        return {"state_dict": self.state_dict(), "optimizer": self.opt.state_dict()}
+
+    def load_checkpoint(self, ckpt):
+        sd = ckpt["state_dict"]
+        with torch.no_grad():
+            for k in self.names:
+                self.sd[k].copy_(sd[k].to(self.sd[k].device, torch.float32))
+            for k, b in self.buffers.items():
+                b.copy_(sd[k].to(b.device, torch.float32))
+        self.opt.load_state_dict(ckpt["optimizer"])
+        self._prepare()

@@ -21,12 +21,29 @@ def load(d):
     return out
 
 
+def stamp():
+    """Identity of the build the counters were taken from: source fingerprint (+ git HEAD when the tree
+    has one); bench.py refuses counter data whose fingerprint differs from the tree it runs from."""
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    sys.path.insert(0, root)
+    from thinktwice_amd import build
+    out = {"csrc_sha": build.source_fingerprint()}
+    try:
+        out["git_head"] = subprocess.check_output(["git", "-C", root, "rev-parse", "HEAD"], stderr=subprocess.DEVNULL,
+                                                  text=True).strip()
+    except Exception:
+        out["git_head"] = None
+    return out
+
+
 def main():
-    res = {}
+    res = {"_stamp": stamp()}
     for d in sys.argv[1:]:
         for (name, c), (n, tot) in load(d).items():
             short = name.split("(")[0].replace("void ", "").replace("tt::", "")[:110]    # keep the kernel name itself
             res.setdefault(short, {})[c] = {"dispatches": n, "sum": tot, "per_dispatch": tot / max(n, 1)}
+    res["_stamp"]["kernels"] = sorted(k for k in res if k != "_stamp")
     print(json.dumps(res, indent=1))
 
 
