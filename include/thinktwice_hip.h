@@ -547,9 +547,10 @@ int tt_lidar_merge_half_sweeps(const float* prev_xyzi, int n_prev, const float* 
  * one pass per sweep in the reference, lss.py:690-717); m_dev != NULL: sparse rows, live count on the device, groups == 1.
  *   stats  : double [groups][2C + 2] = per-channel sum | sum of squares | row count | 0 -- the block a SyncBN all-reduce
  *            (SUM) runs over, between tt_bn_stats and tt_bn_finalize
- *   scale / shift / mean / invstd : float [groups][C]; running_mean / running_var (nullable) are updated like torch does
+ *   scale (= gamma * invstd) / shift (= beta) / mean / invstd : float [groups][C]; running_mean / running_var (nullable) are updated like torch does
  *            (momentum, unbiased variance), group 0 (the key sweep) first, like lss.py:689-714
- *   tt_bn_apply      out[m][out_coff + c] = act(z * scale + shift + res1 + res2), act in {TT_ACT_NONE, TT_ACT_RELU}
+ *   tt_bn_apply      out[m][out_coff + c] = act((z - mean) * scale + shift + res1 + res2), act in {TT_ACT_NONE, TT_ACT_RELU}
+ *            (centred like torch: folding the mean into the shift loses ulp(mean * scale) where the variance is ~0)
  *   tt_bn_bwd_reduce dy := dy * act'(y) in place, dres += it, sums = double [groups][2C] = sum g | sum g * xhat (LOCAL;
  *            dgamma / dbeta are these; under SyncBN they are all-reduced before tt_bn_bwd_apply)
  *   tt_bn_bwd_apply  dz = scale * (g - sum_g / n - xhat * sum_gxhat / n), n = stats[g][2C]
@@ -561,7 +562,7 @@ int tt_bn_finalize(const double* stats, int C, int groups, const float* gamma, c
                    float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd,
                    void* stream);
 int tt_bn_apply(const float* z, long long M, int C, int z_cstride, int z_coff, const int* m_dev, int groups,
-                const float* scale, const float* shift, const float* res1, int r1_cstride, int r1_coff, const float* res2,
+                const float* scale, const float* shift, const float* mean, const float* res1, int r1_cstride, int r1_coff, const float* res2,
                 int r2_cstride, int r2_coff, int act, float* out, int out_cstride, int out_coff, void* stream);
 int tt_bn_bwd_reduce(float* dy, int dy_cstride, int dy_coff, const float* y, int y_cstride, int y_coff, const float* z,
                      int z_cstride, int z_coff, long long M, int C, const int* m_dev, int groups, const float* mean,

@@ -383,6 +383,9 @@ def gen_f10():
     _save("f10_train_losses_b2.npz", **pack)
 
 
+TRAIN_CALIB_JITTER = 77      # seed of the per-(sample, camera) calibration jitter of the train-mode goldens F11 / F16
+
+
 def gen_f11():
     """F11: as F10 but under model.train(): batch-statistics BatchNorm everywhere (each sweep through the camera trunk
     on its own) and the live ASPP Dropout(0.5); the same torch seed is set before the reference and the oracle
@@ -393,7 +396,7 @@ def gen_f11():
     cfg = config.model_config(final_dim=hw)
     sd = params.init_params(cfg, seed=seed)
     model = build_reference_model(cfg, sd)
-    batch = synth.make_batch(B, img_hw=hw, num_points=npts)
+    batch = synth.make_batch(B, img_hw=hw, num_points=npts, jitter_calib=TRAIN_CALIB_JITTER)   # (see synth.make_img_metas)
     batch.update(synth.make_train_targets(B, img_hw=hw))
     model.train()
     with torch.no_grad(), TR.train_mode():            # the third-party stand-ins call the oracle blocks: same switch
@@ -411,7 +414,7 @@ def gen_f11():
         print(f"  {k:40s} {tuple(v.shape)} ref {float(v.mean()):+.6e}  oracle rel err {e:.2e}")
         pack[k] = v.numpy()
     assert worst < 1e-5, worst
-    pack["meta"] = np.array([B, hw[0], hw[1], npts, seed, rng])
+    pack["meta"] = np.array([B, hw[0], hw[1], npts, seed, rng, TRAIN_CALIB_JITTER])
     pack["oracle_vs_reference_worst_rel_err"] = np.array([worst])
     _save("f11_train_losses_trainmode_b2.npz", **pack)
 
@@ -445,7 +448,7 @@ def _gen_gradients(fname, train):
     B, hw, npts, seed = 2, (128, 256), 20000, 0
     cfg = config.model_config(final_dim=hw)
     sd = params.init_params(cfg, seed=seed)
-    batch = synth.make_batch(B, img_hw=hw, num_points=npts)
+    batch = synth.make_batch(B, img_hw=hw, num_points=npts, jitter_calib=TRAIN_CALIB_JITTER if train else None)
     batch.update(synth.make_train_targets(B, img_hw=hw))
     import contextlib
     rng = 20240607
@@ -501,6 +504,7 @@ def _gen_gradients(fname, train):
     if train:       # the loss terms too (F11 holds them for the no-grad forward; here from the run the gradients belong to)
         extra = {"loss__" + k: v.detach().float().numpy() for k, v in losses.items()}
         extra["rng"] = np.array([rng])
+        extra["calib_jitter"] = np.array([TRAIN_CALIB_JITTER])
         extra["noise"] = np.array(noise)
     _save(fname, names=np.array(names), norms=np.array(norms), idx=np.stack(idxs),
           samples=np.stack(samples), dead=np.array(dead), total_loss=np.array([float(loss_ref)]),

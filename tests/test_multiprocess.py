@@ -137,3 +137,98 @@ def test_parse_losses_two_ranks_gloo():
     assert abs(v0["wp_loss"] - 1.5) < 1e-6 and abs(v0["value_loss"] - 1.25) < 1e-6
     assert abs(v0["lateral_offset"] - 15.0) < 1e-6 and abs(v0["aux"] - 7.0) < 1e-6
     assert abs(v0["loss"] - 2.75) < 1e-6 and list(v0) == ["wp_loss", "value_loss", "lateral_offset", "aux", "loss"]
+
+
+# ------------------------------------------------------------------------------------------------- GPU collectives
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_flat_gradient_all_reduce():
+    """First RCCL execution of the training collective: a 1-rank backend="nccl" (= RCCL on ROCm) process
+    group on this box's GPU, the flat gradient buffer's all-reduce (a no-op arithmetic-wise at world size 1 -- FlatGradBuffer
+    short-cuts it, so the collective is also issued directly) and the packed scalar all-reduce of parse_losses."""
+    from thinktwice_amd.grad_sync import FlatGradBuffer
+    from thinktwice_amd.losses import parse_losses
+    port = 32500 + (os.getpid() % 2000)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        params = [torch.randn(1000, 37, device=dev).requires_grad_(True), torch.randn(5, device=dev).requires_grad_(True)]
+        buf = FlatGradBuffer(params)
+        buf.flat.copy_(torch.arange(buf.numel, device=dev, dtype=torch.float32) / buf.numel)
+        want = buf.flat.clone()
+        assert buf.all_reduce_mean() is None                       # world size 1: short-cut
+        dist.all_reduce(buf.flat, op=dist.ReduceOp.SUM)            # the collective itself, on RCCL
+        stats = torch.full((2, 130), 3.0, dtype=torch.float64, device=dev)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)               # the SyncBN statistics block (f64)
+        torch.cuda.synchronize()
+        assert torch.equal(buf.flat, want) and bool((stats == 3.0).all())
+        loss, log_vars = parse_losses({"a_loss": torch.tensor(1.5, device=dev), "b_offset": torch.tensor(2.0, device=dev)})
+        assert abs(float(loss) - 1.5) < 1e-6 and abs(log_vars["b_offset"] - 2.0) < 1e-6
+    finally:
+        dist.destroy_process_group()
+
+
+def _syncbn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from thinktwice_amd import autodiff, ops
+        g = torch.Generator().manual_seed(77)
+        C = 24
+        z_all = torch.randn(2, 3, 5, 6, C, generator=g) * 2.0 + 1.0          # [rank][N,H,W,C]
+        R_all = torch.randn(2, 3, 5, 6, C, generator=g)
+        gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        spec = ops.BNSpec("bn", gamma.cuda(), beta.cuda(), torch.zeros(C).cuda(), torch.ones(C).cuda(), 1e-5, 0.1)
+        z = z_all[rank].cuda()
+        with autodiff.Tape() as tape:
+            y = ops.batchnorm_train(z, spec, 1)
+            tape.seed(y, R_all[rank])
+            tape.backward()
+            dz = tape.grad(z).cpu()
+        torch.cuda.synchronize()
+        q.put((rank, y.cpu().numpy(), dz.numpy(), spec.running_mean.cpu().numpy(), spec.running_var.cpu().numpy(),
+               tape.param_grads["bn.weight"].cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_syncbn_two_ranks_share_statistics_gloo():
+    """SyncBN (configs/thinktwice.py:39, apis/mmdet_train.py:86-87): two ranks (both on this box's GPU, gloo) normalise their
+    own half of a batch with the statistics of the WHOLE batch -- outputs, input gradients and running statistics equal
+    torch's single-process BatchNorm over the concatenated batch; the running statistics are identical on both ranks."""
+    import numpy as np
+    import torch.nn.functional as F
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(77)
+    C = 24
+    z_all = (torch.randn(2, 3, 5, 6, C, generator=g) * 2.0 + 1.0).requires_grad_(True)
+    R_all = torch.randn(2, 3, 5, 6, C, generator=g)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).requires_grad_(True), torch.randn(C, generator=g)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    zz = z_all.reshape(6, 5, 6, C).permute(0, 3, 1, 2)
+    y = torch.relu(F.batch_norm(zz, rm, rv, gamma, beta, True, 0.1, 1e-5)).permute(0, 2, 3, 1).reshape(2, 3, 5, 6, C)
+    (y * R_all).sum().backward()
+    for rank, yy, dz, grm, grv, dgamma in got:
+        np.testing.assert_allclose(yy, y[rank].detach().numpy(), atol=2e-5)
+        np.testing.assert_allclose(dz, z_all.grad[rank].numpy(), atol=2e-4 * float(z_all.grad.abs().max()))
+        np.testing.assert_allclose(grm, rm.numpy(), atol=1e-6)
+        np.testing.assert_allclose(grv, rv.numpy(), atol=1e-5)
+    np.testing.assert_array_equal(got[0][3], got[1][3])
+    np.testing.assert_array_equal(got[0][4], got[1][4])
+    # dgamma is the LOCAL sum on each rank; the two add up to the whole batch's (the gradient all-reduce averages them)
+    np.testing.assert_allclose(got[0][5] + got[1][5], gamma.grad.numpy(), atol=2e-4 * float(gamma.grad.abs().max()))

@@ -110,10 +110,10 @@ def test_oracle_train_mode_losses_match_reference_golden(golden_dir):
     seed as the generator (F11)."""
     from oracle import train_ref as TR
     pack = np.load(os.path.join(golden_dir, "f11_train_losses_trainmode_b2.npz"))
-    B, H, W, npts, seed, rng = (int(v) for v in pack["meta"])
+    B, H, W, npts, seed, rng, jitter = (int(v) for v in pack["meta"])
     cfg = config.model_config(final_dim=(H, W))
     sd = params.init_params(cfg, seed=seed)
-    batch = synth.make_batch(B, img_hw=(H, W), num_points=npts)
+    batch = synth.make_batch(B, img_hw=(H, W), num_points=npts, jitter_calib=jitter)   # (see synth.make_img_metas)
     batch.update(synth.make_train_targets(B, img_hw=(H, W)))
     with torch.no_grad(), TR.train_mode():
         torch.manual_seed(rng)

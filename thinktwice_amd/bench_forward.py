@@ -244,7 +244,44 @@ class ForwardWorkload:
                         "roofline": {k: r[k] for k in ("achieved", "peak", "unit", "frac", "conv_ms_per_step")},
                         "decoder_gemm": w._decoder_gemm}
             del w
+        if single and os.environ.get("TT_BENCH_TRAIN", "1") != "0":
+            out["train_step"] = self.train_step_leg()
         return out
+
+    def train_step_leg(self, iters=3):
+        """BASELINE config 4 on ONE GPU, timed inside the default bench run so that the driver's record holds it (VERDICT r2
+        item 4): trainer.Trainer.step at the same batch (forward_train + teacher pass + 23 losses, tape backward, flat
+        all-reduce -- a no-op at world size 1 --, clip + AdamW, operand re-preparation) under model.train() semantics."""
+        import time
+        from .bench_train import TrainStepWorkload
+        self.last = None
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        try:
+            w = TrainStepWorkload(self.B, self.batch["img"].device, dtype="bf16x3")
+            w.step()                                    # warm-up (allocator, lazy buffers)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                w.step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / iters
+            w.collect()
+            r = w.roofline()
+            leg = {"value": round(self.B / dt, 3), "unit": "samples/s", "ms_per_iteration": round(dt * 1e3, 2),
+                   "batch": self.B, "iterations_timed": iters, "dtype": "bf16x3 forward / input gradients, f32 weight gradients",
+                   "semantics": w._phases.get("batchnorm"), "wgrad_tflops": r["wgrad"]["tflops"], "wgrad_ms": r["wgrad"]["ms"],
+                   "conv_launches": r["launches"], "conv_kernel_ms": r["kernel_ms"],
+                   "all_reduce_ms": w._phases.get("all_reduce_ms"), "clip_adamw_ms": w._phases.get("clip_adamw_ms"),
+                   "prepare_operands_ms": w._phases.get("prepare_operands_ms"), "peak_memory_gb": w._phases.get("peak_memory_gb"),
+                   "loss": w._phases.get("loss"),
+                   "note": "one process, one GPU: the gradient all-reduce is the world-size-1 short cut; data-parallel runs: "
+                           "bench.py --workload train_step --gpus N"}
+            del w
+            torch.cuda.empty_cache()
+            return leg
+        except Exception as e:          # a failing side leg must not take the headline line down with it
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
 
     def h2d_inclusive(self, steps=5):
         """The same step with the batch handed over as HOST buffers (pinned): H2D copy of the f32 images / points +

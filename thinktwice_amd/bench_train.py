@@ -1,7 +1,9 @@
 """bench.py --workload train_step: one data-parallel training iteration (trainer.Trainer.step) at the thinktwice.py
 configuration -- forward_train, the tape's reverse sweep, ONE all-reduce of the flat gradient buffer over RCCL (world > 1),
-global-norm clip + AdamW, operand re-preparation.  Frozen-BatchNorm fine-tuning mode (running statistics), synthetic batch and
-targets, random-init weights.  Not the BASELINE.json metric (that is the inference forward): an auxiliary line for SURVEY 8f-4."""
+global-norm clip + AdamW, operand re-preparation.  model.train() semantics by default (batch-statistics BatchNorm with the
+SyncBN statistic exchange, live ASPP dropout: the reference's training mode; TT_BENCH_TRAIN_FROZEN_BN=1 selects the
+running-statistics fine-tuning mode), synthetic batch and targets, random-init weights.  Not the BASELINE.json metric (that
+is the inference forward): BASELINE config 4's single-GPU number, also reported as the `train_step` leg of the default line."""
 import os
 import time
 
@@ -13,9 +15,9 @@ from .bench_forward import MFMA_PEAK_TF, TORCH_DTYPE
 
 
 class TrainStepWorkload:
-    metric = "training samples/sec (forward_train + backward + all-reduce + clip/AdamW, thinktwice.py cfg, frozen BN)"
+    metric = "training samples/sec (forward_train + backward + all-reduce + clip/AdamW, thinktwice.py cfg)"
 
-    def __init__(self, batch, device, dtype=None):
+    def __init__(self, batch, device, dtype=None, frozen_bn=None):
         from .trainer import Trainer
         dtype = dtype or os.environ.get("TT_BENCH_DTYPE", "bf16x3")
         assert dtype in ("f32", "bf16x3"), "training runs on f32 activation storage"
@@ -27,7 +29,10 @@ class TrainStepWorkload:
         self.launch_note = "eager launches, one stream"
         self.model, self.cfg = tm.build_thinktwice(dtype=TORCH_DTYPE[dtype], device=str(device))
         sd = params.init_params(self.cfg, seed=0)
-        self.trainer = Trainer(self.model, sd)
+        if frozen_bn is None:
+            frozen_bn = os.environ.get("TT_BENCH_TRAIN_FROZEN_BN", "0") == "1"
+        self.frozen_bn = frozen_bn
+        self.trainer = Trainer(self.model, sd, frozen_bn=frozen_bn)
         del sd
         rank = int(os.environ.get("RANK", "0"))
         self.batch = tm.batch_to_device(synth.make_batch(batch, seed=1234 + rank * batch), device)
@@ -72,7 +77,7 @@ class TrainStepWorkload:
         torch.cuda.synchronize()
         ph["all_reduce_ms"] = (time.perf_counter() - t0) * 1e3
         t0 = time.perf_counter()
-        self.trainer.opt.step()
+        self.trainer.opt.step(live_ranges=self.trainer.live_ranges)
         torch.cuda.synchronize()
         ph["clip_adamw_ms"] = (time.perf_counter() - t0) * 1e3
         t0 = time.perf_counter()
@@ -83,6 +88,7 @@ class TrainStepWorkload:
         self._phases = {k: round(v, 2) for k, v in ph.items()}
         self._phases["loss"] = float(self.last["loss"]) if self.last is not None else None
         self._phases["peak_memory_gb"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+        self._phases["batchnorm"] = "running statistics (frozen)" if self.frozen_bn else "batch statistics (model.train())"
         peak = MFMA_PEAK_TF[self.dtype]
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         self._roofline = {

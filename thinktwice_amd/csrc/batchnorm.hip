@@ -10,8 +10,8 @@
 //                     one batch of T equal image groups, each normalised with its own statistics like the reference's
 //                     per-sweep passes, lss.py:690-717); f64 accumulation, per-workgroup partials added in index order
 //   (host)            SyncBN: ONE all-reduce of the [groups][2C + 2] statistics block (thinktwice_amd/ops.py)
-//   tt_bn_finalize    mean / invstd / folded scale + shift per group, running-statistics update
-//   tt_bn_apply       y = act(z * scale + shift + res1 + res2) into a channel window of the consumer's buffer
+//   tt_bn_finalize    mean / invstd / scale = gamma * invstd / shift = beta per group, running-statistics update
+//   tt_bn_apply       y = act((z - mean) * scale + shift + res1 + res2) into a channel window of the consumer's buffer
 //   tt_bn_bwd_reduce  g = dy * act'(y) (written over dy), residual gradients, per-channel sum g and sum g * xhat
 //   (host)            SyncBN: one all-reduce of the [groups][2C] sums
 //   tt_bn_bwd_apply   dz = scale * (g - sum_g / n - xhat * sum_gxhat / n)
@@ -113,7 +113,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, int 
         const float is = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = (gamma ? gamma[c] : 1.f) * is;
         scale[g * C + c] = sc;
-        shift[g * C + c] = (beta ? beta[c] : 0.f) - (float)mu * sc;
+        shift[g * C + c] = beta ? beta[c] : 0.f;      // NOT folded with the mean: tt_bn_apply centres first (see there)
         mean[g * C + c] = (float)mu;
         invstd[g * C + c] = is;
         if (n > 0) {
@@ -126,7 +126,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, int 
 }
 
 struct BnApplyArgs {
-    const float* z; const float* scale; const float* shift; const float* res1; const float* res2; float* out;
+    const float* z; const float* scale; const float* shift; const float* mean; const float* res1; const float* res2; float* out;
     BnRows r;
     int z_cstride, z_coff, r1_cstride, r1_coff, r2_cstride, r2_coff, out_cstride, out_coff, act;
 };
@@ -139,7 +139,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
         const long long m = i / a.r.C;
         const int c = (int)(i - m * a.r.C);
         const int g = (int)(m / per_group);
-        float v = a.z[m * a.z_cstride + a.z_coff + c] * a.scale[g * a.r.C + c] + a.shift[g * a.r.C + c];
+        // centred form (z - mean) * (gamma * invstd) + beta, like torch: the folded z * scale + (beta - mean * scale) loses
+        // ulp(mean * scale) -- 0.008 on the (near-)constant camera-parameter columns of DepthNet's BatchNorm1d, whose
+        // variance is ~0 and invstd = 1 / sqrt(eps) = 316 (measured: 1.4e-3 on the camera BEV before this)
+        float v = (a.z[m * a.z_cstride + a.z_coff + c] - a.mean[g * a.r.C + c]) * a.scale[g * a.r.C + c] + a.shift[g * a.r.C + c];
         if (a.res1) v += a.res1[m * a.r1_cstride + a.r1_coff + c];
         if (a.res2) v += a.res2[m * a.r2_cstride + a.r2_coff + c];
         if (a.act == TT_ACT_RELU) v = v > 0.f ? v : 0.f;
@@ -284,13 +287,13 @@ extern "C" int tt_bn_finalize(const double* stats, int C, int groups, const floa
 }
 
 extern "C" int tt_bn_apply(const float* z, long long M, int C, int z_cstride, int z_coff, const int* m_dev, int groups,
-                           const float* scale, const float* shift, const float* res1, int r1_cstride, int r1_coff,
+                           const float* scale, const float* shift, const float* mean, const float* res1, int r1_cstride, int r1_coff,
                            const float* res2, int r2_cstride, int r2_coff, int act, float* out, int out_cstride, int out_coff,
                            void* stream) {
-    TT_REQUIRE(z && scale && shift && out, "tt_bn_apply: null");
+    TT_REQUIRE(z && scale && shift && mean && out, "tt_bn_apply: null");
     if (int rc = check_rows(M, C, groups, m_dev, "tt_bn_apply")) return rc;
     TT_REQUIRE(act == TT_ACT_NONE || act == TT_ACT_RELU, "tt_bn_apply: activation %d after a train-mode BatchNorm", act);
-    BnApplyArgs a{z, scale, shift, res1, res2, out, BnRows{M, m_dev, C, groups}, z_cstride, z_coff, r1_cstride, r1_coff,
+    BnApplyArgs a{z, scale, shift, mean, res1, res2, out, BnRows{M, m_dev, C, groups}, z_cstride, z_coff, r1_cstride, r1_coff,
                   r2_cstride, r2_coff, out_cstride, out_coff, act};
     const long long total = M * C;
     const int blocks = (int)min((long long)kNumCU * 16, (total + 255) / 256);

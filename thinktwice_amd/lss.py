@@ -67,9 +67,14 @@ class _ResNet50:
     def __call__(self, x, bordered=False):
         if bordered:      # x: (NI, H+6, W+8, 8) with the image at (3, 3)
             NI, Hp, Wp, _ = x.shape
-            y = ops.conv2d(x, self.stem_rr, stride=2, pad=0, scale=self.stem.scale, shift=self.stem.shift,
-                           act=self.stem.act, in_cstride=self.cin_pad, out_hw=((Hp - 6) // 2, (Wp - 8) // 2),
-                           w_x3=self.stem_rr_x3)
+            if layers.BN_TRAIN:       # model.train(): raw row-run convolution, then the stem's batch-statistics BatchNorm
+                z = ops.conv2d(x, self.stem_rr, stride=2, pad=0, act=0, in_cstride=self.cin_pad,
+                               out_hw=((Hp - 6) // 2, (Wp - 8) // 2), w_x3=self.stem_rr_x3, out_dtype=torch.float32)
+                y = ops.batchnorm_train(z, self.stem.bn, self.stem.act, groups=layers.BN_GROUPS)
+            else:
+                y = ops.conv2d(x, self.stem_rr, stride=2, pad=0, scale=self.stem.scale, shift=self.stem.shift,
+                               act=self.stem.act, in_cstride=self.cin_pad, out_hw=((Hp - 6) // 2, (Wp - 8) // 2),
+                               w_x3=self.stem_rr_x3)
         else:
             y = self.stem(x, stop_grad=True)      # (training tape: the image is a leaf without a gradient)
         x = ops.maxpool3x3s2(y)
@@ -221,13 +226,20 @@ class LSS:
         m24 = torch.zeros(mlp_in.shape[0], 24, dtype=torch.float32, device=dev)
         self.bn22(mlp_in, out=m24)        # BatchNorm1d(22) of the camera-parameter vector (train mode: batch statistics)
         x = self.reduce(src)
+        dbg = getattr(self, "_dbg", None)          # tools/debug_trainmode.py: intermediate captures
+        if dbg is not None:
+            dbg.update(src=src, m24=m24, reduce=x)
         g_ctx = ops.repeat_rows(self._se_gate("context", m24), T)
         g_dep = ops.repeat_rows(self._se_gate("depth", m24), T)
         merge_in = torch.empty(NI, h, w, 384, dtype=dt, device=dev)
         self.context_conv(ops.channel_gate(x, g_ctx), out=merge_in, out_coff=0)
         d = ops.channel_gate(x, g_dep)
+        if dbg is not None:
+            dbg.update(se_depth=d)
         for c1, c2 in self.bb:
             d = c2(c1(d), res1=d)
+        if dbg is not None:
+            dbg.update(blocks=d)
         mid = d.shape[-1]
         cat = torch.empty(NI, h, w, 4 * mid, dtype=dt, device=dev)
         for i, br in enumerate(self.aspp):
@@ -237,6 +249,8 @@ class LSS:
         self.aspp_gapw.scale = None if layers.BN_TRAIN else self.aspp_out.scale
         shift_n = unrows(self.aspp_gapw(x5)).contiguous()
         d = self.aspp_out(cat, shift_n=shift_n, shift_n_mod=NI)
+        if dbg is not None:
+            dbg.update(aspp_cat=cat, x5=x5, aspp_pre_dropout=d)
         if layers.BN_TRAIN:
             d = ops.dropout(d, 0.5)                                      # ASPP nn.Dropout(0.5), lss.py:91,110
         off = self.dcn_off(d, out_dtype=torch.float32)

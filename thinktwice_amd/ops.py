@@ -379,7 +379,7 @@ def batchnorm_train(z, spec, act=0, res1=None, res1_coff=0, res2=None, res2_coff
 
     def cs(t):
         return 0 if t is None else t.shape[-1]
-    check(L.tt_bn_apply(ptr(z), _ll(M), _c(C), _c(C), _c(0), ptr(m_dev), _c(groups), ptr(scale), ptr(shift), ptr(res1),
+    check(L.tt_bn_apply(ptr(z), _ll(M), _c(C), _c(C), _c(0), ptr(m_dev), _c(groups), ptr(scale), ptr(shift), ptr(mean), ptr(res1),
                         _c(cs(res1)), _c(res1_coff), ptr(res2), _c(cs(res2)), _c(res2_coff), _c(act), ptr(out),
                         _c(out.shape[-1]), _c(out_coff), st), "tt_bn_apply")
     from . import autodiff

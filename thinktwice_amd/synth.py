@@ -7,12 +7,37 @@ import torch
 from . import calib
 
 
-def make_img_metas(batch_size, num_sweeps=2, curr2key=None, final_dim=(calib.FINAL_H, calib.FINAL_W)):
-    """img_metas[b][t] dicts with the keys LSS.forward reads (backbones/lss.py:667-707)."""
-    intr, l2c, l2i = calib.camera_tables()
-    ida = np.stack([calib.eval_ida_mat(final_dim) for _ in range(4)])
+def make_img_metas(batch_size, num_sweeps=2, curr2key=None, final_dim=(calib.FINAL_H, calib.FINAL_W), jitter_seed=None):
+    """img_metas[b][t] dicts with the keys LSS.forward reads (backbones/lss.py:667-707).
+
+    `jitter_seed`: per (sample, camera) perturbed calibration -- focal lengths x (1 +- 8 %), principal point +- 20 px, the
+    image-augmentation matrix's resize x (1 +- 5 %) and crop offsets +- 6 px (what the reference's training-time
+    IDAImageTransform.sample_ida_augmentation does to `ida_mats`, transform.py:250-263), lidar2img rebuilt from the perturbed
+    intrinsics.  The train-mode goldens (F11 / F16) use it: with the fixed evaluation rig DepthNet's BatchNorm1d over the 22
+    camera parameters (lss.py:206-231) has zero-variance columns of magnitude ~800, whose batch-statistics output is
+    beta + rounding noise of order ulp(800 / sqrt(eps)) ~ 0.01 that depends on the implementation's operation order (torch's
+    CPU kernel folds the mean into the shift) -- not a property any second implementation can reproduce."""
+    intr0, l2c, l2i0 = calib.camera_tables()
+    ida0 = np.stack([calib.eval_ida_mat(final_dim) for _ in range(4)])
+    rng = None if jitter_seed is None else np.random.default_rng(jitter_seed)
     metas = []
     for _ in range(batch_size):
+        intr, ida, l2i = intr0, ida0, l2i0
+        if rng is not None:
+            intr, ida = intr0.copy(), ida0.copy()
+            for c in range(4):
+                intr[c, 0, 0] *= 1.0 + 0.08 * rng.uniform(-1, 1)
+                intr[c, 1, 1] *= 1.0 + 0.08 * rng.uniform(-1, 1)
+                intr[c, 0, 2] += 20.0 * rng.uniform(-1, 1)
+                intr[c, 1, 2] += 20.0 * rng.uniform(-1, 1)
+                s = 1.0 + 0.05 * rng.uniform(-1, 1)
+                ida[c, 0, 0] *= s
+                ida[c, 1, 1] *= s
+                ida[c, 0, 3] += 6.0 * rng.uniform(-1, 1)
+                ida[c, 1, 3] += 6.0 * rng.uniform(-1, 1)
+            k4 = np.tile(np.eye(4, dtype=np.float32), (4, 1, 1))
+            k4[:, :3, :3] = intr
+            l2i = (k4 @ l2c).astype(np.float32)
         per_sweep = []
         for t in range(num_sweeps):
             c2k = np.eye(4, dtype=np.float32)
@@ -31,7 +56,7 @@ def make_img_metas(batch_size, num_sweeps=2, curr2key=None, final_dim=(calib.FIN
 
 
 def make_batch(batch_size, seed=1234, num_points=65536, img_hw=(calib.FINAL_H, calib.FINAL_W),
-               device="cpu", with_img=True):
+               device="cpu", with_img=True, jitter_calib=None):
     """Synthetic `forward_inference` batch: img N(0,1) (B,2,4,3,H,W); points (B,1,Np,5)
     uniform in the point-cloud range with z<4; speed/target_point/command."""
     imgs, pts, speed, tp, cmd = [], [], [], [], []
@@ -60,7 +85,7 @@ def make_batch(batch_size, seed=1234, num_points=65536, img_hw=(calib.FINAL_H, c
         "target_point": torch.stack(tp).to(device),
         "target_command": torch.stack(cmd).to(device),
         "target_command_raw": torch.stack(cmd).argmax(-1).to(device),
-        "img_metas": make_img_metas(batch_size, final_dim=img_hw),
+        "img_metas": make_img_metas(batch_size, final_dim=img_hw, jitter_seed=jitter_calib),
     }
     if with_img:
         batch["img"] = torch.stack(imgs).to(device)
