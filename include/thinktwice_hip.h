@@ -634,6 +634,55 @@ int tt_action_pid_host(const float* wp_last, float speed, float target_x, float 
 int tt_action_arbitrate_host(double steer_ctrl, double throttle_ctrl, double brake_ctrl, double throttle_traj,
                              double brake_traj, float speed, const tt_action_cfg* cfg, tt_action_state* state, double* out);
 
+/* ------------------------------------------------------------------------
+ * launch plans -- the forward sequenced from C (csrc/plan.cpp).
+ * The reference sequences the forward in Python (encoder_decoder_framework.py:194-250: extract_sensor_feat ->
+ * get_fusion_feat -> ThinkTwiceDecoder.forward, thinktwice_decoder.py:419-489).  A plan is that sequence as data: the ordered
+ * C-ABI calls of one forward, every pointer as (buffer id, byte offset) -- buffer 0 = packed weights, 1 = activation arena,
+ * 2.. = inputs -- the stream slot of each call and the cross-stream dependencies.  thinktwice_amd/plan.py compiles a plan by
+ * recording one forward of the Python mirror; this runtime binds a host's buffers and issues the calls on its streams.  Plans
+ * (and the weights blob) are files: a non-Python host runs the path with tt_plan_load + tt_plan_bind + tt_encoder_fwd /
+ * tt_decoder_fwd (tools/plan_host.cpp).  Argument kinds of tt_plan_add_call: 0 = integer (ivals), 1 = float / double (fvals),
+ * 2 = device pointer (buffers[i], ivals[i] = byte offset), 3 = host blob (ivals[i] = offset returned by tt_plan_add_blob;
+ * device pointers stored inside a blob are declared with tt_plan_add_reloc), 4 = NULL.
+ * ---------------------------------------------------------------------- */
+/* buffer plumbing as C-ABI entries, so that a plan holds NO torch kernel: zeros / constant fills (32-bit pattern) and
+ * contiguous device-to-device copies */
+int tt_fill_u32(void* dst, long long n_words, unsigned pattern, void* stream);
+int tt_copy_bytes(void* dst, const void* src, long long nbytes, void* stream);
+typedef struct tt_plan tt_plan;
+tt_plan* tt_plan_create(void);
+void tt_plan_destroy(tt_plan* plan);
+int tt_plan_set_buffer(tt_plan* plan, int id, long long bytes, const char* name);
+long long tt_plan_add_blob(tt_plan* plan, const void* bytes, long long n);
+int tt_plan_add_reloc(tt_plan* plan, long long blob_offset, int buffer, long long offset);
+int tt_plan_add_call(tt_plan* plan, const char* entry, int nargs, const int* kinds, const int* buffers, const long long* ivals,
+                     const double* fvals, int stream_slot);
+int tt_plan_add_sync(tt_plan* plan, int waiter_stream_slot, int signal_stream_slot);
+/* outputs: where a host finds a result tensor -- byte offset of element 0 inside `buffer`, shape and ELEMENT strides (f32) */
+int tt_plan_add_output(tt_plan* plan, const char* name, int buffer, long long offset, int ndim, const long long* shape,
+                       const long long* stride);
+int tt_plan_num_ops(const tt_plan* plan);
+int tt_plan_num_calls(const tt_plan* plan);
+int tt_plan_num_streams(const tt_plan* plan);
+int tt_plan_num_buffers(const tt_plan* plan);
+long long tt_plan_buffer_bytes(const tt_plan* plan, int id);
+const char* tt_plan_buffer_name(const tt_plan* plan, int id);
+int tt_plan_num_outputs(const tt_plan* plan);
+int tt_plan_output(const tt_plan* plan, int i, const char** name, int* buffer, long long* offset, int* ndim, long long* shape8,
+                   long long* stride8);
+int tt_plan_save(const tt_plan* plan, const char* path);
+tt_plan* tt_plan_load(const char* path);
+/* bases[id]: device (or, for host-read arguments, host) address of buffer id, tt_plan_buffer_bytes(id) bytes each */
+int tt_plan_bind(tt_plan* plan, void* const* bases, int nbases);
+/* issue the whole plan / one half on the caller's streams (hipStream_t as void*), asynchronously */
+int tt_plan_run(tt_plan* plan, void* const* streams, int nstreams);
+int tt_plan_run_range(tt_plan* plan, void* const* streams, int nstreams, int first_op, int num_ops);
+/* the encoder half (camera + LiDAR encoders, BEV fusion + flatten network: encoder_decoder_framework.py:194-235) and the
+ * decoder half (ThinkTwiceDecoder.forward, thinktwice_decoder.py:419-489) of a bound forward plan */
+int tt_encoder_fwd(tt_plan* plan, void* const* streams, int nstreams);
+int tt_decoder_fwd(tt_plan* plan, void* const* streams, int nstreams);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,11 +7,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("x3", [False, True])
-def test_camera_trunk_backward_matches_oracle_autograd(x3):
-    from oracle import model_ref as M
-    from thinktwice_amd import autodiff, config, params, weights
-    hw, NI = (64, 128), 2
+@pytest.mark.parametrize("x3,train", [(False, False), (True, False), (False, True)])
+def test_camera_trunk_backward_matches_oracle_autograd(x3, train):
+    """`train`: model.train() semantics -- batch-statistics BatchNorm in the ResNet (oracle inside train_ref.train_mode())."""
+    from oracle import model_ref as M, train_ref as TR
+    from thinktwice_amd import autodiff, config, layers, params, weights
+    import contextlib
+    hw, NI = (64, 128), 4 if train else 2
+    mode = TR.train_mode if train else contextlib.nullcontext
     cfg = config.model_config(final_dim=hw)
     sd = params.init_params(cfg, seed=3, parts=("img_encoder",))
     # ---- oracle: autograd over the trunk's parameters
@@ -22,20 +25,25 @@ def test_camera_trunk_backward_matches_oracle_autograd(x3):
     sdr.update(leaves)
     g = torch.Generator().manual_seed(7)
     img = torch.randn(NI, 3, *hw, generator=g)
-    outs = M.pafpn(sdr, "img_encoder.img_neck", M.resnet50(sdr, "img_encoder.img_backbone", img))
-    R = [torch.randn(o.shape, generator=g) for o in outs]
-    loss = sum((o * r).sum() for o, r in zip(outs, R))
-    loss.backward()
+    with mode():
+        outs = M.pafpn(sdr, "img_encoder.img_neck", M.resnet50(sdr, "img_encoder.img_backbone", img))
+        R = [torch.randn(o.shape, generator=g) for o in outs]
+        loss = sum((o * r).sum() for o, r in zip(outs, R))
+        loss.backward()
     # ---- HIP: taped forward of the same trunk, seeded with R, backward kernels
     from thinktwice_amd.lss import LSS
     enc_cfg = {k: v for k, v in cfg["img_encoder"].items() if k != "type"}
     enc = LSS(**enc_cfg, dtype="f32x3" if x3 else torch.float32).load_state_dict(sd)
     x = weights.to_channel_last(img, torch.float32).cuda()
-    with autodiff.Tape(x3=x3) as tape:
-        bufs = enc._trunk(x)
-        for (t, off, c), r in zip(enc._fpn_views(bufs), R):
-            tape.seed(t[..., off:off + c], r.permute(0, 2, 3, 1))
-        tape.backward()
+    saved, layers.BN_TRAIN = layers.BN_TRAIN, train
+    try:
+        with autodiff.Tape(x3=x3) as tape:
+            bufs = enc._trunk(x)
+            for (t, off, c), r in zip(enc._fpn_views(bufs), R):
+                tape.seed(t[..., off:off + c], r.permute(0, 2, 3, 1))
+            tape.backward()
+    finally:
+        layers.BN_TRAIN = saved
     torch.cuda.synchronize()
     # forward sanity (same maps), then every parameter's gradient
     for (t, off, c), o in zip(enc._fpn_views(bufs), outs):
@@ -43,16 +51,19 @@ def test_camera_trunk_backward_matches_oracle_autograd(x3):
         assert float((got - o.detach()).abs().max() / o.detach().abs().max()) < (2e-4 if x3 else 2e-5)
     missing = [k for k in leaves if leaves[k].grad is not None and k not in tape.param_grads]
     assert not missing, missing[:5]
-    tol = 3e-3 if x3 else 2e-4
+    tol = 3e-3 if x3 else (1e-3 if train else 2e-4)
     worst = {}
     for k, v in leaves.items():
         if v.grad is None:
             continue
+        if train and k.endswith(".bias") and ".conv" in k:
+            continue            # (a conv bias in front of a batch-statistics BatchNorm: zero gradient + rounding noise)
         got = tape.param_grads[k].cpu()
         assert got.shape == v.grad.shape, (k, got.shape, v.grad.shape)
         worst[k] = float((got - v.grad).abs().max() / v.grad.abs().max().clamp_min(1e-12))
     bad = {k: e for k, e in worst.items() if e > tol}
-    print("trunk backward: params", len(worst), "worst rel err", max(worst.values()))
+    print("trunk backward: params", len(worst), "worst rel err", max(worst.values()), "top",
+          [(k[25:], round(e, 5), float(leaves[k].grad.abs().max())) for k, e in sorted(worst.items(), key=lambda kv: -kv[1])[:12]])
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
 
 

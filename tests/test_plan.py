@@ -1,0 +1,117 @@
+"""Launch plans: `thinktwice_amd.plan.compile_forward` records one forward of the Python mirror; the C runtime
+(csrc/plan.cpp) then issues the whole forward from C++ -- `tt_encoder_fwd` + `tt_decoder_fwd`, two ctypes calls, no torch
+kernel in between -- on buffers it is bound to.  Checked: outputs equal the eager forward on a NEW frame, the plan survives a
+move of every buffer (relocation) and a save / load round trip, and the full-size forward driven through the plan matches the
+reference golden F8."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+KEYS = ("pred_wp", "mu_branches", "sigma_branches", "future_mu", "future_sigma", "pred_speed", "pred_value_traj",
+        "pred_value_ctrl", "pred_features_traj", "pred_features_ctrl", "bev_feature", "refine_BEV_feature",
+        "refine_flattned_BEV_feature", "refine_future_BEV_feature")
+
+
+def test_plan_api_is_exported_and_records_only_stream_taking_entries():
+    from thinktwice_amd import _lib
+    L = _lib.lib()
+    L.tt_plan_create.restype = ctypes.c_void_p
+    p = ctypes.c_void_p(L.tt_plan_create())
+    one = (ctypes.c_int * 1)()
+    ll, dd = (ctypes.c_longlong * 1)(), (ctypes.c_double * 1)()
+    assert L.tt_plan_add_call(p, b"tt_version", 0, one, one, ll, dd, 0) != 0          # not a stream-taking entry
+    assert b"tt_version" in L.tt_last_error()
+    assert L.tt_plan_add_call(p, b"tt_fill_u32", 1, one, one, ll, dd, 0) != 0         # wrong argument count
+    kinds = (ctypes.c_int * 3)(4, 0, 0)
+    assert L.tt_plan_add_call(p, b"tt_fill_u32", 3, kinds, (ctypes.c_int * 3)(), (ctypes.c_longlong * 3)(), (ctypes.c_double * 3)(), 0) == 0
+    assert L.tt_plan_add_sync(p, 1, 0) == 0
+    assert L.tt_plan_num_ops(p) == 2 and L.tt_plan_num_calls(p) == 1 and L.tt_plan_num_streams(p) == 2
+    assert L.tt_plan_run(p, None, 0) != 0 and b"bind" in L.tt_last_error()            # unbound plans refuse to run
+    L.tt_plan_destroy(p)
+
+
+def _model(hw, dtype="f32x3", seed=0):
+    from thinktwice_amd import model as tm, params
+    m, cfg = tm.build_thinktwice(dtype=dtype, final_dim=hw)
+    m.load_state_dict(params.init_params(cfg, seed=seed))
+    return m, cfg
+
+
+@pytest.mark.gpu
+def test_forward_plan_runs_from_c_matches_eager_and_relocates(tmp_path):
+    from thinktwice_amd import _lib, model as tm, plan as P, synth
+    hw = (128, 256)
+    m, cfg = _model(hw)
+    b1 = tm.batch_to_device(synth.make_batch(1, img_hw=hw, num_points=20000, seed=11))
+    fp = P.compile_forward(m, b1)
+    assert fp.calls > 200 and fp.nstreams >= 2
+    L = _lib.lib()
+    # a NEW frame: eager forward vs the plan replayed from C on refilled input buffers
+    b2 = tm.batch_to_device(synth.make_batch(1, img_hw=hw, num_points=20000, seed=12))
+    want = {k: v.clone() for k, v in m.forward_inference(b2).items() if k in KEYS}
+    again = {k: v.clone() for k, v in m.forward_inference(b2).items() if k in KEYS}
+    fp.update(b2)
+    got = fp.run()
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-9))      # noqa: E731
+    noise = max(rel(again[k], want[k]) for k in KEYS)      # eager vs eager: the f32 atomics of the splat / split-K
+    worst = max(rel(got[k], want[k]) for k in KEYS)
+    print("plan vs eager", worst, "eager vs eager", noise)
+    assert worst < max(5e-5, 4 * noise), (worst, noise)    # same kernels in the same order: run-to-run noise only
+    # relocation: move the weights blob and the arena, poison the old ones, bind, run
+    first = {k: got[k].clone() for k in KEYS}
+    old_w, old_a = fp.weights_blob, fp.arena
+    fp.weights_blob, fp.arena = old_w.clone(), torch.zeros_like(old_a)
+    old_w.fill_(0xFF)
+    old_a.fill_(0xFF)
+    fp.bind()
+    fp.run(halves=False)
+    torch.cuda.synchronize()
+    name, bid, off, nd = ctypes.c_char_p(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_int()
+    shape, stride = (ctypes.c_longlong * 8)(), (ctypes.c_longlong * 8)()
+    table = {}
+    for i in range(L.tt_plan_num_outputs(fp.plan)):
+        assert L.tt_plan_output(fp.plan, i, ctypes.byref(name), ctypes.byref(bid), ctypes.byref(off), ctypes.byref(nd), shape, stride) == 0
+        table[name.value.decode()] = (bid.value, off.value, list(shape)[:nd.value], list(stride)[:nd.value])
+    for k in KEYS:                       # the results, found the way a foreign host finds them: (buffer, offset, shape, strides)
+        b_, o_, sh, st = table[k]
+        assert b_ == 1 and sh == list(first[k].shape)
+        moved = torch.as_strided(fp.arena[o_:].view(torch.float32), sh, st)
+        e = float((moved - first[k]).abs().max() / first[k].abs().max().clamp_min(1e-9))
+        assert e < max(5e-5, 4 * noise), (k, e)
+    # save / load: a fresh plan object from the file, bound to the same buffers, gives the same outputs
+    d = fp.save(str(tmp_path / "plan"))
+    L.tt_plan_load.restype = ctypes.c_void_p
+    p2 = ctypes.c_void_p(L.tt_plan_load(os.path.join(d, "plan.bin").encode()))
+    assert p2.value and L.tt_plan_num_calls(p2) == fp.calls
+    assert os.path.getsize(os.path.join(d, "weights.bin")) == fp.weights_blob.numel()
+    arr, nb = fp.bases()
+    fp.arena.zero_()
+    assert L.tt_plan_bind(p2, arr, nb) == 0
+    sarr, ns = fp._stream_array()
+    assert L.tt_encoder_fwd(p2, sarr, ns) == 0 and L.tt_decoder_fwd(p2, sarr, ns) == 0
+    torch.cuda.synchronize()
+    e = float((got["pred_wp"] - first["pred_wp"]).abs().max())        # `got` views the ORIGINAL arena: poisoned, not rewritten
+    assert not (e < 1e-3)
+    L.tt_plan_destroy(p2)
+
+
+@pytest.mark.gpu
+def test_full_size_forward_through_the_plan_matches_reference_golden_f8(golden_dir):
+    """The thinktwice.py-size forward issued by tt_encoder_fwd + tt_decoder_fwd against the REFERENCE's own outputs (F8)."""
+    from thinktwice_amd import model as tm, plan as P, synth
+    from test_forward import _check_against_pack
+    pack = np.load(os.path.join(golden_dir, "f8_forward_full_b1.npz"))
+    B, H, W, npts, seed = (int(v) for v in pack["meta"])
+    m, cfg = _model((H, W), seed=seed)
+    batch = tm.batch_to_device(synth.make_batch(B, img_hw=(H, W), num_points=npts))
+    warm = tm.batch_to_device(synth.make_batch(B, img_hw=(H, W), num_points=npts, seed=99))
+    fp = P.compile_forward(m, warm)                 # compiled on a different frame
+    fp.update(batch)
+    out = fp.run()
+    torch.cuda.synchronize()
+    errs = _check_against_pack(pack, out, 1e-3)
+    print("F8 through the C plan:", fp.calls, "calls on", fp.nstreams, "streams; worst", max(errs.values()))

@@ -153,16 +153,23 @@ def _reference_dropout_masks(B, cfg, hw, rng):
     return torch.cat(masks, 0).permute(0, 2, 3, 1).contiguous().to(torch.uint8)
 
 
-def _setup_train_mode(mode):
+def _setup_train_mode(mode, which):
+    """Model, weights and the (calibration-jittered, see synth.make_img_metas) batch of a train-mode golden:
+    `which` = "f11" (losses, B = 2) or "f16" (gradients, B = 4)."""
     from thinktwice_amd import model as tm, params, synth
     gold = os.path.join(os.path.dirname(__file__), "golden")
-    pack = np.load(os.path.join(gold, "f16_train_gradients_trainmode_b2.npz"))
-    B, H, W, npts, seed = (int(v) for v in pack["meta"])
+    if which == "f11":
+        pack = np.load(os.path.join(gold, "f11_train_losses_trainmode_b2.npz"))
+        B, H, W, npts, seed, rng, jitter = (int(v) for v in pack["meta"])
+    else:
+        pack = np.load(os.path.join(gold, "f16_train_gradients_trainmode_b4.npz"))
+        B, H, W, npts, seed = (int(v) for v in pack["meta"])
+        rng, jitter = int(pack["rng"][0]), int(pack["calib_jitter"][0])
     m, cfg = tm.build_thinktwice(final_dim=(H, W), dtype=torch.float32 if mode == "f32" else "f32x3")
     sd = params.init_params(cfg, seed=seed)
-    batch = synth.make_batch(B, img_hw=(H, W), num_points=npts, jitter_calib=int(pack["calib_jitter"][0]))
+    batch = synth.make_batch(B, img_hw=(H, W), num_points=npts, jitter_calib=jitter)
     batch.update(synth.make_train_targets(B, img_hw=(H, W)))
-    return pack, m, cfg, sd, batch, (B, (H, W), int(pack["rng"][0]))
+    return pack, m, cfg, sd, batch, (B, (H, W), rng)
 
 
 # Bounds: 1e-3 in the exact-f32 mode.  The bf16x3 mode's ~1e-5 product error is amplified by the batch-statistics BatchNorm1d
@@ -173,9 +180,7 @@ def test_forward_train_in_train_mode_matches_reference_golden_f11(mode, tol):
     """model.train(): batch-statistics BatchNorm (per sweep in the camera trunk) + the ASPP dropout with the reference's
     masks -> all 23 loss terms against the reference's own forward_train under model.train() (golden F11)."""
     from thinktwice_amd import ops
-    pack, m, cfg, sd, batch, (B, hw, rng) = _setup_train_mode(mode)
-    f11 = np.load(os.path.join(os.path.dirname(__file__), "golden", "f11_train_losses_trainmode_b2.npz"))
-    assert int(f11["meta"][5]) == rng and int(f11["meta"][6]) == int(pack["calib_jitter"][0])
+    f11, m, cfg, sd, batch, (B, hw, rng) = _setup_train_mode(mode, "f11")
     m.load_state_dict(sd)
     m.train()
     ops.DROPOUT_MASKS = iter([_reference_dropout_masks(B, cfg, hw, rng)])
@@ -204,7 +209,7 @@ def test_training_backward_in_train_mode_matches_reference_gradients_golden_f16(
     from thinktwice_amd import ops
     from thinktwice_amd.trainer import Trainer
     monkeypatch.setattr(ops, "_AUTO_SPLITK", False)
-    pack, m, cfg, sd, batch, (B, hw, rng) = _setup_train_mode(mode)
+    pack, m, cfg, sd, batch, (B, hw, rng) = _setup_train_mode(mode, "f16")
     tr = Trainer(m, sd, frozen_bn=False)
     ops.DROPOUT_MASKS = iter([_reference_dropout_masks(B, cfg, hw, rng)])
     try:

@@ -23,7 +23,7 @@ def _sources():
 
 
 def _deps_mtime():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(HERE, "..", "include", "thinktwice_hip.h"))
     hdrs.append(os.path.abspath(__file__))  # flag changes rebuild everything
     return max(os.path.getmtime(h) for h in hdrs)
@@ -57,6 +57,10 @@ def source_fingerprint():
 
 def build(verbose=True, force=False):
     os.makedirs(OBJ, exist_ok=True)
+    # csrc/plan_thunks.inc: one thunk per stream-taking entry of the header (the plan runtime's dispatch table)
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import gen_plan_thunks
+    gen_plan_thunks.main()
     if force:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))

@@ -178,6 +178,9 @@ class EncoderDecoder(torch.nn.Module):
         cam, cam_bev, lidar = self.extract_sensor_feat(batch["img"], batch["img_metas"], batch.get("points"),
                                                        consts=consts, prev_bev=prev_bev)
         flat, bev32, mids = self.fusion(cam_bev, lidar)
+        pb = getattr(self, "_plan_builder", None)
+        if pb is not None:
+            pb.mark("decoder")          # plan compiler (thinktwice_amd/plan.py): tt_encoder_fwd ends / tt_decoder_fwd starts here
         pred = self.decoder(flat, bev32, meas, batch["target_point"], self, teacher,
                             [cam["lidar2img"], cam["ida_mat"], cam["_fpn_cl"], lidar],
                             channel_last_out=channel_last_out)

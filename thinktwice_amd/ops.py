@@ -677,7 +677,11 @@ def deform_im2col3x3(x, offsets, pad=1):
 def repeat_rows(t, times):
     """t (R, C) -> (times * R, C), the rows repeated block-wise (torch's t.repeat(times, 1)); a copy the training tape
     knows how to differentiate (the gradient is the sum over the repeats)."""
-    out = t.repeat(times, 1)
+    assert t.dim() == 2 and t.is_contiguous()
+    out = torch.empty(times * t.shape[0], t.shape[1], dtype=t.dtype, device=t.device)
+    nb = t.numel() * t.element_size()
+    for k in range(times):          # `times` contiguous block copies (tt_copy_bytes): no torch kernel in the forward
+        check(lib().tt_copy_bytes(ctypes.c_void_p(out.data_ptr() + k * nb), ptr(t), _ll(nb), _st(t)), "tt_copy_bytes")
     from . import autodiff
     if autodiff.TAPE is not None:
         autodiff.TAPE.repeat_rows(t, out, times)
