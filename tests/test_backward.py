@@ -1,6 +1,7 @@
 """Training-step backward through the tape (thinktwice_amd/autodiff.py): the ResNet-50 + PAFPN camera trunk's
 parameter gradients against torch autograd through the oracle (oracle/model_ref.py resnet50 / pafpn, which reproduce the
 reference's modules) under a synthetic loss  L = sum_k <fpn_k, R_k>."""
+import numpy as np
 import pytest
 import torch
 
@@ -234,6 +235,8 @@ def test_whole_camera_encoder_backward_matches_oracle_autograd(mode, tol, monkey
     for k, v in leaves.items():
         if v.grad is None or float(v.grad.abs().max()) == 0.0:
             continue
+        if train and k.endswith(".bias") and k.rsplit(".", 1)[0] + ".weight" in leaves and leaves[k.rsplit(".", 1)[0] + ".weight"].dim() > 1:
+            continue            # (a conv bias in front of a batch-statistics BatchNorm: zero gradient + rounding noise)
         if k not in tape.param_grads:
             missing.append(k)
             continue
@@ -248,34 +251,43 @@ def test_whole_camera_encoder_backward_matches_oracle_autograd(mode, tol, monkey
     assert len(worst) > 280 and not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:10]
 
 
-def test_lidar_encoder_backward_matches_oracle_autograd():
-    """LidarNet under the tape: sparse encoder (submanifold + strided rulebook convs with BatchNorm1d, residual blocks),
+@pytest.mark.parametrize("train", [False, True])
+def test_lidar_encoder_backward_matches_oracle_autograd(train):
+    """`train`: model.train() semantics (batch-statistics BatchNorm1d over the live rows of every sparse level, BatchNorm2d in
+    SECOND / SECONDFPN).  LidarNet under the tape: sparse encoder (submanifold + strided rulebook convs with BatchNorm1d, residual blocks),
     dense conversion, SECOND blocks, SECONDFPN (1x1 conv + transposed conv with BN/ReLU); every parameter gradient against
     loss.backward() through oracle.lidar_net under  L = <out, R>."""
-    from oracle import model_ref as M
-    from thinktwice_amd import autodiff, config, params
+    import contextlib
+    from oracle import model_ref as M, train_ref as TR
+    from thinktwice_amd import autodiff, config, layers, params
     from thinktwice_amd.lidarnet import LidarNet
     import test_lidar
+    mode = TR.train_mode if train else contextlib.nullcontext
     cfg = config.model_config()
     sd = params.init_params(cfg, seed=2, parts=("lidar_encoder",))
-    pts = test_lidar._pts(1, 3000, seed=4)
+    pts = test_lidar._pts(2 if train else 1, 3000, seed=4)
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()
               if k.startswith("lidar_encoder.") and v.is_floating_point() and v.dim() > 0
               and not k.endswith(("running_mean", "running_var"))}
     sdr = dict(sd)
     sdr.update(leaves)
-    ref = M.lidar_net(sdr, "lidar_encoder", cfg, pts)[0]
-    g = torch.Generator().manual_seed(13)
-    R = torch.randn(ref.shape, generator=g)
-    (ref * R).sum().backward()
+    with mode():
+        ref = M.lidar_net(sdr, "lidar_encoder", cfg, pts)[0]
+        g = torch.Generator().manual_seed(13)
+        R = torch.randn(ref.shape, generator=g)
+        (ref * R).sum().backward()
 
     le = dict(cfg["lidar_encoder"])
     le.pop("type")
     net = LidarNet(**le).load_state_dict(sd)
-    with autodiff.Tape(x3=False) as tape:
-        out = net(pts.cuda(), channel_last=True)
-        tape.seed(out, R.permute(0, 2, 3, 1))
-        tape.backward()
+    saved, layers.BN_TRAIN = layers.BN_TRAIN, train
+    try:
+        with autodiff.Tape(x3=False) as tape:
+            out = net(pts.cuda(), channel_last=True)
+            tape.seed(out, R.permute(0, 2, 3, 1))
+            tape.backward()
+    finally:
+        layers.BN_TRAIN = saved
     torch.cuda.synchronize()
     got_fwd = out.permute(0, 3, 1, 2).cpu()
     assert float((got_fwd - ref.detach()).abs().max() / ref.detach().abs().max()) < 1e-4
@@ -283,6 +295,8 @@ def test_lidar_encoder_backward_matches_oracle_autograd():
     for k, v in leaves.items():
         if v.grad is None or float(v.grad.abs().max()) == 0.0:
             continue
+        if train and k.endswith(".bias") and k.rsplit(".", 1)[0] + ".weight" in leaves and leaves[k.rsplit(".", 1)[0] + ".weight"].dim() > 1:
+            continue            # (a conv bias in front of a batch-statistics BatchNorm: zero gradient + rounding noise)
         if k not in tape.param_grads:
             missing.append(k)
             continue
@@ -295,18 +309,24 @@ def test_lidar_encoder_backward_matches_oracle_autograd():
           "worst element rel", max(e[1] for e in worst.values()))
     # the forward itself agrees with the oracle to ~1e-4 of the map's max here (27-tap sums in a different order, BN1d
     # folded), so ReLU masks differ on more elements than in the camera trunk: 5e-4 .. 1.1e-3 relative L2 observed
-    bad = {k: e for k, e in worst.items() if e[0] > 3e-3 or e[1] > 2e-2}
+    # train mode: batch statistics are computed in a different order (f64 partial sums here), so the forward agrees to ~1e-6
+    # instead of ~1e-7 and a few more ReLU masks flip on these 3000-point clouds: 4.8e-3 observed on the BatchNorm biases
+    lim = (8e-3, 4e-2) if train else (3e-3, 2e-2)
+    bad = {k: e for k, e in worst.items() if e[0] > lim[0] or e[1] > lim[1]}
     assert len(worst) > 100 and not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:10]
 
 
-def test_fusion_neck_and_flatten_backward_matches_oracle_autograd():
-    """BEV fusion neck + SEBasicBlocks (mean/amax pooling, gated residual) + flatten tail (EDF:213-235, utils.py:84-121) under
+@pytest.mark.parametrize("train", [False, True])
+def test_fusion_neck_and_flatten_backward_matches_oracle_autograd(train):
+    """`train`: model.train() semantics (batch-statistics BatchNorm2d / the BatchNorm1d of output_fc).  BEV fusion neck + SEBasicBlocks (mean/amax pooling, gated residual) + flatten tail (EDF:213-235, utils.py:84-121) under
     the tape, with upstream gradients on everything the losses touch: flat, the 32x21x21 map and the three coarser maps;
     parameter gradients AND the gradients handed back to the camera / LiDAR BEV inputs against oracle autograd."""
-    from oracle import model_ref as M
-    from thinktwice_amd import autodiff, config, params
+    import contextlib
+    from oracle import model_ref as M, train_ref as TR
+    from thinktwice_amd import autodiff, config, layers, params
     from thinktwice_amd.fusion import BEVFusion
-    B = 2
+    mode = TR.train_mode if train else contextlib.nullcontext
+    B = 4 if train else 2
     cfg = config.model_config()
     sd = params.init_params(cfg, seed=4, parts=("fusion",))
     names = [k for k in sd if k.split(".")[0] in ("conv_cam", "conv_lidar", "conv_fusion", "_256_to_32", "MLP21", "MLP10",
@@ -318,20 +338,25 @@ def test_fusion_neck_and_flatten_backward_matches_oracle_autograd():
     g = torch.Generator().manual_seed(14)
     cam = torch.randn(B, 256, 21, 21, generator=g).requires_grad_(True)
     lid = torch.randn(B, 512, 84, 84, generator=g).abs().requires_grad_(True)
-    flat, f21, mids = M.fusion(sdr, cam, lid)
-    outs = [flat, f21] + mids[3:]
-    R = [torch.randn(o.shape, generator=g) for o in outs]
-    sum((o * r).sum() for o, r in zip(outs, R)).backward()
+    with mode():
+        flat, f21, mids = M.fusion(sdr, cam, lid)
+        outs = [flat, f21] + mids[3:]
+        R = [torch.randn(o.shape, generator=g) for o in outs]
+        sum((o * r).sum() for o, r in zip(outs, R)).backward()
 
     fus = BEVFusion(sd, "cuda")
     cl = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()   # noqa: E731
     camq, lidq = cl(cam), cl(lid)
-    with autodiff.Tape(x3=False) as tape:
-        hflat, hf21, hmids = fus(camq, lidq)
-        tape.seed(hflat, R[0])
-        for t, r in zip([hf21] + hmids[3:], R[1:]):
-            tape.seed(t, r.permute(0, 2, 3, 1))
-        tape.backward()
+    saved, layers.BN_TRAIN = layers.BN_TRAIN, train
+    try:
+        with autodiff.Tape(x3=False) as tape:
+            hflat, hf21, hmids = fus(camq, lidq)
+            tape.seed(hflat, R[0])
+            for t, r in zip([hf21] + hmids[3:], R[1:]):
+                tape.seed(t, r.permute(0, 2, 3, 1))
+            tape.backward()
+    finally:
+        layers.BN_TRAIN = saved
     torch.cuda.synchronize()
     assert float((hflat.cpu() - flat.detach()).abs().max() / flat.detach().abs().max()) < 1e-4
     worst = {}
@@ -339,13 +364,21 @@ def test_fusion_neck_and_flatten_backward_matches_oracle_autograd():
         assert k in tape.param_grads, k
         got = tape.param_grads[k].cpu()
         assert got.shape == v.grad.shape, (k, got.shape, v.grad.shape)
+        if train and k.endswith(".bias") and float(v.grad.norm()) < 1e-3 * float(leaves[k[:-4] + "weight"].grad.norm()):
+            continue            # (a conv bias in front of a batch-statistics BatchNorm: zero gradient + rounding noise)
         worst[k] = float((got - v.grad).norm() / v.grad.norm().clamp_min(1e-20))
     for name, t, ref in (("d cam_bev", camq, cam), ("d lidar_bev", lidq, lid)):
         got = tape.grad(t).permute(0, 3, 1, 2).cpu()
         worst[name] = float((got - ref.grad).norm() / ref.grad.norm())
     print("fusion backward: tensors", len(worst), "worst L2 rel", max(worst.values()))
-    bad = {k: e for k, e in worst.items() if e > 1e-3}
+    # train mode: every block of this neck is exact against autograd on its own (tools/debug_se_train.py: 5e-7 per SE block,
+    # 1e-4 through the 4-row BatchNorm1d of the whole tail); composed, a ReLU mask that flips on one of the 10x10 / 4x4 maps
+    # (forward agreement 1e-6, pre-activations centred on 0 by the batch statistics) moves that block's gradients by ~1e-2
+    lim = 2e-2 if train else 1e-3
+    bad = {k: e for k, e in worst.items() if e > lim}
     assert len(worst) > 50 and not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+    if train:
+        assert float(np.median(list(worst.values()))) < 3e-3
 
 
 def test_spatial_gru_backward_matches_oracle_autograd():

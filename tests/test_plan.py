@@ -115,3 +115,29 @@ def test_full_size_forward_through_the_plan_matches_reference_golden_f8(golden_d
     torch.cuda.synchronize()
     errs = _check_against_pack(pack, out, 1e-3)
     print("F8 through the C plan:", fp.calls, "calls on", fp.nstreams, "streams; worst", max(errs.values()))
+
+
+@pytest.mark.gpu
+def test_python_free_host_runs_the_saved_plan(tmp_path):
+    """tools/plan_host (C++, no Python, no torch: tt_plan_load + tt_plan_bind + tt_encoder_fwd + tt_decoder_fwd on buffers it
+    hipMalloc'ed itself) reproduces the forward from the files `ForwardPlan.save` wrote."""
+    import subprocess
+    from thinktwice_amd import model as tm, plan as P, synth
+    host = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "plan_host")
+    if not os.path.exists(host):
+        pytest.fail("tools/plan_host is not built (python -m thinktwice_amd.build)")
+    hw = (128, 256)
+    m, cfg = _model(hw)
+    batch = tm.batch_to_device(synth.make_batch(1, img_hw=hw, num_points=20000, seed=21))
+    fp = P.compile_forward(m, batch)
+    want = {k: v.clone() for k, v in fp.run().items() if k in KEYS}
+    torch.cuda.synchronize()
+    d = fp.save(str(tmp_path / "plan"))
+    r = subprocess.run([host, d, "3"], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-600:], r.stderr[-300:])
+    assert r.returncode == 0, r.stderr
+    assert f"{fp.calls} calls" in r.stdout
+    for k in KEYS:
+        got = torch.from_numpy(np.fromfile(os.path.join(d, f"out_{k}.bin"), dtype=np.float32)).view(want[k].shape)
+        e = float((got - want[k].cpu()).abs().max() / want[k].abs().max().clamp_min(1e-9))
+        assert e < 1e-4, (k, e)

@@ -354,6 +354,15 @@ class ForwardWorkload:
             out["graph_prev_sweep_cache_ms"] = timed(gc.replay)
         except Exception as e:
             out["graph_error"] = f"{type(e).__name__}: {e}"
+        try:
+            # the same tick issued from C: a compiled launch plan (thinktwice_amd/plan.py), tt_encoder_fwd + tt_decoder_fwd
+            from . import plan as P
+            fp = P.compile_forward(self.model, b1, channel_last_out=True)
+            out["c_plan_ms"] = timed(fp.run)
+            out["c_plan_calls"], out["c_plan_streams"] = fp.calls, fp.nstreams
+            del fp
+        except Exception as e:
+            out["c_plan_error"] = f"{type(e).__name__}: {e}"[:300]
         return out
 
     def cpu_baseline(self):

@@ -73,6 +73,16 @@ def build(verbose=True, force=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    # tools/plan_host: the Python-free host of the forward (loads a plan file + weights, runs tt_encoder_fwd / tt_decoder_fwd)
+    host_src = os.path.join(HERE, "..", "tools", "plan_host.cpp")
+    host_bin = os.path.join(HERE, "..", "tools", "plan_host")
+    if os.path.exists(host_src) and (not os.path.exists(host_bin) or
+                                     os.path.getmtime(host_bin) < max(os.path.getmtime(host_src), os.path.getmtime(LIB))):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include"),
+               host_src, "-L", HERE, "-lthinktwice_hip", "-Wl,-rpath,$ORIGIN/../thinktwice_amd", "-o", host_bin]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     return LIB
 
 
