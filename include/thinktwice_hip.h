@@ -331,6 +331,14 @@ int tt_lidar_voxelize(const float* points, int B, int Np, int nfeat, const float
                       const float* voxel_size, const int* grid_xyz, int z_limit, int max_points,
                       void* workspace, long long workspace_bytes, float* voxel_feats, int* coords,
                       int* num_voxels, void* stream);
+/* the same with mmcv's max_voxels cap: voxels are created in order of first appearance (point order) and at most
+ * `max_voxels` per sample exist; points of later voxels are dropped (configs/thinktwice.py:161-165: 120000 train / 160000
+ * eval; call site backbones/lidarnet.py:88).  Needed only when a sample holds more points than the cap (else
+ * tt_lidar_voxelize gives the same rows); rows come out in cell order like there */
+long long tt_lidar_voxelize_capped_workspace_bytes(long long num_points_total);
+int tt_lidar_voxelize_capped(const float* points, int B, int Np, int nfeat, const float* pc_range_lo, const float* voxel_size,
+                             const int* grid_xyz, int z_limit, int max_points, int max_voxels, void* workspace,
+                             long long workspace_bytes, float* voxel_feats, int* coords, int* num_voxels, void* stream);
 /* dense index volume of one resolution level: vol int32 [batch, D, H, W] = feature row or -1 */
 int tt_sp_volume_build(const int* coords, const int* num_rows, long long max_rows, int batch,
                        const int* dims_zyx, int* vol, void* stream);

@@ -100,3 +100,38 @@ def test_lidar_empty_sample_and_collate_padding():
     assert err < 1e-4, err
     feats, coords, num, _ = net.voxelize(pts.cuda())
     assert int((coords[:int(num.item()), 0] == 0).sum()) == 0          # nothing from the empty sample
+
+
+@pytest.mark.parametrize("cap", [700, 2500])
+def test_voxelize_max_voxels_cap_keeps_the_first_appearing_voxels(cap):
+    """mmcv's max_voxels (first-appearance order, per sample; configs/thinktwice.py:161-165): more points than the cap ->
+    tt_lidar_voxelize_capped.  Against oracle.model_ref.hard_voxelize with the same cap, per sample, as sets keyed by cell."""
+    from oracle import model_ref as M
+    from thinktwice_amd import config
+    from thinktwice_amd.lidarnet import LidarNet
+    cfg = config.model_config()
+    le = dict(cfg["lidar_encoder"])
+    le.pop("type")
+    net = LidarNet(**le)
+    pts = _pts(2, 5000, seed=17)
+    feats, coords, num, _ = net.voxelize(pts.cuda(), max_voxels=cap)
+    M_ = int(num.item())
+    cg, fg = coords[:M_].cpu().long(), feats[:M_].cpu()
+    vl = cfg["lidar_encoder"]["pts_voxel_layer"]
+    total = 0
+    for b in range(2):
+        v, c, n = M.hard_voxelize(pts[b], vl["voxel_size"], vl["point_cloud_range"], 10, cap)
+        assert c.shape[0] <= cap
+        keep = c[:, 0] < 41
+        v, c, n = v[keep], c[keep], n[keep]
+        sel = cg[:, 0] == b
+        key_o = (c[:, 0] * 672 + c[:, 1]) * 672 + c[:, 2]
+        key_g = (cg[sel, 1] * 672 + cg[sel, 2]) * 672 + cg[sel, 3]
+        so, sg = torch.argsort(key_o), torch.argsort(key_g)
+        np.testing.assert_array_equal(key_o[so].numpy(), key_g[sg].numpy())
+        np.testing.assert_allclose(fg[sel][sg].numpy(), (v.sum(1) / n[:, None].float())[so].numpy(), rtol=1e-5, atol=1e-6)
+        total += c.shape[0]
+    assert total == M_
+    # the cap really bound: the uncapped pipeline finds more voxels
+    _, _, num_all, _ = net.voxelize(pts.cuda())
+    assert int(num_all.item()) > M_

@@ -84,6 +84,81 @@ __global__ void vfe_mean_kernel(const float* __restrict__ pts, const unsigned* _
     feats[v * nfeat + f] = sum / (float)cnt;     // HardSimpleVFE: sum / num_points
 }
 
+
+// ----------------------------------------------------------------------------- max_voxels cap (first-appearance order)
+// mmcv's hard voxelisation creates voxels in the order their first point appears and stops creating new ones at
+// `max_voxels` per sample (points of later voxels are dropped; configs/thinktwice.py:161-165 (120000, 160000), call site
+// backbones/lidarnet.py:88).  The sorted pipeline above emits voxels in CELL order; the capped variant ranks every voxel by
+// the index of its first point (stable sort: the head of a run is its earliest point), keeps rank < max_voxels, and only
+// then drops the voxels beyond the sparse grid's z extent (the cap counts them, like mmcv does).
+__global__ void cap_head_points_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ flags,
+                                       const int* __restrict__ scan_h, const unsigned* __restrict__ vals, long long n,
+                                       int* __restrict__ head_pos, int* __restrict__ pt_flag, int* __restrict__ n_heads) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flags[i]) {
+        head_pos[scan_h[i]] = (int)i;
+        pt_flag[vals[i]] = 1;
+    }
+    if (i == n - 1) *n_heads = scan_h[i] + flags[i];
+}
+
+__global__ void cap_keep_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ flags,
+                                const unsigned* __restrict__ vals, const int* __restrict__ scan_p, long long n, int Np, int gx,
+                                int gy, int gz, int zlimit, int max_voxels, int* __restrict__ keep) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int k = 0;
+    if (flags[i]) {
+        unsigned long long key = keys[i];
+        key /= gx; key /= gy;
+        const int z = (int)(key % gz);
+        const long long p = vals[i];
+        const long long b = p / Np;
+        const int rank = scan_p[p] - scan_p[b * Np];          // voxels of this sample created before this one
+        k = (rank < max_voxels && z < zlimit) ? 1 : 0;
+    }
+    keep[i] = k;
+}
+
+__global__ void cap_emit_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ keep,
+                                const int* __restrict__ scan_k, const int* __restrict__ scan_h,
+                                const int* __restrict__ head_pos, const int* __restrict__ n_heads,
+                                const int* __restrict__ n_valid, long long n, int gx, int gy, int gz, int* __restrict__ coords,
+                                int* __restrict__ first, int* __restrict__ last, int* __restrict__ num_voxels) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (keep[i]) {
+        const int v = scan_k[i], h = scan_h[i];
+        unsigned long long k = keys[i];
+        const int x = (int)(k % gx); k /= gx;
+        const int y = (int)(k % gy); k /= gy;
+        const int z = (int)(k % gz); k /= gz;
+        coords[v * 4 + 0] = (int)k;
+        coords[v * 4 + 1] = z;
+        coords[v * 4 + 2] = y;
+        coords[v * 4 + 3] = x;
+        first[v] = (int)i;
+        last[v] = (h + 1 < *n_heads) ? head_pos[h + 1] : *n_valid;
+    }
+    if (i == n - 1) *num_voxels = scan_k[i] + keep[i];
+}
+
+__global__ void vfe_mean_capped_kernel(const float* __restrict__ pts, const unsigned* __restrict__ vals,
+                                       const int* __restrict__ first, const int* __restrict__ last,
+                                       const int* __restrict__ num_voxels, int nfeat, int max_points, long long max_rows,
+                                       float* __restrict__ feats) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long v = t / nfeat;
+    const int f = (int)(t % nfeat);
+    if (v >= *num_voxels || v >= max_rows) return;
+    const int s = first[v];
+    const int cnt = min(last[v] - s, max_points);
+    float sum = 0.f;
+    for (int j = 0; j < cnt; ++j) sum += pts[(long long)vals[s + j] * nfeat + f];
+    feats[v * nfeat + f] = sum / (float)cnt;
+}
+
 // ----------------------------------------------------------------------------- dense index volumes
 // Each resolution level keeps vol[b][z][y][x] = feature row or -1.  The synthetic / real LiDAR grids of this
 // model are small enough (<= 148 M cells at the input level for B = 8) that a dense volume beats a hash
@@ -268,6 +343,74 @@ extern "C" int tt_lidar_voxelize(const float* points, int B, int Np, int nfeat, 
     hipLaunchKernelGGL(vfe_mean_kernel, dim3((unsigned)div_up(n * nfeat, 256)), dim3(256), 0, st, points, vals_out,
                        first, num_voxels, n_valid, nfeat, max_points, n, voxel_feats);
     return check_launch("tt_lidar_voxelize");
+}
+
+
+extern "C" long long tt_lidar_voxelize_capped_workspace_bytes(long long num_points_total) {
+    const long long n = num_points_total;
+    return tt_lidar_voxelize_workspace_bytes(n) + (long long)(8 * align256(sizeof(int) * (n + 1)));
+}
+
+extern "C" int tt_lidar_voxelize_capped(const float* points, int B, int Np, int nfeat, const float* pc_range_lo,
+                                        const float* voxel_size, const int* grid_xyz, int z_limit, int max_points,
+                                        int max_voxels, void* workspace, long long workspace_bytes, float* voxel_feats,
+                                        int* coords, int* num_voxels, void* stream) {
+    TT_REQUIRE(points && pc_range_lo && voxel_size && grid_xyz && workspace && voxel_feats && coords && num_voxels,
+               "tt_lidar_voxelize_capped: null");
+    const long long n = (long long)B * Np;
+    TT_REQUIRE(n > 0 && n < (1ll << 30) && max_voxels > 0, "tt_lidar_voxelize_capped: bad sizes");
+    TT_REQUIRE(workspace_bytes >= tt_lidar_voxelize_capped_workspace_bytes(n), "tt_lidar_voxelize_capped: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)workspace;
+    auto take = [&](size_t bytes) { char* p = w; w += align256(bytes); return p; };
+    auto* keys_in = (unsigned long long*)take(sizeof(unsigned long long) * n);
+    auto* keys_out = (unsigned long long*)take(sizeof(unsigned long long) * n);
+    auto* vals_in = (unsigned*)take(sizeof(unsigned) * n);
+    auto* vals_out = (unsigned*)take(sizeof(unsigned) * n);
+    auto* flags = (int*)take(sizeof(int) * n);
+    auto* scan_h = (int*)take(sizeof(int) * n);
+    auto* first = (int*)take(sizeof(int) * (n + 1));
+    auto* n_valid = (int*)take(sizeof(int) * 4);
+    auto* head_pos = (int*)take(sizeof(int) * (n + 1));
+    auto* pt_flag = (int*)take(sizeof(int) * (n + 1));
+    auto* scan_p = (int*)take(sizeof(int) * (n + 1));
+    auto* keep = (int*)take(sizeof(int) * (n + 1));
+    auto* scan_k = (int*)take(sizeof(int) * (n + 1));
+    auto* last = (int*)take(sizeof(int) * (n + 1));
+    auto* n_heads = (int*)take(sizeof(int) * (n + 1));
+    void* tmp = w;
+    size_t tmp_bytes = (size_t)(workspace_bytes - (w - (char*)workspace));
+    (void)hipMemsetAsync(n_valid, 0, sizeof(int), st);
+    (void)hipMemsetAsync(num_voxels, 0, sizeof(int), st);
+    (void)hipMemsetAsync(n_heads, 0, sizeof(int), st);
+    (void)hipMemsetAsync(pt_flag, 0, sizeof(int) * n, st);
+    const unsigned blocks = (unsigned)div_up(n, 256);
+    // keys over the WHOLE voxel grid (z_limit = grid z): the cap counts the voxels beyond the sparse grid too
+    hipLaunchKernelGGL(lidar_keys_kernel, dim3(blocks), dim3(256), 0, st, points, B, Np, nfeat, pc_range_lo[0],
+                       pc_range_lo[1], pc_range_lo[2], voxel_size[0], voxel_size[1], voxel_size[2], grid_xyz[0],
+                       grid_xyz[1], grid_xyz[2], grid_xyz[2], keys_in, vals_in);
+    size_t sb = tmp_bytes;
+    if (hipcub::DeviceRadixSort::SortPairs(tmp, sb, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 64, st) != hipSuccess) {
+        set_error("tt_lidar_voxelize_capped: radix sort failed");
+        return -2;
+    }
+    hipLaunchKernelGGL(mark_heads_kernel, dim3(blocks), dim3(256), 0, st, keys_out, n, flags, n_valid);
+    auto scan = [&](const int* in, int* out) {
+        size_t b = tmp_bytes;
+        return hipcub::DeviceScan::ExclusiveSum(tmp, b, in, out, (int)n, st) == hipSuccess;
+    };
+    if (!scan(flags, scan_h)) { set_error("tt_lidar_voxelize_capped: scan failed"); return -2; }
+    hipLaunchKernelGGL(cap_head_points_kernel, dim3(blocks), dim3(256), 0, st, keys_out, flags, scan_h, vals_out, n, head_pos,
+                       pt_flag, n_heads);
+    if (!scan(pt_flag, scan_p)) { set_error("tt_lidar_voxelize_capped: scan failed"); return -2; }
+    hipLaunchKernelGGL(cap_keep_kernel, dim3(blocks), dim3(256), 0, st, keys_out, flags, vals_out, scan_p, n, Np, grid_xyz[0],
+                       grid_xyz[1], grid_xyz[2], z_limit, max_voxels, keep);
+    if (!scan(keep, scan_k)) { set_error("tt_lidar_voxelize_capped: scan failed"); return -2; }
+    hipLaunchKernelGGL(cap_emit_kernel, dim3(blocks), dim3(256), 0, st, keys_out, keep, scan_k, scan_h, head_pos, n_heads,
+                       n_valid, n, grid_xyz[0], grid_xyz[1], grid_xyz[2], coords, first, last, num_voxels);
+    hipLaunchKernelGGL(vfe_mean_capped_kernel, dim3((unsigned)div_up(n * nfeat, 256)), dim3(256), 0, st, points, vals_out,
+                       first, last, num_voxels, nfeat, max_points, n, voxel_feats);
+    return check_launch("tt_lidar_voxelize_capped");
 }
 
 static ConvGeom geom_of(const int* g) { return ConvGeom{g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8]}; }

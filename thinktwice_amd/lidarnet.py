@@ -228,22 +228,27 @@ class LidarNet:
         self.de1 = deconv2x2_from_sd(sd, q + ".1.0", self.wdtype, dev, bn=q + ".1.1", eps=eps, act="relu", bn_momentum=mom)
         return self
 
-    def voxelize(self, pts):
-        """MVXTwoStageDetector.voxelize + HardSimpleVFE on the device.  mmcv's hard voxelization keeps at most
-        max_voxels (120000 train / 160000 eval, per sample) voxels in first-appearance order; a sample has at most one
-        voxel per point, so the cap cannot bind while Np <= max_voxels (65536 points per sweep in the reference data).
-        The cap itself is not implemented: a larger cloud is refused instead of silently diverging."""
+    def voxelize(self, pts, max_voxels=None):
+        """MVXTwoStageDetector.voxelize + HardSimpleVFE on the device.  mmcv's hard voxelization keeps at most max_voxels
+        (120000 train / 160000 eval, per sample) voxels in first-appearance order; a sample has at most one voxel per point,
+        so the cap cannot bind while Np <= max_voxels (65536 points per sweep in the reference data): the sorted pipeline
+        then runs as is; larger clouds take `tt_lidar_voxelize_capped` (first-appearance ranking of the voxels).
+        `max_voxels`: override of the configured cap (tests)."""
         B, Np, nf = pts.shape
         vl = self.vl
-        cap = vl.get("max_voxels", (120000, 160000))
-        cap = cap[1] if isinstance(cap, (tuple, list)) else cap
-        if Np > cap:
-            raise _lib.TTError(f"LidarNet.voxelize: {Np} points per sample can exceed max_voxels={cap}; the first-"
-                               f"appearance voxel cap of mmcv hard voxelization is not implemented")
+        if max_voxels is None:
+            cap = vl.get("max_voxels", (120000, 160000))
+            max_voxels = (cap[0] if self.training else cap[1]) if isinstance(cap, (tuple, list)) else cap
         rng, vs = vl["point_cloud_range"], vl["voxel_size"]
         grid = [int(round((rng[3 + d] - rng[d]) / vs[d])) for d in range(3)]
         n = B * Np
-        ws_bytes = int(lib().tt_lidar_voxelize_workspace_bytes(_ll(n)))
+        L = lib()
+        capped = Np > max_voxels
+        if capped:
+            L.tt_lidar_voxelize_capped_workspace_bytes.restype = ctypes.c_longlong
+            ws_bytes = int(L.tt_lidar_voxelize_capped_workspace_bytes(_ll(n)))
+        else:
+            ws_bytes = int(L.tt_lidar_voxelize_workspace_bytes(_ll(n)))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pts.device)
         feats = torch.empty(n, nf, dtype=F32, device=pts.device)
         coords = torch.empty(n, 4, dtype=torch.int32, device=pts.device)
@@ -251,7 +256,12 @@ class LidarNet:
         lo = (ctypes.c_float * 3)(*rng[:3])
         vsz = (ctypes.c_float * 3)(*vs)
         g = (ctypes.c_int * 3)(*grid)
-        check(lib().tt_lidar_voxelize(ptr(pts), _c(B), _c(Np), _c(nf), lo, vsz, g, _c(self.middle.sparse_shape[0]),
+        if capped:
+            check(L.tt_lidar_voxelize_capped(ptr(pts), _c(B), _c(Np), _c(nf), lo, vsz, g, _c(self.middle.sparse_shape[0]),
+                                             _c(vl["max_num_points"]), _c(int(max_voxels)), ptr(ws), _ll(ws_bytes), ptr(feats),
+                                             ptr(coords), ptr(num), ops.cur_stream(pts.device)), "tt_lidar_voxelize_capped")
+        else:
+            check(L.tt_lidar_voxelize(ptr(pts), _c(B), _c(Np), _c(nf), lo, vsz, g, _c(self.middle.sparse_shape[0]),
                                       _c(vl["max_num_points"]), ptr(ws), _ll(ws_bytes), ptr(feats), ptr(coords),
                                       ptr(num), ops.cur_stream(pts.device)), "tt_lidar_voxelize")
         return feats, coords, num, n
