@@ -114,6 +114,18 @@ int tt_lift_splat_fwd(int batch_size, int num_cams, int D, int fH, int fW, int C
                       const int32_t* geom_xyz, float* out, int out_cstride,
                       int out_coff, int rot_flip, void* stream);
 
+/* Same with a caller-provided workspace (tt_lift_splat_workspace_bytes; its contents do not matter): every image strip
+ * stores one partial row per BEV cell it touches plus its cell -> slot table, and a second kernel adds each cell's
+ * partial rows to `out` in strip order -- no floating-point atomics, so equal inputs give bit-identical output.
+ * ws == NULL, or a shape the strip kernel does not take (workspace_bytes == 0), is tt_lift_splat_fwd. */
+long long tt_lift_splat_workspace_bytes(int batch_size, int num_cams, int D, int fH, int fW, int C,
+                                        int num_voxel_x, int num_voxel_y);
+int tt_lift_splat_fwd_ws(int batch_size, int num_cams, int D, int fH, int fW, int C,
+                         int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                         const void* depth_logits, const void* context, int dtype,
+                         const int32_t* geom_xyz, float* out, int out_cstride,
+                         int out_coff, int rot_flip, void* ws, long long ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Implicit-GEMM convolution / linear on MFMA, channel-last activations.
  *   out[n,oh,ow,co] = act( scale[co]*sum(...) + shift[co] + shift_n[n%mod,co]
@@ -158,9 +170,15 @@ typedef struct tt_conv_desc {
      * row_perm[256 i .. 256 i + 255] and multiplies only the taps set in the union of their masks */
     const int* row_perm;
     const unsigned* row_mask;
+    /* split-K without atomics: `splitk_ws` holds this many [N*OH*OW][Cout] f32 slices (>= tt_conv2d_splitk_slices(d), no
+     * zero fill needed); every K split stores its partial tile into its own slice and the finalize kernel adds the slices
+     * in index order -- bit-reproducible.  0: the legacy form (one zero-filled slice, f32 atomics) */
+    int splitk_slices;
 } tt_conv_desc;
 
 int tt_conv2d_fwd(const tt_conv_desc* d, void* stream);
+/* K splits tt_conv2d_fwd would use for this descriptor if it is given a split-K workspace (0: the layer does not split) */
+int tt_conv2d_splitk_slices(const tt_conv_desc* d);
 
 /* ------------------------------------------------------------------------
  * A chain of nn.Linear layers over R rows in ONE launch (the decoder's row-batched MLPs:

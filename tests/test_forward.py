@@ -63,6 +63,18 @@ def test_forward_small_matches_reference_golden_and_oracle(golden_dir):
     assert l2 < 1e-3, l2
 
 
+@pytest.mark.parametrize("dt", [torch.float32, "f32x3"], ids=["f32", "bf16x3"])
+def test_forward_is_bit_reproducible(dt):
+    """Two forwards of the same batch are torch.equal in every output: no floating-point atomics on the inference path
+    (ordered split-K slices, lift-splat partial rows reduced in strip order)."""
+    outs = []
+    for _ in range(2):
+        out, _, _, _ = _run_model(2, (128, 256), 3000, 11, dtype=dt)
+        outs.append({k: out[k].clone() for k in KEYS})
+    for k in KEYS:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
 def test_forward_full_size_matches_reference_golden(golden_dir):
     pack = np.load(os.path.join(golden_dir, "f8_forward_full_b1.npz"))
     B, H, W, npts, seed = (int(v) for v in pack["meta"])

@@ -29,7 +29,6 @@ def _setup(mode):
 def test_training_backward_matches_reference_gradients_golden_f13(mode, tol, monkeypatch):
     from thinktwice_amd import ops
     from thinktwice_amd.trainer import Trainer
-    monkeypatch.setattr(ops, "_AUTO_SPLITK", False)          # (atomic split-K accumulation: not bit-reproducible)
     pack, m, sd, batch = _setup(mode)
     tr = Trainer(m, sd)
     out = tr.backward(batch)
@@ -215,7 +214,6 @@ def test_training_backward_in_train_mode_matches_reference_gradients_golden_f16(
     5e-7 .. 1e-5); this test pins the composition: median <= 2e-2, 90th percentile <= 6e-2, worst <= 0.25."""
     from thinktwice_amd import ops
     from thinktwice_amd.trainer import Trainer
-    monkeypatch.setattr(ops, "_AUTO_SPLITK", False)
     pack, m, cfg, sd, batch, (B, hw, rng) = _setup_train_mode(mode, "f16")
     tr = Trainer(m, sd, frozen_bn=False)
     ops.DROPOUT_MASKS = iter([_reference_dropout_masks(B, cfg, hw, rng)])

@@ -226,3 +226,38 @@ def test_hip_fused_lift_splat_matches_materialised_reference_formulation(dt):
     bev = torch.from_numpy(ref).permute(0, 3, 1, 2)                              # [B,C,Y,X]
     want = torch.rot90(torch.flip(bev, dims=[2]), 1, dims=[2, 3])                # EDF:241
     np.testing.assert_allclose(out_rf.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_lift_splat_workspace_form_is_bit_reproducible_and_matches_the_atomic_form(monkeypatch):
+    """tt_lift_splat_fwd_ws (partial rows per (strip, cell) + ordered per-cell reduce, no f32 atomics) on ray-like geometry
+    (every image column falls into a handful of BEV cells, as with a real frustum): equal to the materialised formulation,
+    to the atomic single-kernel form within rounding, and bit-identical from run to run."""
+    from thinktwice_amd import ops
+    B, N, D, H, W, C, X = 2, 4, 80, 16, 24, 80, 32
+    g = torch.Generator().manual_seed(5)
+    depth = (torch.randn(B * N, H, W, D, generator=g) * 2).cuda()
+    ctx = torch.randn(B * N, H, W, C, generator=g).cuda()
+    # rays: azimuth from (camera, column), range from the depth bin; a few rows look over the grid's edge
+    cam = torch.arange(N).view(1, N, 1, 1, 1).float()
+    d = torch.arange(D).view(1, 1, D, 1, 1).float()
+    h = torch.arange(H).view(1, 1, 1, H, 1).float()
+    w = torch.arange(W).view(1, 1, 1, 1, W).float()
+    b = torch.arange(B).view(B, 1, 1, 1, 1).float()
+    az = cam * (np.pi / 2) + (w / W - 0.5) * 1.4 + 0.05 * b
+    rng = 0.5 + d * 0.25 + 0.0 * h
+    gx = torch.floor(X / 2 + rng * torch.cos(az)).expand(B, N, D, H, W)
+    gy = torch.floor(X / 2 + rng * torch.sin(az)).expand(B, N, D, H, W)
+    gz = torch.where(h.expand(B, N, D, H, W) == H - 1, 1.0, 0.0)
+    geom = torch.stack([gx, gy, gz], -1).reshape(B, N * D * H * W, 3).to(torch.int32).cuda()
+    out1 = ops.lift_splat(depth, ctx, geom, (X, X, 1), B, N)
+    out2 = ops.lift_splat(depth, ctx, geom, (X, X, 1), B, N)
+    assert torch.equal(out1, out2)
+    monkeypatch.setattr(ops, "_LIFT_SPLAT_ATOMIC", True)
+    out_at = ops.lift_splat(depth, ctx, geom, (X, X, 1), B, N)
+    np.testing.assert_allclose(out1.cpu().numpy(), out_at.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    vol = depth.cpu().permute(0, 3, 1, 2).softmax(1).unsqueeze(1) * ctx.cpu().permute(0, 3, 1, 2).unsqueeze(2)
+    vol = vol.reshape(B, N, C, D, H, W).permute(0, 1, 3, 4, 5, 2).contiguous()
+    ref, _ = c_ref.voxel_pool_fwd(geom.cpu().numpy(), vol.reshape(B, -1, C).numpy(), (X, X, 1))
+    np.testing.assert_allclose(out1.cpu().numpy(), ref, rtol=2e-4, atol=2e-5)
+    assert float(out1.abs().sum()) > 0

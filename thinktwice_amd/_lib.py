@@ -38,6 +38,8 @@ def lib():
             _lib.tt_sp_strided_outputs_workspace_bytes.restype = ctypes.c_longlong
         if hasattr(_lib, "tt_lidar_voxelize_workspace_bytes"):
             _lib.tt_lidar_voxelize_workspace_bytes.restype = ctypes.c_longlong
+        if hasattr(_lib, "tt_lift_splat_workspace_bytes"):
+            _lib.tt_lift_splat_workspace_bytes.restype = ctypes.c_longlong
     return _lib
 
 

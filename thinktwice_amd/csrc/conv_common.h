@@ -40,6 +40,7 @@ struct ConvArgs {
     int splits;          // split-K factor (gridDim.y)
     int tiles_n;
     int m_begin;         // first output row of this launch (tail-split launches of the LDS-DMA kernel), else 0
+    int ws_slices;       // split-K: > 0 = every split stores into its own [M][Cout] slice of ws (ordered finalize)
     int flags;           // bit 0: s_setprio(1) around the MFMA groups of the LDS-DMA kernel (TT_GLDS_SETPRIO=1, A/B knob)
 };
 
@@ -328,7 +329,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (m < Mlim) unsafeAtomicAdd(p.ws + (long long)m * p.Cout + col, acc[i][j][r]);
+                    if (m < Mlim) {
+                        if (p.ws_slices > 0) p.ws[((long long)blockIdx.y * p.M + m) * p.Cout + col] = acc[i][j][r];
+                        else unsafeAtomicAdd(p.ws + (long long)m * p.Cout + col, acc[i][j][r]);
+                    }
                 }
         }
         return;

@@ -242,7 +242,9 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const ConvArgs p) 
     int oh = rem / p.OW, ow = rem - oh * p.OW, OWo = p.OW;
     if (p.pixel_shuffle2) { oh = 2 * oh + (q >> 1); ow = 2 * ow + (q & 1); OWo = 2 * p.OW; }
     const long long o = (long long)n * p.out_nstride + ((long long)oh * OWo + ow) * p.out_cstride + p.out_coff + co;
-    float v = p.ws[t] * (p.scale ? p.scale[co] : 1.f) + (p.shift ? p.shift[co] : 0.f);
+    float acc = p.ws[t];
+    for (int sl = 1; sl < p.ws_slices; ++sl) acc += p.ws[(long long)sl * p.M * p.Cout + t];     // the K splits, in index order
+    float v = acc * (p.scale ? p.scale[co] : 1.f) + (p.shift ? p.shift[co] : 0.f);
     if (p.shift_n) v += p.shift_n[(n % p.shift_n_mod) * cout_real + co];
     if (p.res1) v += Elem<T>::ld(reinterpret_cast<const T*>(p.res1) + (long long)m * p.res1_cstride + p.res1_coff + co);
     if (p.res2) v += Elem<T>::ld(reinterpret_cast<const T*>(p.res2) + (long long)m * p.res2_cstride + p.res2_coff + co);
@@ -276,13 +278,21 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
     const int tiles = tiles_m * a.tiles_n;
     const int nk = div_up(a.K, BK);
     a.splits = 1;
-    if (a.ws && !a.m_dev && tiles < 128 && nk >= 8) {
+    if ((a.ws || a.flags < 0) && !a.m_dev && tiles < 128 && nk >= 8) {
         int sp = div_up(512, tiles);
         if (sp > nk / 2) sp = nk / 2;
         if (sp > 64) sp = 64;
         a.splits = sp < 1 ? 1 : sp;
     }
+    if (a.flags < 0) return a.splits > 1 ? a.splits : 0;       // query (tt_conv2d_splitk_slices): no launch
     if (a.splits <= 1) a.ws = nullptr;
+    if (a.ws && a.ws_slices > 0) {
+        // ordered form: the non-empty splits (the K tiles are dealt in runs of ceil(nk / splits)) store into their own slices
+        const int per = div_up(nk, a.splits);
+        const int eff = div_up(nk, per);
+        TT_REQUIRE(a.ws_slices >= eff, "tt_conv2d_fwd: split-K workspace holds %d slices, %d needed", a.ws_slices, eff);
+        a.ws_slices = eff;
+    }
     snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_igemm_kernel<%s, %d, %d>%s", sizeof(T) == 4 ? "float" : "16-bit",
              BM, BN, a.ws ? " split-K" : "");
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)a.splits), dim3(256), smem, st, a);
@@ -309,7 +319,16 @@ static int dispatch_conv(ConvArgs& a, hipStream_t st) {
 
 using namespace tt;
 
-extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
+static int conv2d_run(const tt_conv_desc* d, void* stream, bool query);
+
+extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) { return conv2d_run(d, stream, false); }
+
+extern "C" int tt_conv2d_splitk_slices(const tt_conv_desc* d) {
+    const int n = conv2d_run(d, nullptr, true);
+    return n > 0 ? n : 0;
+}
+
+static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     TT_REQUIRE(d && d->in && d->weight && d->out, "tt_conv2d_fwd: null pointer");
     TT_REQUIRE(d->dtype == TT_F32 || d->dtype == TT_BF16 || d->dtype == TT_F16, "tt_conv2d_fwd: bad dtype %d", d->dtype);
     TT_REQUIRE(d->out_dtype == TT_F32 || d->out_dtype == d->dtype,
@@ -334,6 +353,7 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
     a.row_mask = d->gather_idx ? d->row_mask : nullptr;
     TT_REQUIRE(!a.row_perm == !a.row_mask, "tt_conv2d_fwd: row_perm and row_mask come together");
     a.ws = d->splitk_ws;
+    a.ws_slices = d->splitk_ws ? d->splitk_slices : 0;
     TT_REQUIRE(!d->gather_idx || (d->H == 1 && d->W == 1 && d->OH == 1 && d->OW == 1 && d->KH == 1 &&
                                   !d->pixel_shuffle2),
                "tt_conv2d_fwd: gather mode wants H=W=OH=OW=KH=1, KW=taps");
@@ -365,6 +385,7 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
         static const int x3_pipe = [] { const char* e = getenv("TT_GLDS_X3_PIPE"); return e ? atoi(e) : 0; }();
         a.flags = (setprio ? 1 : 0) | (x3_pipe ? 0 : 2);
     }
+    if (query) a.flags = -1;       // launch_conv returns the split count instead of launching
     {
         const int co_vec = d->out_dtype == TT_F32 ? 4 : 8;
         const int osz = d->out_dtype == TT_F32 ? 4 : 2;
@@ -381,6 +402,14 @@ extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) {
         a.res_vec = (res_ok(d->res1, d->res1_cstride, d->res1_coff) && res_ok(d->res2, d->res2_cstride, d->res2_coff)) ? 1 : 0;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (query) {
+        a.ws = nullptr;
+        a.row_perm = nullptr;
+        a.row_mask = nullptr;
+        if (d->dtype == TT_F32) return dispatch_conv<float>(a, st);
+        if (d->dtype == TT_F16) return dispatch_conv<f16_t>(a, st);
+        return dispatch_conv<uint16_t>(a, st);
+    }
     if (!d->splitk_ws && try_launch_conv_small(a, d->dtype, st)) {
         snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_small_kernel");
         return check_launch("tt_conv2d_fwd(small)");

@@ -574,6 +574,10 @@ __global__ __launch_bounds__(256) void lift_splat_kernel(
 //   3. forms sum_pixel W[slot][pixel] * context[pixel, :] with one wave per slot (context rows are
 //      coalesced 1 KiB loads, L2 resident) and issues ONE atomic row per (strip, cell)
 // -- ~13x fewer global atomics than the one-wave-per-pixel kernel above.
+// With a workspace (tt_lift_splat_fwd_ws) there are no atomics at all: step 2 builds W with one thread per pixel
+// walking its ray in depth order, step 3 stores the (strip, cell) partial rows to ws_rows[block][slot][C] and the
+// block's cell -> slot table to slot_of[block][cell]; lift_splat_cells_kernel then adds every cell's partial rows to
+// the output in block order.  Same inputs => bit-identical output.
 // ---------------------------------------------------------------------------
 constexpr int kStripW = 2;
 constexpr int kMaxStripPix = 64;     // fH * kStripW <= 64
@@ -584,7 +588,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void lift_splat_strip_kernel(
     int B, int ncam, int D, int fH, int fW, int C, int X, int Y, int Z, const T* __restrict__ depth_logits,
     const T* __restrict__ ctx, const int32_t* __restrict__ geom, float* __restrict__ out, int out_cstride,
-    int out_coff, int rot_flip) {
+    int out_coff, int rot_flip, float* __restrict__ ws_rows, unsigned char* __restrict__ slot_of) {
     __shared__ float prob[kMaxStripPix][kMaxD];
     __shared__ short cellid[kMaxStripPix][kMaxD];
     __shared__ int table[kMaxCells];
@@ -665,12 +669,35 @@ __global__ __launch_bounds__(256) void lift_splat_strip_kernel(
         return out + (((long long)b * OH + oi) * OW + oj) * out_cstride + out_coff;
     };
     // W[slot][pixel]; (pixel, depth) pairs whose slot is over budget go straight to global atomics
-    for (int i = tid; i < npx * D; i += 256) {
-        const int p = i / D, d = i % D;
-        const int c = cellid[p][d];
-        if (c < 0) continue;
-        const int sidx = table[c];
-        if (sidx < kMaxSlots) atomicAdd(&Wt[sidx][p], prob[p][d]);
+    if (ws_rows) {
+        // ordered: one thread per pixel walks its ray front to back; consecutive depths in one cell are summed in a register
+        for (int i = tid; i < cells; i += 256) {
+            const int t = table[i];
+            slot_of[(long long)blockIdx.x * cells + i] = (unsigned char)((t >= 0 && t < kMaxSlots) ? t : 255);
+        }
+        if (tid < npx) {
+            int cur = -1;
+            float w = 0.f;
+            for (int d = 0; d < D; ++d) {
+                const int c = cellid[tid][d];
+                const int sidx = (c < 0) ? -1 : table[c];
+                if (sidx != cur) {
+                    if (cur >= 0 && cur < kMaxSlots) Wt[cur][tid] += w;
+                    cur = sidx;
+                    w = 0.f;
+                }
+                w += prob[tid][d];
+            }
+            if (cur >= 0 && cur < kMaxSlots) Wt[cur][tid] += w;
+        }
+    } else {
+        for (int i = tid; i < npx * D; i += 256) {
+            const int p = i / D, d = i % D;
+            const int c = cellid[p][d];
+            if (c < 0) continue;
+            const int sidx = table[c];
+            if (sidx < kMaxSlots) atomicAdd(&Wt[sidx][p], prob[p][d]);
+        }
     }
     __syncthreads();
     // 3. one wave per slot
@@ -694,6 +721,15 @@ __global__ __launch_bounds__(256) void lift_splat_strip_kernel(
                 }
             }
         }
+        if (ws_rows) {
+            float4* wr = reinterpret_cast<float4*>(ws_rows + ((long long)blockIdx.x * kMaxSlots + sidx) * C);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ch = lane + 64 * v;
+                if (ch < c4) wr[ch] = acc[v];
+            }
+            continue;
+        }
         float* dst = out_row(slot_cell[sidx]);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -716,6 +752,62 @@ __global__ __launch_bounds__(256) void lift_splat_strip_kernel(
             const T* crow = ctx + (((long long)bc * fH + h) * fW + w) * C;
             float* dst = out_row(c);
             for (int ch = lane; ch < C; ch += 64) unsafeAtomicAdd(dst + ch, wgt * Elem<T>::ld(crow + ch));
+        }
+    }
+}
+
+// second pass of the atomics-free lift-splat: one wave per (sample, BEV cell) finds the strips that produced a partial
+// row for the cell (slot_of[block][cell], the blocks of one sample are contiguous) and adds them in block order.
+__global__ __launch_bounds__(256) void lift_splat_cells_kernel(int B, int blocks_per_sample, int C, int X, int Y,
+                                                               const float* __restrict__ ws_rows,
+                                                               const unsigned char* __restrict__ slot_of,
+                                                               float* __restrict__ out, int out_cstride, int out_coff,
+                                                               int rot_flip) {
+    const int lane = threadIdx.x & 63;
+    const int cells = X * Y;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long long)B * cells) return;
+    const int b = (int)(wid / cells), cell = (int)(wid % cells);
+    const int c4 = C >> 2;
+    float4 acc[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool any = false;
+    for (int k0 = 0; k0 < blocks_per_sample; k0 += 64) {
+        const int k = k0 + lane;
+        int s = 255;
+        if (k < blocks_per_sample) s = slot_of[((long long)b * blocks_per_sample + k) * cells + cell];
+        unsigned long long mk = __ballot(s != 255);
+        while (mk) {
+            const int l = __ffsll((long long)mk) - 1;
+            mk &= mk - 1;
+            const int sl = __shfl(s, l);
+            const float4* wr = reinterpret_cast<const float4*>(
+                ws_rows + (((long long)b * blocks_per_sample + k0 + l) * kMaxSlots + sl) * C);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ch = lane + 64 * v;
+                if (ch < c4) {
+                    const float4 r = wr[ch];
+                    acc[v].x += r.x; acc[v].y += r.y; acc[v].z += r.z; acc[v].w += r.w;
+                }
+            }
+            any = true;
+        }
+    }
+    if (!any) return;
+    const int y = cell / X, x = cell % X;
+    int oi = y, oj = x;
+    if (rot_flip) { oi = X - 1 - x; oj = Y - 1 - y; }
+    const int OW = rot_flip ? Y : X, OH = rot_flip ? X : Y;
+    float4* dst = reinterpret_cast<float4*>(out + (((long long)b * OH + oi) * OW + oj) * out_cstride + out_coff);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int ch = lane + 64 * v;
+        if (ch < c4) {
+            float4 o = dst[ch];
+            o.x += acc[v].x; o.y += acc[v].y; o.z += acc[v].z; o.w += acc[v].w;
+            dst[ch] = o;
         }
     }
 }
@@ -1053,60 +1145,91 @@ extern "C" int tt_frustum_voxel_index(int batch_size, int num_cams, int D, int f
     return check_launch("tt_frustum_voxel_index");
 }
 
+static size_t vp_align(size_t v) { return (v + 255) / 256 * 256; }
+
+static bool lift_splat_strip_ok(int D, int fH, int X, int Y) {
+    return fH * kStripW <= kMaxStripPix && D <= kMaxD && X * Y <= kMaxCells;
+}
+
+extern "C" long long tt_lift_splat_workspace_bytes(int batch_size, int num_cams, int D, int fH, int fW, int C,
+                                                   int num_voxel_x, int num_voxel_y) {
+    if (!lift_splat_strip_ok(D, fH, num_voxel_x, num_voxel_y)) return 0;
+    const long long blocks = (long long)batch_size * num_cams * div_up(fW, kStripW);
+    return (long long)vp_align((size_t)blocks * kMaxSlots * C * sizeof(float)) +
+           (long long)vp_align((size_t)blocks * num_voxel_x * num_voxel_y);
+}
+
+template <typename T>
+static void launch_lift_splat(int batch_size, int num_cams, int D, int fH, int fW, int C, int X, int Y, int Z,
+                              const void* depth_logits, const void* context, const int32_t* geom_xyz, float* out,
+                              int out_cstride, int out_coff, int rot_flip, float* ws_rows, unsigned char* slot_of,
+                              hipStream_t st) {
+    if (lift_splat_strip_ok(D, fH, X, Y)) {
+        const int strips = div_up(fW, kStripW);
+        const unsigned sblocks = (unsigned)(batch_size * num_cams * strips);
+        hipLaunchKernelGGL(lift_splat_strip_kernel<T>, dim3(sblocks), dim3(256), 0, st, batch_size, num_cams, D, fH, fW, C,
+                           X, Y, Z, (const T*)depth_logits, (const T*)context, geom_xyz, out, out_cstride, out_coff,
+                           rot_flip, ws_rows, slot_of);
+        if (ws_rows) {
+            const long long waves = (long long)batch_size * X * Y;
+            hipLaunchKernelGGL(lift_splat_cells_kernel, dim3((unsigned)div_up(waves, 4)), dim3(256), 0, st, batch_size,
+                               num_cams * strips, C, X, Y, ws_rows, slot_of, out, out_cstride, out_coff, rot_flip);
+        }
+        return;
+    }
+    const long long npix = (long long)batch_size * num_cams * fH * fW;
+    hipLaunchKernelGGL(lift_splat_kernel<T>, dim3((unsigned)div_up(npix, 4)), dim3(256), 0, st, batch_size, num_cams, D,
+                       fH, fW, C, X, Y, Z, (const T*)depth_logits, (const T*)context, geom_xyz, out, out_cstride,
+                       out_coff, rot_flip);
+}
+
+// `ws` (tt_lift_splat_workspace_bytes, contents don't matter) selects the atomics-free, bit-reproducible form; without
+// it (or for shapes outside the strip kernel's limits) the partial rows are added with f32 atomics.
+extern "C" int tt_lift_splat_fwd_ws(int batch_size, int num_cams, int D, int fH, int fW, int C,
+                                    int num_voxel_x, int num_voxel_y, int num_voxel_z,
+                                    const void* depth_logits, const void* context, int dtype,
+                                    const int32_t* geom_xyz, float* out, int out_cstride, int out_coff,
+                                    int rot_flip, void* ws, long long ws_bytes, void* stream) {
+    TT_REQUIRE(depth_logits && context && geom_xyz && out, "tt_lift_splat_fwd: null pointer");
+    TT_REQUIRE(D > 0 && D <= 128, "tt_lift_splat_fwd: D=%d unsupported (1..128)", D);
+    TT_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "tt_lift_splat_fwd: C=%d unsupported", C);
+    TT_REQUIRE(out_cstride % 4 == 0 && out_coff % 4 == 0 || !ws, "tt_lift_splat_fwd: workspace form needs 16 B aligned rows");
+    const long long npix = (long long)batch_size * num_cams * fH * fW;
+    if (npix == 0) return 0;
+    float* ws_rows = nullptr;
+    unsigned char* slot_of = nullptr;
+    const long long need = tt_lift_splat_workspace_bytes(batch_size, num_cams, D, fH, fW, C, num_voxel_x, num_voxel_y);
+    if (ws && need > 0) {
+        TT_REQUIRE(ws_bytes >= need, "tt_lift_splat_fwd_ws: workspace %lld B < %lld B", ws_bytes, need);
+        const long long blocks = (long long)batch_size * num_cams * div_up(fW, kStripW);
+        ws_rows = (float*)ws;
+        slot_of = (unsigned char*)ws + vp_align((size_t)blocks * kMaxSlots * C * sizeof(float));
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TT_F32)
+        launch_lift_splat<float>(batch_size, num_cams, D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z, depth_logits,
+                                 context, geom_xyz, out, out_cstride, out_coff, rot_flip, ws_rows, slot_of, st);
+    else if (dtype == TT_BF16)
+        launch_lift_splat<uint16_t>(batch_size, num_cams, D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z, depth_logits,
+                                    context, geom_xyz, out, out_cstride, out_coff, rot_flip, ws_rows, slot_of, st);
+    else if (dtype == TT_F16)
+        launch_lift_splat<f16_t>(batch_size, num_cams, D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z, depth_logits,
+                                 context, geom_xyz, out, out_cstride, out_coff, rot_flip, ws_rows, slot_of, st);
+    else
+        TT_REQUIRE(false, "tt_lift_splat_fwd: bad dtype %d", dtype);
+    return check_launch("tt_lift_splat_fwd");
+}
+
 extern "C" int tt_lift_splat_fwd(int batch_size, int num_cams, int D, int fH, int fW, int C,
                                  int num_voxel_x, int num_voxel_y, int num_voxel_z,
                                  const void* depth_logits, const void* context, int dtype,
                                  const int32_t* geom_xyz, float* out, int out_cstride, int out_coff,
                                  int rot_flip, void* stream) {
-    TT_REQUIRE(depth_logits && context && geom_xyz && out, "tt_lift_splat_fwd: null pointer");
-    TT_REQUIRE(D > 0 && D <= 128, "tt_lift_splat_fwd: D=%d unsupported (1..128)", D);
-    TT_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "tt_lift_splat_fwd: C=%d unsupported", C);
-    const long long npix = (long long)batch_size * num_cams * fH * fW;
-    if (npix == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    const bool strip_ok = fH * kStripW <= kMaxStripPix && D <= kMaxD && num_voxel_x * num_voxel_y <= kMaxCells;
-    if (strip_ok) {
-        const unsigned sblocks = (unsigned)(batch_size * num_cams * div_up(fW, kStripW));
-        if (dtype == TT_F32)
-            hipLaunchKernelGGL(lift_splat_strip_kernel<float>, dim3(sblocks), dim3(256), 0, st, batch_size, num_cams, D,
-                               fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z, (const float*)depth_logits,
-                               (const float*)context, geom_xyz, out, out_cstride, out_coff, rot_flip);
-        else if (dtype == TT_BF16)
-            hipLaunchKernelGGL(lift_splat_strip_kernel<uint16_t>, dim3(sblocks), dim3(256), 0, st, batch_size, num_cams,
-                               D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z, (const uint16_t*)depth_logits,
-                               (const uint16_t*)context, geom_xyz, out, out_cstride, out_coff, rot_flip);
-        else if (dtype == TT_F16)
-            hipLaunchKernelGGL(lift_splat_strip_kernel<f16_t>, dim3(sblocks), dim3(256), 0, st, batch_size, num_cams,
-                               D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z, (const f16_t*)depth_logits,
-                               (const f16_t*)context, geom_xyz, out, out_cstride, out_coff, rot_flip);
-        else
-            TT_REQUIRE(false, "tt_lift_splat_fwd: bad dtype %d", dtype);
-        return check_launch("tt_lift_splat_fwd");
-    }
-    const unsigned blocks = (unsigned)div_up(npix, 4);
-    if (dtype == TT_F32) {
-        hipLaunchKernelGGL(lift_splat_kernel<float>, dim3(blocks), dim3(256), 0, st, batch_size,
-                           num_cams, D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z,
-                           (const float*)depth_logits, (const float*)context, geom_xyz, out,
-                           out_cstride, out_coff, rot_flip);
-    } else if (dtype == TT_BF16) {
-        hipLaunchKernelGGL(lift_splat_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, batch_size,
-                           num_cams, D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z,
-                           (const uint16_t*)depth_logits, (const uint16_t*)context, geom_xyz, out,
-                           out_cstride, out_coff, rot_flip);
-    } else if (dtype == TT_F16) {
-        hipLaunchKernelGGL(lift_splat_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, batch_size,
-                           num_cams, D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z,
-                           (const f16_t*)depth_logits, (const f16_t*)context, geom_xyz, out,
-                           out_cstride, out_coff, rot_flip);
-    } else {
-        TT_REQUIRE(false, "tt_lift_splat_fwd: bad dtype %d", dtype);
-    }
-    return check_launch("tt_lift_splat_fwd");
+    return tt_lift_splat_fwd_ws(batch_size, num_cams, D, fH, fW, C, num_voxel_x, num_voxel_y, num_voxel_z, depth_logits,
+                                context, dtype, geom_xyz, out, out_cstride, out_coff, rot_flip, nullptr, 0, stream);
 }
 
 // ---- static-geometry plan ------------------------------------------------------------------------------------
-static size_t vp_align(size_t v) { return (v + 255) / 256 * 256; }
 
 extern "C" long long tt_voxel_pool_plan_bytes(int batch_size, int num_points, int num_voxel_x, int num_voxel_y) {
     const long long total = (long long)batch_size * num_points;

@@ -41,6 +41,9 @@ def frustum_voxel_index(frustum, mats, voxel_lo, voxel_size, batch_size, num_cam
     return (geom, gf) if want_f32 else geom
 
 
+_LIFT_SPLAT_ATOMIC = os.environ.get("TT_LIFT_SPLAT_ATOMIC", "0") == "1"
+
+
 def lift_splat(depth_logits, context, geom_xyz, voxel_num, batch_size, num_cams, out=None,
                out_coff=0, rot_flip=False, record=True):
     """depth_logits [B*ncam,fH,fW,D], context [B*ncam,fH,fW,C] (channel-last, f32 or bf16),
@@ -53,12 +56,21 @@ def lift_splat(depth_logits, context, geom_xyz, voxel_num, batch_size, num_cams,
     if out is None:
         oh, ow = (vx, vy) if rot_flip else (vy, vx)
         out = torch.zeros(batch_size, oh, ow, C, dtype=torch.float32, device=context.device)
-    rc = lib().tt_lift_splat_fwd(_c(batch_size), _c(num_cams), _c(D), _c(fH), _c(fW), _c(C), _c(vx),
-                                 _c(vy), _c(vz), ptr(depth_logits), ptr(context),
-                                 _c(dtype_code(context)), ptr(geom_xyz), ptr(out),
-                                 _c(out.shape[-1]), _c(out_coff), _c(1 if rot_flip else 0),
-                                 cur_stream(context.device))
-    check(rc, "tt_lift_splat_fwd")
+    # workspace form: (strip, cell) partial rows + an ordered per-cell reduce instead of f32 atomics (bit-reproducible);
+    # TT_LIFT_SPLAT_ATOMIC=1 selects the single-kernel atomic form for A/B
+    ws, ws_bytes = None, 0
+    if not _LIFT_SPLAT_ATOMIC:
+        ws_bytes = int(lib().tt_lift_splat_workspace_bytes(_c(batch_size), _c(num_cams), _c(D), _c(fH), _c(fW), _c(C),
+                                                           _c(vx), _c(vy)))
+        if ws_bytes > 0:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=context.device)
+    rc = lib().tt_lift_splat_fwd_ws(_c(batch_size), _c(num_cams), _c(D), _c(fH), _c(fW), _c(C), _c(vx),
+                                    _c(vy), _c(vz), ptr(depth_logits), ptr(context),
+                                    _c(dtype_code(context)), ptr(geom_xyz), ptr(out),
+                                    _c(out.shape[-1]), _c(out_coff), _c(1 if rot_flip else 0),
+                                    ptr(ws) if ws is not None else None, ctypes.c_longlong(ws_bytes),
+                                    cur_stream(context.device))
+    check(rc, "tt_lift_splat_fwd_ws")
     if record:
         from . import autodiff
         if autodiff.TAPE is not None:
@@ -102,6 +114,7 @@ class _ConvDesc(ctypes.Structure):
         ("act", _c), ("dtype", _c), ("out_dtype", _c),
         ("gather_idx", ctypes.c_void_p), ("m_dev", ctypes.c_void_p), ("splitk_ws", ctypes.c_void_p),
         ("weight_x3", ctypes.c_void_p), ("row_perm", ctypes.c_void_p), ("row_mask", ctypes.c_void_p),
+        ("splitk_slices", _c),
     ]
 
 
@@ -273,7 +286,11 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
         # few rows, very long K (BEV-update conv K=18720, flatten MLPs): cross-workgroup split-K with an f32 workspace
         # beats conv_small.hip's in-workgroup split there (277 vs 416 us on the BEV-update conv: the direct 32 B/row
         # operand loads of the small kernel waste L2 sectors on a 10 MB weight matrix).  TT_CONV_AUTO_SPLITK=0 disables.
-        splitk_ws = torch.zeros(N * OH * OW, Cout, dtype=torch.float32, device=x.device)
+        # ordered form (no atomics, no zero fill): one [M][Cout] slice per K split, added in index order by the finalize kernel
+        slices = int(lib().tt_conv2d_splitk_slices(ctypes.byref(d)))
+        if slices > 0:
+            splitk_ws = torch.empty(slices, N * OH * OW, Cout, dtype=torch.float32, device=x.device)
+            d.splitk_slices = slices
     if splitk_ws is not None:
         d.splitk_ws = splitk_ws.data_ptr()
     if w_x3 is not None:
