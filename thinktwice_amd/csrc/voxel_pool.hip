@@ -584,61 +584,182 @@ constexpr int kMaxStripPix = 64;     // fH * kStripW <= 64
 constexpr int kMaxSlots = 64;
 constexpr int kMaxD = 128;
 
+// dynamic LDS: W f32 [kMaxStripPix][kWS] | table int [cells] | slot_cell int [kMaxSlots] | a region that holds
+// { prob f32 [kMaxStripPix][PD], tag short [D][npx] } until W is built and the staged context rows
+// f32 [kMaxStripPix][min(C, kStageC)] afterwards  (50 KiB at the thinktwice.py shapes: three workgroups per CU)
+constexpr int kStageC = 128;
+constexpr int kWS = kMaxSlots + 4;        // W row stride: 16 B rows, = 4 mod 8 words
+__host__ __device__ inline int lift_splat_prob_stride(int D) {      // 16 B rows, = 4 mod 8 words: 16 rows on 16 bank quads
+    int pd = (D + 3) & ~3;
+    if ((pd & 4) == 0) pd += 4;
+    return pd;
+}
+__host__ __device__ inline int lift_splat_table_words(int cells) { return (cells + kMaxSlots + 3) & ~3; }
+static size_t lift_splat_strip_lds(int D, int C, int cells) {
+    const size_t a = (size_t)kMaxStripPix * lift_splat_prob_stride(D) * 4 + (size_t)kMaxStripPix * D * 2;
+    const size_t c = (size_t)kMaxStripPix * (C < kStageC ? C : kStageC) * 4;
+    const size_t b = (size_t)kWS * kMaxStripPix * 4 + (size_t)lift_splat_table_words(cells) * 4 + (a > c ? a : c);
+    return (b + 15) / 16 * 16;
+}
+
+struct __attribute__((packed, aligned(4))) GeomPoint { int x, y, z; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void lift_splat_strip_kernel(
     int B, int ncam, int D, int fH, int fW, int C, int X, int Y, int Z, const T* __restrict__ depth_logits,
     const T* __restrict__ ctx, const int32_t* __restrict__ geom, float* __restrict__ out, int out_cstride,
     int out_coff, int rot_flip, float* __restrict__ ws_rows, unsigned char* __restrict__ slot_of) {
-    __shared__ float prob[kMaxStripPix][kMaxD];
-    __shared__ short cellid[kMaxStripPix][kMaxD];
-    __shared__ int table[kMaxCells];
-    __shared__ float Wt[kMaxSlots][kMaxStripPix];
-    __shared__ int slot_cell[kMaxSlots];
+    extern __shared__ __attribute__((aligned(16))) unsigned char ls_smem[];
     __shared__ int nslots_sh;
+    const int cells = X * Y;
+    const int CW = min(C, kStageC);                 // channels per staged chunk of the context rows
+    const int PD = lift_splat_prob_stride(D);
+    float* Wt = reinterpret_cast<float*>(ls_smem);                          // [p][slot]
+    int* table = reinterpret_cast<int*>(Wt + kWS * kMaxStripPix);
+    int* slot_cell = table + cells;
+    float* prob = reinterpret_cast<float*>(table + lift_splat_table_words(cells));      // [p][PD]
+    short* tag = reinterpret_cast<short*>(prob + kMaxStripPix * PD);        // [d][npx]: cell, then slot
+    float* ctxs = prob;                                                     // [p][CW], once prob / tag are spent
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int strips = (fW + kStripW - 1) / kStripW;
-    const int bc = blockIdx.x / strips;            // b * ncam + cam
-    const int strip = blockIdx.x % strips;
+    // workgroup -> strip: hardware deals consecutive workgroups to the 8 XCDs in turn; give every XCD a CONTIGUOUS range of
+    // strips, so that the neighbouring image columns that share 128 B lines of geom_xyz (10.7 points per line, 2 per strip
+    // row) are fetched through the same L2
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, full = nblk >> 3, rem = nblk & 7;
+    const int vb = xcd * full + min(xcd, rem) + (blockIdx.x >> 3);
+    const int bc = vb / strips;            // b * ncam + cam
+    const int strip = vb % strips;
     const int b = bc / ncam, cam = bc % ncam;
     const int w0 = strip * kStripW;
     const int sw = min(kStripW, fW - w0);
     const int npx = fH * sw;                        // pixels in this strip: p -> (h = p / sw, w = w0 + p % sw)
-    const int cells = X * Y;
+
+    // context rows of one channel chunk: global -> registers (issued early, under other work) -> LDS as f32
+    constexpr int kS = kMaxStripPix * (kStageC / 4) / 256;         // 8 float4 pieces per thread at the limits
+    float4 cv[kS];
+    auto ctx_fetch = [&](int c0) {
+        const int cw4 = min(kStageC, C - c0) >> 2, tot = npx * cw4;
+#pragma unroll
+        for (int k = 0; k < kS; ++k) {
+            const int i = k * 256 + tid;
+            cv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < tot) {
+                const int p = i / cw4, j = i - p * cw4;
+                const int h = p / sw, w = w0 + p - h * sw;
+                const T* crow = ctx + (((long long)bc * fH + h) * fW + w) * C + c0 + j * 4;
+                if constexpr (sizeof(T) == 4) {
+                    cv[k] = *reinterpret_cast<const float4*>(crow);
+                } else {
+                    cv[k].x = Elem<T>::ld(crow + 0); cv[k].y = Elem<T>::ld(crow + 1);
+                    cv[k].z = Elem<T>::ld(crow + 2); cv[k].w = Elem<T>::ld(crow + 3);
+                }
+            }
+        }
+    };
+    auto ctx_commit = [&](int c0) {
+        const int cw4 = min(kStageC, C - c0) >> 2, tot = npx * cw4;
+#pragma unroll
+        for (int k = 0; k < kS; ++k) {
+            const int i = k * 256 + tid;
+            if (i < tot) {
+                const int p = i / cw4, j = i - p * cw4;
+                reinterpret_cast<float4*>(ctxs + p * CW)[j] = cv[k];
+            }
+        }
+    };
+
     for (int i = tid; i < cells; i += 256) table[i] = -1;
-    for (int i = tid; i < kMaxSlots * kMaxStripPix; i += 256) (&Wt[0][0])[i] = 0.f;
+    for (int i = tid; i < kWS * kMaxStripPix; i += 256) Wt[i] = 0.f;
+    // depth logits of the strip: coalesced 16 B pieces -> registers now, LDS after the geometry pass
+    constexpr int kL = kMaxStripPix * (kMaxD / 4) / 256;          // 8 pieces per thread at the limits
+    const bool logits16 = (D & 3) == 0 && sizeof(T) == 4;
+    float4 lv[kL];
+    if (logits16) {
+        const int d4 = D >> 2, tot4 = npx * d4;
+#pragma unroll
+        for (int k = 0; k < kL; ++k) {
+            const int i = k * 256 + tid;
+            lv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < tot4) {
+                const int p = i / d4, j = i - p * d4;
+                const int h = p / sw, w = w0 + p - h * sw;
+                lv[k] = reinterpret_cast<const float4*>(depth_logits + (((long long)bc * fH + h) * fW + w) * D)[j];
+            }
+        }
+    }
     __syncthreads();
     const long long per_cam = (long long)D * fH * fW;
-    const int32_t* g = geom + ((long long)b * ncam + cam) * per_cam * 3;
-    // 1. softmax + cell tags, one wave per pixel in turn
-    for (int p = wave; p < npx; p += 4) {
-        const int h = p / sw, w = w0 + p % sw;
-        const long long pix = ((long long)bc * fH + h) * fW + w;
-        const T* lg = depth_logits + pix * D;
-        const float l0 = (lane < D) ? Elem<T>::ld(lg + lane) : -INFINITY;
-        const float l1 = (lane + 64 < D) ? Elem<T>::ld(lg + lane + 64) : -INFINITY;
-        float m = fmaxf(l0, l1);
+    const GeomPoint* g = reinterpret_cast<const GeomPoint*>(geom) + ((long long)b * ncam + cam) * per_cam;
+    // 1a. cell tags: every thread takes (depth, pixel) pairs, one 12 B load per point, a batch of loads before the first use
+    {
+        constexpr int kG = 18;
+        const int tot = D * npx;
+        for (int i0 = 0; i0 < tot; i0 += 256 * kG) {
+            GeomPoint gp[kG];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        const float e0 = (lane < D) ? expf(l0 - m) : 0.f;
-        const float e1 = (lane + 64 < D) ? expf(l1 - m) : 0.f;
-        float ssum = e0 + e1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
-        const float inv = 1.f / ssum;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int d = lane + 64 * half;
-            if (d < D) {
-                const int32_t* q = g + ((long long)d * fH * fW + (long long)h * fW + w) * 3;
-                const int x = q[0], y = q[1], z = q[2];
-                int c = -1;
-                if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {
-                    c = y * X + x;
-                    table[c] = -2;
+            for (int k = 0; k < kG; ++k) {
+                const int i = i0 + k * 256 + tid;
+                gp[k].x = -1; gp[k].y = -1; gp[k].z = -1;
+                if (i < tot) {
+                    const int d = i / npx, p = i - d * npx;
+                    const int h = p / sw, w = w0 + p - h * sw;
+                    gp[k] = g[(long long)d * fH * fW + (long long)h * fW + w];
                 }
-                cellid[p][d] = (short)c;
-                prob[p][d] = (half ? e1 : e0) * inv;
             }
+#pragma unroll
+            for (int k = 0; k < kG; ++k) {
+                const int i = i0 + k * 256 + tid;
+                if (i < tot) {
+                    const int d = i / npx, p = i - d * npx;
+                    const int x = gp[k].x, y = gp[k].y, z = gp[k].z;
+                    int c = -1;
+                    if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {
+                        c = y * X + x;
+                        table[c] = -2;
+                    }
+                    tag[i] = (short)c;
+                }
+            }
+        }
+    }
+    // 1b. softmax over depth: logits -> LDS (coalesced rows), then four adjacent lanes per pixel (depth bins q, q+4, ...)
+    // with two quad-shuffle steps per reduction
+    {
+        if (logits16) {
+            const int d4 = D >> 2, tot4 = npx * d4;
+#pragma unroll
+            for (int k = 0; k < kL; ++k) {
+                const int i = k * 256 + tid;
+                if (i < tot4) {
+                    const int p = i / d4, j = i - p * d4;
+                    reinterpret_cast<float4*>(prob + p * PD)[j] = lv[k];
+                }
+            }
+        } else {
+            for (int i = tid; i < npx * D; i += 256) {
+                const int p = i / D, d = i - p * D;
+                const int h = p / sw, w = w0 + p - h * sw;
+                prob[p * PD + d] = Elem<T>::ld(depth_logits + (((long long)bc * fH + h) * fW + w) * D + d);
+            }
+        }
+        __syncthreads();
+        const int p = tid >> 2, q = tid & 3;
+        if (p < npx) {                              // whole quads take the branch together
+            float* pr = prob + p * PD;
+            float m = -INFINITY;
+            for (int d = q; d < D; d += 4) m = fmaxf(m, pr[d]);
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            float ssum = 0.f;
+            for (int d = q; d < D; d += 4) {
+                const float e = expf(pr[d] - m);
+                pr[d] = e;
+                ssum += e;
+            }
+            ssum += __shfl_xor(ssum, 1);
+            ssum += __shfl_xor(ssum, 2);
+            const float inv = 1.f / ssum;
+            for (int d = q; d < D; d += 4) pr[d] *= inv;
         }
     }
     __syncthreads();
@@ -660,7 +781,6 @@ __global__ __launch_bounds__(256) void lift_splat_strip_kernel(
     }
     __syncthreads();
     const int ns = nslots_sh;
-    const int c4 = C >> 2;
     auto out_row = [&](int cell) {
         const int y = cell / X, x = cell % X;
         int oi = y, oj = x;
@@ -668,90 +788,108 @@ __global__ __launch_bounds__(256) void lift_splat_strip_kernel(
         const int OW = rot_flip ? Y : X, OH = rot_flip ? X : Y;
         return out + (((long long)b * OH + oi) * OW + oj) * out_cstride + out_coff;
     };
-    // W[slot][pixel]; (pixel, depth) pairs whose slot is over budget go straight to global atomics
-    if (ws_rows) {
-        // ordered: one thread per pixel walks its ray front to back; consecutive depths in one cell are summed in a register
+    if (slot_of) {
         for (int i = tid; i < cells; i += 256) {
             const int t = table[i];
-            slot_of[(long long)blockIdx.x * cells + i] = (unsigned char)((t >= 0 && t < kMaxSlots) ? t : 255);
+            slot_of[(long long)vb * cells + i] = (unsigned char)((t >= 0 && t < kMaxSlots) ? t : 255);
         }
-        if (tid < npx) {
-            int cur = -1;
-            float w = 0.f;
-            for (int d = 0; d < D; ++d) {
-                const int c = cellid[tid][d];
-                const int sidx = (c < 0) ? -1 : table[c];
-                if (sidx != cur) {
-                    if (cur >= 0 && cur < kMaxSlots) Wt[cur][tid] += w;
-                    cur = sidx;
-                    w = 0.f;
-                }
-                w += prob[tid][d];
+    }
+    // cell tags -> slot tags (over-budget cells keep their cell as -(cell + 2))
+    {
+        constexpr int kT = 4;
+        const int tot = D * npx;
+        for (int i0 = 0; i0 < tot; i0 += 256 * kT) {
+            int c[kT], t[kT];
+#pragma unroll
+            for (int k = 0; k < kT; ++k) {
+                const int i = i0 + k * 256 + tid;
+                c[k] = (i < tot) ? (int)tag[i] : -1;
             }
-            if (cur >= 0 && cur < kMaxSlots) Wt[cur][tid] += w;
+#pragma unroll
+            for (int k = 0; k < kT; ++k) t[k] = table[c[k] < 0 ? 0 : c[k]];
+#pragma unroll
+            for (int k = 0; k < kT; ++k) {
+                const int i = i0 + k * 256 + tid;
+                if (i < tot && c[k] >= 0) tag[i] = (short)(t[k] < kMaxSlots ? t[k] : -(c[k] + 2));
+            }
         }
-    } else {
-        for (int i = tid; i < npx * D; i += 256) {
-            const int p = i / D, d = i % D;
-            const int c = cellid[p][d];
-            if (c < 0) continue;
-            const int sidx = table[c];
-            if (sidx < kMaxSlots) atomicAdd(&Wt[sidx][p], prob[p][d]);
+    }
+    ctx_fetch(0);           // first chunk of context rows: in flight under the W build
+    __syncthreads();
+    // W[pixel][slot] += prob, one thread per pixel walking its ray front to back.  ds_add_f32 is used as a fire-and-forget
+    // add (no read-modify-write round trip per depth bin): every address has exactly one writer thread and the LDS executes a
+    // wave's operations in program order, so the sum is formed in depth order -- deterministic.  Pairs whose slot is over
+    // budget go straight to global atomics below.
+    if (tid < npx) {
+        constexpr int kW = 8;
+        for (int d0 = 0; d0 < D; d0 += kW) {
+            int sg[kW];
+            float pr[kW];
+#pragma unroll
+            for (int k = 0; k < kW; ++k) {
+                const int d = min(d0 + k, D - 1);
+                sg[k] = tag[d * npx + tid];
+                pr[k] = prob[tid * PD + d];
+            }
+#pragma unroll
+            for (int k = 0; k < kW; ++k)
+                if (d0 + k < D && sg[k] >= 0) atomicAdd(&Wt[tid * kWS + sg[k]], pr[k]);
         }
     }
     __syncthreads();
-    // 3. one wave per slot
-    for (int sidx = wave; sidx < min(ns, kMaxSlots); sidx += 4) {
-        float4 acc[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int p = 0; p < npx; ++p) {
-            const float wgt = Wt[sidx][p];
-            if (wgt == 0.f) continue;
-            const int h = p / sw, w = w0 + p % sw;
-            const T* crow = ctx + (((long long)bc * fH + h) * fW + w) * C;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int ch = lane + 64 * v;
-                if (ch < c4) {
-                    acc[v].x += wgt * Elem<T>::ld(crow + ch * 4 + 0);
-                    acc[v].y += wgt * Elem<T>::ld(crow + ch * 4 + 1);
-                    acc[v].z += wgt * Elem<T>::ld(crow + ch * 4 + 2);
-                    acc[v].w += wgt * Elem<T>::ld(crow + ch * 4 + 3);
-                }
-            }
-        }
-        if (ws_rows) {
-            float4* wr = reinterpret_cast<float4*>(ws_rows + ((long long)blockIdx.x * kMaxSlots + sidx) * C);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int ch = lane + 64 * v;
-                if (ch < c4) wr[ch] = acc[v];
-            }
-            continue;
-        }
-        float* dst = out_row(slot_cell[sidx]);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int ch = lane + 64 * v;
-            if (ch < c4) {
-                unsafeAtomicAdd(dst + ch * 4 + 0, acc[v].x);
-                unsafeAtomicAdd(dst + ch * 4 + 1, acc[v].y);
-                unsafeAtomicAdd(dst + ch * 4 + 2, acc[v].z);
-                unsafeAtomicAdd(dst + ch * 4 + 3, acc[v].w);
-            }
-        }
-    }
     if (ns > kMaxSlots) {   // rare (never with Lift-Splat geometry): per-(pixel,depth) atomics for the excess cells
         for (int i = wave; i < npx * D; i += 4) {
-            const int p = i / D, d = i % D;
-            const int c = cellid[p][d];
-            if (c < 0 || table[c] < kMaxSlots) continue;
-            const float wgt = prob[p][d];
+            const int tg = tag[i];
+            if (tg >= -1) continue;
+            const int c = -tg - 2;
+            const int d = i / npx, p = i - d * npx;
+            const float wgt = prob[p * PD + d];
             const int h = p / sw, w = w0 + p % sw;
             const T* crow = ctx + (((long long)bc * fH + h) * fW + w) * C;
             float* dst = out_row(c);
             for (int ch = lane; ch < C; ch += 64) unsafeAtomicAdd(dst + ch, wgt * Elem<T>::ld(crow + ch));
+        }
+    }
+    const int nsl = min(ns, kMaxSlots);
+    // 3. rows[slot][:] = sum_p W[p][slot] * ctx[p][:] as a small dense product, kStageC channels at a time: the strip's
+    // context rows are staged in LDS (f32); a task = (4 slots, one float4 column): 2 x 16 B of LDS per 16 FMAs, only live
+    // slots get tasks, pixels in index order
+    for (int c0 = 0; c0 < C; c0 += kStageC) {
+        const int cw4 = min(kStageC, C - c0) >> 2;
+        __syncthreads();        // prob / tag (first chunk) or the previous chunk's rows are no longer read
+        ctx_commit(c0);
+        __syncthreads();
+        if (c0 + kStageC < C) ctx_fetch(c0 + kStageC);     // next chunk's rows fly under this chunk's product
+        const int ntask = (kStageC / 4) * ((nsl + 3) >> 2);
+        for (int task = tid; task < ntask; task += 256) {
+            const int j = task & (kStageC / 4 - 1), sgp = task / (kStageC / 4);
+            if (j >= cw4) continue;
+            float4 acc[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+            for (int p = 0; p < npx; ++p) {
+                const float4 wq = *reinterpret_cast<const float4*>(Wt + p * kWS + sgp * 4);
+                const float4 x = reinterpret_cast<const float4*>(ctxs + p * CW)[j];
+                acc[0].x += wq.x * x.x; acc[0].y += wq.x * x.y; acc[0].z += wq.x * x.z; acc[0].w += wq.x * x.w;
+                acc[1].x += wq.y * x.x; acc[1].y += wq.y * x.y; acc[1].z += wq.y * x.z; acc[1].w += wq.y * x.w;
+                acc[2].x += wq.z * x.x; acc[2].y += wq.z * x.y; acc[2].z += wq.z * x.z; acc[2].w += wq.z * x.w;
+                acc[3].x += wq.w * x.x; acc[3].y += wq.w * x.y; acc[3].z += wq.w * x.z; acc[3].w += wq.w * x.w;
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int slot = sgp * 4 + v;
+                if (slot >= nsl) continue;
+                if (ws_rows) {
+                    reinterpret_cast<float4*>(ws_rows + ((long long)vb * kMaxSlots + slot) * C + c0)[j] = acc[v];
+                } else {
+                    float* dst = out_row(slot_cell[slot]) + c0 + j * 4;
+                    unsafeAtomicAdd(dst + 0, acc[v].x);
+                    unsafeAtomicAdd(dst + 1, acc[v].y);
+                    unsafeAtomicAdd(dst + 2, acc[v].z);
+                    unsafeAtomicAdd(dst + 3, acc[v].w);
+                }
+            }
         }
     }
 }
@@ -1167,7 +1305,15 @@ static void launch_lift_splat(int batch_size, int num_cams, int D, int fH, int f
     if (lift_splat_strip_ok(D, fH, X, Y)) {
         const int strips = div_up(fW, kStripW);
         const unsigned sblocks = (unsigned)(batch_size * num_cams * strips);
-        hipLaunchKernelGGL(lift_splat_strip_kernel<T>, dim3(sblocks), dim3(256), 0, st, batch_size, num_cams, D, fH, fW, C,
+        const size_t lds = lift_splat_strip_lds(D, C, X * Y);
+        static bool attr_set = false;
+        if (!attr_set) {    // once per instantiation: the largest request the limits allow
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lift_splat_strip_kernel<T>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lift_splat_strip_lds(kMaxD, kStageC, kMaxCells));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(lift_splat_strip_kernel<T>, dim3(sblocks), dim3(256), lds, st, batch_size, num_cams, D, fH, fW, C,
                            X, Y, Z, (const T*)depth_logits, (const T*)context, geom_xyz, out, out_cstride, out_coff,
                            rot_flip, ws_rows, slot_of);
         if (ws_rows) {
