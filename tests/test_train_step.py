@@ -10,9 +10,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(mode):
+def _setup(mode, fname="f13_train_gradients_b2.npz"):
     from thinktwice_amd import model as tm, params, synth
-    pack = np.load(os.path.join(os.path.dirname(__file__), "golden", "f13_train_gradients_b2.npz"))
+    pack = np.load(os.path.join(os.path.dirname(__file__), "golden", fname))
     B, H, W, npts, seed = (int(v) for v in pack["meta"])
     dtype = torch.float32 if mode == "f32" else "f32x3"
     m, cfg = tm.build_thinktwice(final_dim=(H, W), dtype=dtype)
@@ -25,11 +25,17 @@ def _setup(mode):
 # Bounds: relative error of the per-parameter gradient NORM and of the 8 sampled entries (relative to the norm).  The exact-f32
 # mode differs from the reference only by summation order and by the folded-BatchNorm rounding that flips a few ReLU masks on
 # these small maps (see tests/test_backward.py); the bf16x3 mode adds its ~1e-5 product error to every layer.
-@pytest.mark.parametrize("mode,tol", [("f32", 5e-3), ("f32x3", 3e-2)])
-def test_training_backward_matches_reference_gradients_golden_f13(mode, tol, monkeypatch):
+@pytest.mark.parametrize("mode,tol,fname", [("f32", 5e-3, "f13_train_gradients_b2.npz"),
+                                            ("f32x3", 3e-2, "f13_train_gradients_b2.npz"),
+                                            # F13b: the thinktwice.py size (B=1, 448x896, 65536 points), where one flipped
+                                            # ReLU mask is a negligible share of a channel's gradient sum
+                                            ("f32", 5e-3, "f13b_train_gradients_fullsize_b1.npz"),
+                                            ("f32x3", 1e-2, "f13b_train_gradients_fullsize_b1.npz")],
+                         ids=["f13-f32", "f13-bf16x3", "f13b-fullsize-f32", "f13b-fullsize-bf16x3"])
+def test_training_backward_matches_reference_gradients_golden_f13(mode, tol, fname, monkeypatch):
     from thinktwice_amd import ops
     from thinktwice_amd.trainer import Trainer
-    pack, m, sd, batch = _setup(mode)
+    pack, m, sd, batch = _setup(mode, fname)
     tr = Trainer(m, sd)
     out = tr.backward(batch)
     torch.cuda.synchronize()
@@ -50,10 +56,18 @@ def test_training_backward_matches_reference_gradients_golden_f13(mode, tol, mon
         samp_err[name] = float(np.abs(got - smp).max()) / max(norm, 1e-12)
     wn = sorted(norm_err.items(), key=lambda kv: -kv[1])[:5]
     ws = sorted(samp_err.items(), key=lambda kv: -kv[1])[:5]
+    ne = np.array(list(norm_err.values()))
     print(mode, "params", len(live), "worst norm rel", wn[0], "worst sample/norm", ws[0],
-          "median norm rel", float(np.median(list(norm_err.values()))))
+          "median norm rel", float(np.median(ne)), "share of parameters within 1e-3:", float((ne < 1e-3).mean()),
+          "99th percentile", float(np.quantile(ne, 0.99)))
     assert wn[0][1] < tol, wn
     assert ws[0][1] < tol, ws
+    if "fullsize" in fname:
+        # at the thinktwice.py size the camera / LiDAR encoders (most parameters) see maps of 10^3..10^5 pixels: >= 99 % of
+        # all gradient norms are within 1e-3 in exact f32 (measured 93.6 % in bf16x3, whose product error of ~1e-5 per layer
+        # accumulates through the 50+ layers of the reverse sweep); what is left are the decoder's layers on the 21 x 21 BEV /
+        # 2 x 2 flatten maps, where a flipped ReLU mask still shows, whatever the image size
+        assert float((ne < 1e-3).mean()) >= (0.99 if mode == "f32" else 0.90), float((ne < 1e-3).mean())
 
 
 def test_training_step_updates_parameters_and_reduces_the_loss():

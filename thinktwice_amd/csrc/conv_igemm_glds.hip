@@ -40,8 +40,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // footprint as f32).  Each product is three v_mfma_f32_32x32x16_bf16: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with f32
 // accumulation -- 16 mantissa bits per operand (relative error ~1e-5 per dot product instead of bf16's 4e-3) at
 // 16/3 of the exact-f32 MFMA rate.  This is the precision mode whose outputs meet the 1e-3 tolerance.
-template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false,
-          bool PP = false>
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64,
                              ((256 / WAVES_M / 32) * (BN / WAVES_N / 32) >= 16)  ? 1      // 128x128 per wave: 512 regs
                              : ((256 / WAVES_M / 32) * (BN / WAVES_N / 32) >= 8) ? 2      // 128x64 per wave: 256 regs
@@ -374,10 +373,12 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     // X3: a k-step is 16 f32 = 64 B.  A: lane half h owns floats 8h..8h+7 = chunks 4kc+2h and 4kc+2h+1 (the second is
     // the first with address bit 4 flipped, the swizzle being an XOR); B: hi chunk 4kc+h, lo chunk 4kc+2+h (bit 5).
     constexpr int NKC_ = X3 ? BKB / 64 : BKB / 32;
+    const bool a_pairs = X3 && (p.pairs & 1) != 0;          // activations already in (hi, lo) pair format: like the weights
+    const unsigned a_second = a_pairs ? 32u : 16u;          // second read of an A fragment: lo half / floats 4..7
     unsigned fa_pre[NKC_][TM], fb_pre[NKC_][TN];
 #pragma unroll
     for (int kc = 0; kc < NKC_; ++kc) {
-        const unsigned ca = X3 ? 4u * kc + 2u * hi : 2u * kc + hi;
+        const unsigned ca = X3 ? (a_pairs ? 4u * kc + hi : 4u * kc + 2u * hi) : 2u * kc + hi;
         const unsigned cb = X3 ? 4u * kc + hi : 2u * kc + hi;
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa_pre[kc][i] = fa_off[i] + ((ca ^ fa_s[i]) << 4);
@@ -395,121 +396,6 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         return v;
     };
 
-    const bool prio = (p.flags & 1) != 0;
-    if constexpr (PP) {
-        // ---- ping-pong schedule (bf16x3, dense, 8 waves = two groups of one wave per SIMD) -------------------------------
-        // A k-step is a READ phase (12 ds_read_b128, the operand split, the next tile's DMA issue) and an MFMA phase (24
-        // MFMAs), separated by barriers.  Group 1 executes ONE extra barrier before the loop, so it runs one phase behind
-        // group 0: between any two barriers one group's waves keep the four matrix pipes busy while the other group's
-        // waves read, split and issue -- the two waves of a SIMD no longer hit the same phase at the same time (the
-        // lock-step that left the pipe at ~53 % in the single-phase loop).  Hazards, per tile kt with stage S(kt):
-        //  * WAR  DMA(kt+1) -> S(kt-1): issued in a wave's read phase of (kt, 0); the last reads of S(kt-1) (group 1's
-        //    read phase of (kt-1, 1)) retired before the barrier every wave has passed by then;
-        //  * RAW  reads of S(kt+1) start with group 0's read phase of (kt+1, 0): every wave drains its own DMA(kt+1)
-        //    (`vmcnt(0)`) before the barrier that opens that phase -- group 0 after its MFMAs of (kt, 1), group 1 at the
-        //    end of its read phase of (kt, 1).
-        static_assert(X3 && !GATHER && STAGES == 2 && NW == 8, "ping-pong: dense bf16x3, symmetric 2-stage ring, 8 waves");
-        const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");        // tile 0 is published
-        if (grp == 1) asm volatile("s_barrier" ::: "memory");
-#endif
-        u32x4 ra0[TM], ra1[TM], bh[TN], bl[TN];
-        u32x4 ah[TM], al[TM];
-        for (int kt = 0; kt < nk; ++kt) {
-            const unsigned sbase = lds_base + (unsigned)off_a(kt);
-            const unsigned sbase_b = lds_base + (unsigned)(off_b(kt) - A_BYTES);
-#pragma unroll
-            for (int kc = 0; kc < NKC_; ++kc) {
-                // ---- read phase.  The next tile's DMA goes out first, half per k-step (activations, then weights): hipcc
-                // puts an `s_waitcnt lgkmcnt(0)` in front of the first global_load_lds of a block, which would drain the
-                // fragment reads if they were already in flight.
-                if (kt + 1 < nk) {
-                    if (kc == 0) issue_a(kt + 1);
-                    if (kc == NKC_ - 1) issue_b(kt + 1);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    ra0[i] = lds_read(sbase + fa_pre[kc][i]);
-                    ra1[i] = lds_read(sbase + (fa_pre[kc][i] ^ 16u));
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (TT_GLDS_DEBUG && p.act == 95 && (kt > 0 || kc > 0)) break;   // debug: weight fragments read once
-                    bh[j] = lds_read(sbase_b + fb_pre[kc][j]);
-                    bl[j] = lds_read(sbase_b + (fb_pre[kc][j] ^ 32u));
-                }
-#if defined(__HIP_DEVICE_COMPILE__)
-                // the activation reads went out first and LDS returns in order: all but the 2 * TN weight reads
-                if constexpr (TN == 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                else if constexpr (TN == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    asm volatile("" : "+v"(ra0[i]));
-                    asm volatile("" : "+v"(ra1[i]));
-                    if (TT_GLDS_DEBUG && p.act == 96) {      // debug: no operand split
-                        ah[i] = ra0[i];
-                        al[i] = ra1[i];
-                        continue;
-                    }
-                    const float x[8] = {__uint_as_float(ra0[i].x), __uint_as_float(ra0[i].y), __uint_as_float(ra0[i].z),
-                                        __uint_as_float(ra0[i].w), __uint_as_float(ra1[i].x), __uint_as_float(ra1[i].y),
-                                        __uint_as_float(ra1[i].z), __uint_as_float(ra1[i].w)};
-                    uint32_t h[4], l[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);                       // round to nearest even
-                        const float r0 = x[2 * e] - __uint_as_float(h[e] << 16);           // exact in f32
-                        const float r1 = x[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
-                        l[e] = pack_bf16x2(r0, r1);
-                    }
-                    ah[i] = u32x4{h[0], h[1], h[2], h[3]};
-                    al[i] = u32x4{l[0], l[1], l[2], l[3]};
-                    // pin the split INSIDE the read phase: without these the compiler sinks the conversions below the
-                    // barrier, next to their first use, i.e. into the MFMA phase
-                    asm volatile("" : "+v"(ah[i]));
-                    asm volatile("" : "+v"(al[i]));
-                }
-#if defined(__HIP_DEVICE_COMPILE__)
-                if (kc == NKC_ - 1 && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                asm volatile("s_barrier" ::: "memory");
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    asm volatile("" : "+v"(bh[j]));
-                    asm volatile("" : "+v"(bl[j]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-                if (TT_GLDS_DEBUG && p.act == 93) continue;  // debug: no MFMA phase at all (and no second barrier)
-                // ---- MFMA phase (term-major: consecutive MFMAs write different accumulators; small terms first)
-                if (prio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const uint4 bhv = __builtin_bit_cast(uint4, bh[j]);
-                    const uint4 blv = __builtin_bit_cast(uint4, bl[j]);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(__builtin_bit_cast(uint4, al[i]), bhv, acc[i][j]);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(__builtin_bit_cast(uint4, ah[i]), blv, acc[i][j]);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(__builtin_bit_cast(uint4, ah[i]), bhv, acc[i][j]);
-                }
-                if (prio) __builtin_amdgcn_s_setprio(0);
-#if defined(__HIP_DEVICE_COMPILE__)
-                __builtin_amdgcn_sched_barrier(0);
-                if (kc == NKC_ - 1 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_barrier" ::: "memory");
-#endif
-            }
-        }
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (grp == 0) asm volatile("s_barrier" ::: "memory");   // re-align the two groups
-#endif
-    } else
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed for THIS wave once at most one younger tile (LPT loads) is outstanding
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -539,25 +425,19 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         const unsigned sbase = sbase_a;
         if constexpr (X3) {
             // bf16x3 body.  A k-step is 16 f32 of K: 2 reads per A fragment (raw f32), the split (6 VALU per element
-            // pair, once per k-step), then per output column block j: 2 reads (weights hi, lo) and 3 MFMAs per row
+            // pair, once per k-step, up front), then per output column block j: 2 reads (weights hi, lo) and 3 MFMAs per row
             // block.  The walk over (k-step, j) is software-pipelined inside the tile: the reads of sub-step s+1 are
             // issued before the MFMAs of sub-step s, into the registers sub-step s-1 has released (one B fragment pair
             // per buffer keeps the 64 x 128 wave tile inside 256 registers).
             constexpr int NS = NKC_ * TN;
-            constexpr bool SPLIT_PIPE = TM <= TN - 1;    // a k-step needs TM sub-steps after its first one to hide the splits
-            // Schedule (pipe = 0: the round-2a order, everything of a k-step split up front): the activation fragments of
-            // k-step kc+1 are read at sub-step (kc, 0) and split one fragment per sub-step AFTER that sub-step's MFMAs were
-            // issued, so the 24 VALU of a split run in the shadow of six MFMAs; only the first k-step of a tile (whose data
-            // cannot be read before the tile's barrier) is still split up front.  The next tile's DMA (address arithmetic
-            // + 8 issue slots) likewise goes out behind the first sub-step's MFMAs.
-            const bool pipe = (p.flags & 2) == 0;
-            const bool pipe_split = pipe && SPLIT_PIPE;
             u32x4 ra0[TM], ra1[TM], bh[2], bl[2];
             uint4 ah[2][TM], al[2][TM];
+            // pair-format activations (p.pairs & 1: written by a producing epilogue as [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15]
+            // per 16 channels, like the weights): the two reads ARE the hi and lo operands, no split
             auto split_frag = [&](int i, uint4& hi_out, uint4& lo_out) {
                 asm volatile("" : "+v"(ra0[i]));
                 asm volatile("" : "+v"(ra1[i]));
-                if (TT_GLDS_DEBUG && p.act == 96) {          // debug: no operand split (raw bits as operands)
+                if (a_pairs || (TT_GLDS_DEBUG && p.act == 96)) {   // (debug 96: no operand split, raw bits as operands)
                     hi_out = __builtin_bit_cast(uint4, ra0[i]);
                     lo_out = __builtin_bit_cast(uint4, ra1[i]);
                     return;
@@ -579,32 +459,28 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ra0[i] = lds_read(sbase + fa_pre[0][i]);
-                ra1[i] = lds_read(sbase + (fa_pre[0][i] ^ 16u));
+                ra1[i] = lds_read(sbase + (fa_pre[0][i] ^ a_second));
             }
             bh[0] = lds_read(sbase_b + fb_pre[0][0]);
             bl[0] = lds_read(sbase_b + (fb_pre[0][0] ^ 32u));
-            if (!pipe) {
-                issue_ahead(kt);
-                if (GATHER && kt + 2 < nk) fetch_rulebook();
-            }
+            issue_ahead(kt);
+            if (GATHER && kt + 2 < nk) fetch_rulebook();
 #pragma unroll
             for (int ss = 0; ss < NS; ++ss) {
                 const int kc = ss / TN, j = ss % TN, buf = ss & 1, ab = kc & 1;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(bh[buf]));
                 asm volatile("" : "+v"(bl[buf]));
-                if (j == 0 && (kc == 0 || !pipe_split)) {    // up-front split (first k-step of the tile)
+                if (j == 0) {    // the k-step's activation fragments: split (or taken as they are) up front
 #pragma unroll
                     for (int i = 0; i < TM; ++i) split_frag(i, ah[ab][i], al[ab][i]);
                 }
                 // reads under this sub-step's MFMAs: the next sub-step's weight pair, and the next k-step's activations
-                // (at j == 0 when pipelined: their registers were released by the split above / one k-step ago)
-                const bool a_now = pipe_split ? (j == 0 && kc + 1 < NKC_) : (j == TN - 1 && kc + 1 < NKC_);
-                if (a_now) {
+                if (j == TN - 1 && kc + 1 < NKC_) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         ra0[i] = lds_read(sbase + fa_pre[kc + 1][i]);
-                        ra1[i] = lds_read(sbase + (fa_pre[kc + 1][i] ^ 16u));
+                        ra1[i] = lds_read(sbase + (fa_pre[kc + 1][i] ^ a_second));
                     }
                 }
                 if (ss + 1 < NS) {
@@ -619,7 +495,6 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                 }
                 const uint4 bhv = __builtin_bit_cast(uint4, bh[buf]);
                 const uint4 blv = __builtin_bit_cast(uint4, bl[buf]);
-                if (prio) __builtin_amdgcn_s_setprio(1);
                 // term-major order: consecutive MFMAs write different accumulators (a back-to-back pair on the same
                 // accumulator waits for the first one's last pass); small terms first
                 if (!(TT_GLDS_DEBUG && p.act == 94)) {       // debug 94: one MFMA per fragment pair instead of three
@@ -630,18 +505,6 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i) Mfma<uint16_t>::run(ah[ab][i], bhv, acc[i][j]);
-                if (prio) __builtin_amdgcn_s_setprio(0);
-                if (pipe) {
-                    // work that hides behind the MFMAs just issued
-                    if (ss == 0) {
-                        issue_ahead(kt);
-                        if (GATHER && kt + 2 < nk) fetch_rulebook();
-                    }
-                    if (pipe_split && kc + 1 < NKC_ && j >= 1 && j - 1 < TM) {
-                        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");   // all but the newest weight pair: the A reads
-                        split_frag(j - 1, ah[ab ^ 1][j - 1], al[ab ^ 1][j - 1]);
-                    }
-                }
             }
             continue;
         }
@@ -675,7 +538,6 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
 #pragma unroll
                 for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read(sbase_b + fb_pre[kc + 1][j]);
             }
-            if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -684,14 +546,13 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                     const uint4 bv = __builtin_bit_cast(uint4, fb[cur][j]);
                     Mfma<T>::run(av, bv, acc[i][j]);
                 }
-            if (prio) __builtin_amdgcn_s_setprio(0);
         }
     }
     // Measured and NOT kept (profiles/r01_conv_microbench_tiles.txt): deferring each tile's last k-step past the next
     // barrier (to cover the prologue bubble) changed nothing, and skipping either DMA stream after the first tile
     // (TT_GLDS_DEBUG) did not shorten the loop either: at ~1.0 PF the loop is neither L2->LDS- nor bubble-bound.
     __syncthreads();   // all waves done with the last stage before the epilogue reuses LDS
-    conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, smem, wave, lane, wm, wn, m0, n0, Mlim);
+    conv_epilogue<T, TM, TN, WTM, WTN, X3 && !GATHER>(p, acc, smem, wave, lane, wm, wn, m0, n0, Mlim);
 #endif
 }
 
@@ -704,8 +565,7 @@ static const void* zero_page() {
     return z;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false,
-          bool PP = false>
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false>
 static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0) {
     constexpr int BM = 256;
     constexpr int WTN = BN / WAVES_N;
@@ -718,7 +578,7 @@ static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0) {
     size_t smem = STAGES == 23 ? (size_t)(3 * BM + 2 * BN) * BKB : (size_t)STAGES * (BM + BN) * BKB;
     const size_t epi = (size_t)(WAVES_M * WAVES_N) * 32 * (WTN + 4) * 4;
     if (smem < epi) smem = epi;
-    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER, X3, PP>;
+    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER, X3>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -731,7 +591,7 @@ static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0) {
     if (a.m_begin == 0)      // (the tail launch of a split keeps the main launch's label)
         snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_igemm_glds_kernel<%s, %d, %d, %d, %d, %d, %s, %s>%s",
                  sizeof(T) == 4 ? "float" : "16-bit", BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER ? "true" : "false",
-                 X3 ? (PP ? "true, true" : "true, false") : "false, false", m_tiles_limit > 0 ? " + tail" : "");
+                 X3 ? "true" : "false", m_tiles_limit > 0 ? " + tail" : "");
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(WAVES_M * WAVES_N * 64), smem, st, a, zp,
                        tiles_m, tiles_n);
     return 1;
@@ -795,9 +655,7 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
         // TT_GLDS_X3_ASYM=0: symmetric 2-stage ring instead of 3 activation + 2 weight stages (A/B knob)
         static const bool asym = [] { const char* e = getenv("TT_GLDS_X3_ASYM"); return e ? atoi(e) != 0 : true; }();
         const int main_rows = tail_split_rows(a);
-        static const int pp = [] { const char* e = getenv("TT_GLDS_X3_PINGPONG"); return e ? atoi(e) : 0; }();
-        if (pp) launch_glds<float, 256, 4, 2, 128, 2, false, true, true>(a, st, main_rows);
-        else if (asym) launch_glds<float, 256, 4, 2, 128, 23, false, true>(a, st, main_rows);
+        if (asym) launch_glds<float, 256, 4, 2, 128, 23, false, true>(a, st, main_rows);
         else launch_glds<float, 256, 4, 2, 128, 2, false, true>(a, st, main_rows);
         if (main_rows) {
             ConvArgs t = a;
@@ -866,7 +724,7 @@ static int launch_glds16(ConvArgs& a, int dtype, hipStream_t st, int min_tiles) 
     // Auto: Cout % 256 == 0 -> 256x256 tile of eight 128x64 waves (128 B rows if Cin % 64 == 0); short K -> four
     // 128x64 waves on 256x128; Cout <= 64 -> 256x64 tile with 128 B rows; else eight 64x64 waves on 256x128.
     // Retired after measurement (same file): 16-wave 256x256, 8x1 wave grid, 128 B rows x 3 stages (1 workgroup/CU),
-    // 128 B x 2 stages on the 256x128 tile.  TT_GLDS_VARIANT forces 0 / 1 / 2 / 6 / 7 (Cout > 64) for A/B runs.
+    // 128 B x 2 stages on the 256x128 tile.  TT_GLDS_VARIANT forces 0 / 1 / 2 / 6 (Cout > 64) for A/B runs.
     static int variant = -2;
     if (variant == -2) {
         const char* e = getenv("TT_GLDS_VARIANT");
@@ -889,10 +747,6 @@ static int launch_glds16(ConvArgs& a, int dtype, hipStream_t st, int min_tiles) 
             }
             return launch_glds<T16, 256, 2, 4, 128, 2>(a, st);
         }
-        // not measured yet (added after the round's GPU budget was spent): the same 256x256 / 128 B-row / 2-stage tile
-        // as sixteen 64x64 waves = 4 waves per SIMD at a 128-register budget, to test whether the loop is issue-bound
-        // with 2 lock-stepped waves per SIMD
-        if (v == 7 && a.Cout % 256 == 0 && a.Cin % 64 == 0) return launch_glds<T16, 256, 4, 4, 128, 2>(a, st);
         if (v == 1) return launch_glds<T16, 128, 2, 2, 64>(a, st);                         // 4 waves x 128x64
         if (v == 2 && a.Cout % 256 == 0) return launch_glds<T16, 256, 2, 4, 64>(a, st);    // 8 waves x 128x64
         return launch_glds<T16, 128, 4, 2, 64>(a, st);                                     // 8 waves x 64x64

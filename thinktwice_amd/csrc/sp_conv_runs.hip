@@ -36,13 +36,12 @@ constexpr int kNG = 9;     // groups (dz, dy)
 constexpr int kRowB = 128; // staged bytes per row: a 32-channel f32 slice
 }  // namespace
 
-template <int NCB, int WR, int WC, int RB>
+template <int NCB, int WR, int WC>
 __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const ConvArgs p, int tiles_m) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WR * WC;
     constexpr int NT = NW * 64;
-    constexpr int TM = WR * RB * 32;            // output rows per tile (RB 32-row blocks per wave row)
-    static_assert(NT >= TM, "one prologue thread per tile row");
+    constexpr int TM = WR * 32;                 // output rows per tile (one 32-row block per wave row)
     constexpr int BN = WC * NCB * 32;           // output channels (all of them: one column tile)
     constexpr int WTN = NCB * 32;
     constexpr int S = TM + 32;                  // staged input rows per chunk
@@ -252,36 +251,25 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
     };
     // rulebook entries of this lane's output row for the three taps of group g (asm LDS reads, see `rng`)
     const unsigned ent_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)s_ent +
-                              4u * (unsigned)((wm * RB * 32 + (lane & 31)) * KV);
-    bool row_live[RB];
+                              4u * (unsigned)((wm * 32 + (lane & 31)) * KV);
+    const bool row_live = m0 + wm * 32 + (lane & 31) < Mlim;
+    auto load_ent = [&](int g, int (&e)[kG]) {
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) row_live[rb] = m0 + wm * RB * 32 + rb * 32 + (lane & 31) < Mlim;
-    auto load_ent = [&](int g, int (&e)[RB][kG]) {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int t = 0; t < kG; ++t)
-                asm volatile("ds_read_b32 %0, %1"
-                             : "=v"(e[rb][t])
-                             : "v"(ent_base + 4u * (unsigned)(rb * 32 * KV + g * kG + t))
-                             : "memory");
+        for (int t = 0; t < kG; ++t)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(e[t]) : "v"(ent_base + 4u * (unsigned)(g * kG + t)) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int t = 0; t < kG; ++t) {
-                asm volatile("" : "+v"(e[rb][t]));
-                e[rb][t] = row_live[rb] ? e[rb][t] : -1;            // rows beyond the live count: garbage in the rulebook
-            }
+        for (int t = 0; t < kG; ++t) {
+            asm volatile("" : "+v"(e[t]));
+            e[t] = row_live ? e[t] : -1;            // rows beyond the live count: garbage in the rulebook
+        }
     };
 
-    f32x16 acc[RB][NCB];
+    f32x16 acc[NCB];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+    for (int j = 0; j < NCB; ++j)
 #pragma unroll
-        for (int j = 0; j < NCB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rb][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto lds_read = [](unsigned addr) {
@@ -301,11 +289,7 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
     Walk wc{0, 0, 0, 0};
     seek(wc);
     Walk wi = wc;
-    int ent_cur[RB][kG];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int t = 0; t < kG; ++t) ent_cur[rb][t] = -1;
+    int ent_cur[kG] = {-1, -1, -1};
     int cur_g = -1;
     if (wc.g < kNG) {
         issue(wi, 0);
@@ -326,32 +310,26 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
         // ---- compute stage (wc.g, wc.c, wc.sl) from buffer `buf`
         const unsigned sa = lds_base + (unsigned)buf * ABUF, sb = lds_base + 2u * ABUF + (unsigned)buf * BBUF;
         const int nrows = (wc.hi - wc.c) < S ? (wc.hi - wc.c) : S;
-        unsigned a_off[RB][kG], a_swz[RB][kG];
+        unsigned a_off[kG], a_swz[kG];
         bool any = false;
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int t = 0; t < kG; ++t) {
-                const int s = ent_cur[rb][t] - wc.c;
-                const bool ok = ent_cur[rb][t] >= 0 && (unsigned)s < (unsigned)nrows;
-                any = any || ok;
-                const unsigned ar = (ok && !dbg_zero_a) ? (unsigned)s : (unsigned)S;   // absent (or in another chunk): the zero row
-                a_off[rb][t] = sa + ar * kRowB;
-                a_swz[rb][t] = (ar >> 1) & 7;
-            }
+        for (int t = 0; t < kG; ++t) {
+            const int s = ent_cur[t] - wc.c;
+            const bool ok = ent_cur[t] >= 0 && (unsigned)s < (unsigned)nrows;
+            any = any || ok;
+            const unsigned ar = (ok && !dbg_zero_a) ? (unsigned)s : (unsigned)S;   // absent (or in another chunk): the zero row
+            a_off[t] = sa + ar * kRowB;
+            a_swz[t] = (ar >> 1) & 7;
+        }
         // no row of this wave has a neighbour of this group in this chunk (chunked ranges, isolated sites): nothing to add
         if (__builtin_amdgcn_ballot_w64(any) != 0ull && !dbg_no_mfma) {
-            // 6 sub-steps (tap, k-step); the LDS reads of sub-step i+1 are in flight under the split + MFMAs of sub-step i.
-            // A weight fragment pair is read once per sub-step and serves the wave's RB row blocks.
-            u32x4 ra[2][RB][2], rbh[2][NCB], rbl[2][NCB];
+            // 6 sub-steps (tap, k-step); the LDS reads of sub-step i+1 are in flight under the split + MFMAs of sub-step i
+            u32x4 ra[2][2], rbh[2][NCB], rbl[2][NCB];
             auto reads = [&](int i, int slot) {
                 const int t = i >> 1, ks = i & 1;
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    const unsigned a0 = a_off[rb][t] + (((4u * ks + 2u * kb) ^ a_swz[rb][t]) << 4);
-                    ra[slot][rb][0] = lds_read(a0);
-                    ra[slot][rb][1] = lds_read(a0 ^ 16u);
-                }
+                const unsigned a0 = a_off[t] + (((4u * ks + 2u * kb) ^ a_swz[t]) << 4);
+                ra[slot][0] = lds_read(a0);
+                ra[slot][1] = lds_read(a0 ^ 16u);
 #pragma unroll
                 for (int j = 0; j < NCB; ++j) {
                     const unsigned b0 = sb + (unsigned)t * (BN * kRowB) + fb_row[j] + (((4u * ks + kb) ^ fb_swz[j]) << 4);
@@ -365,37 +343,29 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
                 const int cur = i & 1;
                 if (i + 1 < 2 * kG) {
                     reads(i + 1, cur ^ 1);
-                    constexpr int kNext = 2 * (RB + NCB);           // LDS reads of one sub-step: only the newest stay in flight
-                    static_assert(kNext == 4 || kNext == 6 || kNext == 8, "lgkmcnt immediate");
-                    if constexpr (kNext == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                    else if constexpr (kNext == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                    if constexpr (NCB == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
-                uint4 ah[RB], al[RB];
+                u32x4 r0 = ra[cur][0], r1 = ra[cur][1];
+                asm volatile("" : "+v"(r0));
+                asm volatile("" : "+v"(r1));
+                const float x[8] = {__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z),
+                                    __uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y),
+                                    __uint_as_float(r1.z), __uint_as_float(r1.w)};
+                uint32_t h[4], l[4];
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    u32x4 r0 = ra[cur][rb][0], r1 = ra[cur][rb][1];
-                    asm volatile("" : "+v"(r0));
-                    asm volatile("" : "+v"(r1));
-                    const float x[8] = {__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z),
-                                        __uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y),
-                                        __uint_as_float(r1.z), __uint_as_float(r1.w)};
-                    uint32_t h[4], l[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);                       // round to nearest even
-                        const float q0 = x[2 * e] - __uint_as_float(h[e] << 16);           // exact in f32
-                        const float q1 = x[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
-                        l[e] = pack_bf16x2(q0, q1);
-                    }
-                    ah[rb] = uint4{h[0], h[1], h[2], h[3]};
-                    al[rb] = uint4{l[0], l[1], l[2], l[3]};
-                    if (dbg_no_split) {
-                        ah[rb] = __builtin_bit_cast(uint4, r0);
-                        al[rb] = __builtin_bit_cast(uint4, r1);
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);                       // round to nearest even
+                    const float q0 = x[2 * e] - __uint_as_float(h[e] << 16);           // exact in f32
+                    const float q1 = x[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
+                    l[e] = pack_bf16x2(q0, q1);
+                }
+                uint4 ah = uint4{h[0], h[1], h[2], h[3]}, al = uint4{l[0], l[1], l[2], l[3]};
+                if (dbg_no_split) {
+                    ah = __builtin_bit_cast(uint4, r0);
+                    al = __builtin_bit_cast(uint4, r1);
                 }
                 u32x4 bh[NCB], bl[NCB];
 #pragma unroll
@@ -406,17 +376,11 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
                     asm volatile("" : "+v"(bl[j]));
                 }
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
+                for (int j = 0; j < NCB; ++j) Mfma<uint16_t>::run(al, __builtin_bit_cast(uint4, bh[j]), acc[j]);
 #pragma unroll
-                    for (int j = 0; j < NCB; ++j) Mfma<uint16_t>::run(al[rb], __builtin_bit_cast(uint4, bh[j]), acc[rb][j]);
+                for (int j = 0; j < NCB; ++j) Mfma<uint16_t>::run(ah, __builtin_bit_cast(uint4, bl[j]), acc[j]);
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                    for (int j = 0; j < NCB; ++j) Mfma<uint16_t>::run(ah[rb], __builtin_bit_cast(uint4, bl[j]), acc[rb][j]);
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                    for (int j = 0; j < NCB; ++j) Mfma<uint16_t>::run(ah[rb], __builtin_bit_cast(uint4, bh[j]), acc[rb][j]);
+                for (int j = 0; j < NCB; ++j) Mfma<uint16_t>::run(ah, __builtin_bit_cast(uint4, bh[j]), acc[j]);
             }
         }
         next(wc);
@@ -424,18 +388,21 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    conv_epilogue<float, RB, NCB, RB * 32, WTN>(p, acc, smem, wave, lane, wm, wn, m0, 0, Mlim);
+    f32x16 acc2[1][NCB];
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) acc2[0][j] = acc[j];
+    conv_epilogue<float, 1, NCB, 32, WTN>(p, acc2, smem, wave, lane, wm, wn, m0, 0, Mlim);
 #endif
 }
 
-template <int NCB, int WR, int WC, int RB = 1>
+template <int NCB, int WR, int WC>
 static int launch_sp_runs(ConvArgs& a, hipStream_t st) {
-    constexpr int TM = WR * RB * 32, BN = WC * NCB * 32, S = TM + 32, NW = WR * WC;
+    constexpr int TM = WR * 32, BN = WC * NCB * 32, S = TM + 32, NW = WR * WC;
     size_t smem = (size_t)2 * (S + 8) * kRowB + (size_t)2 * kG * BN * kRowB + 128 +
                   (size_t)((TM * kG * kNG * 4 + 1023) / 1024) * 1024;
     const size_t epi = (size_t)NW * 32 * (NCB * 32 + 4) * 4;
     if (smem < epi) smem = epi;
-    auto kern = sp_conv_runs_kernel<NCB, WR, WC, RB>;
+    auto kern = sp_conv_runs_kernel<NCB, WR, WC>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -448,7 +415,7 @@ static int launch_sp_runs(ConvArgs& a, hipStream_t st) {
     a.m_begin = 0;
     static const int dbg = [] { const char* e = getenv("TT_SP_DEBUG"); return e ? atoi(e) : 0; }();
     a.flags = (a.flags & 15) | (dbg << 4);
-    snprintf(g_conv_kernel, sizeof(g_conv_kernel), "sp_conv_runs_kernel<%d, %d, %d, %d>", NCB, WR, WC, RB);
+    snprintf(g_conv_kernel, sizeof(g_conv_kernel), "sp_conv_runs_kernel<%d, %d, %d>", NCB, WR, WC);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles_m), dim3(NW * 64), smem, st, a, tiles_m);
     return 1;
 }
@@ -463,14 +430,6 @@ int try_launch_sp_conv_runs(ConvArgs& a, hipStream_t st) {
     if (a.stride != 1) return 0;
     if (a.Cin % 32 != 0 || a.Cin > 128 || a.M < 2048 || a.pixel_shuffle2) return 0;
     if ((a.in_cstride & 3) || (a.in_coff & 3)) return 0;
-    // TT_SP_RUNS_CFG (A/B knob): 0 = one 32-row block per wave, 8 waves; 1 = 32 channels as two 4-wave workgroups per CU
-    // (80 KiB of LDS each), 64 / 128 channels with two row blocks per wave (a weight fragment read serves both), 4 waves
-    static const int cfg = [] { const char* e = getenv("TT_SP_RUNS_CFG"); return e ? atoi(e) : 1; }();
-    if (cfg == 1) {
-        if (a.Cout == 32) return launch_sp_runs<1, 4, 1, 1>(a, st);
-        if (a.Cout == 64) return launch_sp_runs<2, 4, 1, 2>(a, st);
-        if (a.Cout == 128) return launch_sp_runs<2, 2, 2, 2>(a, st);
-    }
     if (a.Cout == 32) return launch_sp_runs<1, 8, 1>(a, st);
     if (a.Cout == 64) return launch_sp_runs<2, 8, 1>(a, st);
     if (a.Cout == 128) return launch_sp_runs<2, 4, 2>(a, st);
