@@ -174,18 +174,9 @@ typedef struct tt_conv_desc {
      * zero fill needed); every K split stores its partial tile into its own slice and the finalize kernel adds the slices
      * in index order -- bit-reproducible.  0: the legacy form (one zero-filled slice, f32 atomics) */
     int splitk_slices;
-    /* bf16x3 mode (dtype TT_F32 + weight_x3) only: activations in PAIR FORMAT, the same 4 B per element as f32 -- per 16
-     * channels 64 B = [bf16 hi of ch 0-7 | hi 8-15 | lo 0-7 | lo 8-15] with hi = bf16(v) (round to nearest even) and
-     * lo = bf16(v - hi), i.e. exactly the two MFMA operands the kernel would otherwise split an f32 activation into in
-     * registers (identical sums; the consuming K loop saves the split).  bit 0: `in` is pair format, bit 1: write `out`
-     * in pair format, bit 2: `res1` is pair format (mandatory with bit 1).  Rows and channel windows must be 16-channel
-     * aligned and the shape must satisfy tt_conv2d_takes_pairs; anything else is an error, never a silent fallback. */
-    int pair_flags;
 } tt_conv_desc;
 
 int tt_conv2d_fwd(const tt_conv_desc* d, void* stream);
-/* 1 when a dense convolution of this shape runs on the bf16x3 LDS-DMA kernel and may therefore take / produce pair format */
-int tt_conv2d_takes_pairs(int M, int Cin, int Cout, int KH, int KW);
 /* K splits tt_conv2d_fwd would use for this descriptor if it is given a split-K workspace (0: the layer does not split) */
 int tt_conv2d_splitk_slices(const tt_conv_desc* d);
 

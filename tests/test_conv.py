@@ -133,60 +133,6 @@ def test_conv_bf16x3_matches_torch_f32(case):
         assert not torch.equal(exact, out)
 
 
-
-def _decode_pairs(t):
-    """Pair-format tensor (f32 container) -> f32 values: per 16 channels [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] as bf16."""
-    u = t.contiguous().view(torch.int16).reshape(*t.shape[:-1], t.shape[-1] // 16, 4, 8)      # [..., group, quarter, 8]
-    f = (u.to(torch.int32) << 16).view(torch.float32)
-    return (f[..., 0:2, :] + f[..., 2:4, :]).reshape(t.shape)
-
-
-@pytest.mark.parametrize("cmid,cout,wide", [(64, 256, False), (128, 512, True)])
-def test_pair_format_activations_between_bf16x3_convs(cmid, cout, wide):
-    """tt_conv_desc.pair_flags: a producing epilogue writes (bf16 hi, lo) pairs, the consuming K loop takes them as its MFMA
-    operands.  A bottleneck-shaped chain (1x1 -> 3x3 -> 1x1 + residual from a 1x1) in pair format against the same chain
-    on f32 activations: bit-identical wherever no pair-format RESIDUAL is involved (the pair IS what the in-register split
-    computes), ~2^-17 relative where the residual is read as hi + lo; the stored pairs decode to the f32 values within 2^-16."""
-    from thinktwice_amd import ops, weights
-    g = torch.Generator().manual_seed(cmid)
-    N, H, W, cin = 2, 64, 48, 256 if wide else 64
-    x = weights.to_channel_last(_mk((N, cin, H, W), g), torch.float32).cuda()
-
-    def mk(co, ci, k):
-        w = weights.prep_conv_weight(_mk((co, ci, k, k), g, (ci * k * k) ** -0.5), torch.float32).cuda()
-        return w, weights.split_pairs_x3(w)
-    (w1, w1x), (w2, w2x), (w3, w3x), (wd, wdx) = mk(cmid, cin, 1), mk(cmid, cmid, 3), mk(cout, cmid, 1), mk(cout, cin, 1)
-    sh = [(_mk((c,), g, 0.3)).cuda() for c in (cmid, cmid, cout, cout)]
-    assert ops.conv_takes_pairs(N * H * W, cmid, cmid, 3, 3)
-    # f32 activations
-    y1 = ops.conv2d(x, w1, shift=sh[0], act=1, w_x3=w1x)
-    y2 = ops.conv2d(y1, w2, pad=1, shift=sh[1], act=1, w_x3=w2x)
-    r = ops.conv2d(x, wd, shift=sh[3], w_x3=wdx)
-    y3 = ops.conv2d(y2, w3, shift=sh[2], act=1, res1=r, w_x3=w3x)
-    y3n = ops.conv2d(y2, w3, shift=sh[2], act=1, w_x3=w3x)
-    # pair-format activations
-    p1 = ops.conv2d(x, w1, shift=sh[0], act=1, w_x3=w1x, pairs=2)
-    p2 = ops.conv2d(p1, w2, pad=1, shift=sh[1], act=1, w_x3=w2x, pairs=1 | 2)
-    rp = ops.conv2d(x, wd, shift=sh[3], w_x3=wdx, pairs=2)
-    q3n = ops.conv2d(p2, w3, shift=sh[2], act=1, w_x3=w3x, pairs=1)                       # f32 out, no residual
-    q3 = ops.conv2d(p2, w3, shift=sh[2], act=1, res1=rp, w_x3=w3x, pairs=1 | 4)           # f32 out, pair residual
-    q3p = ops.conv2d(p2, w3, shift=sh[2], act=1, res1=rp, w_x3=w3x, pairs=1 | 2 | 4)      # pair out, pair residual
-    torch.cuda.synchronize()
-    for got, want in ((p1, y1), (p2, y2), (rp, r)):
-        d = _decode_pairs(got)
-        assert float((d - want).abs().max()) <= 2.0 ** -16 * float(want.abs().max())
-        assert float(((d - want).abs() / want.abs().clamp_min(1e-30)).max()) < 2.0 ** -15
-    assert torch.equal(q3n, y3n)
-    tol = 2.0 ** -15 * float(y3.abs().max())
-    assert float((q3 - y3).abs().max()) < tol
-    assert float((_decode_pairs(q3p) - q3).abs().max()) < tol
-    # and the contract is enforced, not silently dropped
-    from thinktwice_amd._lib import TTError
-    with pytest.raises(TTError):
-        ops.conv2d(x[:, :8, :8].contiguous(), w1, shift=sh[0], w_x3=w1x, pairs=2)         # M = 128: not the LDS-DMA kernel
-    with pytest.raises(TTError):
-        ops.conv2d(p2, w3, shift=sh[2], res1=r, w_x3=w3x, pairs=1 | 2)                   # pair output, f32 residual
-
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_deconv2x2_pixel_shuffle(dt):
     from thinktwice_amd import ops, weights

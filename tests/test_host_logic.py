@@ -130,13 +130,16 @@ def test_reference_config_file_builds_the_model_verbatim():
     assert cfg.optimizer == {"type": "AdamW", "lr": 1e-4, "weight_decay": 1e-7}
 
 
-def test_lidar_voxelize_refuses_clouds_that_could_exceed_max_voxels():
-    """the max_voxels cap of mmcv hard voxelization is not implemented; the product path must say so
-    (before touching the device) instead of diverging silently."""
+def test_lidar_voxelize_has_no_host_fallback_and_picks_the_configured_cap():
+    """mmcv's max_voxels cap (configs/thinktwice.py:161-165: 120000 training / 160000 inference) is implemented on the device
+    (tt_lidar_voxelize_capped, tests/test_lidar.py); the host side only selects the cap -- and a host tensor is refused, never
+    voxelised on the CPU."""
     import torch
     from thinktwice_amd import _lib, config, lidarnet
     cfg = config.model_config()["lidar_encoder"]
+    assert tuple(cfg["pts_voxel_layer"]["max_voxels"]) == (120000, 160000)
     net = lidarnet.LidarNet.__new__(lidarnet.LidarNet)
     net.vl = cfg["pts_voxel_layer"]
-    with pytest.raises(_lib.TTError, match="max_voxels"):
-        net.voxelize(torch.zeros(1, 160001, 5))
+    net.training = False
+    with pytest.raises(_lib.TTError):
+        net.forward(torch.zeros(1, 1000, 5))

@@ -40,7 +40,6 @@ struct ConvArgs {
     int splits;          // split-K factor (gridDim.y)
     int tiles_n;
     int m_begin;         // first output row of this launch (tail-split launches of the LDS-DMA kernel), else 0
-    int pairs;           // bf16x3: bit 0 input, bit 1 output, bit 2 res1 in pair format (bf16 hi | lo, 16-channel groups)
     int ws_slices;       // split-K: > 0 = every split stores into its own [M][Cout] slice of ws (ordered finalize)
     int flags;           // bit 0: s_setprio(1) around the MFMA groups of the LDS-DMA kernel (TT_GLDS_SETPRIO=1, A/B knob)
 };
@@ -110,16 +109,9 @@ __device__ __forceinline__ void load_scale_shift(const ConvArgs& p, float (&sc)[
 // 128 B lines).  Everything is compile-time indexed so it stays in registers: an earlier version with runtime CO and
 // by-reference lambdas put its small arrays in scratch, and every scratch reload carried an `s_waitcnt vmcnt(0)` that
 // also waited for the in-flight global stores (1.4 TB/s ceiling on every memory-bound layer).
-// PM (bf16x3 kernels only, T = float): 1 = the OUTPUT is written in pair format (CO = 8: per 16 channels 64 B =
-// [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15], hi = bf16(v) round-to-nearest-even, lo = bf16(v - hi) -- bit for bit the operands the
-// consuming kernel's in-register split would have formed from the f32 value) and a residual, if any, is read in pair
-// format; 2 = f32 output (CO = 4), residual read in pair format.
-template <typename T, int CO, int TM, int TN, int WTM, int WTN, int PM = 0>
+template <typename T, int CO, int TM, int TN, int WTM, int WTN>
 __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&acc)[TM][TN], float* sC, int lane, int wm,
                                                   int wn, int m0, int n0, int Mlim) {
-    static_assert(PM == 0 || sizeof(T) == 4, "pair format: f32-storage (bf16x3) kernels");
-    static_assert(PM != 1 || CO == 8, "pair-format output: 8 channels per lane");
-    static_assert(PM != 2 || CO == 4, "f32 output with a pair-format residual: 4 channels per lane");
     constexpr int LDC = WTN + 4;
     constexpr int cpr = WTN / CO;          // 16 B chunks per row of the wave's block
     constexpr int rpp = 64 / cpr;          // rows per pass
@@ -140,43 +132,11 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
     load_scale_shift<TN, WTN>(p, sc, sh, lane, wn, n0);
     const bool has_sn = p.shift_n != nullptr;
     const bool has_r1 = p.res1 != nullptr, has_r2 = p.res2 != nullptr;
-    const bool rvec = PM != 0 || p.res_vec != 0;       // (pair format: 16-channel aligned by contract)
-    struct PairRV {               // CO bf16 hi halves + CO bf16 lo halves
-        typename std::conditional<CO == 8, uint4, uint2>::type hi, lo;
-    };
-    using RV = typename std::conditional<PM != 0, PairRV,
-               typename std::conditional<sizeof(T) == 2 && CO == 8, uint4,
-                                         typename std::conditional<sizeof(T) == 2, uint2, float4>::type>::type>::type;
-    // byte address of the hi halves of CO channels at f32-element offset o inside a pair-format tensor (rows and channel
-    // windows are 16-channel aligned, so o & 15 is the channel's position in its group); the lo halves sit 32 B further
-    auto pair_byte = [](long long o) -> long long { return (o & ~15LL) * 4 + (o & 15) * 2; };
-    auto load_rv = [&](const void* base, long long o) -> RV {
-        if constexpr (PM != 0) {
-            const unsigned char* bp = reinterpret_cast<const unsigned char*>(base) + pair_byte(o);
-            RV r;
-            r.hi = *reinterpret_cast<const decltype(r.hi)*>(bp);
-            r.lo = *reinterpret_cast<const decltype(r.lo)*>(bp + 32);
-            return r;
-        } else {
-            return *reinterpret_cast<const RV*>(reinterpret_cast<const T*>(base) + o);
-        }
-    };
+    const bool rvec = p.res_vec != 0;
+    using RV = typename std::conditional<sizeof(T) == 2 && CO == 8, uint4,
+                                         typename std::conditional<sizeof(T) == 2, uint2, float4>::type>::type;
     auto add_rv = [](float (&v)[CO], const RV& u) {
-        if constexpr (PM != 0) {
-            uint32_t wh[CO / 2], wl[CO / 2];
-            if constexpr (CO == 8) {
-                wh[0] = u.hi.x; wh[1] = u.hi.y; wh[2] = u.hi.z; wh[3] = u.hi.w;
-                wl[0] = u.lo.x; wl[1] = u.lo.y; wl[2] = u.lo.z; wl[3] = u.lo.w;
-            } else {
-                wh[0] = u.hi.x; wh[1] = u.hi.y;
-                wl[0] = u.lo.x; wl[1] = u.lo.y;
-            }
-#pragma unroll
-            for (int e = 0; e < CO / 2; ++e) {
-                v[2 * e] += __uint_as_float(wh[e] << 16) + __uint_as_float(wl[e] << 16);
-                v[2 * e + 1] += __uint_as_float(wh[e] & 0xffff0000u) + __uint_as_float(wl[e] & 0xffff0000u);
-            }
-        } else if constexpr (sizeof(T) == 2 && CO == 8) {
+        if constexpr (sizeof(T) == 2 && CO == 8) {
             const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -214,22 +174,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
         return (long long)n * p.out_nstride + ((long long)oh * OWo + ow) * p.out_cstride + p.out_coff + cc;
     };
     auto store_row = [&](long long o, const float (&v)[CO]) {
-        if constexpr (PM == 1) {
-            uint4 h, l;
-            uint32_t hw[4], lw[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hw[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);                              // round to nearest even
-                const float r0 = v[2 * e] - __uint_as_float(hw[e] << 16);                   // exact in f32
-                const float r1 = v[2 * e + 1] - __uint_as_float(hw[e] & 0xffff0000u);
-                lw[e] = pack_bf16x2(r0, r1);
-            }
-            h = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-            l = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-            unsigned char* bp = reinterpret_cast<unsigned char*>(p.out) + pair_byte(o);
-            *reinterpret_cast<uint4*>(bp) = h;
-            *reinterpret_cast<uint4*>(bp + 32) = l;
-        } else if constexpr (CO == 4) {
+        if constexpr (CO == 4) {
             *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
             // 16-bit output: the storage type of the operands (f32-compute layers never take the CO == 8 path)
@@ -297,7 +242,8 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                     if constexpr (R1) {
 #pragma unroll
                         for (int q = 0; q < PG; ++q)
-                            r1[q] = load_rv(p.res1, (long long)mrow[q] * p.res1_cstride + p.res1_coff + co);
+                            r1[q] = *reinterpret_cast<const RV*>(reinterpret_cast<const T*>(p.res1) +
+                                                                (long long)mrow[q] * p.res1_cstride + p.res1_coff + co);
                     }
 #pragma unroll
                     for (int q = 0; q < PG; ++q) {
@@ -346,11 +292,11 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                 for (int which = 0; which < 2; ++which) {
                     const void* rb = which ? p.res2 : p.res1;
                     if (!rb) continue;
-                    const long long ro = (long long)mo * (which ? p.res2_cstride : p.res1_cstride) +
-                                         (which ? p.res2_coff : p.res1_coff) + co;
-                    const T* rp = reinterpret_cast<const T*>(rb) + ro;
+                    const T* rp = reinterpret_cast<const T*>(rb) +
+                                  (long long)mo * (which ? p.res2_cstride : p.res1_cstride) +
+                                  (which ? p.res2_coff : p.res1_coff) + co;
                     if (rvec) {
-                        add_rv(v, load_rv(rb, ro));
+                        add_rv(v, *reinterpret_cast<const RV*>(rp));
                     } else {
 #pragma unroll
                         for (int e = 0; e < CO; ++e) v[e] += Elem<T>::ld(rp + e);
@@ -366,7 +312,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
 
 // Fused epilogue shared by both kernels.  C/D map of the 32x32 MFMA: col = lane&31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-template <typename T, int TM, int TN, int WTM, int WTN, bool PAIRS_OK = false>
+template <typename T, int TM, int TN, int WTM, int WTN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], unsigned char* smem,
                                               int wave, int lane, int wm, int wn, int m0, int n0, int Mlim) {
     // ---- epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -393,16 +339,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
     }
     float* sC = reinterpret_cast<float*>(smem) + wave * (32 * (WTN + 4));
     __syncthreads();   // every wave is done with the K-loop tiles before LDS is reused
-    if constexpr (PAIRS_OK) {
-        if (p.pairs & 2) {          // pair-format output (and residual): tt_conv2d_fwd has checked the alignment rules
-            conv_epilogue_vec<T, 8, TM, TN, WTM, WTN, 1>(p, acc, sC, lane, wm, wn, m0, n0, Mlim);
-            return;
-        }
-        if (p.pairs & 4) {          // f32 output, pair-format residual
-            conv_epilogue_vec<T, 4, TM, TN, WTM, WTN, 2>(p, acc, sC, lane, wm, wn, m0, n0, Mlim);
-            return;
-        }
-    }
     if (p.vec_epi) {
         if (p.out_dtype == TT_F32)
             conv_epilogue_vec<T, 4, TM, TN, WTM, WTN>(p, acc, sC, lane, wm, wn, m0, n0, Mlim);

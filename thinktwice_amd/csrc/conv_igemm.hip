@@ -321,12 +321,6 @@ using namespace tt;
 
 static int conv2d_run(const tt_conv_desc* d, void* stream, bool query);
 
-// the contract of try_launch_conv_glds_x3 for dense convolutions (csrc/conv_igemm_glds.hip), for callers that want to
-// write a producer's output in pair format: is this consumer shape one the kernel takes?
-extern "C" int tt_conv2d_takes_pairs(int M, int Cin, int Cout, int KH, int KW) {
-    return (M > 4096 && Cout >= 64 && KH * KW <= 32 && Cin % 32 == 0 && (long long)KH * KW * Cin >= 64) ? 1 : 0;
-}
-
 extern "C" int tt_conv2d_fwd(const tt_conv_desc* d, void* stream) { return conv2d_run(d, stream, false); }
 
 extern "C" int tt_conv2d_splitk_slices(const tt_conv_desc* d) {
@@ -381,25 +375,6 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
                "tt_conv2d_fwd: residuals are not supported with pixel_shuffle2");
     a.tiles_n = 1; a.cin_fast = 0; a.m_begin = 0;
     a.flags = 0;
-    a.pairs = d->pair_flags;
-    if (a.pairs) {
-        // pair-format activations (bf16 hi | lo per element, 16-channel groups like the pre-split weights): an operand / result
-        // format of the bf16x3 LDS-DMA kernel only
-        TT_REQUIRE(d->dtype == TT_F32 && d->out_dtype == TT_F32 && d->weight_x3 && !a.gather && !d->splitk_ws &&
-                       !d->pixel_shuffle2 && !d->res2,
-                   "tt_conv2d_fwd: pair_flags need the bf16x3 mode (f32 storage, weight_x3), a dense conv and at most one residual");
-        TT_REQUIRE(tt_conv2d_takes_pairs(a.M, d->Cin, d->Cout, d->KH, d->KW),
-                   "tt_conv2d_fwd: pair_flags on a shape the bf16x3 LDS-DMA kernel does not take (M=%d Cin=%d Cout=%d %dx%d)",
-                   a.M, d->Cin, d->Cout, d->KH, d->KW);
-        TT_REQUIRE(!(a.pairs & 1) || (d->in_cstride % 16 == 0 && d->in_coff % 16 == 0),
-                   "tt_conv2d_fwd: pair-format input needs 16-channel aligned rows");
-        TT_REQUIRE(!(a.pairs & 2) || (d->Cout % 16 == 0 && d->out_cstride % 16 == 0 && d->out_coff % 16 == 0),
-                   "tt_conv2d_fwd: pair-format output needs 16-channel aligned rows");
-        TT_REQUIRE(!(a.pairs & 4) || (d->res1 && d->res1_cstride % 16 == 0 && d->res1_coff % 16 == 0),
-                   "tt_conv2d_fwd: pair-format residual needs 16-channel aligned rows");
-        TT_REQUIRE(!((a.pairs & 2) && d->res1) || (a.pairs & 4),
-                   "tt_conv2d_fwd: a pair-format output takes its residual in pair format too");
-    }
     if (query) a.flags = -1;       // launch_conv returns the split count instead of launching
     {
         const int co_vec = d->out_dtype == TT_F32 ? 4 : 8;
@@ -425,7 +400,7 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
         if (d->dtype == TT_F16) return dispatch_conv<f16_t>(a, st);
         return dispatch_conv<uint16_t>(a, st);
     }
-    if (!d->splitk_ws && !a.pairs && try_launch_conv_small(a, d->dtype, st)) {
+    if (!d->splitk_ws && try_launch_conv_small(a, d->dtype, st)) {
         snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_small_kernel");
         return check_launch("tt_conv2d_fwd(small)");
     }
@@ -436,7 +411,6 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
         ax.weight = d->weight_x3;
         if (try_launch_conv_glds_x3(ax, st)) return check_launch("tt_conv2d_fwd(glds x3)");
     }
-    TT_REQUIRE(!a.pairs, "tt_conv2d_fwd: pair_flags set but the bf16x3 LDS-DMA kernel did not take the launch");
     if (!d->splitk_ws && try_launch_conv_glds(a, d->dtype, st)) return check_launch("tt_conv2d_fwd(glds)");
     a.row_perm = nullptr;      // the tile plan is an LDS-DMA-kernel feature: the other kernels walk rows and taps in
     a.row_mask = nullptr;      // natural order (same result)

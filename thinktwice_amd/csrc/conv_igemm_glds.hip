@@ -373,12 +373,10 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     // X3: a k-step is 16 f32 = 64 B.  A: lane half h owns floats 8h..8h+7 = chunks 4kc+2h and 4kc+2h+1 (the second is
     // the first with address bit 4 flipped, the swizzle being an XOR); B: hi chunk 4kc+h, lo chunk 4kc+2+h (bit 5).
     constexpr int NKC_ = X3 ? BKB / 64 : BKB / 32;
-    const bool a_pairs = X3 && (p.pairs & 1) != 0;          // activations already in (hi, lo) pair format: like the weights
-    const unsigned a_second = a_pairs ? 32u : 16u;          // second read of an A fragment: lo half / floats 4..7
     unsigned fa_pre[NKC_][TM], fb_pre[NKC_][TN];
 #pragma unroll
     for (int kc = 0; kc < NKC_; ++kc) {
-        const unsigned ca = X3 ? (a_pairs ? 4u * kc + hi : 4u * kc + 2u * hi) : 2u * kc + hi;
+        const unsigned ca = X3 ? 4u * kc + 2u * hi : 2u * kc + hi;
         const unsigned cb = X3 ? 4u * kc + hi : 2u * kc + hi;
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa_pre[kc][i] = fa_off[i] + ((ca ^ fa_s[i]) << 4);
@@ -432,12 +430,10 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
             constexpr int NS = NKC_ * TN;
             u32x4 ra0[TM], ra1[TM], bh[2], bl[2];
             uint4 ah[2][TM], al[2][TM];
-            // pair-format activations (p.pairs & 1: written by a producing epilogue as [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15]
-            // per 16 channels, like the weights): the two reads ARE the hi and lo operands, no split
             auto split_frag = [&](int i, uint4& hi_out, uint4& lo_out) {
                 asm volatile("" : "+v"(ra0[i]));
                 asm volatile("" : "+v"(ra1[i]));
-                if (a_pairs || (TT_GLDS_DEBUG && p.act == 96)) {   // (debug 96: no operand split, raw bits as operands)
+                if (TT_GLDS_DEBUG && p.act == 96) {          // debug: no operand split (raw bits as operands)
                     hi_out = __builtin_bit_cast(uint4, ra0[i]);
                     lo_out = __builtin_bit_cast(uint4, ra1[i]);
                     return;
@@ -459,7 +455,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ra0[i] = lds_read(sbase + fa_pre[0][i]);
-                ra1[i] = lds_read(sbase + (fa_pre[0][i] ^ a_second));
+                ra1[i] = lds_read(sbase + (fa_pre[0][i] ^ 16u));
             }
             bh[0] = lds_read(sbase_b + fb_pre[0][0]);
             bl[0] = lds_read(sbase_b + (fb_pre[0][0] ^ 32u));
@@ -471,7 +467,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(bh[buf]));
                 asm volatile("" : "+v"(bl[buf]));
-                if (j == 0) {    // the k-step's activation fragments: split (or taken as they are) up front
+                if (j == 0) {    // the k-step's activation fragments: split up front
 #pragma unroll
                     for (int i = 0; i < TM; ++i) split_frag(i, ah[ab][i], al[ab][i]);
                 }
@@ -480,7 +476,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         ra0[i] = lds_read(sbase + fa_pre[kc + 1][i]);
-                        ra1[i] = lds_read(sbase + (fa_pre[kc + 1][i] ^ a_second));
+                        ra1[i] = lds_read(sbase + (fa_pre[kc + 1][i] ^ 16u));
                     }
                 }
                 if (ss + 1 < NS) {
@@ -552,7 +548,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     // barrier (to cover the prologue bubble) changed nothing, and skipping either DMA stream after the first tile
     // (TT_GLDS_DEBUG) did not shorten the loop either: at ~1.0 PF the loop is neither L2->LDS- nor bubble-bound.
     __syncthreads();   // all waves done with the last stage before the epilogue reuses LDS
-    conv_epilogue<T, TM, TN, WTM, WTN, X3 && !GATHER>(p, acc, smem, wave, lane, wm, wn, m0, n0, Mlim);
+    conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, smem, wave, lane, wm, wn, m0, n0, Mlim);
 #endif
 }
 

@@ -44,7 +44,6 @@ class _ResNet50:
             wr[:, :, 0, :28] = torch.nn.functional.pad(w.permute(0, 2, 3, 1), (0, 1)).reshape(w.shape[0], 7, 28)
             self.stem_rr = wr.contiguous()
             self.stem_rr_x3 = weights.split_pairs_x3(self.stem_rr)
-        self.x3 = dtype == weights.X3
         self.blocks = []
         for li, nb in enumerate((3, 4, 6, 3), start=1):
             stage = []
@@ -80,39 +79,11 @@ class _ResNet50:
             y = self.stem(x, stop_grad=True)      # (training tape: the image is a leaf without a gradient)
         x = ops.maxpool3x3s2(y)
         outs = []
-        # bf16x3 inference: activations that only bf16x3 convs read travel in PAIR FORMAT (tt_conv_desc.pair_flags: the
-        # producing epilogue writes the (hi, lo) operand pair, the consuming K loop skips its in-register split; identical
-        # sums).  Inside a bottleneck that is conv1 -> conv2 -> conv3 and the downsample branch; between the blocks of a
-        # stage the block output too (read by conv1 and as the next block's identity).  A stage's LAST block writes f32:
-        # the laterals / the UNet read it.
-        from . import autodiff
-        pf = self.x3 and not layers.BN_TRAIN and autodiff.TAPE is None
-        x_pairs = False
         for stage in self.blocks:
-            for bi, blk in enumerate(stage):
-                N_, H_, W_, cin = x.shape
-                s = blk["c2"].stride
-                Mi, Mo = N_ * H_ * W_, N_ * ((H_ - 1) // s + 1) * ((W_ - 1) // s + 1)
-                cmid, cout = blk["c1"].w.shape[0], blk["c3"].w.shape[0]
-                # which of the block's convs run on the bf16x3 LDS-DMA kernel (only that kernel reads / writes pairs)
-                g1 = pf and ops.conv_takes_pairs(Mi, cin, cmid)
-                g2 = pf and ops.conv_takes_pairs(Mo, cmid, cmid, 3, 3)
-                g3 = pf and ops.conv_takes_pairs(Mo, cmid, cout)
-                p12, p23 = g1 and g2, g2 and g3
-                in_bit = 1 if x_pairs else 0
-                if blk["ds"] is not None:           # its output is only read as conv3's residual
-                    idt_pairs = g3 and ops.conv_takes_pairs(Mo, cin, cout)
-                    idt = blk["ds"](x, pairs=in_bit | (2 if idt_pairs else 0))
-                else:
-                    idt, idt_pairs = x, x_pairs
-                # block output in pairs: written by conv3, read by the next block's conv1 and as its identity
-                pout = (g3 and idt_pairs and bi + 1 < len(stage) and
-                        ops.conv_takes_pairs(Mo, cout, stage[bi + 1]["c1"].w.shape[0]))
-                y = blk["c1"](x, pairs=in_bit | (2 if p12 else 0))
-                y = blk["c2"](y, pairs=(1 if p12 else 0) | (2 if p23 else 0))
-                x = blk["c3"](y, res1=idt, pairs=(1 if p23 else 0) | (2 if pout else 0) | (4 if idt_pairs else 0))
-                x_pairs = pout                      # relu(bn3(conv3) + identity)
-            assert not x_pairs
+            for blk in stage:
+                idt = blk["ds"](x) if blk["ds"] is not None else x
+                y = blk["c2"](blk["c1"](x))
+                x = blk["c3"](y, res1=idt)          # relu(bn3(conv3) + identity)
             outs.append(x)
         return outs
 

@@ -114,7 +114,7 @@ class _ConvDesc(ctypes.Structure):
         ("act", _c), ("dtype", _c), ("out_dtype", _c),
         ("gather_idx", ctypes.c_void_p), ("m_dev", ctypes.c_void_p), ("splitk_ws", ctypes.c_void_p),
         ("weight_x3", ctypes.c_void_p), ("row_perm", ctypes.c_void_p), ("row_mask", ctypes.c_void_p),
-        ("splitk_slices", _c), ("pair_flags", _c),
+        ("splitk_slices", _c),
     ]
 
 
@@ -242,11 +242,8 @@ def sp_from_dense(gdense, coords, rows, max_rows, dims, grows):
 def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=None, res1_coff=0,
            res2=None, res2_coff=0, out=None, out_coff=0, in_coff=0, cin=None, pixel_shuffle2=False,
            shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None, splitk_ws=None,
-           in_cstride=None, w_x3=None, _no_tape=False, stop_grad=False, bn_raw=False, pairs=0):
+           in_cstride=None, w_x3=None, _no_tape=False, stop_grad=False, bn_raw=False):
     """Channel-last implicit-GEMM convolution on MFMA (tt_conv2d_fwd).
-
-    pairs (bf16x3 mode only): bit 0 = `x` holds pair-format activations, bit 1 = write `out` in pair format, bit 2 = `res1`
-    is pair format (tt_conv_desc.pair_flags; same tensor shapes and dtype as f32 -- only a bf16x3 conv can read them).
 
     x   [N,H,W,Cs]  (f32 or bf16); channels [in_coff, in_coff+cin) are convolved
     w   [Cout,KH,KW,cin] same dtype (for pixel_shuffle2: [4*Cout_real,1,1,cin])
@@ -299,10 +296,6 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     if w_x3 is not None:
         assert x.dtype == torch.float32 and w_x3.shape == w.shape and w_x3.is_contiguous()
         d.weight_x3 = w_x3.data_ptr()
-    if pairs:
-        from . import autodiff
-        assert autodiff.TAPE is None, "pair-format activations are an inference-path format"
-        d.pair_flags = pairs
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -326,14 +319,6 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
             autodiff.TAPE.conv(x, w, out, stride, pad, dil, scale, shift, act, in_coff, cin, out_coff, res1, res1_coff,
                                res2, res2_coff, pixel_shuffle2, in_cstride, shift_n, shift_n_mod, stop_grad, bn_raw)
     return out
-
-
-PAIRS = os.environ.get("TT_X3_PAIRS", "1") == "1"      # A/B knob: pair-format activations between bf16x3 convs
-
-
-def conv_takes_pairs(M, Cin, Cout, KH=1, KW=1):
-    """Does a dense bf16x3 conv of this shape run on the LDS-DMA kernel, i.e. may its input be handed over in pair format?"""
-    return PAIRS and bool(lib().tt_conv2d_takes_pairs(_c(M), _c(Cin), _c(Cout), _c(KH), _c(KW)))
 
 
 # ----------------------------------------------------------------------------- glue kernels
