@@ -161,6 +161,8 @@ __device__ __forceinline__ float4 vp_load_row16(const float4* p, bool nt) {
     return *p;
 }
 
+struct __attribute__((packed, aligned(4))) VpPoint { int x, y, z; };
+
 // NV = float4 chunks per lane (ceil(C / 256)), RF = point rows in flight per wave (1 KiB loads each)
 template <int NV, int RF, bool NT>
 __global__ __launch_bounds__(512) void voxel_pool_p1_kernel(
@@ -182,21 +184,37 @@ __global__ __launch_bounds__(512) void voxel_pool_p1_kernel(
     const int npts = min(kChunk, num_points - cis * kChunk);
     for (int i = tid; i < cells; i += 512) table[i] = -1;
     __syncthreads();
-    // pass A: cell per point, presence, pos_memo
-    for (int i = tid; i < npts; i += 512) {
-        const long long p = p0 + i;
-        const int x = geom[p * 3], y = geom[p * 3 + 1], z = geom[p * 3 + 2];
-        int c = -1;
-        if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {
-            c = y * X + x;
-            table[c] = -2;
-            if (pos_memo) {
-                pos_memo[p * 3] = b;
-                pos_memo[p * 3 + 1] = y;
-                pos_memo[p * 3 + 2] = x;
+    // pass A: cell per point, presence, pos_memo.  All of a thread's points are fetched (one 12 B load each) before the first
+    // is used: one memory round trip per chunk instead of kChunk / 512
+    {
+        constexpr int kPA = kChunk / 512;
+        const VpPoint* gp = reinterpret_cast<const VpPoint*>(geom) + p0;
+        VpPoint pt[kPA];
+#pragma unroll
+        for (int k = 0; k < kPA; ++k) {
+            const int i = tid + 512 * k;
+            pt[k].x = -1; pt[k].y = -1; pt[k].z = -1;
+            if (i < npts) pt[k] = gp[i];
+        }
+#pragma unroll
+        for (int k = 0; k < kPA; ++k) {
+            const int i = tid + 512 * k;
+            if (i < npts) {
+                const int x = pt[k].x, y = pt[k].y, z = pt[k].z;
+                int c = -1;
+                if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {
+                    c = y * X + x;
+                    table[c] = -2;
+                    if (pos_memo) {
+                        const long long p = p0 + i;
+                        pos_memo[p * 3] = b;
+                        pos_memo[p * 3 + 1] = y;
+                        pos_memo[p * 3 + 2] = x;
+                    }
+                }
+                cell_of[i] = (short)c;
             }
         }
-        cell_of[i] = (short)c;
     }
     __syncthreads();
     if (wave == 0) {   // slot assignment by ballot compaction (cell order)
@@ -244,7 +262,13 @@ __global__ __launch_bounds__(512) void voxel_pool_p1_kernel(
         if (c >= 0) sorted[atomicAdd(&cursor[table[c]], 1)] = (unsigned short)i;
     }
     __syncthreads();
-    // pass B: one wave per slot, register accumulation, no atomics for slots < smax
+    // slot_table layout [b][cell][chunk_in_sample]: phase 2 reads a cell's chunks contiguously
+    for (int c = tid; c < cells; c += 512) {
+        const int sl = table[c];
+        slot_table[((long long)b * cells + c) * chunks_per_sample + cis] = (sl >= 0 && sl < smax) ? sl : -1;
+    }
+    // pass B: one wave per slot, register accumulation, no atomics for slots < smax (no barrier after it: a wave leaves
+    // as soon as its slots are done)
     const int c4 = C >> 2;
     for (int sl = wave; sl < ns; sl += 8) {
         const int beg = cnt[sl], end = cnt[sl + 1];
@@ -294,11 +318,6 @@ __global__ __launch_bounds__(512) void voxel_pool_p1_kernel(
                 }
             }
         }
-    }
-    // slot_table layout [b][cell][chunk_in_sample]: phase 2 reads a cell's chunks contiguously
-    for (int c = tid; c < cells; c += 512) {
-        const int sl = table[c];
-        slot_table[((long long)b * cells + c) * chunks_per_sample + cis] = (sl >= 0 && sl < smax) ? sl : -1;
     }
 }
 
