@@ -16,23 +16,45 @@
 //   (host)            SyncBN: one all-reduce of the [groups][2C] sums
 //   tt_bn_bwd_apply   dz = scale * (g - sum_g / n - xhat * sum_gxhat / n)
 // dgamma = sum g * xhat and dbeta = sum g are the LOCAL sums (the gradient all-reduce averages them like DDP does).
+#include <initializer_list>
+
 #include "tt_common.h"
 
 namespace tt {
 
-constexpr int kBnBlocks = 128;     // workgroups per row group in the reductions
+constexpr int kBnBlocks = 512;     // most workgroups per row group in the reductions (= stride of the partial sums)
 
 struct BnRows {
     long long M;          // allocated rows
     const int* m_dev;     // sparse layers: device count of live rows (groups == 1), else null
     int C, groups;
+    int nb;               // workgroups per row group of this launch (<= kBnBlocks; >= 256 rows each where the group has them)
 };
+
+static BnRows bn_rows(long long M, const int* m_dev, int C, int groups) {
+    const long long per_group = M / groups;
+    long long nb = (per_group + 255) / 256;
+    nb = nb < 1 ? 1 : (nb > kBnBlocks ? kBnBlocks : nb);
+    return BnRows{M, m_dev, C, groups, (int)nb};
+}
+
+// 16-byte path of the four streaming kernels: every tensor window starts on a 16 B boundary and is a whole number of
+// 4-channel pieces wide
+static bool bn_vec_ok(int C, std::initializer_list<const void*> ptrs, std::initializer_list<int> strides_offsets) {
+    if (C % 4) return false;
+    for (const void* q : ptrs) if (q && (reinterpret_cast<uintptr_t>(q) & 15)) return false;
+    for (int v : strides_offsets) if (v % 4) return false;
+    return true;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 
 __device__ __forceinline__ void group_range(const BnRows& r, int g, int blk, long long& r0, long long& r1) {
     const long long Mlive = r.m_dev ? min(r.M, (long long)*r.m_dev) : r.M;
     const long long per_group = r.m_dev ? Mlive : r.M / r.groups;
     const long long g0 = (long long)g * per_group;
-    const long long rows_per = (per_group + kBnBlocks - 1) / kBnBlocks;
+    const long long rows_per = (per_group + r.nb - 1) / r.nb;
     r0 = g0 + (long long)blk * rows_per;
     r1 = min(g0 + per_group, r0 + rows_per);
 }
@@ -78,6 +100,55 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
+// 16 B form of bn_stats_kernel: a thread owns 4 consecutive channels, TY rows of the block's range are in flight at a time,
+// two rows per thread per trip; f64 accumulators, LDS reduction over the row lanes in index order (deterministic)
+__global__ __launch_bounds__(256) void bn_stats_vec_kernel(const float* __restrict__ z, int z_cstride, int z_coff, BnRows r,
+                                                           double* __restrict__ partial) {
+    __shared__ double red[8][256];
+    const int tid = threadIdx.x, g = blockIdx.y, blk = blockIdx.x;
+    const int C = r.C, C4 = C >> 2;
+    const int TX = C4 < 256 ? C4 : 256, TY = 256 / TX;
+    const int tx = tid % TX, ty = tid / TX;
+    long long r0, r1;
+    group_range(r, g, blk, r0, r1);
+    for (int q0 = 0; q0 < C4; q0 += TX) {
+        const int q = q0 + tx, c = q * 4;
+        double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+        if (ty < TY && q < C4) {
+            const float* zp = z + z_coff + c;
+            for (long long m = r0 + ty; m < r1; m += 4LL * TY) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long mm = m + (long long)u * TY;
+                    v[u] = mm < r1 ? ld4(zp + mm * z_cstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s[0] += (double)v[u].x; ss[0] += (double)v[u].x * (double)v[u].x;
+                    s[1] += (double)v[u].y; ss[1] += (double)v[u].y * (double)v[u].y;
+                    s[2] += (double)v[u].z; ss[2] += (double)v[u].z * (double)v[u].z;
+                    s[3] += (double)v[u].w; ss[3] += (double)v[u].w * (double)v[u].w;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[k][tid] = s[k]; red[4 + k][tid] = ss[k]; }
+        __syncthreads();
+        if (ty == 0 && q < C4) {
+            double* p = partial + ((long long)g * kBnBlocks + blk) * 2 * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double t0 = 0.0, t1 = 0.0;
+                for (int j = 0; j < TY; ++j) { t0 += red[k][j * TX + tx]; t1 += red[4 + k][j * TX + tx]; }
+                p[c + k] = t0;
+                p[C + c + k] = t1;
+            }
+        }
+    }
+}
+
 // out[g][0..C) = sum of partial[.][0], out[g][C..2C) = sum of partial[.][1] (index order); with `count`: out[g][2C] = rows
 __global__ void bn_finish_kernel(const double* __restrict__ partial, BnRows r, int out_stride, int with_count,
                                  double* __restrict__ out) {
@@ -85,7 +156,7 @@ __global__ void bn_finish_kernel(const double* __restrict__ partial, BnRows r, i
     if (c < 2 * r.C) {
         const int which = c / r.C, cc = c % r.C;
         double s = 0.0;
-        for (int b = 0; b < kBnBlocks; ++b) s += partial[((long long)g * kBnBlocks + b) * 2 * r.C + which * r.C + cc];
+        for (int b = 0; b < r.nb; ++b) s += partial[((long long)g * kBnBlocks + b) * 2 * r.C + which * r.C + cc];
         out[(long long)g * out_stride + c] = s;
     }
     if (with_count && c == 0) {
@@ -147,6 +218,41 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
         if (a.res2) v += a.res2[m * a.r2_cstride + a.r2_coff + c];
         if (a.act == TT_ACT_RELU) v = v > 0.f ? v : 0.f;
         a.out[m * a.out_cstride + a.out_coff + c] = v;
+    }
+}
+
+// 16 B form: thread = (4 channels, row lane); a block walks rows with a grid stride, no per-element division
+__global__ __launch_bounds__(256) void bn_apply_vec_kernel(const BnApplyArgs a) {
+    const int tid = threadIdx.x;
+    const int C = a.r.C, C4 = C >> 2;
+    const int TX = C4 < 256 ? C4 : 256, TY = 256 / TX;
+    const int tx = tid % TX, ty = tid / TX;
+    const long long Mlive = a.r.m_dev ? min(a.r.M, (long long)*a.r.m_dev) : a.r.M;
+    const long long per_group = a.r.m_dev ? (Mlive > 0 ? Mlive : 1) : a.r.M / a.r.groups;
+    if (ty >= TY) return;
+    for (long long m = (long long)blockIdx.x * TY + ty; m < Mlive; m += (long long)gridDim.x * TY) {
+        const int g = (int)(m / per_group);
+        for (int q = tx; q < C4; q += TX) {
+            const int c = q * 4;
+            const float4 z = ld4(a.z + m * a.z_cstride + a.z_coff + c);
+            const float4 mu = ld4(a.mean + g * C + c), sc = ld4(a.scale + g * C + c), sh = ld4(a.shift + g * C + c);
+            // centred form, see bn_apply_kernel
+            float4 v = make_float4((z.x - mu.x) * sc.x + sh.x, (z.y - mu.y) * sc.y + sh.y, (z.z - mu.z) * sc.z + sh.z,
+                                   (z.w - mu.w) * sc.w + sh.w);
+            if (a.res1) {
+                const float4 t = ld4(a.res1 + m * a.r1_cstride + a.r1_coff + c);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            if (a.res2) {
+                const float4 t = ld4(a.res2 + m * a.r2_cstride + a.r2_coff + c);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            if (a.act == TT_ACT_RELU) {
+                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+            }
+            st4(a.out + m * a.out_cstride + a.out_coff + c, v);
+        }
     }
 }
 
@@ -222,6 +328,123 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
     }
 }
 
+// 16 B forms of the two backward kernels (same sums in the same order per block as the scalar forms' structure: f64
+// accumulators, row lanes reduced through LDS in index order)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const BnBwdArgs a) {
+    __shared__ double red[8][256];
+    const int tid = threadIdx.x, g = blockIdx.y, blk = blockIdx.x;
+    const int C = a.r.C, C4 = C >> 2;
+    const int TX = C4 < 256 ? C4 : 256, TY = 256 / TX;
+    const int tx = tid % TX, ty = tid / TX;
+    const bool relu = a.act == TT_ACT_RELU;
+    long long r0, r1;
+    group_range(a.r, g, blk, r0, r1);
+    for (int q0 = 0; q0 < C4; q0 += TX) {
+        const int q = q0 + tx, c = q * 4;
+        double s[4] = {0.0, 0.0, 0.0, 0.0}, sx[4] = {0.0, 0.0, 0.0, 0.0};
+        if (ty < TY && q < C4) {
+            const float4 mu = ld4(a.mean + g * C + c), is = ld4(a.invstd + g * C + c);
+            for (long long m = r0 + ty; m < r1; m += 2LL * TY) {
+                float4 gv[2], yv[2], zv[2];
+                bool ok[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const long long mm = m + (long long)u * TY;
+                    ok[u] = mm < r1;
+                    gv[u] = yv[u] = zv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok[u]) {
+                        gv[u] = ld4(a.dy + mm * a.dy_cstride + a.dy_coff + c);
+                        zv[u] = ld4(a.z + mm * a.z_cstride + a.z_coff + c);
+                        if (relu) yv[u] = ld4(a.y + mm * a.y_cstride + a.y_coff + c);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (!ok[u]) continue;
+                    const long long mm = m + (long long)u * TY;
+                    float4 gg = gv[u];
+                    if (relu) {
+                        gg.x = yv[u].x > 0.f ? gg.x : 0.f; gg.y = yv[u].y > 0.f ? gg.y : 0.f;
+                        gg.z = yv[u].z > 0.f ? gg.z : 0.f; gg.w = yv[u].w > 0.f ? gg.w : 0.f;
+                        st4(a.dy + mm * a.dy_cstride + a.dy_coff + c, gg);
+                    }
+                    if (a.dres1) {
+                        float* d = a.dres1 + mm * a.d1_cstride + a.d1_coff + c;
+                        float4 t = ld4(d);
+                        t.x += gg.x; t.y += gg.y; t.z += gg.z; t.w += gg.w;
+                        st4(d, t);
+                    }
+                    if (a.dres2) {
+                        float* d = a.dres2 + mm * a.d2_cstride + a.d2_coff + c;
+                        float4 t = ld4(d);
+                        t.x += gg.x; t.y += gg.y; t.z += gg.z; t.w += gg.w;
+                        st4(d, t);
+                    }
+                    const float x0 = (zv[u].x - mu.x) * is.x, x1 = (zv[u].y - mu.y) * is.y;
+                    const float x2 = (zv[u].z - mu.z) * is.z, x3 = (zv[u].w - mu.w) * is.w;
+                    s[0] += (double)gg.x; sx[0] += (double)gg.x * (double)x0;
+                    s[1] += (double)gg.y; sx[1] += (double)gg.y * (double)x1;
+                    s[2] += (double)gg.z; sx[2] += (double)gg.z * (double)x2;
+                    s[3] += (double)gg.w; sx[3] += (double)gg.w * (double)x3;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[k][tid] = s[k]; red[4 + k][tid] = sx[k]; }
+        __syncthreads();
+        if (ty == 0 && q < C4) {
+            double* p = a.partial + ((long long)g * kBnBlocks + blk) * 2 * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double t0 = 0.0, t1 = 0.0;
+                for (int j = 0; j < TY; ++j) { t0 += red[k][j * TX + tx]; t1 += red[4 + k][j * TX + tx]; }
+                p[c + k] = t0;
+                p[C + c + k] = t1;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BnBwdApplyArgs a) {
+    const int tid = threadIdx.x;
+    const int C = a.r.C, C4 = C >> 2;
+    const int TX = C4 < 256 ? C4 : 256, TY = 256 / TX;
+    const int tx = tid % TX, ty = tid / TX;
+    const long long Mlive = a.r.m_dev ? min(a.r.M, (long long)*a.r.m_dev) : a.r.M;
+    const long long per_group = a.r.m_dev ? (Mlive > 0 ? Mlive : 1) : a.r.M / a.r.groups;
+    if (ty >= TY) return;
+    for (long long m = (long long)blockIdx.x * TY + ty; m < Mlive; m += (long long)gridDim.x * TY) {
+        const int g = (int)(m / per_group);
+        const double n = a.stats[(long long)g * (2 * C + 2) + 2 * C];
+        const float inv_n = n > 0 ? (float)(1.0 / n) : 0.f;
+        for (int q = tx; q < C4; q += TX) {
+            const int c = q * 4;
+            const double* sp = a.sums + (long long)g * 2 * C;
+            const float4 zz = ld4(a.z + m * a.z_cstride + a.z_coff + c), gv = ld4(a.g + m * a.g_cstride + a.g_coff + c);
+            const float4 mu = ld4(a.mean + g * C + c), is = ld4(a.invstd + g * C + c), sc = ld4(a.scale + g * C + c);
+            float4 o;
+            {
+                const float sg = (float)sp[c] * inv_n, sgx = (float)sp[C + c] * inv_n;
+                o.x = sc.x * (gv.x - sg - (zz.x - mu.x) * is.x * sgx);
+            }
+            {
+                const float sg = (float)sp[c + 1] * inv_n, sgx = (float)sp[C + c + 1] * inv_n;
+                o.y = sc.y * (gv.y - sg - (zz.y - mu.y) * is.y * sgx);
+            }
+            {
+                const float sg = (float)sp[c + 2] * inv_n, sgx = (float)sp[C + c + 2] * inv_n;
+                o.z = sc.z * (gv.z - sg - (zz.z - mu.z) * is.z * sgx);
+            }
+            {
+                const float sg = (float)sp[c + 3] * inv_n, sgx = (float)sp[C + c + 3] * inv_n;
+                o.w = sc.w * (gv.w - sg - (zz.w - mu.w) * is.w * sgx);
+            }
+            st4(a.dz + m * a.dz_cstride + a.dz_coff + c, o);
+        }
+    }
+}
+
 // nn.Dropout in train mode.  Keep decision: splitmix64(seed + element index) uniform in [0, 1) >= p
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, long long n, float p,
                                    unsigned long long seed, const uint8_t* __restrict__ mask_in, uint8_t* __restrict__ mask_out) {
@@ -270,8 +493,11 @@ extern "C" int tt_bn_stats(const float* z, long long M, int C, int z_cstride, in
     if (int rc = check_rows(M, C, groups, m_dev, "tt_bn_stats")) return rc;
     TT_REQUIRE(workspace_bytes >= tt_bn_workspace_bytes(C, groups), "tt_bn_stats: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    BnRows r{M, m_dev, C, groups};
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(kBnBlocks, groups), dim3(256), 0, st, z, z_cstride, z_coff, r, (double*)workspace);
+    const BnRows r = bn_rows(M, m_dev, C, groups);
+    if (bn_vec_ok(C, {z}, {z_cstride, z_coff}))
+        hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(r.nb, groups), dim3(256), 0, st, z, z_cstride, z_coff, r, (double*)workspace);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(r.nb, groups), dim3(256), 0, st, z, z_cstride, z_coff, r, (double*)workspace);
     hipLaunchKernelGGL(bn_finish_kernel, dim3(div_up(2 * C, 256), groups), dim3(256), 0, st, (const double*)workspace, r,
                        2 * C + 2, 1, stats);
     return check_launch("tt_bn_stats");
@@ -293,9 +519,17 @@ extern "C" int tt_bn_apply(const float* z, long long M, int C, int z_cstride, in
     TT_REQUIRE(z && scale && shift && mean && out, "tt_bn_apply: null");
     if (int rc = check_rows(M, C, groups, m_dev, "tt_bn_apply")) return rc;
     TT_REQUIRE(act == TT_ACT_NONE || act == TT_ACT_RELU, "tt_bn_apply: activation %d after a train-mode BatchNorm", act);
-    BnApplyArgs a{z, scale, shift, mean, res1, res2, out, BnRows{M, m_dev, C, groups}, z_cstride, z_coff, r1_cstride, r1_coff,
+    BnApplyArgs a{z, scale, shift, mean, res1, res2, out, bn_rows(M, m_dev, C, groups), z_cstride, z_coff, r1_cstride, r1_coff,
                   r2_cstride, r2_coff, out_cstride, out_coff, act};
     const long long total = M * C;
+    if (bn_vec_ok(C, {z, res1, res2, out, scale, shift, mean},
+                  {z_cstride, z_coff, res1 ? r1_cstride : 0, res1 ? r1_coff : 0, res2 ? r2_cstride : 0, res2 ? r2_coff : 0,
+                   out_cstride, out_coff})) {
+        const int ty = 256 / (C / 4 < 256 ? C / 4 : 256);
+        const int blocks = (int)min((long long)kNumCU * 8, (M + ty - 1) / ty);
+        hipLaunchKernelGGL(bn_apply_vec_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        return check_launch("tt_bn_apply");
+    }
     const int blocks = (int)min((long long)kNumCU * 16, (total + 255) / 256);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("tt_bn_apply");
@@ -311,9 +545,14 @@ extern "C" int tt_bn_bwd_reduce(float* dy, int dy_cstride, int dy_coff, const fl
     TT_REQUIRE(act == TT_ACT_NONE || act == TT_ACT_RELU, "tt_bn_bwd_reduce: activation %d", act);
     TT_REQUIRE(workspace_bytes >= tt_bn_workspace_bytes(C, groups), "tt_bn_bwd_reduce: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    BnBwdArgs a{dy, y, z, mean, invstd, dres1, dres2, (double*)workspace, BnRows{M, m_dev, C, groups}, dy_cstride, dy_coff,
+    BnBwdArgs a{dy, y, z, mean, invstd, dres1, dres2, (double*)workspace, bn_rows(M, m_dev, C, groups), dy_cstride, dy_coff,
                 y_cstride, y_coff, z_cstride, z_coff, d1_cstride, d1_coff, d2_cstride, d2_coff, act};
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(kBnBlocks, groups), dim3(256), 0, st, a);
+    if (bn_vec_ok(C, {dy, y, z, dres1, dres2, mean, invstd},
+                  {dy_cstride, dy_coff, y_cstride, y_coff, z_cstride, z_coff, dres1 ? d1_cstride : 0, dres1 ? d1_coff : 0,
+                   dres2 ? d2_cstride : 0, dres2 ? d2_coff : 0}))
+        hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(a.r.nb, groups), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(a.r.nb, groups), dim3(256), 0, st, a);
     hipLaunchKernelGGL(bn_finish_kernel, dim3(div_up(2 * C, 256), groups), dim3(256), 0, st, (const double*)workspace, a.r,
                        2 * C, 0, sums);
     return check_launch("tt_bn_bwd_reduce");
@@ -325,9 +564,15 @@ extern "C" int tt_bn_bwd_apply(const float* g, int g_cstride, int g_coff, const 
                                int dz_coff, void* stream) {
     TT_REQUIRE(g && z && sums && stats && scale && mean && invstd && dz, "tt_bn_bwd_apply: null");
     if (int rc = check_rows(M, C, groups, m_dev, "tt_bn_bwd_apply")) return rc;
-    BnBwdApplyArgs a{g, z, scale, mean, invstd, sums, stats, dz, BnRows{M, m_dev, C, groups}, g_cstride, g_coff, z_cstride,
+    BnBwdApplyArgs a{g, z, scale, mean, invstd, sums, stats, dz, bn_rows(M, m_dev, C, groups), g_cstride, g_coff, z_cstride,
                      z_coff, dz_cstride, dz_coff};
     const long long total = M * C;
+    if (bn_vec_ok(C, {g, z, dz, scale, mean, invstd}, {g_cstride, g_coff, z_cstride, z_coff, dz_cstride, dz_coff})) {
+        const int ty = 256 / (C / 4 < 256 ? C / 4 : 256);
+        const int blocks = (int)min((long long)kNumCU * 8, (M + ty - 1) / ty);
+        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        return check_launch("tt_bn_bwd_apply");
+    }
     const int blocks = (int)min((long long)kNumCU * 16, (total + 255) / 256);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("tt_bn_bwd_apply");
