@@ -559,7 +559,8 @@ def test_look_module_backward_matches_oracle_autograd(B):
     assert len(worst) >= 30 and not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
 
 
-def test_decoder_backward_matches_oracle_autograd(monkeypatch):
+@pytest.mark.parametrize("split_k,tol", [(False, 2e-3), (True, 1e-2)], ids=["in-workgroup-K", "product-split-K"])
+def test_decoder_backward_matches_oracle_autograd(monkeypatch, split_k, tol):
     """The whole look-and-predict decoder (thinktwice_decoder.py:419-533): coarse heads, five refinement layers (conv-GRU
     + shared flatten network, look module, merge MLP, offset heads, BEV / flattened-feature updates) chained through the
     DETACHED previous outputs (DEC:429-430), and the teacher-forcing pass over the same layers.  Random cotangents on every
@@ -572,6 +573,12 @@ def test_decoder_backward_matches_oracle_autograd(monkeypatch):
     from thinktwice_amd.encoder_decoder import EncoderDecoder
     from thinktwice_amd.fusion import BEVFusion
     from thinktwice_amd import ops
+    # The backward kernels are exact against autograd wherever the forward's ReLU masks agree with the CPU forward (worst
+    # 3.0e-4 over the 443 tensors).  WHICH borderline pre-activations flip depends on the forward's K-summation order: with
+    # the in-workgroup order none does on this input; the product's ordered cross-workgroup split-K (K >= 2048 layers at
+    # M <= 4096: the BEV-update conv, the flatten MLPs) flips a handful on the flatten network's 2 x 2 / 4 x 4 maps and on
+    # the 21 x 21 GRU maps (measured worst 6.7e-3 / 2.8e-3).  Both orders are run; both are deterministic.
+    monkeypatch.setattr(ops, "_AUTO_SPLITK", split_k)
     B, hw, Rn = 2, (128, 256), 5
     cfg = config.model_config(final_dim=hw)
     sd = params.init_params(cfg, seed=6, parts=("fusion", "decoder"))
@@ -654,5 +661,5 @@ def test_decoder_backward_matches_oracle_autograd(monkeypatch):
     w_tail = max(e for k, e in worst.items() if k.startswith(tail))
     rest = sorted(((k, e) for k, e in worst.items() if not k.startswith(tail)), key=lambda kv: -kv[1])
     print("  flatten network worst", w_tail, "| other tensors worst 5:", rest[:5])
-    bad = {k: e for k, e in worst.items() if e > 2e-3}           # measured worst: 3.0e-4
+    bad = {k: e for k, e in worst.items() if e > tol}
     assert len(worst) >= 400 and not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
