@@ -467,16 +467,22 @@ class Tape:
             if not bn_raw:
                 self.add_param_grad(meta.bn + ".weight", (dscale - meta.mean * dshift) / meta.sigma)
                 self.add_param_grad(meta.bn + ".bias", dshift)
-            # input rows: the same gathered GEMM on the transposed rulebook, accumulated into the input's gradient
+            # input rows: the same gathered GEMM on the transposed rulebook, accumulated into the input's gradient -- in bf16x3
+            # like the dense input gradients when the tape runs in that mode (a submanifold layer's transposed rulebook is a
+            # submanifold rulebook again: the run-staged kernel takes it; was the exact-f32 register-staged gather kernel,
+            # 47 ms per iteration at batch 8)
+            from . import weights
             gx = self.grad(feats)
             if in_rows is None:     # submanifold: nbr[m][t] = j  <=>  nbr[j][taps - 1 - t] = m
                 wt = w.flip(2).permute(3, 1, 2, 0).contiguous()
-                ops.gather_conv(dconv, nbr, m_dev, wt, res=gx, out=gx, _no_tape=True)
+                ops.gather_conv(dconv, nbr, m_dev, wt, res=gx, out=gx, _no_tape=True,
+                                w_x3=weights.split_pairs_x3(wt) if self.x3 else None)
             else:
                 rows_dev, rows_max = in_rows
                 inv = ops.sp_inverse_rulebook(nbr, m_dev, rows_max)
                 wt = w.permute(3, 1, 2, 0).contiguous()
-                ops.gather_conv(dconv, inv, rows_dev, wt, res=gx, out=gx, _no_tape=True)
+                ops.gather_conv(dconv, inv, rows_dev, wt, res=gx, out=gx, _no_tape=True, stride=2,
+                                w_x3=weights.split_pairs_x3(wt) if self.x3 else None)
 
         self.nodes.append(bwd)
 
