@@ -374,7 +374,10 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     TT_REQUIRE(!(d->pixel_shuffle2 && (d->res1 || d->res2)),
                "tt_conv2d_fwd: residuals are not supported with pixel_shuffle2");
     a.tiles_n = 1; a.cin_fast = 0; a.m_begin = 0;
-    a.flags = 0;
+    {
+        static const bool spread = [] { const char* e = getenv("TT_GLDS_X3_SPREAD"); return !(e && e[0] == '0'); }();   // A/B knob
+        a.flags = spread ? 0 : 8;
+    }
     if (query) a.flags = -1;       // launch_conv returns the split count instead of launching
     {
         const int co_vec = d->out_dtype == TT_F32 ? 4 : 8;

@@ -335,6 +335,44 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         }
     };
 
+    // The same DMA, one instruction at a time (dense bf16x3 body): when all eight waves issue their 8 pieces of the next tile
+    // together right after the barrier, the CU's one texture path (64 B/clk: 16 clk per 1 KiB piece) queues 64 pieces and every
+    // wave sits ~1000 cycles in instruction issue before its first MFMA.  Spread over the sub-steps of the tile -- one piece
+    // behind each group of MFMAs -- the queue never fills.  Order of issue is unchanged (weights of tile kt+1, then
+    // activations of kt+2), so the counted waits at the top of the next tile still hold.
+    struct DmaCtx {
+        unsigned st;
+        int tap, k0;
+        long long tap_off;
+        bool on;
+    };
+    auto a_begin = [&](int kt, bool on) {
+        DmaCtx c{0u, 0, 0, 0, on};
+        if (!on) return c;
+        c.st = lds_dma_base + (unsigned)off_a(kt);
+        c.tap = wa.kh * p.KW + wa.kw;
+        c.tap_off = ((long long)(wa.kh * p.dil) * p.W + wa.kw * p.dil) * p.in_cstride + wa.ci;
+        advance(wa);
+        return c;
+    };
+    auto a_emit = [&](const DmaCtx& c, int j) {
+        const T* src = ((a_mask[j] >> c.tap) & 1u) ? a_ptr[j] + c.tap_off : zp;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(uintptr_t)(c.st + (unsigned)(wave_s + NW * j) * 1024u), 16, 0, 0);
+    };
+    auto b_begin = [&](int kt, bool on) {
+        DmaCtx c{0u, 0, 0, 0, on};
+        if (!on) return c;
+        c.st = lds_dma_base + (unsigned)off_b(kt);
+        c.k0 = (wb.kh * p.KW + wb.kw) * p.Cin + wb.ci;
+        advance(wb);
+        return c;
+    };
+    auto b_emit = [&](const DmaCtx& c, int j) {
+        const T* src = b_ok[j] ? b_ptr[j] + c.k0 : zp;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(uintptr_t)(c.st + (unsigned)((wave_s + NW * j) % NB_INSTR) * 1024u),
+                                         16, 0, 0);
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -373,6 +411,10 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     // X3: a k-step is 16 f32 = 64 B.  A: lane half h owns floats 8h..8h+7 = chunks 4kc+2h and 4kc+2h+1 (the second is
     // the first with address bit 4 flipped, the swizzle being an XOR); B: hi chunk 4kc+h, lo chunk 4kc+2+h (bit 5).
     constexpr int NKC_ = X3 ? BKB / 64 : BKB / 32;
+    // spread DMA issue (below): 256-wide tiles only -- a 64 x 128 wave tile has 6 MFMAs (192 cycles) per sub-step to put one
+    // 16-cycle DMA piece behind; the narrow tiles' 3-MFMA sub-steps do not cover the texture path's time for 8 waves' pieces
+    // (measured +3 % on them).  TT_GLDS_X3_SPREAD=0 (A/B knob): whole-tile issue after the barrier everywhere
+    const bool spread = BN == 256 && (p.flags & 8) == 0;
     unsigned fa_pre[NKC_][TM], fb_pre[NKC_][TN];
 #pragma unroll
     for (int kc = 0; kc < NKC_; ++kc) {
@@ -459,14 +501,48 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
             }
             bh[0] = lds_read(sbase_b + fb_pre[0][0]);
             bl[0] = lds_read(sbase_b + (fb_pre[0][0] ^ 32u));
-            issue_ahead(kt);
-            if (GATHER && kt + 2 < nk) fetch_rulebook();
+            constexpr bool SPREAD = !GATHER;
+            constexpr int PER = (NIA + NIB + NS - 1) / NS;         // DMA pieces per sub-step
+            DmaCtx ca{0u, 0, 0, 0, false}, cb{0u, 0, 0, 0, false};
+            if constexpr (SPREAD) {
+                if (spread) {
+                    // first pieces issued: weights (ASYM: of tile kt+1; else of kt+STAGES-1, after its activations)
+                    if (ASYM) {
+                        cb = b_begin(kt + 1, kt + 1 < nk);
+                        ca = a_begin(kt + 2, kt + 2 < nk);
+                    } else {
+                        ca = a_begin(kt + STAGES - 1, kt + STAGES - 1 < nk);
+                        cb = b_begin(kt + STAGES - 1, kt + STAGES - 1 < nk);
+                    }
+                } else {
+                    issue_ahead(kt);
+                }
+            } else {
+                issue_ahead(kt);
+                if (kt + 2 < nk) fetch_rulebook();
+            }
 #pragma unroll
             for (int ss = 0; ss < NS; ++ss) {
                 const int kc = ss / TN, j = ss % TN, buf = ss & 1, ab = kc & 1;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(bh[buf]));
                 asm volatile("" : "+v"(bl[buf]));
+                if constexpr (SPREAD) {
+                    if (spread) {
+                        // this sub-step's share of the next tile's DMA (no LDS read is in flight here: the compiler's
+                        // lgkmcnt(0) in front of a global_load_lds costs nothing)
+#pragma unroll
+                        for (int q = ss * PER; q < (ss + 1) * PER && q < NIA + NIB; ++q) {
+                            if (ASYM) {
+                                if (q < NIB) { if (cb.on) b_emit(cb, q); }
+                                else if (ca.on) a_emit(ca, q - NIB);
+                            } else {
+                                if (q < NIA) { if (ca.on) a_emit(ca, q); }
+                                else if (cb.on) b_emit(cb, q - NIA);
+                            }
+                        }
+                    }
+                }
                 if (j == 0) {    // the k-step's activation fragments: split up front
 #pragma unroll
                     for (int i = 0; i < TM; ++i) split_frag(i, ah[ab][i], al[ab][i]);
