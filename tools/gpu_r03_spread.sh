@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_conv.py -m gpu -x -q 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_conv.py tests/test_lidar.py -m gpu -x -q 2>&1 | tail -2
 export TT_BENCH_F32=0 TT_BENCH_BF16=0 TT_BENCH_TICK=0 TT_BENCH_H2D=0 TT_BENCH_VOXEL=0 TT_BENCH_TRAIN=0
 for it in 1 2; do
 for sp in 1 0; do
