@@ -472,6 +472,14 @@ long long tt_conv2d_wgrad_workspace_bytes(int N, int OH, int Cout, int Cin, int 
 int tt_conv2d_wgrad(const float* x, int N, int H, int W, int Cin, int x_cstride, int x_coff, const float* dy, int OH,
                     int OW, int Cout, int dy_cstride, int dy_coff, int KH, int KW, int stride, int pad, int dil,
                     int cin_pad, int accumulate, float* dw, void* workspace, long long workspace_bytes, void* stream);
+/* Same contract in the forward's bf16x3 arithmetic (dy and x split into bf16 hi + lo, three MFMAs per product, f32
+ * accumulation: ~2^-17 relative per product): layers with >= 128 channels on both sides run on an LDS-staged
+ * v_mfma_f32_32x32x16_bf16 kernel (the contraction index -- the pixel -- is the slow index of both operands: tiles of 32
+ * pixels are staged as they lie in memory and read column-wise); everything else falls through to tt_conv2d_wgrad's kernels.
+ * Same workspace query, same determinism. */
+int tt_conv2d_wgrad_x3(const float* x, int N, int H, int W, int Cin, int x_cstride, int x_coff, const float* dy, int OH,
+                    int OW, int Cout, int dy_cstride, int dy_coff, int KH, int KW, int stride, int pad, int dil,
+                    int cin_pad, int accumulate, float* dw, void* workspace, long long workspace_bytes, void* stream);
 /* Backward of tt_conv2d_fwd's fused epilogue  y = act(scale[c]*conv + shift[c] + res1 + res2)  from dy and the saved
  * output y (all [M][*] channel-last f32 with channel stride / offset):  g = dy * act'(.)  (TT_ACT_NONE / RELU / SIGMOID);
  * dconv = g * scale[c] (feeds tt_conv2d_wgrad and the dgrad convolution); dres / dres2 (optional): g added to

@@ -224,7 +224,7 @@ class Tape:
                                                                  dres2=g2, dres2_coff=res2_coff, pre=pre, conv_raw=zraw)
             dconv = dconv.view(N, OH, OW, Cout)
             # parameters
-            dw = ops.conv2d_wgrad(xd, dconv, KH, KW, stride, pad, dil, cin=cin, in_coff=in_coff, cin_pad=cin_p)
+            dw = ops.conv2d_wgrad(xd, dconv, KH, KW, stride, pad, dil, cin=cin, in_coff=in_coff, cin_pad=cin_p, x3=self.x3)
             meta.place_weight_grad(self, dw)
             if bn_raw:
                 if meta.bias is not None and shift is not None:
@@ -271,7 +271,7 @@ class Tape:
             gs, _, dscale, dshift = ops.conv_epilogue_bwd(self.grad(y), y, scale, shift, act, C=Cout, dy_coff=out_coff,
                                                           y_coff=out_coff)
             dconv = gs.view(N, H, 2, W_, 2, Cout).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W_, C4).contiguous()
-            dw = ops.conv2d_wgrad(x, dconv, 1, 1, 1, 0, 1, cin=cin, in_coff=in_coff, cin_pad=w.shape[-1])
+            dw = ops.conv2d_wgrad(x, dconv, 1, 1, 1, 0, 1, cin=cin, in_coff=in_coff, cin_pad=w.shape[-1], x3=self.x3)
             # prepared rows are (dh*2+dw)*Cout + co; the reference weight is [Cin, Cout, 2, 2]
             self.add_param_grad(meta.name + ".weight",
                                 dw[:, 0, 0, :meta.cin].reshape(2, 2, Cout, meta.cin).permute(3, 2, 0, 1).contiguous())

@@ -36,6 +36,20 @@ struct WgradArgs {
 // the MFMAs (measured on the 64 x 64 kernel: the conditional loads are FASTER there, 55 vs 36 TF/s, so it keeps them)
 __device__ __forceinline__ float masked(float v, bool ok) { return v * (ok ? 1.f : 0.f); }
 
+// f32 x 8 -> bf16 (hi, lo) operand pair: hi = bf16(x) round-to-nearest-even, lo = bf16(x - hi)
+__device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);
+        const float q0 = x[2 * e] - __uint_as_float(h[e] << 16);           // exact in f32
+        const float q1 = x[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
+        l[e] = pack_bf16x2(q0, q1);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
 constexpr int kWgUnroll = 4;       // pixel pairs in flight per wave (each: 2 + 2 dword loads, 4 MFMAs)
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
@@ -232,6 +246,197 @@ __global__ __launch_bounds__(256) void conv_wgrad_wide_kernel(const WgradArgs a)
                 if (co0 + row < a.Cout && ci0 + col < a.cin_p)
                     ws[((long long)(co0 + row) * taps + tap) * a.cin_p + ci0 + col] = (ci0 + col < a.Cin) ? acc[i][j][e] : 0.f;
             }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-staged bf16x3 weight gradient for layers with >= 128 channels on both sides (round 3).
+//
+// dW[co][tap][ci] = sum over pixels p of dy[p][co] * x[p + tap][ci] is a GEMM whose contraction index (the pixel) is the SLOW
+// index of both operands in memory (channel-last rows).  The f32 MFMA form above feeds one pixel pair per instruction
+// straight from global memory (K = 2 in 64 cycles: 53 TF/s over an iteration).  v_mfma_f32_32x32x16_bf16 contracts 16 pixels in
+// 32 cycles, but a lane must then hold 8 CONSECUTIVE PIXELS of one channel -- a transposed read.  Here a workgroup (four
+// waves, 2 x 2, each a (32 BI) x (32 BJ) tile of dW[.][tap][.]) stages, per 32 output pixels of an image row, the dy rows
+// [32][64 BI channels] and the tap-shifted x rows [32][64 BJ] in LDS as they lie in memory (1 KiB LDS-DMA pieces, one or two
+// pixels each, padding / stride / dilation / channel tails by per-lane source selection with a zero page; double buffered)
+// and every lane gathers its operand with 8 ds_read_b32 down a column (lanes = consecutive channels: conflict-free), splits
+// it into bf16 (hi, lo) and issues dy_lo*x_hi + dy_hi*x_lo + dy_hi*x_hi (the forward's bf16x3 arithmetic, ~2^-17 per
+// product, f32 accumulation).  Per 16 pixels a wave does 8 (BI + BJ) LDS reads and 3 BI BJ MFMAs: 64 + 48 at 128 x 128.
+// One partial tile per (workgroup, row split), added by the ordered reduce kernel: deterministic.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int OFF>
+__device__ __forceinline__ float lds_rd_f32(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int ROWB>
+__device__ __forceinline__ void lds_col8(unsigned addr, float (&v)[8]) {      // 8 rows of one column, ROWB bytes apart
+    v[0] = lds_rd_f32<0 * ROWB>(addr); v[1] = lds_rd_f32<1 * ROWB>(addr);
+    v[2] = lds_rd_f32<2 * ROWB>(addr); v[3] = lds_rd_f32<3 * ROWB>(addr);
+    v[4] = lds_rd_f32<4 * ROWB>(addr); v[5] = lds_rd_f32<5 * ROWB>(addr);
+    v[6] = lds_rd_f32<6 * ROWB>(addr); v[7] = lds_rd_f32<7 * ROWB>(addr);
+}
+
+template <int BI, int BJ>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_lds_kernel(const WgradArgs a, const float* __restrict__ zp) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    constexpr int TA = 64 * BI, TB = 64 * BJ;             // channels per staged row = the workgroup's tile of dW
+    constexpr int PX = 32;                                // output pixels per stage (two 16-pixel MFMA steps)
+    constexpr int RA = TA * 4, RB = TB * 4;               // row bytes
+    constexpr int ABYTES = PX * RA, BBYTES = PX * RB, STAGE = ABYTES + BBYTES;
+    constexpr int NIA = ABYTES / 1024 / 4, NIB = BBYTES / 1024 / 4;     // 1 KiB DMA pieces per wave and stage
+    constexpr int LPA = RA / 16, LPB = RB / 16;           // lanes per pixel row inside a piece (64: one pixel, 32: two)
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int wy = wave >> 1, wx = wave & 1;
+    const int c = lane & 31, kg = lane >> 5;
+    const int taps = a.KH * a.KW;
+    int t = blockIdx.x;
+    const int tap = t % taps;
+    t /= taps;
+    const int ci0 = (t % a.ci_tiles) * TB, co0 = (t / a.ci_tiles) * TA;
+    const int kh = tap / a.KW, kw = tap % a.KW;
+    const int rows = a.N * a.OH;
+    const int r_begin = blockIdx.y * a.rows_per_split;
+    const int r_end = min(rows, r_begin + a.rows_per_split);
+    const int segs = (a.OW + PX - 1) / PX;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wsm;
+
+    f32x16 acc[BI][BJ];
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- stage walker: (row r, 32-pixel segment); rows whose tap row falls outside the image are skipped
+    struct It {
+        int r, seg;
+    };
+    auto row_ih = [&](int r) {
+        const int n = r / a.OH, oh = r - n * a.OH;
+        return oh * a.stride - a.pad + kh * a.dil;
+    };
+    auto seek = [&](It& it) {
+        while (it.r < r_end) {
+            const int ih = row_ih(it.r);
+            if (ih >= 0 && ih < a.H) break;
+            ++it.r;
+        }
+        it.seg = 0;
+    };
+    auto next = [&](It& it) {
+        if (++it.seg < segs) return;
+        ++it.r;
+        seek(it);
+    };
+    // per-lane constants of the DMA pieces: piece i of an operand covers 64 / LP pixels, lane = (pixel in piece, 16 B slot)
+    const int pa_px = lane / LPA, pa_ch = (lane % LPA) * 4;
+    const int pb_px = lane / LPB, pb_ch = (lane % LPB) * 4;
+    const bool a_ch_ok = co0 + pa_ch < a.Cout;            // (Cout, Cin multiples of 4: a 16 B slot is all in or all out)
+    const bool b_ch_ok = ci0 + pb_ch < a.Cin;
+    auto issue = [&](const It& it, int buf) {
+        const int n = it.r / a.OH;
+        const int ih = row_ih(it.r);
+        const float* dyrow = a.dy + ((long long)it.r * a.OW) * a.dy_cstride + a.dy_coff + co0 + pa_ch;
+        const float* xrow = a.x + (((long long)n * a.H + ih) * a.W) * a.x_cstride + a.x_coff + ci0 + pb_ch;
+        const unsigned sa = lds_base + (unsigned)buf * STAGE, sb = sa + ABYTES;
+        const int ow0 = it.seg * PX;
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) {
+            const int i = wave_s + 4 * j;                                  // piece
+            const int ow = ow0 + i * (64 / LPA) + pa_px;
+            const float* src = (ow < a.OW && a_ch_ok) ? dyrow + (long long)ow * a.dy_cstride : zp;
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(uintptr_t)(sa + (unsigned)i * 1024u), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NIB; ++j) {
+            const int i = wave_s + 4 * j;
+            const int ow = ow0 + i * (64 / LPB) + pb_px;
+            const int iw = ow * a.stride - a.pad + kw * a.dil;
+            const float* src = (ow < a.OW && iw >= 0 && iw < a.W && b_ch_ok) ? xrow + (long long)iw * a.x_cstride : zp;
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(uintptr_t)(sb + (unsigned)i * 1024u), 16, 0, 0);
+        }
+    };
+    // fragment columns of this lane: row block i of dy / column block j of x, pixel group kg (8 pixels) of a 16-pixel step
+    unsigned fa[BI], fb[BJ];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) fa[i] = lds_base + (unsigned)(kg * 8 * RA + (wy * 32 * BI + 32 * i + c) * 4);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) fb[j] = lds_base + (unsigned)(ABYTES + kg * 8 * RB + (wx * 32 * BJ + 32 * j + c) * 4);
+
+    It ic{r_begin, 0};
+    seek(ic);
+    It ii = ic;
+    if (ic.r < r_end) {
+        issue(ii, 0);
+        next(ii);
+    }
+    int buf = 0;
+    while (ic.r < r_end) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");        // stage `buf` is published; everyone is done with the other buffer
+        if (ii.r < r_end) {
+            issue(ii, buf ^ 1);
+            next(ii);
+        }
+        const unsigned boff = (unsigned)buf * STAGE;
+#pragma unroll
+        for (int st = 0; st < PX / 16; ++st) {
+            uint4 ah[BI], al[BI], bh[BJ], bl[BJ];
+            float ra[BI][8], rb[BJ][8];
+#pragma unroll
+            for (int i = 0; i < BI; ++i) lds_col8<RA>(fa[i] + boff + (unsigned)(st * 16 * RA), ra[i]);
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) lds_col8<RB>(fb[j] + boff + (unsigned)(st * 16 * RB), rb[j]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < BI; ++i) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(ra[i][e]));
+                split8(ra[i], ah[i], al[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(rb[j][e]));
+                split8(rb[j], bh[j], bl[j]);
+            }
+            // term-major: consecutive MFMAs write different accumulators; small terms first
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) Mfma<uint16_t>::run(al[i], bh[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) Mfma<uint16_t>::run(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) Mfma<uint16_t>::run(ah[i], bh[j], acc[i][j]);
+        }
+        next(ic);
+        buf ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // C/D map of the 32x32 MFMA: col = lane & 31 (input channel), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (output channel)
+    float* ws = a.ws + (long long)blockIdx.y * a.Cout * taps * a.cin_p;
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = co0 + wy * 32 * BI + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * kg;
+                const int col = ci0 + wx * 32 * BJ + 32 * j + c;
+                if (row < a.Cout && col < a.cin_p)
+                    ws[((long long)row * taps + tap) * a.cin_p + col] = (col < a.Cin) ? acc[i][j][e] : 0.f;
+            }
+#endif
 }
 
 // dw[i] = (accumulate ? dw[i] : 0) + sum over the partial slices ws[s][i], in a FIXED order: 32 elements per workgroup, eight
@@ -641,6 +846,15 @@ static int wgrad_splits(int N, int OH, int Cout, int Cin, int taps) {
     return (int)s;
 }
 
+static const float* wgrad_zero_page() {      // source of the LDS-DMA pieces that lie outside the image / the channel window
+    static void* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+        (void)hipMemset(z, 0, 256);
+    }
+    return (const float*)z;
+}
+
 // partial-sum slices in the workspace: one per split, x 4 in the wide kernel (one per wave)
 static int wgrad_slices(int N, int OH, int Cout, int Cin, int taps) {
     int bi, bj;
@@ -656,10 +870,10 @@ extern "C" long long tt_conv2d_wgrad_workspace_bytes(int N, int OH, int Cout, in
     return (long long)wgrad_slices(N, OH, Cout, Cin, KH * KW) * Cout * KH * KW * cin_pad * 4;
 }
 
-extern "C" int tt_conv2d_wgrad(const float* x, int N, int H, int W, int Cin, int x_cstride, int x_coff, const float* dy,
-                               int OH, int OW, int Cout, int dy_cstride, int dy_coff, int KH, int KW, int stride, int pad,
-                               int dil, int cin_pad, int accumulate, float* dw, void* workspace, long long workspace_bytes,
-                               void* stream) {
+static int wgrad_run(const float* x, int N, int H, int W, int Cin, int x_cstride, int x_coff, const float* dy,
+                     int OH, int OW, int Cout, int dy_cstride, int dy_coff, int KH, int KW, int stride, int pad,
+                     int dil, int cin_pad, int accumulate, float* dw, void* workspace, long long workspace_bytes,
+                     void* stream, bool x3) {
     TT_REQUIRE(x && dy && dw && workspace && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && OH > 0 && OW > 0 &&
                    KH > 0 && KW > 0 && stride > 0 && dil > 0 && cin_pad >= Cin,
                "tt_conv2d_wgrad: bad argument");
@@ -673,11 +887,68 @@ extern "C" int tt_conv2d_wgrad(const float* x, int N, int H, int W, int Cin, int
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_cstride = x_cstride; a.x_coff = x_coff;
     a.OH = OH; a.OW = OW; a.Cout = Cout; a.dy_cstride = dy_cstride; a.dy_coff = dy_coff;
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil; a.cin_p = cin_pad;
+    hipStream_t st = (hipStream_t)stream;
+    // >= 128 channels on both sides: the LDS-staged bf16x3 kernel (TT_WGRAD_LDS=0: A/B knob, the f32-MFMA wave-tile form)
+    static const bool lds_on = [] { const char* e = getenv("TT_WGRAD_LDS"); return !(e && e[0] == '0'); }();
+    if (x3 && lds_on && Cout >= 128 && Cin >= 128 && Cout % 4 == 0 && Cin % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0 &&
+        dy_cstride % 4 == 0 && dy_coff % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+        const float* zp = wgrad_zero_page();
+        // the kernel walks image rows in 32-pixel segments: a 1x1 / stride-1 / unpadded layer (linear layers over rows: OW = 1)
+        // is the same sum over ANY regrouping of its pixels, so short rows are merged into pseudo-rows of >= 128 pixels;
+        // other layers with rows shorter than 16 pixels (the 1 x 9 grouped deformable-conv GEMM) keep the f32 kernels
+        WgradArgs al = a;
+        if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && OW < 128) {
+            const long long prow = (long long)N * OH;
+            long long m = (128 + OW - 1) / OW;
+            while (m < prow && prow % m) ++m;
+            if (m <= prow && prow % m == 0) {
+                al.N = 1;
+                al.OW = al.W = (int)(OW * m);
+                al.OH = al.H = (int)(prow / m);
+            }
+        }
+        const int cap = wgrad_slices(N, OH, Cout, Cin, taps);         // partial-sum slices the caller's workspace holds
+        if (zp && al.OW >= 16) {
+            WgradArgs& a = al;      // (shadows the caller's view for this launch)
+            const int N = a.N, OH = a.OH;
+            const int BI = Cout >= 256 ? 4 : 2, BJ = Cin >= 256 ? 4 : 2;
+            a.ci_tiles = div_up(cin_pad, 64 * BJ);
+            const long long tiles = (long long)div_up(Cout, 64 * BI) * a.ci_tiles * taps;
+            const int rows = N * OH;
+            long long sp = (2LL * kNumCU + tiles - 1) / tiles;           // ~2 workgroups' worth of work per CU
+            if (sp > cap) sp = cap;
+            if (sp > rows) sp = rows;
+            if (sp < 1) sp = 1;
+            a.rows_per_split = div_up(rows, (int)sp);
+            const int nsplit = div_up(rows, a.rows_per_split);
+            a.xcd_tiles = 0;
+            const dim3 grid((unsigned)tiles, (unsigned)nsplit);
+            const size_t smem = (size_t)2 * 32 * (64 * BI + 64 * BJ) * 4;
+#define TT_WGL(BI_, BJ_)                                                                                                  \
+    do {                                                                                                                  \
+        static bool attr = false;                                                                                         \
+        if (!attr) {                                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_lds_kernel<BI_, BJ_>),                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                             \
+            attr = true;                                                                                                  \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((conv_wgrad_lds_kernel<BI_, BJ_>), grid, dim3(256), smem, st, a, zp);                          \
+    } while (0)
+            if (BI == 4 && BJ == 4) TT_WGL(4, 4);
+            else if (BI == 4) TT_WGL(4, 2);
+            else if (BJ == 4) TT_WGL(2, 4);
+            else TT_WGL(2, 2);
+#undef TT_WGL
+            const long long n = (long long)Cout * taps * cin_pad;
+            hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)div_up(n, 32)), dim3(256), 0, st, (const float*)workspace,
+                               n, nsplit, accumulate, dw);
+            return check_launch("tt_conv2d_wgrad");
+        }
+    }
     int bi, bj;
     wgrad_blocks(Cout, Cin, &bi, &bj);
     a.ci_tiles = div_up(cin_pad, 32 * bj);
     a.rows_per_split = div_up(N * OH, splits);
-    hipStream_t st = (hipStream_t)stream;
     const unsigned tiles = (unsigned)(div_up(Cout, 32 * bi) * a.ci_tiles * taps);
     int slices = splits;
     if (bi == 2 && bj == 2) {
@@ -700,6 +971,22 @@ extern "C" int tt_conv2d_wgrad(const float* x, int N, int H, int W, int Cin, int
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)div_up(n, 32)), dim3(256), 0, st, (const float*)workspace, n,
                        slices, accumulate, dw);
     return check_launch("tt_conv2d_wgrad");
+}
+
+extern "C" int tt_conv2d_wgrad(const float* x, int N, int H, int W, int Cin, int x_cstride, int x_coff, const float* dy,
+                               int OH, int OW, int Cout, int dy_cstride, int dy_coff, int KH, int KW, int stride, int pad,
+                               int dil, int cin_pad, int accumulate, float* dw, void* workspace, long long workspace_bytes,
+                               void* stream) {
+    return wgrad_run(x, N, H, W, Cin, x_cstride, x_coff, dy, OH, OW, Cout, dy_cstride, dy_coff, KH, KW, stride, pad, dil,
+                     cin_pad, accumulate, dw, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int tt_conv2d_wgrad_x3(const float* x, int N, int H, int W, int Cin, int x_cstride, int x_coff, const float* dy,
+                                  int OH, int OW, int Cout, int dy_cstride, int dy_coff, int KH, int KW, int stride, int pad,
+                                  int dil, int cin_pad, int accumulate, float* dw, void* workspace,
+                                  long long workspace_bytes, void* stream) {
+    return wgrad_run(x, N, H, W, Cin, x_cstride, x_coff, dy, OH, OW, Cout, dy_cstride, dy_coff, KH, KW, stride, pad, dil,
+                     cin_pad, accumulate, dw, workspace, workspace_bytes, stream, true);
 }
 
 extern "C" long long tt_conv_epilogue_bwd_workspace_bytes(int C) { return (long long)kEpiBlocks * 2 * C * 4; }

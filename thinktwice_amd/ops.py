@@ -840,7 +840,7 @@ def mlp_chain(x, stages, n_split=1):
 
 # ----------------------------------------------------------------------------- convolution backward (training step)
 def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, dil=1, cin=None, in_coff=0, cout=None, dy_coff=0, cin_pad=None,
-                 out=None, accumulate=False):
+                 out=None, accumulate=False, x3=False):
     """Weight gradient of `conv2d` (tt_conv2d_wgrad): x [N,H,W,Cs] f32, dy [N,OH,OW,Cd] f32 (the gradient w.r.t. the
     convolution's raw output) -> dw [cout][kh][kw][cin_pad] f32 in the weight layout (added to `out` if accumulate)."""
     require_cuda(x, dy)
@@ -862,7 +862,8 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=0, dil=1, cin=None, in_coff=0, cou
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(L.tt_conv2d_wgrad(ptr(x), _c(N), _c(H), _c(W), _c(cin), _c(Cs), _c(in_coff), ptr(dy), _c(OH), _c(OW), _c(cout),
+    fn = L.tt_conv2d_wgrad_x3 if x3 else L.tt_conv2d_wgrad      # x3: the forward's bf16x3 arithmetic (wide layers: LDS-staged kernel)
+    check(fn(ptr(x), _c(N), _c(H), _c(W), _c(cin), _c(Cs), _c(in_coff), ptr(dy), _c(OH), _c(OW), _c(cout),
                             _c(Cd), _c(dy_coff), _c(kh), _c(kw), _c(stride), _c(pad), _c(dil), _c(cin_pad),
                             _c(1 if accumulate else 0), ptr(out), ptr(ws), _ll(nb), _st(x)), "tt_conv2d_wgrad")
     if CONV_PROFILE is not None:
