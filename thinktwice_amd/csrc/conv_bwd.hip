@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_wide_kernel(const WgradArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// LDS-staged bf16x3 weight gradient for layers with >= 128 channels on both sides (round 3).
+// LDS-staged bf16x3 weight gradient for layers with >= 64 channels on both sides (round 3).
 //
 // dW[co][tap][ci] = sum over pixels p of dy[p][co] * x[p + tap][ci] is a GEMM whose contraction index (the pixel) is the SLOW
 // index of both operands in memory (channel-last rows).  The f32 MFMA form above feeds one pixel pair per instruction
@@ -888,9 +888,9 @@ static int wgrad_run(const float* x, int N, int H, int W, int Cin, int x_cstride
     a.OH = OH; a.OW = OW; a.Cout = Cout; a.dy_cstride = dy_cstride; a.dy_coff = dy_coff;
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil; a.cin_p = cin_pad;
     hipStream_t st = (hipStream_t)stream;
-    // >= 128 channels on both sides: the LDS-staged bf16x3 kernel (TT_WGRAD_LDS=0: A/B knob, the f32-MFMA wave-tile form)
+    // >= 64 channels on both sides: the LDS-staged bf16x3 kernel (TT_WGRAD_LDS=0: A/B knob, the f32-MFMA wave-tile form)
     static const bool lds_on = [] { const char* e = getenv("TT_WGRAD_LDS"); return !(e && e[0] == '0'); }();
-    if (x3 && lds_on && Cout >= 128 && Cin >= 128 && Cout % 4 == 0 && Cin % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0 &&
+    if (x3 && lds_on && Cout >= 64 && Cin >= 64 && Cout % 4 == 0 && Cin % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0 &&
         dy_cstride % 4 == 0 && dy_coff % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
         const float* zp = wgrad_zero_page();
         // the kernel walks image rows in 32-pixel segments: a 1x1 / stride-1 / unpadded layer (linear layers over rows: OW = 1)
@@ -911,11 +911,12 @@ static int wgrad_run(const float* x, int N, int H, int W, int Cin, int x_cstride
         if (zp && al.OW >= 16) {
             WgradArgs& a = al;      // (shadows the caller's view for this launch)
             const int N = a.N, OH = a.OH;
-            const int BI = Cout >= 256 ? 4 : 2, BJ = Cin >= 256 ? 4 : 2;
+            const int BI = Cout >= 256 ? 4 : (Cout >= 128 ? 2 : 1), BJ = Cin >= 256 ? 4 : (Cin >= 128 ? 2 : 1);
             a.ci_tiles = div_up(cin_pad, 64 * BJ);
             const long long tiles = (long long)div_up(Cout, 64 * BI) * a.ci_tiles * taps;
             const int rows = N * OH;
-            long long sp = (2LL * kNumCU + tiles - 1) / tiles;           // ~2 workgroups' worth of work per CU
+            const long long per_cu = BI * BJ >= 16 ? 2 : (BI * BJ >= 4 ? 3 : 4);     // resident workgroups (LDS) x ~1.5 rounds
+            long long sp = (per_cu * kNumCU + tiles - 1) / tiles;
             if (sp > cap) sp = cap;
             if (sp > rows) sp = rows;
             if (sp < 1) sp = 1;
@@ -934,10 +935,17 @@ static int wgrad_run(const float* x, int N, int H, int W, int Cin, int x_cstride
         }                                                                                                                 \
         hipLaunchKernelGGL((conv_wgrad_lds_kernel<BI_, BJ_>), grid, dim3(256), smem, st, a, zp);                          \
     } while (0)
-            if (BI == 4 && BJ == 4) TT_WGL(4, 4);
-            else if (BI == 4) TT_WGL(4, 2);
-            else if (BJ == 4) TT_WGL(2, 4);
-            else TT_WGL(2, 2);
+            switch (BI * 8 + BJ) {
+                case 4 * 8 + 4: TT_WGL(4, 4); break;
+                case 4 * 8 + 2: TT_WGL(4, 2); break;
+                case 4 * 8 + 1: TT_WGL(4, 1); break;
+                case 2 * 8 + 4: TT_WGL(2, 4); break;
+                case 2 * 8 + 2: TT_WGL(2, 2); break;
+                case 2 * 8 + 1: TT_WGL(2, 1); break;
+                case 1 * 8 + 4: TT_WGL(1, 4); break;
+                case 1 * 8 + 2: TT_WGL(1, 2); break;
+                default: TT_WGL(1, 1); break;
+            }
 #undef TT_WGL
             const long long n = (long long)Cout * taps * cin_pad;
             hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)div_up(n, 32)), dim3(256), 0, st, (const float*)workspace,
