@@ -269,7 +269,7 @@ class ForwardWorkload:
             w.collect()
             r = w.roofline()
             leg = {"value": round(self.B / dt, 3), "unit": "samples/s", "ms_per_iteration": round(dt * 1e3, 2),
-                   "batch": self.B, "iterations_timed": iters, "dtype": "bf16x3 forward / input gradients, f32 weight gradients",
+                   "batch": self.B, "iterations_timed": iters, "dtype": "bf16x3 forward / input gradients / weight gradients of the >= 64-channel layers, f32 for the rest",
                    "semantics": w._phases.get("batchnorm"), "wgrad_tflops": r["wgrad"]["tflops"], "wgrad_ms": r["wgrad"]["ms"],
                    "conv_launches": r["launches"], "conv_kernel_ms": r["kernel_ms"],
                    "all_reduce_ms": w._phases.get("all_reduce_ms"), "clip_adamw_ms": w._phases.get("clip_adamw_ms"),

@@ -24,8 +24,9 @@ class TrainStepWorkload:
         self.dtype, self.B = dtype, batch
         self.name = (f"train_step thinktwice.py cfg: {batch} samples x (2 sweeps x 4 cams x 448x896 + 65536-pt LiDAR), "
                      f"23 loss terms incl. the teacher-forcing pass, 878 live / 968 parameters")
-        self.precision_note = ("f32 storage; forward and input-gradient convolutions in bf16x3, weight gradients on the "
-                               "exact-f32 MFMA" if dtype == "bf16x3" else "f32 everywhere (exact-f32 MFMA)")
+        self.precision_note = ("f32 storage; forward, input-gradient and (>= 64 channels a side) weight-gradient convolutions in "
+                               "bf16x3, the remaining weight gradients on the exact-f32 MFMA"
+                               if dtype == "bf16x3" else "f32 everywhere (exact-f32 MFMA)")
         self.launch_note = "eager launches, one stream"
         self.model, self.cfg = tm.build_thinktwice(dtype=TORCH_DTYPE[dtype], device=str(device))
         sd = params.init_params(self.cfg, seed=0)
@@ -97,7 +98,9 @@ class TrainStepWorkload:
             "launches": len(dense), "kernel_ms": round(ms, 2), "gflop": round(flops / 1e9, 1),
             "wgrad": {"launches": len(wg), "ms": round(wg_ms, 2),
                       "tflops": round(sum(r[0] for r in wg) / max(wg_ms * 1e-3, 1e-9) / 1e12, 1),
-                      "note": "exact-f32 MFMA (peak 157.3 TFLOP/s)"}}
+                      "note": ("layers with >= 64 channels a side: LDS-staged bf16x3 kernel (three bf16 MFMAs per product); the "
+                               "rest: exact-f32 MFMA (peak 157.3 TFLOP/s)") if self.dtype == "bf16x3"
+                      else "exact-f32 MFMA (peak 157.3 TFLOP/s)"}}
 
     def roofline(self):
         return self._roofline

@@ -6,7 +6,7 @@ ROOT="$GRAFT_REPO_ROOT"
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
-timeout 900 python -m pytest tests/test_conv.py tests/test_forward.py -m gpu -q -x 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_train_step.py -m gpu -q -x 2>&1 | tail -2
 export TT_BENCH_F32=0 TT_BENCH_BF16=0 TT_BENCH_TICK=0 TT_BENCH_H2D=0 TT_BENCH_VOXEL=0 TT_BENCH_TRAIN=0
 cd /tmp && export TMPDIR=/tmp
 F="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
