@@ -1,5 +1,7 @@
 """Host-side logic that needs no GPU: the closed-loop previous-sweep cache driver and the img_metas constants that
 a captured graph takes as inputs."""
+import os
+
 import pytest
 import torch
 
@@ -143,3 +145,37 @@ def test_lidar_voxelize_has_no_host_fallback_and_picks_the_configured_cap():
     net.training = False
     with pytest.raises(_lib.TTError):
         net.forward(torch.zeros(1, 1000, 5))
+
+
+def test_ctypes_mirrors_match_the_c_header_layout(tmp_path):
+    """The Python host talks to the C ABI through ctypes mirrors of four structs of include/thinktwice_hip.h.  Compile the
+    header with gcc, print sizeof / offsetof of every field, and compare with the mirrors: a field appended on one side
+    only (tt_conv_desc grew twice in round 3) would otherwise shift every later pointer silently."""
+    import ctypes
+    import re
+    import subprocess
+    from thinktwice_amd import control, ops
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    header = open(os.path.join(root, "include", "thinktwice_hip.h")).read()
+    mirrors = {"tt_conv_desc": ops._ConvDesc, "tt_chain_stage": ops._ChainStage, "tt_action_cfg": control.ActionCfg,
+               "tt_action_state": control.ActionState}
+    rename = {"in_": "in"}                      # `in` is a Python keyword
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "thinktwice_hip.h"', "int main(void) {"]
+    for cname, cls in mirrors.items():
+        assert re.search(r"typedef struct %s\b" % cname, header), cname
+        lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, rename.get(fname, fname)))
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        c, f, v = ln.split()
+        got[(c, f)] = int(v)
+    for cname, cls in mirrors.items():
+        assert got[(cname, "sizeof")] == ctypes.sizeof(cls), (cname, got[(cname, "sizeof")], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
