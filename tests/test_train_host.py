@@ -4,6 +4,7 @@ prepared-weight gradients back to the reference's parameter layouts, the trainab
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from thinktwice_amd import autodiff
@@ -86,6 +87,28 @@ def test_trainable_split_matches_the_reference_gradient_golden():
     got = sorted(k for k, v in fake.items() if _trainable(k, v))
     want = sorted([str(n) for n in pack["names"]] + [str(n) for n in pack["dead"]])
     assert len(want) == 968 and got == want
+
+
+@pytest.mark.parametrize("fname,B,hw,npts", [("f13_train_gradients_b2.npz", 2, (128, 256), 20000),
+                                              ("f13b_train_gradients_fullsize_b1.npz", 1, (448, 896), 65536),
+                                              ("f16_train_gradients_trainmode_b4.npz", 4, (128, 256), 20000)])
+def test_gradient_goldens_are_complete_and_consistent(fname, B, hw, npts):
+    """The three gradient fixtures the `-m gpu` training tests read (they do not exist on the GPU box unless committed): same
+    968 parameters split into the same 878 live / 90 dead names, finite positive norms, 8 sampled entries each inside the
+    tensor, the documented batch / image size / point count."""
+    from thinktwice_amd import config, params
+    pack = np.load(os.path.join(os.path.dirname(__file__), "golden", fname))
+    names, dead = [str(n) for n in pack["names"]], [str(n) for n in pack["dead"]]
+    assert len(names) == 878 and len(dead) == 90 and not set(names) & set(dead)
+    assert [int(v) for v in pack["meta"][:4]] == [B, hw[0], hw[1], npts]
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "f13_train_gradients_b2.npz"))
+    assert sorted(names) == sorted(str(n) for n in ref["names"]) and sorted(dead) == sorted(str(n) for n in ref["dead"])
+    norms = pack["norms"]
+    assert norms.shape == (878,) and np.isfinite(norms).all() and (norms >= 0).all() and float(np.isfinite(pack["total_loss"][0]))
+    spec = params.param_spec(config.model_config(final_dim=hw))
+    assert pack["idx"].shape == (878, 8) and pack["samples"].shape == (878, 8)
+    for n, idx in zip(names, pack["idx"]):
+        assert int(idx.max()) < int(np.prod(spec[n][0])), n
 
 
 def test_parse_losses_single_process():
