@@ -18,6 +18,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
          "-Wno-unused-result"]
 
 
+# per-source extra flags.  conv_x3_pipe.hip: its K loop is a hand-placed instruction stream; the SLP vectoriser would fuse the
+# operand split's f32 subtractions into v_pk_add_f32, which is slower than two plain VALU beside MFMAs (MI355X_MICROARCH.md)
+EXTRA_FLAGS = {"conv_x3_pipe.hip": ["-fno-slp-vectorize"]}
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
@@ -34,7 +39,7 @@ def _compile(src, hdr_mtime, verbose):
     spath = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(spath), hdr_mtime):
         return obj
-    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", spath, "-o", obj]
+    cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", spath, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

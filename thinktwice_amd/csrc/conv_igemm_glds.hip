@@ -727,7 +727,14 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
         // TT_GLDS_X3_ASYM=0: symmetric 2-stage ring instead of 3 activation + 2 weight stages (A/B knob)
         static const bool asym = [] { const char* e = getenv("TT_GLDS_X3_ASYM"); return e ? atoi(e) != 0 : true; }();
         const int main_rows = tail_split_rows(a);
-        if (asym) launch_glds<float, 256, 4, 2, 128, 23, false, true>(a, st, main_rows);
+        // Long-K layers (every 3x3 of the trunks): four hand-pipelined waves, one per SIMD (csrc/conv_x3_pipe.hip): MFMA pipe 77 %
+        // busy against 58 % (profiles/r04_conv_sq_counters_noepilogue.txt).  Short K keeps the 8-wave tile: there the
+        // tile's prologue + epilogue dominate and eight waves issue the output stores faster than four (K = 1024: 0.203 vs
+        // 0.216 ms, K = 256 N = 1280: 0.52 vs 0.77 ms; profiles/r04_pipe_ab_first.txt).  TT_X3_PIPE=0: never; TT_X3_PIPE_MINK=k.
+        static const bool pipe = [] { const char* e = getenv("TT_X3_PIPE"); return e ? atoi(e) != 0 : true; }();
+        static const int pipe_mink = [] { const char* e = getenv("TT_X3_PIPE_MINK"); return e ? atoi(e) : 1152; }();
+        if (pipe && a.K >= pipe_mink && try_launch_conv_x3_pipe(a, st, main_rows)) { /* taken */ }
+        else if (asym) launch_glds<float, 256, 4, 2, 128, 23, false, true>(a, st, main_rows);
         else launch_glds<float, 256, 4, 2, 128, 2, false, true>(a, st, main_rows);
         if (main_rows) {
             ConvArgs t = a;
