@@ -1,8 +1,10 @@
 """Oracle (TEST INFRASTRUCTURE): eval image pipeline of the reference restated with torch CPU ops
 (datasets/pipelines/transform.py: IDAImageTransform.__call__ :283-286, img_transform :346-356 (T.Resize on
 a float tensor == F.interpolate bilinear, align_corners=False, no antialias in torchvision 0.13),
-ImageTransformMulti aug=False :163).  The undistortion map itself comes from cv2 in the reference;
-OpenCV is absent here, so `thinktwice_amd.calib.undistort_rectify_map` restates it (parity unpinned)."""
+ImageTransformMulti aug=False :163).  PINNED by golden F17 (tests/golden/gen_golden.py::gen_f17 runs the reference's own
+transform.py on two seeded sweeps; tests/test_preprocess.py holds this file to it at 1e-5).  The undistortion TABLE comes
+from cv2 in the reference; OpenCV is absent here, so `thinktwice_amd.calib.undistort_rectify_map` restates the published
+pinhole + Brown-Conrady model (that table alone stays unpinned; everything downstream of it is pinned)."""
 import torch
 import torch.nn.functional as F
 

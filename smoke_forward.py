@@ -4,7 +4,7 @@ import torch
 
 def run():
     from oracle import model_ref as M
-    from . import model as tm, params, synth
+    from thinktwice_amd import model as tm, params, synth
     hw = (128, 256)
     m, cfg = tm.build_thinktwice(final_dim=hw)
     sd = params.init_params(cfg, seed=0)

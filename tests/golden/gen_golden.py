@@ -595,7 +595,58 @@ def gen_f15():
           arb_stuck_threshold=np.array([40]))
 
 
-FIXTURES = {"F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8, "F9": gen_f9, "F10": gen_f10, "F11": gen_f11,
+
+# ---------------------------------------------------------------------------
+# F17: the evaluation image pipeline (datasets/pipelines/transform.py): IDAImageTransform.__call__ :275-341 (undistortion
+# grid_sample, per-camera img_transform :346-378 = T.Resize + crop, ida_mats) followed by ImageTransformMulti(aug=False)
+# :154-156 (/255, Normalize :144).  The module is imported from where it lies; its third-party imports are stand-ins:
+# torchvision Resize / Normalize / Compose (ref_stubs, documented torchvision-0.13 tensor semantics), the registries, and
+# cv2.initUndistortRectifyMap -> thinktwice_amd.calib.undistort_rectify_map (OpenCV is not installed: the table itself is
+# therefore the restated one, everything downstream of it is the reference's own code).
+# ---------------------------------------------------------------------------
+def gen_f17():
+    import importlib.util
+    import types
+    from thinktwice_amd import calib
+    ref_stubs.install()
+    cv2 = sys.modules["cv2"]
+    cv2.initUndistortRectifyMap = lambda mtx, dist, R, newmtx, size, m1type: calib.undistort_rectify_map(size[0], size[1])
+    for name in ("matplotlib", "matplotlib.pyplot", "imgaug", "imgaug.augmenters", "mmcv.parallel", "mmdet.datasets",
+                 "mmdet.datasets.builder", "mmdet.datasets.pipelines"):
+        ref_stubs._mod(name)
+    sys.modules["mmdet.datasets.builder"].PIPELINES = ref_stubs._Registry("pipelines")
+    sys.modules["mmcv.parallel"].DataContainer = lambda x, **k: x
+    sys.modules["mmdet.datasets.pipelines"].to_tensor = torch.as_tensor
+    path = os.path.join(ref_stubs.OLT, "code", "datasets", "pipelines", "transform.py")
+    spec = importlib.util.spec_from_file_location("ttref_transform", path)
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)
+
+    cfg = dict(img_size=(448, 896), camera_names=["rgb_front", "rgb_left", "rgb_right", "rgb_back"], undistort=True,
+               unreal_coord=True, use_depth=False, use_seg=False, num_cams=4, queue_length=2)   # configs/thinktwice.py:41-120
+    ida_aug_conf = {"resize_lim": (0.56, 0.6255), "final_dim": (448, 896), "rot_lim": (0, 0), "H": 900, "W": 1600,
+                    "rand_flip": True, "bot_pct_lim": (0.0, 0.0)}                               # configs/thinktwice.py:111-119
+    from thinktwice_amd import synth
+    raw = synth.raw_camera_frames(seed=17)
+    T_, N = raw.shape[:2]
+    queue = [{"img": types.SimpleNamespace(data=raw[t]), "img_metas": types.SimpleNamespace(data={})} for t in range(T_)]
+    with torch.no_grad():
+        queue = tr.IDAImageTransform(cfg, ida_aug_conf, is_train=False)(queue)
+        ida = torch.stack([q["img_metas"].data["ida_mats"] for q in queue]).numpy()            # [T, N, 4, 4]
+        meta0 = queue[-1]["img_metas"].data
+        queue = tr.ImageTransformMulti(aug=False, batch_size=1)(queue)
+    out = torch.stack([q["img"] for q in queue]).numpy()                                        # [T, N, 3, 448, 896]
+    assert out.shape == (T_, N, 3, 448, 896), out.shape
+    rng = np.random.default_rng(1717)
+    idx = rng.choice(out.size, size=16384, replace=False)
+    _save("f17_image_pipeline.npz", seed=np.array([17]), sample_idx=idx.astype(np.int64), sample_val=out.reshape(-1)[idx],
+          per_image_mean=out.mean(axis=(2, 3, 4)), per_image_abs_mean=np.abs(out).mean(axis=(2, 3, 4)),
+          # one full row and one full column of every image of the key sweep: dense checks along both axes
+          row_200=out[-1, :, :, 200, :], col_431=out[-1, :, :, :, 431],
+          ida_mats=ida, cam_intrinsic=meta0["cam_intrinsic"].numpy(), lidar2img=meta0["lidar2img"].numpy(),
+          lidar2cam=meta0["lidar2cam"].numpy())
+
+FIXTURES = {"F17": gen_f17, "F3": gen_f3, "F12": gen_f12, "F7": gen_f7, "F8": gen_f8, "F9": gen_f9, "F10": gen_f10, "F11": gen_f11,
             "F13": gen_f13, "F13b": gen_f13b, "F14": gen_f14, "F15": gen_f15, "F16": gen_f16}
 
 

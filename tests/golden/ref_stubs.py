@@ -206,17 +206,44 @@ def install(third_party=None):
 
     class _InterpolationMode:          # [3P] torchvision.transforms.InterpolationMode
         NEAREST = "nearest"
+        BILINEAR = "bilinear"
 
-    class _Resize:                     # [3P] torchvision.transforms.Resize on tensors = F.interpolate
-        def __init__(self, size, interpolation="nearest"):
-            assert interpolation == "nearest"
+    class _Resize:                     # [3P] torchvision.transforms.Resize on float TENSORS = F.interpolate (torchvision 0.13:
+        # default interpolation bilinear, align_corners=False, antialias off for tensors)
+        def __init__(self, size, interpolation="bilinear"):
+            assert interpolation in ("nearest", "bilinear")
             self.size = tuple(size)
+            self.mode = interpolation
 
         def __call__(self, x):
             import torch.nn.functional as F
-            return F.interpolate(x[None].float(), size=self.size, mode="nearest")[0].to(x.dtype)
+            lead = x.shape[:-3]
+            y = x.reshape(-1, *x.shape[-3:]).float()
+            if self.mode == "nearest":
+                y = F.interpolate(y, size=self.size, mode="nearest")
+            else:
+                y = F.interpolate(y, size=self.size, mode="bilinear", align_corners=False)
+            return y.reshape(*lead, *y.shape[-3:]).to(x.dtype)
 
-    _mod("torchvision.transforms", Resize=_Resize, InterpolationMode=_InterpolationMode)
+    class _Normalize:                  # [3P] torchvision.transforms.Normalize: (x - mean) / std per channel
+        def __init__(self, mean, std):
+            self.mean = torch.tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+            self.std = torch.tensor(std, dtype=torch.float32).view(-1, 1, 1)
+
+        def __call__(self, x):
+            return (x - self.mean.to(x.dtype)) / self.std.to(x.dtype)
+
+    class _Compose:                    # [3P] torchvision.transforms.Compose
+        def __init__(self, ts):
+            self.ts = list(ts)
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    _mod("torchvision.transforms", Resize=_Resize, InterpolationMode=_InterpolationMode, Normalize=_Normalize,
+         Compose=_Compose)
 
     # the reference's python wrapper imports `voxel_pooling_ext` relative to ops.voxel_pooling
     ext = types.ModuleType("ops.voxel_pooling.voxel_pooling_ext")

@@ -179,3 +179,36 @@ def test_ctypes_mirrors_match_the_c_header_layout(tmp_path):
         assert got[(cname, "sizeof")] == ctypes.sizeof(cls), (cname, got[(cname, "sizeof")], ctypes.sizeof(cls))
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is the checker: only tests/, __graft_entry__.smoke() (smoke_forward.py) and bench.py's cpu_baseline leg
+    (bench_cpu_baseline.py) may import it -- nothing inside the product package (VERDICT r3 weak #9)."""
+    import ast
+    pkg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "thinktwice_amd")
+    bad = []
+    for f in sorted(os.listdir(pkg)):
+        if not f.endswith(".py"):
+            continue
+        for node in ast.walk(ast.parse(open(os.path.join(pkg, f)).read())):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            bad += [(f, n) for n in names if n == "oracle" or n.startswith("oracle.")]
+    assert not bad, bad
+
+
+def test_bench_counts_three_mfmas_per_product_for_every_bf16x3_kernel():
+    """VERDICT r3 weak #4: the label test looked at the GATHER template flag; the X3 flag is the last one."""
+    from thinktwice_amd.bench_forward import mfma_per_product as f
+    assert f("conv_igemm_glds_kernel<float, 256, 4, 2, 128, 23, false, true>", "bf16x3") == 3       # dense x3 tile
+    assert f("conv_igemm_glds_kernel<float, 256, 4, 2, 128, 23, false, true> + tail", "bf16x3") == 3
+    assert f("conv_igemm_glds_kernel<float, 64, 8, 1, 128, 2, true, true>", "bf16x3") == 3           # gathered x3
+    assert f("conv_igemm_glds_kernel<float, 128, 4, 2, 64, 3, false, false>", "bf16x3") == 1         # exact f32 layer
+    assert f("conv_igemm_glds_kernel<float, 128, 4, 2, 64, 3, true, false>", "bf16x3") == 1          # GATHER alone is not x3
+    assert f("conv_x3_pipe_kernel<4, 1>", "bf16x3") == 3
+    assert f("sp_conv_runs_kernel<2, 4, 2>", "bf16x3") == 3
+    assert f("conv_small_kernel", "bf16x3") == 1
+    assert f("conv_igemm_glds_kernel<float, 256, 4, 2, 128, 23, false, true>", "f32") == 1

@@ -232,3 +232,40 @@ def test_syncbn_two_ranks_share_statistics_gloo():
     np.testing.assert_array_equal(got[0][4], got[1][4])
     # dgamma is the LOCAL sum on each rank; the two add up to the whole batch's (the gradient all-reduce averages them)
     np.testing.assert_allclose(got[0][5] + got[1][5], gamma.grad.numpy(), atol=2e-4 * float(gamma.grad.abs().max()))
+
+
+def _allreduce_report_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from thinktwice_amd.bench_train import TrainStepWorkload
+    from thinktwice_amd.grad_sync import FlatGradBuffer
+    p = torch.zeros(1 << 16).requires_grad_()
+    buf = FlatGradBuffer([p])
+    buf.flat.fill_(float(rank + 1))
+    wl = TrainStepWorkload.__new__(TrainStepWorkload)          # the report only needs trainer.grads
+    wl.trainer = type("T", (), {"grads": buf})()
+    rep = wl.all_reduce_report(repeats=3)
+    q.put((rank, rep, float(buf.flat[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_all_reduce_report_two_ranks_gloo():
+    """The N-GPU bench record of the training collective (VERDICT r3 missing #3): every rank runs the report, it times the
+    flat-gradient all-reduce and prices it as a ring (busbw = algbw x 2 (N-1) / N, per link = busbw / (N-1))."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_allreduce_report_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rep, v in out:
+        assert rep["world"] == 2 and rep["bytes"] == 4 << 16 and len(rep["ms_all"]) == 3 and rep["ms"] > 0
+        assert abs(rep["busbw_gbs"] - rep["algbw_gbs"]) <= 0.11           # 2 (N-1) / N = 1 at N = 2 (rounded to 0.1)
+        assert abs(rep["per_link_gbs"] - rep["busbw_gbs"]) <= 0.11 and 0 <= rep["per_link_frac"]
+        # three repeated means of (1, 2): 1.5 -> stays 1.5 on both ranks after the first (mean of equal values)
+        assert abs(v - 1.5) < 1e-6

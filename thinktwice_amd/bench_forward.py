@@ -12,6 +12,22 @@ from . import ops, params, synth
 MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0}
 TORCH_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "bf16x3": "f32x3"}
 HBM_PEAK_GBS = 8000.0
+PROFILE_TAG = "r04"            # profiles/<tag>_forward_<dtype>_{kernel_stats.csv,pmc.json}: the committed rocprofv3 passes of this build
+
+
+def mfma_per_product(kernel_label, dtype):
+    """MFMAs executed per algorithmic product by the kernel a conv launch ran on (label = tt_conv_last_kernel()).  bf16x3
+    kernels issue three bf16 MFMAs per product: conv_igemm_glds_kernel<..., GATHER, X3> with X3 = true (the LAST template
+    argument -- round 3 tested the GATHER flag and printed 1 for the dominant dense tile), conv_x3_pipe_kernel, the run-staged
+    sparse kernel.  The exact-f32 / 16-bit kernels issue one."""
+    if dtype != "bf16x3":
+        return 1
+    k = kernel_label.replace(" + tail", "").strip()
+    if k.startswith("conv_x3_pipe_kernel") or k.startswith("sp_conv_runs"):
+        return 3
+    if k.startswith("conv_igemm_glds_kernel<") and k.endswith(", true>"):
+        return 3
+    return 1
 
 
 class ForwardWorkload:
@@ -151,16 +167,16 @@ class ForwardWorkload:
             a[1] += r[1].elapsed_time(r[2])
             a[2] += r[0]
         dk, dv = max(by_k.items(), key=lambda kv: kv[1][1])
-        mult = 3 if self.dtype == "bf16x3" and ("true, false>" in dk or "true, true>" in dk) else 1
+        mult = mfma_per_product(dk, self.dtype)
         dom_tf = dv[2] / (dv[1] * 1e-3) / 1e12
         dominant = {"kernel": dk, "launches": dv[0], "avg_launch_ms": round(dv[1] / dv[0], 4),
                     "ms_per_step": round(dv[1], 3), "algorithmic_tflops": round(dom_tf, 1), "frac": round(dom_tf / peak, 4),
                     "mfma_per_product": mult, "executed_mfma_frac": round(mult * dom_tf / peak, 4),
                     "note": "HIP events around each launch of this kernel in one SERIALISED forward (single stream); a "
                             "tail-split launch (256x64 tiles over the last row tiles) is timed with its main launch.  The "
-                            "rocprofv3 --stats average of the same kernel over the timed steps (profiles/r02_forward_*_"
-                            "kernel_stats.csv) is ~20 % higher because the LiDAR branch's kernels share the chip on a second "
-                            "stream there"}
+                            f"rocprofv3 --stats average of the same kernel over the timed steps (profiles/{PROFILE_TAG}_forward_"
+                            f"{self.dtype}_kernel_stats.csv) is higher because the LiDAR branch's kernels share the chip on a "
+                            "second stream there"}
         traffic, traffic_note = self._pmc_traffic()
         x3 = {}
         if self.dtype == "bf16x3":
@@ -190,7 +206,7 @@ class ForwardWorkload:
         import json
         from . import build
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles",
-                            f"r03_forward_{self.dtype}_pmc.json")
+                            f"{PROFILE_TAG}_forward_{self.dtype}_pmc.json")
         if self.B != 8 or not os.path.exists(path):
             return None, "no PMC summary for this dtype / batch"
         data = json.load(open(path))
@@ -244,9 +260,17 @@ class ForwardWorkload:
                         "roofline": {k: r[k] for k in ("achieved", "peak", "unit", "frac", "conv_ms_per_step")},
                         "decoder_gemm": w._decoder_gemm}
             del w
-        if single and os.environ.get("TT_BENCH_TRAIN", "1") != "0":
-            out["train_step"] = self.train_step_leg()
+        if os.environ.get("TT_BENCH_TRAIN", "1") != "0":
+            # world > 1: the leg ran on EVERY rank in collect() (it issues the iteration's collectives); rank 0 reports it
+            out["train_step"] = self.train_step_leg() if single else getattr(self, "_train_leg", None)
         return out
+
+    def collect(self):
+        """bench.py calls this on every rank after the timed steps.  With more than one rank the data-parallel training
+        iteration (BASELINE config 4) runs here on all of them, so that the N-GPU record holds the ONE collective the design is
+        built around: time, bytes and achieved xGMI bandwidth of the flat-gradient all-reduce over RCCL."""
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("TT_BENCH_TRAIN", "1") != "0":
+            self._train_leg = self.train_step_leg()
 
     def train_step_leg(self, iters=3):
         """BASELINE config 4 on ONE GPU, timed inside the default bench run so that the driver's record holds it (VERDICT r2
@@ -254,6 +278,7 @@ class ForwardWorkload:
         all-reduce -- a no-op at world size 1 --, clip + AdamW, operand re-preparation) under model.train() semantics."""
         import time
         from .bench_train import TrainStepWorkload
+        world = int(os.environ.get("WORLD_SIZE", "1"))
         self.last = None
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
@@ -274,9 +299,13 @@ class ForwardWorkload:
                    "conv_launches": r["launches"], "conv_kernel_ms": r["kernel_ms"],
                    "all_reduce_ms": w._phases.get("all_reduce_ms"), "clip_adamw_ms": w._phases.get("clip_adamw_ms"),
                    "prepare_operands_ms": w._phases.get("prepare_operands_ms"), "peak_memory_gb": w._phases.get("peak_memory_gb"),
-                   "loss": w._phases.get("loss"),
-                   "note": "one process, one GPU: the gradient all-reduce is the world-size-1 short cut; data-parallel runs: "
-                           "bench.py --workload train_step --gpus N"}
+                   "loss": w._phases.get("loss"), "n_gpus": world,
+                   "note": ("one process, one GPU: the gradient all-reduce is the world-size-1 short cut; the N-GPU record "
+                            "(bench.py --gpus N) times the RCCL all-reduce in this leg") if world == 1 else
+                           "data parallel, one rank per GPU, batch per GPU fixed (weak scaling); value = all ranks' samples / s"}
+            if world > 1:
+                leg["value"] = round(self.B * world / dt, 3)
+                leg["all_reduce"] = w.all_reduce_report()
             del w
             torch.cuda.empty_cache()
             return leg
@@ -366,16 +395,18 @@ class ForwardWorkload:
         return out
 
     def cpu_baseline(self):
-        """oracle on ONE frame in a bounded subprocess (<= 32 threads, 240 s cap)."""
+        """The oracle on ONE frame in a bounded subprocess (bench_cpu_baseline.py beside bench.py: <= 32 threads, 2 warm-ups
+        + 5 timed passes, per-stage medians, CPU model string; TT_BENCH_CPU_PASSES=n for fewer timed passes)."""
         import json
         import subprocess
         import sys
         threads = min(os.cpu_count() or 1, 32)
+        timed = os.environ.get("TT_BENCH_CPU_PASSES", "5")
         root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
         try:
-            r = subprocess.run([sys.executable, "-m", "thinktwice_amd.cpu_baseline", str(threads)], cwd=root,
-                               capture_output=True, text=True, timeout=240)
+            r = subprocess.run([sys.executable, os.path.join(root, "bench_cpu_baseline.py"), str(threads), timed, "2"], cwd=root,
+                               capture_output=True, text=True, timeout=420)
             return json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:   # timeout / failure: report, never block the bench
             return {"value": None, "unit": "frames/s", "cores": threads, "kind": "port",
-                    "sample": f"oracle forward did not finish within 240 s ({type(e).__name__})"}
+                    "sample": f"oracle forward did not finish within 420 s ({type(e).__name__})"}

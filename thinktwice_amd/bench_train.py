@@ -90,6 +90,9 @@ class TrainStepWorkload:
         self._phases["loss"] = float(self.last["loss"]) if self.last is not None else None
         self._phases["peak_memory_gb"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
         self._phases["batchnorm"] = "running statistics (frozen)" if self.frozen_bn else "batch statistics (model.train())"
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self._all_reduce = self.all_reduce_report()
         peak = MFMA_PEAK_TF[self.dtype]
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         self._roofline = {
@@ -105,8 +108,39 @@ class TrainStepWorkload:
     def roofline(self):
         return self._roofline
 
+    def all_reduce_report(self, repeats=5):
+        """The iteration's one data-path collective on its own (every rank calls this): the flat f32 gradient buffer through
+        `FlatGradBuffer.all_reduce_mean` (RCCL over xGMI), `repeats` times, host-synchronised -- median time, bytes, and the
+        bandwidths a ring prices: algbw = bytes / t; busbw = algbw x 2 (N-1) / N (what each GPU sends and receives); per-link =
+        busbw / (N - 1) outgoing xGMI links in use on a fully connected node (7 links x ~153 GB/s per GPU at N = 8)."""
+        import statistics
+        import torch.distributed as dist
+        g = self.trainer.grads
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        nbytes = g.flat.numel() * g.flat.element_size()
+        ts = []
+        sync = torch.cuda.synchronize if g.flat.is_cuda else (lambda: None)
+        for _ in range(repeats):
+            sync()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            g.all_reduce_mean()
+            sync()
+            ts.append(time.perf_counter() - t0)
+        t = statistics.median(ts)
+        rep = {"bytes": nbytes, "ms": round(t * 1e3, 3), "ms_all": [round(x * 1e3, 3) for x in ts], "world": world,
+               "collective": "one all-reduce (SUM of pre-scaled f32) over the flat gradient buffer, RCCL"}
+        if world > 1:
+            alg = nbytes / t / 1e9
+            bus = alg * 2 * (world - 1) / world
+            rep.update({"algbw_gbs": round(alg, 1), "busbw_gbs": round(bus, 1), "per_link_gbs": round(bus / (world - 1), 1),
+                        "xgmi_link_peak_gbs": 153.0, "per_link_frac": round(bus / (world - 1) / 153.0, 3)})
+        return rep
+
     def extra(self):
-        return {"train_step_phases": getattr(self, "_phases", None), "wgrad_top_shapes": getattr(self, "_wgrad_top", None)}
+        return {"train_step_phases": getattr(self, "_phases", None), "wgrad_top_shapes": getattr(self, "_wgrad_top", None),
+                "all_reduce": getattr(self, "_all_reduce", None)}
 
     def cpu_baseline(self):
         return None

@@ -114,3 +114,14 @@ def make_train_targets(batch_size, img_hw=(calib.FINAL_H, calib.FINAL_W), seed=4
         "depth": depth,
         "seg": torch.randint(0, 12, (B, num_cams, H, W), generator=g).float(),
     }
+
+
+def raw_camera_frames(seed=17, T=2, N=4, h=900, w=1600):
+    """Seeded raw camera frames uint8 [T, N, h, w, 3] (what the agent hands the image pipeline): noise on top of smooth
+    structure, so that interpolation errors would show.  Golden F17 was produced from exactly these frames."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    noise = rng.integers(0, 256, (T, N, h, w, 3), dtype=np.uint8).astype(np.float32)
+    yy = (np.arange(h, dtype=np.float32)[:, None, None] % 200) * 0.9
+    xx = (np.arange(w, dtype=np.float32)[None, :, None] % 320) * 0.35
+    return np.clip(noise * 0.25 + yy + xx, 0, 255).astype(np.uint8)
