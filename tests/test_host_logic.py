@@ -212,3 +212,80 @@ def test_bench_counts_three_mfmas_per_product_for_every_bf16x3_kernel():
     assert f("sp_conv_runs_kernel<2, 4, 2>", "bf16x3") == 3
     assert f("conv_small_kernel", "bf16x3") == 1
     assert f("conv_igemm_glds_kernel<float, 256, 4, 2, 128, 23, false, true>", "f32") == 1
+
+
+def _plan_file_bytes(nstreams=2, buffers=(("weights", 64), ("arena", 256)), blob=b"\0" * 32, relocs=((8, 1, 16),),
+                     ops=None, outputs=((b"out", 1, 0, 1, (4,), (1,)),)):
+    """A plan file in tt_plan_save's format (little-endian i64 / f64 fields; thinktwice_amd/csrc/plan.cpp)."""
+    import struct
+    q = lambda v: struct.pack("<q", v)
+    st = lambda b: q(len(b)) + b
+    if ops is None:   # one call (tt_fill_u32(dst, n_words, pattern) on stream 0), one dependency (stream 1 waits for 0)
+        ops = [("call", b"tt_fill_u32", 0, [(2, 1, 0, 0.0), (0, 0, 4, 0.0), (0, 0, 7, 0.0)]), ("sync", 1, 0)]
+    out = q(0x314E414C50545454) + q(nstreams) + q(len(buffers))
+    for name, nbytes in buffers:
+        out += st(name.encode()) + q(nbytes)
+    out += q(len(blob)) + blob + q(len(relocs))
+    for r in relocs:
+        out += q(r[0]) + q(r[1]) + q(r[2])
+    out += q(len(ops))
+    for o in ops:
+        if o[0] == "sync":
+            out += q(1) + q(o[1]) + q(o[2])
+        else:
+            out += q(0) + st(o[1]) + q(o[2]) + q(len(o[3]))
+            for kind, buf, val, f in o[3]:
+                out += q(kind) + q(buf) + q(val) + struct.pack("<d", f)
+    out += q(len(outputs))
+    for name, buf, off, ndim, shape, stride in outputs:
+        out += st(name) + q(buf) + q(off) + q(ndim)
+        out += b"".join(q(shape[i] if i < len(shape) else 0) for i in range(8))
+        out += b"".join(q(stride[i] if i < len(stride) else 0) for i in range(8))
+    return out
+
+
+def test_plan_load_rejects_malformed_files(tmp_path):
+    """tt_plan_load must apply the builder's checks to a whole file -- a relocation outside the blob would be a
+    heap write in tt_plan_bind, a stream index outside the plan a wild read of streams[] in tt_plan_run."""
+    import ctypes
+    from thinktwice_amd import _lib
+    L = _lib.lib()
+    L.tt_plan_load.restype = ctypes.c_void_p
+    L.tt_last_error.restype = ctypes.c_char_p
+
+    def load(data):
+        f = tmp_path / "p.plan"
+        f.write_bytes(data)
+        h = L.tt_plan_load(str(f).encode())
+        if h:
+            L.tt_plan_destroy(ctypes.c_void_p(h))
+        return bool(h), L.tt_last_error().decode()
+
+    ok, _ = load(_plan_file_bytes())
+    assert ok, "the well-formed plan must load"
+    call = lambda args, stream=0: [("call", b"tt_fill_u32", stream, args)]
+    good = [(2, 1, 0, 0.0), (0, 0, 4, 0.0), (0, 0, 7, 0.0)]
+    bad = {
+        "stream count": _plan_file_bytes(nstreams=-1),
+        "stream count (huge)": _plan_file_bytes(nstreams=1 << 20),
+        "outside the blob": _plan_file_bytes(relocs=((28, 1, 0),)),            # 28 + 8 > 32
+        "outside the blob (negative)": _plan_file_bytes(relocs=((-8, 1, 0),)),
+        "points outside buffer": _plan_file_bytes(relocs=((0, 5, 0),)),
+        "points outside buffer (offset)": _plan_file_bytes(relocs=((0, 1, 1 << 20),)),
+        "runs on stream": _plan_file_bytes(ops=call(good, stream=9)),
+        "stream dependency": _plan_file_bytes(ops=[("sync", 0, 7)]),
+        "stream dependency (negative)": _plan_file_bytes(ops=[("sync", -1, 0)]),
+        "argument kind": _plan_file_bytes(ops=call([(9, 1, 0, 0.0)] + good[1:])),
+        "device pointer outside buffer": _plan_file_bytes(ops=call([(2, 40, 0, 0.0)] + good[1:])),
+        "device pointer outside buffer (offset)": _plan_file_bytes(ops=call([(2, 1, 1 << 30, 0.0)] + good[1:])),
+        "blob argument": _plan_file_bytes(ops=call([(3, 0, 4096, 0.0)] + good[1:])),
+        "argument count mismatch": _plan_file_bytes(ops=call(good[:2])),
+        "unknown entry": _plan_file_bytes(ops=[("call", b"tt_no_such_entry", 0, good)]),
+        "decoder marker": _plan_file_bytes(outputs=((b"__decoder_first_op", -1, 99, 0, (), ()),)),
+        "output outside buffer": _plan_file_bytes(outputs=((b"o", 7, 0, 1, (4,), (1,)),)),
+        "truncated": _plan_file_bytes()[:-40],
+    }
+    for what, data in bad.items():
+        ok, err = load(data)
+        assert not ok, f"{what}: a malformed plan loaded"
+        assert what.split(" (")[0] in err, (what, err)

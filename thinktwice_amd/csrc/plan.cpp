@@ -112,6 +112,62 @@ static int find_thunk(const char* name) {
     return -1;
 }
 
+// Structural checks of a whole plan: everything tt_plan_bind / tt_plan_run index with.  The builder entries enforce these call
+// by call; a plan that arrives as a FILE (tt_plan_load: a stale or corrupt plan next to a newer library, tools/plan_host.cpp)
+// has to pass them as a whole before it may be bound -- a bad index there would be a write outside a host vector
+// (relocations are memcpy'd into the blob) or a read of streams[] / bases[] out of range.
+static const int kMaxPlanStreams = 64;
+static const char* plan_defect(const tt_plan* p) {
+    static thread_local char why[160];
+    auto say = [&](const char* fmt, long long a, long long b) { snprintf(why, sizeof(why), fmt, a, b); return (const char*)why; };
+    if (p->nstreams < 1 || p->nstreams > kMaxPlanStreams) return say("stream count %lld outside 1..%lld", p->nstreams, kMaxPlanStreams);
+    const long long nbuf = (long long)p->buffers.size(), nblob = (long long)p->blob.size(), nargs = (long long)p->args.size();
+    for (const PlanBuffer& b : p->buffers)
+        if (b.bytes < 0) return say("buffer with a negative size (%lld)%.0lld", b.bytes, 0);
+    auto devptr_ok = [&](int buffer, long long offset) {
+        return buffer >= 0 && buffer < nbuf && offset >= 0 && offset <= p->buffers[buffer].bytes;
+    };
+    for (size_t i = 0; i < p->relocs.size(); ++i) {
+        const PlanReloc& r = p->relocs[i];
+        if (r.blob_offset < 0 || r.blob_offset + 8 > nblob) return say("relocation %lld writes outside the blob (offset %lld)", (long long)i, r.blob_offset);
+        if (!devptr_ok(r.buffer, r.offset)) return say("relocation %lld points outside buffer %lld", (long long)i, r.buffer);
+    }
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const PlanOp& o = p->ops[i];
+        if (o.kind == 1) {
+            if (o.a < 0 || o.a >= p->nstreams || o.b < 0 || o.b >= p->nstreams) return say("op %lld: stream dependency on a stream outside 0..%lld", (long long)i, p->nstreams - 1);
+            continue;
+        }
+        if (o.kind != 0) return say("op %lld: unknown kind %lld", (long long)i, o.kind);
+        if (o.thunk < 0 || o.thunk >= (int)(sizeof(kPlanThunks) / sizeof(kPlanThunks[0]))) return say("op %lld: entry index %lld", (long long)i, o.thunk);
+        if (o.stream < 0 || o.stream >= p->nstreams) return say("op %lld runs on stream %lld, outside the plan's streams", (long long)i, o.stream);
+        if (o.nargs != kPlanThunks[o.thunk].nargs || o.first_arg < 0 || (long long)o.first_arg + o.nargs > nargs)
+            return say("op %lld: argument range (%lld arguments)", (long long)i, o.nargs);
+        for (int k = 0; k < o.nargs; ++k) {
+            const PlanArgRec& a = p->args[o.first_arg + k];
+            switch (a.kind) {
+                case kI64: case kF64: case kNull: break;
+                case kBlob:
+                    if (a.value < 0 || a.value >= nblob) return say("op %lld: blob argument at offset %lld outside the blob", (long long)i, a.value);
+                    break;
+                case kDevPtr:
+                    if (!devptr_ok(a.buffer, a.value)) return say("op %lld: device pointer outside buffer %lld", (long long)i, a.buffer);
+                    break;
+                default: return say("op %lld: argument kind %lld", (long long)i, a.kind);
+            }
+        }
+    }
+    for (const PlanOutput& o : p->outputs) {
+        if (o.ndim < 0 || o.ndim > 8) return say("output with %lld dimensions%.0lld", o.ndim, 0);
+        if (o.name == "__decoder_first_op") {
+            if (o.offset < 0 || o.offset > (long long)p->ops.size()) return say("decoder marker at op %lld of %lld", o.offset, (long long)p->ops.size());
+        } else if (o.buffer >= nbuf || (o.buffer >= 0 && (o.offset < 0 || o.offset > p->buffers[o.buffer].bytes))) {
+            return say("output outside buffer %lld (offset %lld)", o.buffer, o.offset);
+        }
+    }
+    return nullptr;
+}
+
 extern "C" tt_plan* tt_plan_create(void) { return new tt_plan(); }
 
 extern "C" void tt_plan_destroy(tt_plan* p) {
@@ -149,7 +205,7 @@ extern "C" int tt_plan_add_reloc(tt_plan* p, long long blob_offset, int buffer, 
 // runs on stream slot `stream`.
 extern "C" int tt_plan_add_call(tt_plan* p, const char* entry, int nargs, const int* kinds, const int* buffers,
                                 const long long* ivals, const double* fvals, int stream) {
-    TT_REQUIRE(p && entry && nargs >= 0 && stream >= 0, "tt_plan_add_call: bad argument");
+    TT_REQUIRE(p && entry && nargs >= 0 && stream >= 0 && stream < kMaxPlanStreams, "tt_plan_add_call: bad argument");
     const int th = find_thunk(entry);
     TT_REQUIRE(th >= 0, "tt_plan_add_call: %s is not a stream-taking entry of this library", entry);
     TT_REQUIRE(kPlanThunks[th].nargs == nargs, "tt_plan_add_call: %s takes %d arguments before its stream, got %d", entry,
@@ -163,7 +219,8 @@ extern "C" int tt_plan_add_call(tt_plan* p, const char* entry, int nargs, const 
 }
 
 extern "C" int tt_plan_add_sync(tt_plan* p, int waiter_stream, int signal_stream) {
-    TT_REQUIRE(p && waiter_stream >= 0 && signal_stream >= 0, "tt_plan_add_sync: bad argument");
+    TT_REQUIRE(p && waiter_stream >= 0 && signal_stream >= 0 && waiter_stream < kMaxPlanStreams && signal_stream < kMaxPlanStreams,
+               "tt_plan_add_sync: bad argument");
     p->ops.push_back(PlanOp{1, -1, 0, waiter_stream, signal_stream, 0, 0});
     const int m = (waiter_stream > signal_stream ? waiter_stream : signal_stream) + 1;
     if (m > p->nstreams) p->nstreams = m;
@@ -214,6 +271,10 @@ extern "C" int tt_plan_output(const tt_plan* p, int i, const char** name, int* b
 // Resolve every (buffer, offset) against the base addresses the host owns.  bases[id] must hold tt_plan_buffer_bytes(id).
 extern "C" int tt_plan_bind(tt_plan* p, void* const* bases, int nbases) {
     TT_REQUIRE(p && bases && nbases >= (int)p->buffers.size(), "tt_plan_bind: %d buffers needed", p ? (int)p->buffers.size() : 0);
+    if (const char* why = plan_defect(p)) {
+        set_error("tt_plan_bind: malformed plan: %s", why);
+        return -1;
+    }
     p->bases.assign(bases, bases + nbases);
     p->bound_blob = p->blob;
     auto resolve = [&](int buffer, long long offset, void** out) -> int {
@@ -421,6 +482,7 @@ extern "C" tt_plan* tt_plan_load(const char* path) {
         p->outputs.push_back(o);
     }
     if (!r.ok) return fail("truncated file");
+    if (const char* why = plan_defect(p)) return fail(why);
     fclose(f);
     return p;
 }

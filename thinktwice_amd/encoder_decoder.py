@@ -30,19 +30,13 @@ class EncoderDecoder(torch.nn.Module):
         self.config = train_cfg if train_cfg is not None else cfg
         self.num_cams = num_cams
         self.dtype = dtype
-        self.device = torch.device(device)
-        self.img_encoder = build_backbone(img_encoder, dtype=dtype, device=device)
-        # precision mode of the LiDAR branch (default: the model's; its own knob because the sparse encoder is the one
-        # part of the forward whose 16-bit rounding barely reaches the outputs)
-        self.lidar_encoder = (build_backbone(lidar_encoder, device=device, dtype=dtype if lidar_dtype is None else lidar_dtype)
-                              if lidar_encoder is not None else None)
-        dec = dict(decoder)
-        dec.setdefault("config", self.config)
-        self.decoder = build_head(dec, dtype=dtype, device=device)
+        self._lidar_dtype = lidar_dtype
+        # the constructor's module configs, kept as given: `.to(device)` rebuilds the sub-objects on another GPU from them,
+        # `init_weights()` derives the state_dict layout from them
+        self._ctor = dict(img_encoder=dict(img_encoder), decoder=dict(decoder),
+                          lidar_encoder=None if lidar_encoder is None else dict(lidar_encoder))
+        self._build(torch.device(device))
         self.training = False
-        self.loaded = False
-        self._side = None
-        self._loss_red = None
         tc = self.config or {}                                                   # EDF:42-43: train_cfg decides
         self.use_depth, self.use_seg = bool(tc.get("use_depth", False)), bool(tc.get("use_seg", False))
         self.downsample_factor, self.seg_downsample_factor = downsample_factor, seg_downsample_factor
@@ -52,6 +46,29 @@ class EncoderDecoder(torch.nn.Module):
         if "turn_KP" in c:   # EDF:47-48
             self.turn_controller = control.PIDController(c["turn_KP"], c["turn_KI"], c["turn_KD"], c["turn_n"])
             self.speed_controller = control.PIDController(c["speed_KP"], c["speed_KI"], c["speed_KD"], c["speed_n"])
+
+    def _build(self, device):
+        """(Re)create the sub-objects on `device` (their kernels' operand buffers live where they are built)."""
+        if device.type != "cuda":
+            raise _lib.TTError(f"EncoderDecoder lives on an MI355X (device '{device}' requested): there is no CPU product path")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        if torch.cuda.is_available() and device.index >= torch.cuda.device_count():
+            raise _lib.TTError(f"EncoderDecoder: {device} requested, {torch.cuda.device_count()} GPU(s) visible")
+        self.device = device
+        c = self._ctor
+        self.img_encoder = build_backbone(c["img_encoder"], dtype=self.dtype, device=device)
+        # precision mode of the LiDAR branch (default: the model's; its own knob because the sparse encoder is the one
+        # part of the forward whose 16-bit rounding barely reaches the outputs, see DESIGN.md section 4b)
+        self.lidar_encoder = (build_backbone(c["lidar_encoder"], device=device,
+                                             dtype=self.dtype if self._lidar_dtype is None else self._lidar_dtype)
+                              if c["lidar_encoder"] is not None else None)
+        dec = dict(c["decoder"])
+        dec.setdefault("config", self.config)
+        self.decoder = build_head(dec, dtype=self.dtype, device=device)
+        self.loaded = False
+        self._side = None
+        self._loss_red = None
 
     # closed-loop post-processing (thinktwice_agent.py:458-509).  `action_post()` is the one-call device path
     # (tt_action_post: control branch + waypoint PID + arbitration on the output tensors where they are, one D2H copy);
@@ -67,30 +84,97 @@ class EncoderDecoder(torch.nn.Module):
         return control.control_pid(self.config, self.turn_controller, self.speed_controller, waypoints, velocity,
                                    target, stuck_desired_speed)
 
-    # mmcv / torch.nn.Module surface used by the callers (AGENT:170-172)
-    def eval(self):
-        self.training = False
-        return self
-
+    # mmcv / torch.nn.Module surface used by the callers (AGENT:170-172, train.py:225,238)
     def train(self, mode=True):
         """model.train(): `forward_train` / `train_step` then run the reference's TRAINING semantics -- batch-statistics
         BatchNorm (SyncBN across ranks, configs/thinktwice.py:39; running statistics updated) and the live ASPP
         Dropout(0.5) (lss.py:91).  model.eval() (the default) keeps running-statistics BatchNorm, which is also the
-        frozen-BN fine-tuning mode (`trainer.Trainer(frozen_bn=True)`).  `forward_inference` is eval-mode either way."""
+        frozen-BN fine-tuning mode (`trainer.Trainer(frozen_bn=True)`).  `forward_inference` is eval-mode either way.
+        The mode reaches the sub-objects that key on it (nn.Module.train() walks children; this shell has none): the LiDAR
+        voxeliser picks its train / eval voxel cap by it (max_voxels=(120000, 160000), configs/thinktwice.py:164)."""
         self.training = bool(mode)
+        for sub in (self.img_encoder, self.lidar_encoder, self.decoder):
+            if sub is not None and hasattr(sub, "training"):
+                sub.training = self.training
         return self
 
-    def to(self, *a, **k):
+    def eval(self):
+        return self.train(False)
+
+    def to(self, *args, **kwargs):
+        """nn.Module.to for the one thing callers use it for -- placing the model on a device (thinktwice_agent.py:171
+        `self.model.to(self.device)`, train.py's MMDistributedDataParallel(model.cuda(), device_ids=[local_rank])).  The same
+        device: no-op.  Another GPU: the sub-objects are rebuilt there and the loaded checkpoint is prepared again (the
+        kernels' operand layouts are device buffers).  A dtype: refused -- the precision mode is a constructor argument
+        (`dtype=`), not a cast.  The CPU: refused, there is no CPU product path."""
+        device = kwargs.get("device")
+        for a in args:
+            if isinstance(a, (str, torch.device, int)):
+                device = a
+            elif isinstance(a, torch.dtype):
+                raise _lib.TTError(f"EncoderDecoder.to({a}): the precision mode is chosen at construction (dtype=...), not cast")
+            elif torch.is_tensor(a):
+                device = a.device
+        if kwargs.get("dtype") is not None:
+            raise _lib.TTError("EncoderDecoder.to(dtype=...): the precision mode is chosen at construction (dtype=...)")
+        if device is None:
+            return self
+        device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else self.device.index or 0)
+        if device == self.device:
+            return self
+        sd, mode = self._ref_sd, self.training
+        self._build(device)                    # raises for a non-GPU device before anything is torn down
+        if sd is not None:
+            self.load_state_dict(sd)
+        self.train(mode)
         return self
 
-    def cuda(self, *a, **k):
-        return self
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else
+                                    (device if isinstance(device, int) else torch.device(device).index or 0)))
+
+    def cpu(self):
+        return self.to("cpu")
 
     def set_epoch(self, epoch):
         self.epoch = epoch
 
-    def init_weights(self):
-        pass
+    def model_config(self):
+        """The module configs in the layout thinktwice_amd.params walks (img_encoder / lidar_encoder / decoder / cfg)."""
+        return dict(img_encoder=self._ctor["img_encoder"], lidar_encoder=self._ctor["lidar_encoder"],
+                    decoder=self._ctor["decoder"], cfg=self.config, num_cams=self.num_cams)
+
+    def init_weights(self, seed=0, pretrained=None):
+        """train.py:225 `model.init_weights()`: give a freshly built model its initial weights.  The reference's rules
+        (dense_heads/utils.py:26-47, code/utils.py:59-80, lss.py:40-46,112-118, the MSDA sampling-offset grid
+        multi_scale_deformable_attn_function.py:403-421, thinktwice_decoder.py:369-376) are what `params.init_params`
+        restates per tensor, seeded per NAME (every rank builds bit-identical weights without a broadcast).  `pretrained`
+        (default: img_backbone_conf.init_cfg.checkpoint when it names a local file -- 'torchvision://resnet50',
+        configs/thinktwice.py:147, needs a download and is skipped offline): a torchvision-layout ResNet-50 state_dict
+        loaded over `img_encoder.img_backbone.*`.  A model that already holds a checkpoint keeps it (mmcv's init_weights does
+        not overwrite weights loaded through init_cfg either): call `load_state_dict` to replace weights."""
+        import os
+        from . import params
+        if self.loaded:
+            return self
+        sd = params.init_params(self.model_config(), seed=seed)
+        if pretrained is None:
+            ic = (self._ctor["img_encoder"].get("img_backbone_conf") or {}).get("init_cfg") or {}
+            pretrained = ic.get("checkpoint") if ic.get("type") == "Pretrained" else None
+        if pretrained and os.path.isfile(str(pretrained)):
+            ck = torch.load(pretrained, map_location="cpu")
+            ck = ck.get("state_dict", ck)
+            pre = "img_encoder.img_backbone."
+            hit = 0
+            for k, v in ck.items():
+                if pre + k in sd and tuple(sd[pre + k].shape) == tuple(v.shape):
+                    sd[pre + k] = v.to(sd[pre + k].dtype)
+                    hit += 1
+            if hit == 0:
+                raise _lib.TTError(f"init_weights: no tensor of {pretrained} matches the ResNet-50 layout")
+        return self.load_state_dict(sd)
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                               error_msgs):
