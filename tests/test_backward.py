@@ -453,7 +453,7 @@ def test_mlp_building_blocks_backward_match_autograd():
     l1 = layers.linear_from_sd(sd, "l1", "cuda", act="gelu")
     l2 = layers.linear_from_sd(sd, "l2", "cuda")
     gam, bet = sd["ln.weight"].cuda(), sd["ln.bias"].cuda()
-    autodiff.LN_META[id(gam)] = ("ln.weight", "ln.bias")
+    autodiff.LN_META[gam] = ("ln.weight", "ln.bias")
     ff, lk, tp = fflat.detach().cuda(), look.detach().cuda(), temporal.detach().cuda()
     with autodiff.Tape(x3=False) as tape:
         hin_d = torch.empty(B * 4, 112, device="cuda")

@@ -202,7 +202,7 @@ def test_frozen_bn_layer_backward_with_zero_and_tiny_gamma_channels():
     assert autodiff.refresh_small_scale_flags() == 1
     xq = weights.to_channel_last(x, torch.float32).cuda()
     for flagged in (True, False):
-        autodiff.CONV_META[id(conv.w)].small_scale = flagged
+        autodiff.CONV_META[conv.w].small_scale = flagged
         with autodiff.Tape(x3=False) as tape:
             out = conv(xq)
             tape.seed(out, R.permute(0, 2, 3, 1))

@@ -120,3 +120,42 @@ def test_parse_losses_single_process():
     assert list(log_vars) == ["wp_loss", "value_loss", "lateral_offset", "aux", "loss"]
     assert log_vars["aux"] == 7.0 and log_vars["lateral_offset"] == 10.0 and abs(log_vars["loss"] - 2.0) < 1e-6
     assert all(isinstance(v, float) for v in log_vars.values())
+
+
+def test_tape_metadata_tables_are_scoped_per_model_and_never_alias():
+    """the tensor -> parameter-name tables of the training tape were process-global id(tensor) dicts: one
+    Trainer re-preparing its operands wiped every other model's entries, and a recycled id() could hand a dead tensor's entry to
+    a new one.  They are weak, identity-checked and owner-scoped now."""
+    import gc
+    import torch
+    from thinktwice_amd import autodiff as A
+    t = A.MetaTable()
+
+    class Model:
+        pass
+    m1, m2 = Model(), Model()
+    a, b = torch.zeros(3), torch.zeros(3)
+    with A.owned_by(m1):
+        t[a] = "A"
+    with A.owned_by(m2):
+        t[b] = "B"
+    assert t.get(a) == "A" and t.get(b) == "B" and len(t) == 2 and a in t
+    t.clear(m1)                                    # model 1 re-prepares its operands ...
+    assert t.get(a) is None and t.get(b) == "B"    # ... model 2 keeps its entries
+    assert t.values(m2) == ["B"] and t.values(m1) == []
+    del b
+    gc.collect()
+    assert len(t) == 0                             # entries die with their tensors
+    c, d = torch.zeros(2), torch.zeros(2)
+    t[c] = "C"
+    t._d[id(d)] = t._d[id(c)]                      # what a recycled id() amounts to: c's entry found under d's id
+    assert t.get(d) is None and t.get(c) == "C"
+    # the module-level tables are MetaTables and clear_metas(owner) only touches that owner
+    x, y = torch.zeros(1), torch.zeros(1)
+    with A.owned_by(m1):
+        A.CONV_META[x] = "x"
+    with A.owned_by(m2):
+        A.CONV_META[y] = "y"
+    A.clear_metas(m1)
+    assert A.CONV_META.get(x) is None and A.CONV_META.get(y) == "y"
+    A.clear_metas(m2)

@@ -265,3 +265,26 @@ def test_training_backward_in_train_mode_matches_reference_gradients_golden_f16(
     # running statistics moved (momentum update), parameters did not (backward only)
     k = "img_encoder.img_backbone.bn1.running_mean"
     assert float((tr.buffers[k].cpu() - sd[k]).abs().max()) > 0
+
+
+def test_two_trainers_in_one_process_do_not_disturb_each_other():
+    """a second Trainer preparing (and re-preparing) its operands must leave the first one's tape
+    metadata alone -- the first model's backward gives the same gradients before and after (to the f32 atomics of the three backward scatters)."""
+    from thinktwice_amd import model as tm, params, synth
+    from thinktwice_amd.trainer import Trainer
+    hw = (128, 256)
+    ma, cfg = tm.build_thinktwice(final_dim=hw, dtype="f32x3")
+    ta = Trainer(ma, params.init_params(cfg, seed=0), lr=1e-4)
+    batch = tm.batch_to_device(synth.make_batch(1, img_hw=hw, num_points=4096, seed=3))
+    batch.update(synth.make_train_targets(1, img_hw=hw, seed=4))
+    ta.backward(batch)
+    g0 = ta.grads.flat.clone()
+    n_a = len(ta.param_grads)
+    mb, _ = tm.build_thinktwice(final_dim=hw, dtype="f32x3")
+    tb = Trainer(mb, params.init_params(cfg, seed=1), lr=1e-4)          # prepares model B: clears ITS entries only
+    tb.step(batch)                                                      # ... and re-prepares them after its update
+    ta.backward(batch)                                                  # model A's tape still finds every parameter
+    assert len(ta.param_grads) == n_a
+    assert float((ta.grads.flat - g0).norm()) <= 1e-4 * float(g0.norm())
+    tb.backward(batch)
+    assert len(tb.param_grads) == n_a

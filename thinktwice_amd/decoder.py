@@ -79,7 +79,7 @@ class _GRU:
 def _layer_norm_params(sd, name, dev):
     gamma = sd[name + ".weight"].to(dev, F32).contiguous()
     beta = sd[name + ".bias"].to(dev, F32).contiguous()
-    autodiff.LN_META[id(gamma)] = (name + ".weight", name + ".bias")
+    autodiff.LN_META[gamma] = (name + ".weight", name + ".bias")
     return gamma, beta
 
 

@@ -196,13 +196,15 @@ class EncoderDecoder(torch.nn.Module):
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items() if k != "_metadata"}
         self._ref_sd = sd
         dev = self.device
-        self.img_encoder.load_state_dict(sd, "img_encoder")
-        if self.lidar_encoder is not None:
-            self.lidar_encoder.load_state_dict(sd, "lidar_encoder")
-        self.fusion = BEVFusion(sd, dev)
-        self.meas0 = linear_from_sd(sd, "measurements_encoder.0", dev, act="relu", in_pad=12)
-        self.meas2 = linear_from_sd(sd, "measurements_encoder.2", dev, act="relu")
-        self.decoder.load_state_dict(sd, "decoder")
+        autodiff.clear_metas(self)            # the previous checkpoint's operand registrations of THIS model
+        with autodiff.owned_by(self):         # (the training tape's tensor -> parameter-name tables are scoped per model)
+            self.img_encoder.load_state_dict(sd, "img_encoder")
+            if self.lidar_encoder is not None:
+                self.lidar_encoder.load_state_dict(sd, "lidar_encoder")
+            self.fusion = BEVFusion(sd, dev)
+            self.meas0 = linear_from_sd(sd, "measurements_encoder.0", dev, act="relu", in_pad=12)
+            self.meas2 = linear_from_sd(sd, "measurements_encoder.2", dev, act="relu")
+            self.decoder.load_state_dict(sd, "decoder")
         self.loaded = True
         return self
 

@@ -42,7 +42,7 @@ class FlattenTail:
         wp = w.view(w.shape[0], 256, 4).permute(0, 2, 1).reshape(w.shape[0], 1024).contiguous()
         self.fc0 = linear_from_sd({"w.weight": wp, "w.bias": sd["output_fc.0.bias"]}, "w", dev, act="relu")
         from . import autodiff            # training tape: the gradient goes back under the reference name / column order
-        autodiff.CONV_META[id(self.fc0.w)] = autodiff.ConvMeta("output_fc.0", 1024, None, None, None, self.fc0.shift,
+        autodiff.CONV_META[self.fc0.w] = autodiff.ConvMeta("output_fc.0", 1024, None, None, None, self.fc0.shift,
                                                                kind="linear_hwc", lo=4)
         self.bn = layers.bn_affine(sd, "output_fc.2", dev)
         self.fc3 = linear_from_sd(sd, "output_fc.3", dev, act="relu")

@@ -85,13 +85,13 @@ def conv_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, stride=1, pad=0, di
     # what the training tape needs for this layer's parameter gradients (autodiff.py)
     from . import autodiff
     full = sd[name + ".weight"]
-    autodiff.CONV_META[id(wq)] = autodiff.ConvMeta(
+    autodiff.CONV_META[wq] = autodiff.ConvMeta(
         name, w.shape[1], bn,
         None if bn is None else _dev(sd[bn + ".running_mean"], device),
         None if bn is None else torch.sqrt(_dev(sd[bn + ".running_var"], device) + eps), _dev(bias, device),
         kind="conv" if weight is None else "cin_slice", full_shape=tuple(full.shape), lo=cin_lo)
     if bn is not None:
-        autodiff.CONV_META[id(wq)].scale_ref = _dev(scale, device)
+        autodiff.CONV_META[wq].scale_ref = _dev(scale, device)
     return Conv(wq, _dev(scale, device), _dev(shift, device), stride, pad, dil, act, x3=dtype == weights.X3,
                 bn=None if bn is None else _bn_spec(sd, bn, device, eps, bn_momentum), bias=_dev(bias, device))
 
@@ -112,7 +112,7 @@ def linear_from_sd(sd, name, device, act="none", in_pad=None, dtype=torch.float3
     else:
         scale, shift = None, bias
     from . import autodiff
-    autodiff.CONV_META[id(wq)] = autodiff.ConvMeta(
+    autodiff.CONV_META[wq] = autodiff.ConvMeta(
         name, w.shape[1], bn,
         None if bn is None else _dev(sd[bn + ".running_mean"], device),
         None if bn is None else torch.sqrt(_dev(sd[bn + ".running_var"], device) + eps), _dev(bias, device),
@@ -126,7 +126,7 @@ def deconv2x2_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, act="none", bn
     wq = weights.prep_deconv2x2_weight(sd[name + ".weight"].to(device), dtype)
     bias = sd.get(name + ".bias")
     from . import autodiff
-    autodiff.CONV_META[id(wq)] = autodiff.ConvMeta(
+    autodiff.CONV_META[wq] = autodiff.ConvMeta(
         name, sd[name + ".weight"].shape[0], bn,
         None if bn is None else _dev(sd[bn + ".running_mean"], device),
         None if bn is None else torch.sqrt(_dev(sd[bn + ".running_var"], device) + eps), _dev(bias, device))
@@ -170,6 +170,6 @@ def bn_affine(sd, bn, device, eps=1e-5, momentum=0.1):
                            sd[bn + ".running_var"], eps)
     s, t = _dev(s, device), _dev(t, device)
     from . import autodiff
-    autodiff.AFFINE_META[id(s)] = (bn, _dev(sd[bn + ".running_mean"], device),
+    autodiff.AFFINE_META[s] = (bn, _dev(sd[bn + ".running_mean"], device),
                                    torch.sqrt(_dev(sd[bn + ".running_var"], device) + eps))
     return BNAffine(s, t, _bn_spec(sd, bn, device, eps, momentum))

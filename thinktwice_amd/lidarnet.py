@@ -128,7 +128,7 @@ class SparseEncoder_fp32:
             w = _sp_w(wt, dev)
             b = _bn1d(sd, bnn, dev)
             from . import autodiff
-            autodiff.CONV_META[id(w[0])] = autodiff.ConvMeta(
+            autodiff.CONV_META[w[0]] = autodiff.ConvMeta(
                 conv, wt.shape[-1], bnn, sd[bnn + ".running_mean"].float().to(dev),
                 torch.sqrt(sd[bnn + ".running_var"].float().to(dev) + 1e-3), None, kind="spconv", full_shape=tuple(wt.shape))
             return w, b

@@ -161,7 +161,7 @@ class LSS:
             wg = wg.permute(0, 2, 3, 1).reshape(og, 1, 9, wg.shape[1])  # [Cout][1][tap][cin]
             self.dcn_w.append(conv_from_weight(wg.to(self.dtype).contiguous(), dt))
             from . import autodiff
-            autodiff.CONV_META[id(self.dcn_w[-1].w)] = autodiff.ConvMeta(q, wd.shape[1], kind="dcn_group",
+            autodiff.CONV_META[self.dcn_w[-1].w] = autodiff.ConvMeta(q, wd.shape[1], kind="dcn_group",
                                                                          full_shape=tuple(wd.shape), lo=g * og)
         self.depth_out = conv_from_sd(sd, d + ".depth_conv.5", dt, dev)
         s = p + ".seg_net"

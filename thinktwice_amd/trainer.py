@@ -77,20 +77,20 @@ class Trainer:
         the device once), so nothing crosses PCIe.  TT_TRAIN_PREPARE=host takes the route a checkpoint takes instead (one
         0.5 GB device-to-host copy + host-side preparation per iteration); it is also the fallback if the load code meets
         a host-only operation on a device tensor."""
-        autodiff.clear_metas()
+        autodiff.clear_metas(self.model)
         with torch.no_grad():
             if self._prepare_on_device:
                 try:
                     self.model.load_state_dict({k: (v.detach() if k in self._trainable else self._dev_buffers.get(k, v))
                                                 for k, v in self.sd.items()})
                     if self.frozen_bn:
-                        autodiff.refresh_small_scale_flags()
+                        autodiff.refresh_small_scale_flags(owner=self.model)
                     return
                 except (RuntimeError, TypeError) as e:
                     print(f"[trainer] device-side operand preparation failed ({type(e).__name__}: {e}); "
                           f"using the host path", file=sys.stderr, flush=True)
                     self._prepare_on_device = False
-                    autodiff.clear_metas()
+                    autodiff.clear_metas(self.model)
             self.model.load_state_dict({k: (v.detach().cpu() if k in self._trainable else v) for k, v in self.sd.items()})
 
     def backward(self, batch):
