@@ -117,3 +117,32 @@ def test_dropout_replays_a_mask_and_its_own_generator_keeps_about_half():
     assert 0.45 < kept < 0.55 and torch.equal(y2[y2 != 0], (x * 2.0)[y2 != 0])
     y3 = ops.dropout(xd, 0.5).cpu()
     assert not torch.equal(y2 != 0, y3 != 0)           # a new mask per call
+
+
+def test_row_batchnorm_running_statistics_take_one_update_per_sweep():
+    """the reference runs DepthNet's BatchNorm1d(22) once per SWEEP on the key frame's camera vector (lss.py:689-714),
+    so its running statistics take T momentum updates per iteration with the same batch statistics.  `running_updates=T` must
+    leave exactly what torch leaves after T train-mode calls on the same input, and the same normalised output."""
+    from thinktwice_amd import layers
+    g = torch.Generator().manual_seed(22)
+    C, R, T = 22, 16, 2
+    x = torch.randn(R, C, generator=g) * torch.rand(C, generator=g) * 30 + torch.randn(C, generator=g) * 5
+    sd = {"bn.weight": torch.rand(C, generator=g) + 0.5, "bn.bias": torch.randn(C, generator=g) * 0.2,
+          "bn.running_mean": torch.randn(C, generator=g), "bn.running_var": torch.rand(C, generator=g) + 0.5}
+    ref = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        ref.weight.copy_(sd["bn.weight"]); ref.bias.copy_(sd["bn.bias"])
+        ref.running_mean.copy_(sd["bn.running_mean"]); ref.running_var.copy_(sd["bn.running_var"])
+    ref.train()
+    for _ in range(T):
+        y_ref = ref(x)
+    bn = layers.bn_affine(sd, "bn", "cuda")
+    old = layers.BN_TRAIN
+    layers.BN_TRAIN = True
+    try:
+        y = bn(x.cuda(), running_updates=T)
+    finally:
+        layers.BN_TRAIN = old
+    assert float((y.cpu()[:, :C] - y_ref.detach()).abs().max()) < 2e-5
+    assert float((bn.spec.running_mean.cpu() - ref.running_mean).abs().max()) < 1e-5
+    assert float(((bn.spec.running_var.cpu() - ref.running_var) / ref.running_var).abs().max()) < 1e-5

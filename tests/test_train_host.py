@@ -159,3 +159,29 @@ def test_tape_metadata_tables_are_scoped_per_model_and_never_alias():
     A.clear_metas(m1)
     assert A.CONV_META.get(x) is None and A.CONV_META.get(y) == "y"
     A.clear_metas(m2)
+
+
+def test_lr_schedule_is_mmcv_cosine_by_epoch_with_per_iteration_warmup():
+    """the reference's lr_config (configs/thinktwice.py:286-291) under EpochBasedRunner is mmcv's
+    CosineAnnealingLrUpdaterHook with its default by_epoch=True: the regular rate steps per EPOCH
+    (annealing_cos(base, base * min_lr_ratio, epoch / max_epochs)), the linear warmup multiplies it per ITERATION."""
+    import math
+    from thinktwice_amd.optim import warmup_cosine_lr
+    base, ipe, epochs = 1e-4, 500, 60
+    total = ipe * epochs
+
+    def mmcv(it):       # mmcv/runner/hooks/lr_updater.py: CosineAnnealingLrUpdaterHook.get_lr + LrUpdaterHook.get_warmup_lr
+        epoch = it // ipe
+        target = base * 1e-3
+        regular = target + 0.5 * (base - target) * (math.cos(math.pi * epoch / epochs) + 1)
+        if it < 1000:
+            k = (1 - it / 1000) * (1 - 1.0 / 3)
+            return regular * (1 - k)
+        return regular
+    for it in (0, 1, 499, 500, 999, 1000, 1001, 12_345, total - 1):
+        assert abs(warmup_cosine_lr(base, it, total, iters_per_epoch=ipe) - mmcv(it)) < 1e-18 + 1e-12 * base, it
+    # constant inside an epoch after the warmup, a step at the epoch boundary
+    a, b, c = (warmup_cosine_lr(base, it, total, iters_per_epoch=ipe) for it in (1500, 1999, 2000))
+    assert a == b and c < b
+    # the per-iteration form stays available
+    assert warmup_cosine_lr(base, 1500, total, iters_per_epoch=ipe, by_epoch=False) > warmup_cosine_lr(base, 1999, total, by_epoch=False)

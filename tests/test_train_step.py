@@ -288,3 +288,65 @@ def test_two_trainers_in_one_process_do_not_disturb_each_other():
     assert float((ta.grads.flat - g0).norm()) <= 1e-4 * float(g0.norm())
     tb.backward(batch)
     assert len(tb.param_grads) == n_a
+
+
+def test_checkpoint_has_the_torch_layout_and_resumes_bit_identically():
+    """`Trainer.checkpoint()` = mmcv's save_checkpoint content: meta (epoch, iter), state_dict (reference names,
+    BatchNorm call counters advanced), optimizer in torch.optim.AdamW.state_dict() layout -- loadable by a real torch AdamW
+    over parameters of the same shapes -- and a resumed Trainer continues exactly where the saved one was."""
+    from thinktwice_amd import model as tm, params, synth
+    from thinktwice_amd.trainer import Trainer
+    hw = (128, 256)
+    m, cfg = tm.build_thinktwice(final_dim=hw, dtype="f32x3")
+    sd0 = params.init_params(cfg, seed=0)
+    tr = Trainer(m, sd0, lr=1e-4, frozen_bn=False)
+    batch = tm.batch_to_device(synth.make_batch(2, img_hw=hw, num_points=4096, seed=3))
+    batch.update(synth.make_train_targets(2, img_hw=hw, seed=4))
+    tr.step(batch)
+    tr.step(batch)
+    ck = tr.checkpoint(epoch=3)
+    assert ck["meta"] == {"epoch": 3, "iter": 2}
+    osd = ck["optimizer"]
+    assert set(osd) == {"state", "param_groups"} and osd["param_groups"][0]["params"] == list(range(len(tr.names)))
+    live = [i for i, k in enumerate(tr.names) if k in tr.param_grads]
+    assert sorted(osd["state"]) == live and len(live) == 878                  # the 90 dead parameters carry no state (torch)
+    i0 = live[0]
+    assert osd["state"][i0]["exp_avg"].shape == tr.sd[tr.names[i0]].shape and float(osd["state"][i0]["step"]) == 2.0
+    # a real torch AdamW over same-shaped parameters accepts it
+    ps = [torch.nn.Parameter(torch.zeros(tr.sd[k].shape)) for k in tr.names]
+    opt = torch.optim.AdamW(ps, lr=1e-4)
+    opt.load_state_dict(osd)
+    assert torch.equal(opt.state[ps[i0]]["exp_avg"], osd["state"][i0]["exp_avg"])
+    # BatchNorm call counters: T = 2 calls per iteration inside the per-sweep camera pass, 1 elsewhere
+    k_cam = "img_encoder.img_backbone.bn1.num_batches_tracked"
+    k_lid = next(k for k in sd0 if k.startswith("lidar_encoder.") and k.endswith("num_batches_tracked"))
+    assert int(ck["state_dict"][k_cam]) == int(sd0[k_cam]) + 4 and int(ck["state_dict"][k_lid]) == int(sd0[k_lid]) + 2
+    # resume: a fresh Trainer loaded from the checkpoint takes the same third step
+    m2, _ = tm.build_thinktwice(final_dim=hw, dtype="f32x3")
+    tr2 = Trainer(m2, params.init_params(cfg, seed=1), lr=1e-4, frozen_bn=False)
+    tr2.load_checkpoint(ck)
+    assert (tr2.iteration, tr2.epoch, tr2.opt.steps) == (2, 3, 2)
+    assert torch.equal(tr2.flat_param, tr.flat_param) and torch.equal(tr2.opt.m, tr.opt.m) and torch.equal(tr2.opt.v, tr.opt.v)
+    for k, b in tr.buffers.items():
+        assert torch.equal(tr2.buffers[k], b), k
+
+
+def test_non_finite_gradient_norm_skips_the_update_on_the_device():
+    """the finite check used to run AFTER AdamW had written NaNs into the weights.  tt_grad_norm_clip now hands the
+    update a NaN factor for a non-finite norm and tt_adamw_step leaves p / m / v untouched."""
+    from thinktwice_amd.optim import FlatAdamW
+    n = 100_000
+    p = torch.randn(n, device="cuda")
+    g = torch.randn(n, device="cuda")
+    opt = FlatAdamW(p, g, lr=1e-3)
+    opt.step()
+    p1, m1, v1 = p.clone(), opt.m.clone(), opt.v.clone()
+    for poison in (float("nan"), float("inf")):
+        g.normal_()
+        g[12345] = poison
+        ns = opt.step().cpu()
+        assert not torch.isfinite(ns[0]) and ns[1] != ns[1]
+        assert torch.equal(p, p1) and torch.equal(opt.m, m1) and torch.equal(opt.v, v1)
+    g.normal_()
+    opt.step()
+    assert not torch.equal(p, p1) and torch.isfinite(p).all()

@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restr
         const float norm = (float)sqrt(red[0]);
         const float coef = max_norm / (norm + 1e-6f);
         out[0] = norm;
-        out[1] = coef < 1.f ? coef : 1.f;
+        // a non-finite gradient norm (overflow, NaN anywhere in the buffer): the factor is NaN = "skip this update"; adamw_kernel
+        // then leaves p / m / v untouched, so a bad iteration cannot poison the weights before the host has looked at the norm
+        out[1] = (norm == norm && norm <= 3.0e38f) ? (coef < 1.f ? coef : 1.f) : __builtin_nanf("");
     }
 }
 
@@ -54,6 +56,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                              float weight_decay, float bias_c1, float bias_c2_sqrt,
                              const float* __restrict__ grad_scale) {
     const float gs = grad_scale ? *grad_scale : 1.f;
+    if (gs != gs) return;          // NaN clip factor: non-finite gradient norm, the update is skipped (block-uniform)
     const float step_size = lr / bias_c1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gs;

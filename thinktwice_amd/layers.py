@@ -158,10 +158,18 @@ class BNAffine:
     def __getitem__(self, i):
         return (self.scale, self.shift)[i]
 
-    def __call__(self, x, act=0, out=None):
-        """x (R, C) f32 rows -> (R, C') rows of `out` (allocated if None; wider outputs keep their extra columns)."""
+    def __call__(self, x, act=0, out=None, running_updates=1):
+        """x (R, C) f32 rows -> (R, C') rows of `out` (allocated if None; wider outputs keep their extra columns).
+        `running_updates` = n (train mode): the running statistics take n momentum updates with this batch's statistics
+        (the reference runs this BatchNorm once per sweep on the SAME input: n updates of momentum m are one update of
+        momentum 1 - (1 - m)^n)."""
         if BN_TRAIN:
-            return ops.batchnorm_train(x.contiguous(), self.spec, act, out=out)
+            if running_updates == 1:
+                return ops.batchnorm_train(x.contiguous(), self.spec, act, out=out)
+            import copy
+            spec = copy.copy(self.spec)               # shares gamma / beta / running buffers; only the momentum differs
+            spec.momentum = 1.0 - (1.0 - float(self.spec.momentum)) ** int(running_updates)
+            return ops.batchnorm_train(x.contiguous(), spec, act, out=out)
         return ops.affine_rows(x, self.scale, self.shift, act=act, out=out)
 
 

@@ -224,7 +224,10 @@ class LSS:
         NI, h, w, _ = src.shape
         dev, dt = src.device, self.dtype
         m24 = torch.zeros(mlp_in.shape[0], 24, dtype=torch.float32, device=dev)
-        self.bn22(mlp_in, out=m24)        # BatchNorm1d(22) of the camera-parameter vector (train mode: batch statistics)
+        # BatchNorm1d(22) of the camera-parameter vector (train mode: batch statistics).  The reference calls
+        # _forward_depth_net once per sweep, every time on the KEY frame's mlp_input (lss.py:689-714), so depth_net.bn's
+        # running statistics take T momentum updates per iteration with the same batch statistics
+        self.bn22(mlp_in, out=m24, running_updates=T)
         x = self.reduce(src)
         dbg = getattr(self, "_dbg", None)          # tools/debug_trainmode.py: intermediate captures
         if dbg is not None:

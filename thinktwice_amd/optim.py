@@ -54,13 +54,23 @@ class FlatAdamW:
         return self.norm_scale
 
 
-def warmup_cosine_lr(base_lr, it, total_iters, warmup_iters=1000, warmup_ratio=1.0 / 3, min_lr_ratio=1e-3):
-    """Learning rate of iteration `it` (0-based) under the reference's lr_config (configs/thinktwice.py:289-294: mmcv
-    CosineAnnealingLrUpdaterHook, by iteration here, with linear warmup): cosine from base_lr to base_lr * min_lr_ratio over the
-    run; during the first `warmup_iters` iterations that value is scaled by 1 - (1 - it / warmup_iters) * (1 - warmup_ratio)."""
+def warmup_cosine_lr(base_lr, it, total_iters, warmup_iters=1000, warmup_ratio=1.0 / 3, min_lr_ratio=1e-3,
+                     iters_per_epoch=None, by_epoch=True):
+    """Learning rate of iteration `it` (0-based) under the reference's lr_config (configs/thinktwice.py:286-291: mmcv
+    CosineAnnealingLrUpdaterHook with linear warmup, under `EpochBasedRunner`).  mmcv's hook anneals BY EPOCH by default
+    (`by_epoch=True`): the regular rate is constant within an epoch, base_lr -> base_lr * min_lr_ratio along
+    cos(pi * epoch / max_epochs); only the WARMUP runs per iteration (`warmup_by_epoch=False`): during the first `warmup_iters`
+    iterations the regular rate is scaled by 1 - (1 - it / warmup_iters) * (1 - warmup_ratio).
+    `iters_per_epoch` gives the epoch of an iteration (epoch = it // iters_per_epoch, max_epochs = ceil(total_iters /
+    iters_per_epoch)); without it -- or with by_epoch=False -- the cosine is evaluated per iteration (mmcv's by_epoch=False)."""
     import math
     target = base_lr * min_lr_ratio
-    lr = target + 0.5 * (base_lr - target) * (1.0 + math.cos(math.pi * min(it, total_iters) / max(1, total_iters)))
+    if by_epoch and iters_per_epoch:
+        progress = min(it, total_iters) // iters_per_epoch
+        max_progress = max(1, -(-total_iters // iters_per_epoch))
+    else:
+        progress, max_progress = min(it, total_iters), max(1, total_iters)
+    lr = target + 0.5 * (base_lr - target) * (1.0 + math.cos(math.pi * progress / max_progress))
     if it < warmup_iters:
         lr *= 1.0 - (1.0 - it / warmup_iters) * (1.0 - warmup_ratio)
     return lr

@@ -61,6 +61,8 @@ class Trainer:
         self.opt = FlatAdamW(self.flat_param, self.grads.flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                              max_grad_norm=max_grad_norm)
         self.param_grads = None
+        self._stepped = set()          # names of the parameters the optimizer has updated at least once (torch: those with state)
+        self.iteration, self.epoch, self._bn_steps = 0, 0, 0
         self._prepare_on_device = os.environ.get("TT_TRAIN_PREPARE", "device") != "host"
         # BatchNorm running statistics: device copies the prepared layers alias (train mode updates them in place)
         self.buffers = {k: v.to(dev, torch.float32).contiguous() for k, v in self.sd.items()
@@ -124,40 +126,115 @@ class Trainer:
             self.sd[k].grad.copy_(g.reshape(self.sd[k].shape))
         return out
 
-    def step(self, batch, lr=None):
-        """One iteration; adds `grad_norm` (device tensor [norm, clip factor]) to train_step's dict."""
+    def step(self, batch, lr=None, check_finite=True):
+        """One iteration; adds `grad_norm` (device tensor [norm, clip factor]) to train_step's dict.  A non-finite gradient
+        norm never reaches the weights: tt_grad_norm_clip hands the update a NaN factor and tt_adamw_step skips (p, m, v
+        untouched).  `check_finite` (one host sync per iteration) additionally raises here; pass False to stay asynchronous
+        and look at `grad_norm` whenever convenient."""
         out = self.backward(batch)
         self.grads.all_reduce_mean()
         out["grad_norm"] = self.opt.step(lr, live_ranges=self.live_ranges)
-        if not bool(torch.isfinite(out["grad_norm"][0])):
-            raise FloatingPointError("Trainer.step: non-finite gradient norm (the update was NOT applied cleanly); "
-                                     "restore from the last checkpoint")
+        if check_finite and not bool(torch.isfinite(out["grad_norm"][0])):
+            self.opt.steps -= 1                     # the device skipped the update: the step count stays with the moments
+            raise FloatingPointError("Trainer.step: non-finite gradient norm; the update was skipped on the device (weights, "
+                                     "Adam moments and running statistics of the optimizer are those of the last good step)")
+        self._stepped.update(self.param_grads.keys())
+        self.iteration += 1
+        if not self.frozen_bn:
+            self._bn_steps += 1
         self._prepare()
         return out
 
+    # ---- checkpoints (mmcv CheckpointHook / torch.save layout: meta + state_dict + optimizer)
+    def _num_batches_tracked(self, key, value):
+        """nn.BatchNorm's call counter under model.train(): every BatchNorm inside the per-sweep camera pass is called once
+        per SWEEP and iteration (lss.py:689-714; older sweeps run under no_grad but in train mode), the others once per
+        iteration."""
+        if self.frozen_bn or self._bn_steps == 0:
+            return value
+        T = int((self.model.config or {}).get("queue_length", 1))
+        per_iter = T if (key.startswith("img_encoder.") and "bev_multiframe_merge" not in key) else 1
+        return value + self._bn_steps * per_iter
+
     def state_dict(self):
         """Reference-format weights (own copies: the master tensors are views of one flat buffer), BatchNorm running
-        statistics as they stand now."""
+        statistics and `num_batches_tracked` as they stand now."""
         out = {}
         for k, v in self.sd.items():
             if k in self._trainable:
                 out[k] = v.detach().clone()
             elif k in self.buffers:
                 out[k] = self.buffers[k].detach().clone().cpu()
+            elif k.endswith("num_batches_tracked") and torch.is_tensor(v):
+                out[k] = self._num_batches_tracked(k, v.clone())
             else:
                 out[k] = v
         return out
 
-    def checkpoint(self):
-        """What an mmcv checkpoint holds for a resume (configs/thinktwice.py:292 checkpoint_config): weights + optimizer."""
-        return {"state_dict": self.state_dict(), "optimizer": self.opt.state_dict()}
+    def optimizer_state_dict(self):
+        """torch.optim.AdamW.state_dict() layout (what mmcv saves under 'optimizer' and `optimizer.load_state_dict` takes on
+        resume, train.py:238 / EpochBasedRunner.resume): per-parameter state keyed by the parameter's index in
+        model.parameters() order (= state_dict order without the buffers), plus one param_group.  Parameters that never
+        received a gradient carry no state, exactly like torch's `grad is None` ones (the reference's 90 dead parameters)."""
+        o = self.opt
+        state, off = {}, 0
+        for idx, k in enumerate(self.names):
+            n = self.sd[k].numel()
+            if k in self._stepped:
+                shape = self.sd[k].shape
+                state[idx] = {"step": torch.tensor(float(o.steps)),
+                              "exp_avg": o.m[off:off + n].view(shape).detach().clone().cpu(),
+                              "exp_avg_sq": o.v[off:off + n].view(shape).detach().clone().cpu()}
+            off += n
+        group = {"lr": o.lr, "betas": tuple(o.betas), "eps": o.eps, "weight_decay": o.wd, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "params": list(range(len(self.names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, osd):
+        o = self.opt
+        if "exp_avg" in osd:                       # round-3 flat layout (whole-buffer moments)
+            o.load_state_dict(osd)
+            self._stepped = set(self.names)
+            return
+        o.m.zero_()
+        o.v.zero_()
+        self._stepped = set()
+        off, steps = 0, 0
+        for idx, k in enumerate(self.names):
+            n = self.sd[k].numel()
+            st = osd["state"].get(idx, osd["state"].get(str(idx)))
+            if st is not None:
+                o.m[off:off + n].copy_(st["exp_avg"].reshape(-1).to(o.m.device, torch.float32))
+                o.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(o.v.device, torch.float32))
+                steps = max(steps, int(float(st["step"])))
+                self._stepped.add(k)
+            off += n
+        o.steps = steps
+        g = (osd.get("param_groups") or [{}])[0]
+        o.lr = g.get("lr", o.lr)
+        o.betas = tuple(g.get("betas", o.betas))
+        o.eps, o.wd = g.get("eps", o.eps), g.get("weight_decay", o.wd)
+
+    def checkpoint(self, epoch=None):
+        """What an mmcv checkpoint holds for a resume (configs/thinktwice.py:292 checkpoint_config, mmcv save_checkpoint):
+        `meta` (epoch / iter), `state_dict` (reference key names), `optimizer` (torch AdamW layout)."""
+        return {"meta": {"epoch": self.epoch if epoch is None else epoch, "iter": self.iteration},
+                "state_dict": self.state_dict(), "optimizer": self.optimizer_state_dict()}
 
     def load_checkpoint(self, ckpt):
         sd = ckpt["state_dict"]
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
         with torch.no_grad():
             for k in self.names:
                 self.sd[k].copy_(sd[k].to(self.sd[k].device, torch.float32))
             for k, b in self.buffers.items():
                 b.copy_(sd[k].to(b.device, torch.float32))
-        self.opt.load_state_dict(ckpt["optimizer"])
+            for k, v in sd.items():
+                if k.endswith("num_batches_tracked") and k in self.sd:
+                    self.sd[k] = v.clone()
+        self._bn_steps = 0
+        meta = ckpt.get("meta") or {}
+        self.epoch, self.iteration = int(meta.get("epoch", 0) or 0), int(meta.get("iter", 0) or 0)
+        if "optimizer" in ckpt:
+            self.load_optimizer_state_dict(ckpt["optimizer"])
         self._prepare()
