@@ -25,8 +25,12 @@ def _setup(mode, fname="f13_train_gradients_b2.npz"):
 # Bounds: relative error of the per-parameter gradient NORM and of the 8 sampled entries (relative to the norm).  The exact-f32
 # mode differs from the reference only by summation order and by the folded-BatchNorm rounding that flips a few ReLU masks on
 # these small maps (see tests/test_backward.py); the bf16x3 mode adds its ~1e-5 product error to every layer.
-@pytest.mark.parametrize("mode,tol,fname", [("f32", 5e-3, "f13_train_gradients_b2.npz"),
-                                            ("f32x3", 3e-2, "f13_train_gradients_b2.npz"),
+# Round 4 (VERDICT r3 weak #1c): the bounds sit at the measured level now (profiles/r04_pytest_gpu notes): exact f32 worst
+# 1.8e-3 (99.9 % of the 878 parameters within 1e-3, 99th percentile 4.3e-4, median 5.9e-6); bf16x3 worst 6.0e-3 (93 % within
+# 1e-3).  The parameters beyond 1e-3 in f32 are BatchNorm biases of the LiDAR encoder's first level and GRU biases on the
+# 21 x 21 BEV: sums over few, small maps where one flipped ReLU mask is a visible share of the sum.
+@pytest.mark.parametrize("mode,tol,fname", [("f32", 2.5e-3, "f13_train_gradients_b2.npz"),
+                                            ("f32x3", 1e-2, "f13_train_gradients_b2.npz"),
                                             # F13b: the thinktwice.py size (B=1, 448x896, 65536 points), where one flipped
                                             # ReLU mask is a negligible share of a channel's gradient sum
                                             ("f32", 5e-3, "f13b_train_gradients_fullsize_b1.npz"),
@@ -62,6 +66,10 @@ def test_training_backward_matches_reference_gradients_golden_f13(mode, tol, fna
           "99th percentile", float(np.quantile(ne, 0.99)))
     assert wn[0][1] < tol, wn
     assert ws[0][1] < tol, ws
+    if "fullsize" not in fname:
+        # north_star's 1e-3 holds for all but a handful of parameters in exact f32 (measured 99.9 %), 93 % in bf16x3
+        assert float((ne < 1e-3).mean()) >= (0.995 if mode == "f32" else 0.90), float((ne < 1e-3).mean())
+        assert float(np.median(ne)) < (5e-5 if mode == "f32" else 5e-4)
     if "fullsize" in fname:
         # at the thinktwice.py size the camera / LiDAR encoders (most parameters) see maps of 10^3..10^5 pixels: >= 99 % of
         # all gradient norms are within 1e-3 in exact f32 (measured 93.6 % in bf16x3, whose product error of ~1e-5 per layer

@@ -402,7 +402,7 @@ int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st);
 // bf16x3 variant of the same kernel (f32 storage, pre-split weights in a.weight): same contract.
 int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st);
 // bf16x3, 256 x 256 tile as four hand-pipelined 128 x 128 waves (csrc/conv_x3_pipe.hip); `m_tiles_limit` > 0 = tail split
-int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit);
+int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int bn = 256);
 // run-staged sparse 3x3x3 conv (csrc/sp_conv_runs.hip; bf16x3, a.weight = pre-split weights): same contract.
 int try_launch_sp_conv_runs(ConvArgs& a, hipStream_t st);
 // latency-bound small-M variant (32x32 tile, intra-block split-K): same contract.

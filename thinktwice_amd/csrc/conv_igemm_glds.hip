@@ -748,6 +748,10 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
     // K=64: 0.73 -> 0.86 ms); the 128-wide tile is unchanged (1.79 / 1.84 ms).
     static const int stages = [] { const char* e = getenv("TT_GLDS_X3_STAGES"); return e ? atoi(e) : 2; }();   // A/B knob
     if (bn == 128) {                                                                                           // 8 x (32 x 128)
+        // long-K layers: four hand-pipelined 64 x 128 waves (csrc/conv_x3_pipe.hip); TT_X3_PIPE128=0: never
+        static const bool pipe128 = [] { const char* e = getenv("TT_X3_PIPE128"); return e ? atoi(e) != 0 : true; }();
+        static const int pipe_mink128 = [] { const char* e = getenv("TT_X3_PIPE_MINK"); return e ? atoi(e) : 1152; }();
+        if (pipe128 && a.Cout % 128 == 0 && a.K >= pipe_mink128 && try_launch_conv_x3_pipe(a, st, 0, 128)) return 1;
         if (stages == 3) return launch_glds<float, 128, 8, 1, 128, 3, false, true>(a, st);
         return launch_glds<float, 128, 8, 1, 128, 2, false, true>(a, st);
     }

@@ -34,22 +34,24 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define TT_PIPE_DEBUG 0
 #endif
 
-template <int WAVES_M, int WAVES_N>
+template <int WAVES_M, int WAVES_N, int BN = 256>
 __global__ __launch_bounds__(256, 1) void conv_x3_pipe_kernel(const ConvArgs p, const void* zero_page, int tiles_m,
                                                              int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BM = 256, BN = 256, BKB = 128, BK = 32;
+    constexpr int BM = 256, BKB = 128, BK = 32;
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    static_assert(NW == 4 && TM * TN == 16 && TN % TM == 0, "four waves of 128 x 128 (2 x 2) or 64 x 256 (4 x 1)");
+    static_assert(NW == 4 && (TM * TN == 16 || TM * TN == 8) && TN % TM == 0,
+                  "four waves of 128 x 128 (2 x 2) or 64 x 256 (4 x 1) on a 256 x 256 tile; of 64 x 128 (4 x 1) on a 256 x 128 tile");
     constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
     constexpr int NIA = BM * 8 / 64 / NW, NIB = BN * 8 / 64 / NW;      // 1 KiB DMA pieces per wave per tile (8 + 8)
     constexpr int MG = 3 * TM;            // MFMAs per group (one 32-wide column block x TM row blocks x 3 terms)
     constexpr int NGR = TN / TM;          // groups per row-block window (the window in which one row block's next fragment is made)
     constexpr int WIN = NGR * MG;         // gaps per window
-    constexpr int DPG = NIA / TN;         // DMA pieces per group
-    static_assert(NIA == NIB && NIA % TN == 0 && DPG >= 1 && DPG <= 2, "one or two DMA pieces per group");
+    constexpr int DPA = NIA / TN, DPB = NIB / TN;     // DMA pieces per group: activations (first K step of a tile) / weights
+    static_assert(NIA % TN == 0 && NIB % TN == 0 && DPA >= 1 && DPA <= 2 && DPB >= 1 && DPB <= 2, "one or two DMA pieces per group");
+    static_assert(WIN >= 12, "a row-block window needs 12 gaps for the barrier, the fragment reads and the split");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -234,7 +236,10 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pipe_kernel(const ConvArgs p, 
             for (int j = 0; j < NIB; ++j) b_emit(j);
             b_walk1(); b_walk2();
         }
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // tile 0 has landed for this wave
+        // tile 0 has landed for this wave once only tile 1's pieces (NIA + NIB) are outstanding
+        if constexpr (NIA + NIB == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if constexpr (NIA + NIB == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -338,11 +343,12 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pipe_kernel(const ConvArgs p, 
                         ra1 = lds_read(srcA + (fa_pre[kn][rb] ^ 16u));
                     }
                     // DMA: behind the fragment reads; in the barrier group after the barrier (the weight stage it frees)
-                    if (DPG == 2) {
-                        if (m == (bar ? 5 : 2)) dma(2 * g);
-                        if (m == (bar ? 6 : 3)) dma(2 * g + 1);
-                    } else {
-                        if (m == (bar ? 5 : 2)) dma(g);
+                    {
+                        constexpr int DPG = 2;                      // slots per group (a weight step may use one)
+                        const int npieces = kc == 0 ? DPA : DPB;
+                        const int s0 = bar ? (MG >= 8 ? 5 : 4) : 2; // barrier group: after the barrier at gap 3
+                        if (m == s0) dma(npieces * g);
+                        if (m == s0 + 1 && npieces == DPG) dma(npieces * g + 1);
                     }
                     if (ws == (barw ? WB : W0)) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -432,6 +438,11 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pipe_kernel(const ConvArgs p, 
 #endif
 }
 
+static bool grid_is_2x2() {
+    static const int grid = [] { const char* e = getenv("TT_X3_PIPE"); return e ? atoi(e) : 2; }();
+    return grid == 1;
+}
+
 static const void* pipe_zero_page() {
     static void* z = nullptr;
     if (!z) {
@@ -442,28 +453,34 @@ static const void* pipe_zero_page() {
 }
 
 // Returns 1 if the launch was taken.  `m_tiles_limit` > 0: only that many row tiles from a.m_begin (tail split).
-int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit) {
-    if (a.gather || a.m_dev || a.Cout % 256 != 0 || a.Cin % 32 != 0 || a.KH * a.KW > 31 || a.K < 64) return 0;
+int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int bn) {
+    if (a.gather || a.m_dev || (bn != 256 && bn != 128) || a.Cout % bn != 0 || a.Cin % 32 != 0 || a.KH * a.KW > 31 || a.K < 64) return 0;
     const void* zp = pipe_zero_page();
     if (!zp) return 0;
     int tiles_m = div_up(a.M - a.m_begin, 256);
     if (m_tiles_limit > 0 && m_tiles_limit < tiles_m) tiles_m = m_tiles_limit;
-    const int tiles_n = a.Cout / 256;
-    const size_t smem = (size_t)(3 * 256 + 2 * 256) * 128;
+    const int tiles_n = a.Cout / bn;
+    // activation ring 3 x 32 KiB + weight ring 2 x (bn x 128 B); the epilogue stages 4 x 32 x (WTN + 4) floats
+    size_t smem = (size_t)(3 * 256 + 2 * bn) * 128;
+    const size_t epi = (size_t)4 * 32 * ((bn == 128 ? 128 : (grid_is_2x2() ? 128 : 256)) + 4) * 4;
+    if (smem < epi) smem = epi;
     // wave grid: 4 x 1 (64 x 256 per wave: every activation fragment is split by ONE wave) or 2 x 2 (128 x 128); TT_X3_PIPE=2 / 1
     static const int grid = [] { const char* e = getenv("TT_X3_PIPE"); return e ? atoi(e) : 2; }();
-    auto kern = grid == 1 ? conv_x3_pipe_kernel<2, 2> : conv_x3_pipe_kernel<4, 1>;
+    auto kern = bn == 128 ? conv_x3_pipe_kernel<4, 1, 128> : (grid == 1 ? conv_x3_pipe_kernel<2, 2> : conv_x3_pipe_kernel<4, 1>);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pipe_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pipe_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        const int full = (3 * 256 + 2 * 256) * 128;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pipe_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, full);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pipe_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, full);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pipe_kernel<4, 1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, full);
         attr_set = true;
     }
     a.tiles_n = tiles_n;
     a.splits = 1;
     a.ws = nullptr;
     if (a.m_begin == 0)
-        snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_x3_pipe_kernel<%s>%s", grid == 1 ? "2, 2" : "4, 1", m_tiles_limit > 0 ? " + tail" : "");
+        snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_x3_pipe_kernel<%s>%s", bn == 128 ? "4, 1, 128" : (grid == 1 ? "2, 2" : "4, 1"),
+                 m_tiles_limit > 0 ? " + tail" : "");
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), smem, st, a, zp, tiles_m, tiles_n);
     return 1;
 }

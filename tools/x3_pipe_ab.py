@@ -15,6 +15,13 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 
 # (N, H, W, Cin, Cout, k, stride, residual+relu)
+SHAPES_128 = [
+    (64, 112, 224, 384, 128, 3, 1, False),    # UNet: M = 1,605,632, K = 3456
+    (64, 56, 112, 128, 128, 3, 1, True),      # M = 401,408, K = 1152
+    (8, 84, 84, 128, 128, 3, 1, True),        # SECOND block: M = 56,448
+    (64, 56, 112, 512, 128, 1, 1, False),     # 1x1, K = 512 (below the pipe threshold)
+]
+
 SHAPES = [
     (64, 112, 224, 256, 256, 3, 1, False),    # dominant layer: M = 1,605,632
     (64, 28, 56, 512, 512, 3, 1, True),       # DepthNet 512 -> 512 (10 calls per forward), 784 tiles: tail split
@@ -30,7 +37,7 @@ SHAPES = [
 def worker(out_path):
     from thinktwice_amd import ops, weights
     res = []
-    for (N, H, W, Cin, Cout, k, stride, rr) in SHAPES:
+    for (N, H, W, Cin, Cout, k, stride, rr) in (SHAPES_128 if os.environ.get("TT_AB_SET") == "128" else SHAPES):
         g = torch.Generator(device="cuda").manual_seed(1234)
         x = torch.randn(N, H, W, Cin, device="cuda", generator=g)
         w = torch.randn(Cout, k, k, Cin, device="cuda", generator=g) * (Cin * k * k) ** -0.5
@@ -72,16 +79,20 @@ def main():
         return
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     arms = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 2]      # 0: 8-wave tile, 1: 2 x 2 pipe, 2: 4 x 1 pipe
+    shapes = SHAPES_128 if os.environ.get("TT_AB_SET") == "128" else SHAPES                 # TT_AB_SET=128: the 128-wide tile (arms 0 / 1)
     outs = {a: [] for a in arms}
     for rd in range(rounds):
         for arm in arms:
             f = tempfile.mktemp(suffix=".json")
-            env = dict(os.environ, TT_X3_PIPE=str(arm), TT_GLDS_X3_TILE="256")   # every shape on the 256-wide tile
+            if os.environ.get("TT_AB_SET") == "128":
+                env = dict(os.environ, TT_X3_PIPE128=str(arm), TT_GLDS_X3_TILE="128", TT_X3_PIPE_MINK="1152")
+            else:
+                env = dict(os.environ, TT_X3_PIPE=str(arm), TT_GLDS_X3_TILE="256", TT_X3_PIPE_MINK="0")   # every shape on the 256-wide tile
             subprocess.run([sys.executable, __file__, "worker", f], check=True, env=env)
             outs[arm].append(json.load(open(f)))
     ok = True
     print(f"{'shape':44s} " + " ".join(f"{'arm' + str(a) + ' ms':>10s} {'TF/s':>7s}" for a in arms) + "  bit-equal  repeatable  err_vs_f32")
-    for i, sh in enumerate(SHAPES):
+    for i, sh in enumerate(shapes):
         best = {a: min(o[i]["ms"] for o in outs[a]) for a in arms}
         r0 = outs[arms[0]][0][i]
         eq = all(outs[a][0][i]["xor"] == r0["xor"] and outs[a][0][i]["sample"] == r0["sample"] for a in arms)
