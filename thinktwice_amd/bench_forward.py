@@ -23,7 +23,7 @@ def mfma_per_product(kernel_label, dtype):
     if dtype != "bf16x3":
         return 1
     k = kernel_label.replace(" + tail", "").strip()
-    if k.startswith("conv_x3_pipe_kernel") or k.startswith("sp_conv_runs"):
+    if k.startswith(("conv_x3_pipe_kernel", "conv_x3_run3_kernel", "sp_conv_runs")):
         return 3
     if k.startswith("conv_igemm_glds_kernel<") and k.endswith(", true>"):
         return 3

@@ -715,7 +715,8 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
     };
     const bool wide = a.Cout % 256 == 0 || a.Cout > 512;
     const double c256 = wide ? cost(256, 1.0) : 1e30;
-    const double c128 = a.Cout > 64 ? cost(128, 0.85) : 1e30;
+    // (long-K layers run the 128-wide tile on the hand-pipelined kernel: 404 vs 423 TF/s for the 256-wide one, profiles/r04_run3_ab.txt)
+    const double c128 = a.Cout > 64 ? cost(128, (a.K >= 1152 && a.Cout % 128 == 0) ? 0.95 : 0.85) : 1e30;
     const double c64 = cost(64, 0.63);
     static const int force = [] { const char* e = getenv("TT_GLDS_X3_TILE"); return e ? atoi(e) : 0; }();   // A/B knob
     int bn = (c256 <= c128 && c256 <= c64) ? 256 : (c128 <= c64 ? 128 : 64);

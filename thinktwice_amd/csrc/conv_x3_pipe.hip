@@ -438,6 +438,379 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pipe_kernel(const ConvArgs p, 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// RUN3: the same pipeline for 3 x 3 (KW = 3) stride-1 / dilation-1 "same" convolutions over a dense batch, with the
+// activation stream staged as pixel RUNS.  In channel-last memory the three kw taps of one filter row read the same
+// pixels shifted by one: for the 256 consecutive output pixels of a tile, tap (kh, kw) of output row r is the pixel with
+// linear index  m0 + r + (kh - 1) W + (kw - 1)  (global over the batch: H W pixels per image, OH = H, OW = W).  So ONE staged
+// run of 258 pixels x 32 channels per (channel chunk, kh) serves three K tiles -- activation DMA 8 -> 3 pieces per wave and
+// tile, L2 -> LDS activation bytes / 3 -- and a fragment of tile kw reads LDS row r + kw.  What the per-tap tiles got from
+// the zero page at DMA time (padding) is decided at READ time instead: a lane whose (output row, tap) lies outside the
+// image reads a 256 B zero row in LDS (ds_read takes per-lane addresses).  Rows of the run outside the tensor read the
+// zero page (first / last image).  The K loop is unrolled over the three tiles of a run, so the tile's kw, its vmcnt and
+// its share of the next run's DMA (5 + 4 + 0 pieces) are compile-time.  LDS: 2 run buffers x 36 KiB (288 rows: 36 pieces)
+// + 2 weight stages + the zero row.  Results are bit-identical to the per-tap kernels (same K order, same operands).
+template <int BN>
+__global__ __launch_bounds__(256, 1) void conv_x3_run3_kernel(const ConvArgs p, const void* zero_page, int tiles_m,
+                                                             int tiles_n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 256, BKB = 128, BK = 32, NW = 4;
+    constexpr int WTM = 64, WTN = BN, TM = 2, TN = BN / 32;
+    constexpr int RUN_ROWS = 288, RUN_BYTES = RUN_ROWS * BKB, B_BYTES = BN * BKB;
+    constexpr int NIR = RUN_ROWS * 8 / 64 / NW;        // 9 DMA pieces per wave per run
+    constexpr int NIB = BN * 8 / 64 / NW;              // weight pieces per wave per tile (8 / 4)
+    constexpr int MG = 3 * TM, NGR = TN / TM, WIN = NGR * MG, DPB = NIB / TN;
+    static_assert(NIR == 9 && (TN == 8 || TN == 4) && WIN >= 12 && DPB == 1, "256 x 256 or 256 x 128 tile, four 64-row waves");
+    constexpr unsigned Z_OFF = 2u * RUN_BYTES + 2u * B_BYTES;          // the zero row
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave;
+    const int Mlim = p.M;
+    const int nblk = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nblk) return;
+    int L;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = nblk >> 3, r = nblk & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int tile_n = L % tiles_n, tile_m = L / tiles_n;
+    const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
+    if (m0 >= Mlim) return;
+
+    const float* __restrict__ in = reinterpret_cast<const float*>(p.in);
+    const float* __restrict__ wgt = reinterpret_cast<const float*>(p.weight);
+    const float* zp = reinterpret_cast<const float*>(zero_page);
+    auto swz = [](int row) { return (row >> 1) & 7; };
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned ldsB = lds_base + 2u * RUN_BYTES;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+
+    // ---- run DMA slots: piece (wave + 4 j), j = 0..8, = run rows 8 (wave + 4 j) .. + 7; run row q holds the pixel with global
+    // linear index m0 - W - 1 + kh W + q.  Slot pointer = that pixel for kh = 0, channel 0 (+ the lane's swizzled 16 B chunk);
+    // a_mask bit kh: the pixel lies inside the tensor and the row inside the 258 used rows.
+    const long long npix = (long long)p.N * p.H * p.W;
+    const float* a_ptr[NIR];
+    unsigned a_mask[NIR];
+#pragma unroll
+    for (int j = 0; j < NIR; ++j) {
+        const int g = (wave + NW * j) * 64 + lane;
+        const int q = g >> 3, pos = g & 7;
+        const long long G0 = (long long)m0 - p.W - 1 + q;
+        a_ptr[j] = in + p.in_coff + G0 * p.in_cstride + (pos ^ swz(q)) * 4;
+        unsigned mk = 0;
+        for (int kh = 0; kh < p.KH; ++kh) {
+            const long long G = G0 + (long long)kh * p.W;
+            if (q < BM + 2 && G >= 0 && G < npix) mk |= 1u << kh;
+        }
+        a_mask[j] = mk;
+    }
+    const float* b_ptr0;
+    {
+        const int g = wave * 64 + lane;
+        const int row = g >> 3, pos = g & 7;
+        b_ptr0 = wgt + (long long)(n0 + row) * p.K + (pos ^ swz(row)) * 4;
+    }
+    const long long b_jstride = (long long)(NW * 8) * p.K;
+
+    // ---- per fragment row: which of the KH x 3 taps lie inside the image (padding is applied when the fragment is read)
+    unsigned f_mask[TM];
+    unsigned fa_run[3][2][TM], fb_pre[2][TN];
+    const unsigned hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 32 + (lane & 31);
+        const int m = m0 + row;
+        unsigned mk = 0;
+        if (m < Mlim) {
+            const int n = m / (p.OH * p.OW);
+            const int r = m - n * (p.OH * p.OW);
+            const int oh = r / p.OW, ow = r - oh * p.OW;
+            int tbit = 0;
+            for (int kh = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < 3; ++kw, ++tbit) {
+                    const int ih = oh + kh - 1, iw = ow + kw - 1;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) mk |= 1u << tbit;
+                }
+        }
+        f_mask[i] = mk;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const int q = row + kw;
+                fa_run[kw][kc][i] = q * BKB + (((4u * kc + 2u * hi) ^ swz(q)) << 4);
+            }
+    }
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = j * 32 + (lane & 31);
+            fb_pre[kc][j] = row * BKB + (((4u * kc + hi) ^ swz(row)) << 4);
+        }
+
+    const int nk = p.K / BK, nruns = nk / 3;
+    const int ntaps = p.KH * 3;
+    // run walker: kh inner, channel chunk outer.  off = element offset added to the slot pointers
+    const long long r_d1 = (long long)p.W * p.in_cstride, r_e2 = BK - (long long)p.KH * p.W * p.in_cstride;
+    int r_kh = 0, r_rem = nruns;
+    long long r_off = 0;
+    unsigned r_st = lds_base;                        // buffer of the run being issued
+    auto run_walk = [&]() {
+        const int k1 = r_kh + 1;
+        const bool w = k1 == p.KH;
+        r_kh = w ? 0 : k1;
+        r_off += r_d1 + (w ? r_e2 : 0ll);
+        r_rem -= 1;
+        r_st = r_st == lds_base ? lds_base + RUN_BYTES : lds_base;
+    };
+    auto run_emit = [&](int j) {
+        const int bit = r_rem > 0 ? r_kh : 31;
+        const float* src = ((a_mask[j] >> bit) & 1u) ? a_ptr[j] + r_off : zp;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(uintptr_t)(r_st + (unsigned)(wave_s + NW * j) * 1024u), 16, 0, 0);
+    };
+    // weight walker: per tile, tap inner
+    const long long b_d1 = p.Cin, b_e2 = (BK - (long long)(ntaps - 1) * p.Cin) - b_d1;
+    int b_tap = 0, b_rem = nk;
+    long long b_off = 0;
+    unsigned b_st = ldsB;
+    auto b_walk1 = [&]() {
+        const int tp1 = b_tap + 1;
+        const bool adv = b_rem > 1;
+        const bool w = tp1 == ntaps;
+        b_off += (adv ? b_d1 : 0ll) + ((adv && w) ? b_e2 : 0ll);
+        b_tap = adv ? (w ? 0 : tp1) : b_tap;
+    };
+    auto b_walk2 = [&]() {
+        b_rem -= 1;
+        b_st = b_st == ldsB ? ldsB + B_BYTES : ldsB;
+    };
+    auto b_emit = [&](int j) {
+        const float* src = b_ptr0 + b_off + (long long)j * b_jstride;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(uintptr_t)(b_st + (unsigned)(wave_s + NW * j) * 1024u), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto lds_read = [](unsigned addr) {
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+        return v;
+    };
+    auto split_a = [](float x0, float x1, uint32_t& h, float& t0, float& t1) {
+        h = pack_bf16x2(x0, x1);
+        t0 = __uint_as_float(h << 16);
+        t1 = __uint_as_float(h & 0xffff0000u);
+    };
+    auto split_b = [](float x0, float x1, float t0, float t1) { return pack_bf16x2(x0 - t0, x1 - t1); };
+
+    u32x4 ah[2][TM], al[2][TM], bh[TN], bl[TN], ra0, ra1;
+    const unsigned zaddr = lds_base + Z_OFF;
+
+    // ---- prologue: zero row, run 0, weight tiles 0 and 1; tile 0's fragments
+    if (tid < 16) *reinterpret_cast<float4*>(smem + Z_OFF + tid * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+#pragma unroll
+        for (int j = 0; j < NIR; ++j) run_emit(j);
+        run_walk();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int j = 0; j < NIB; ++j) b_emit(j);
+            b_walk1(); b_walk2();
+        }
+        if constexpr (NIB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // only weight tile 1 outstanding
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const unsigned a0 = ((f_mask[i] >> 0) & 1u) ? lds_base + fa_run[0][0][i] : zaddr;
+            ra0 = lds_read(a0);
+            ra1 = lds_read(a0 ^ 16u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(ra0), "+v"(ra1));
+            const float x[8] = {__uint_as_float(ra0.x), __uint_as_float(ra0.y), __uint_as_float(ra0.z), __uint_as_float(ra0.w),
+                                __uint_as_float(ra1.x), __uint_as_float(ra1.y), __uint_as_float(ra1.z), __uint_as_float(ra1.w)};
+            uint32_t h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t0, t1;
+                split_a(x[2 * e], x[2 * e + 1], h[e], t0, t1);
+                l[e] = split_b(x[2 * e], x[2 * e + 1], t0, t1);
+            }
+            ah[0][i] = u32x4{h[0], h[1], h[2], h[3]};
+            al[0][i] = u32x4{l[0], l[1], l[2], l[3]};
+        }
+#pragma unroll
+        for (int j = 0; j < TN - 1; ++j) {
+            bh[j] = lds_read(ldsB + fb_pre[0][j]);
+            bl[j] = lds_read(ldsB + (fb_pre[0][j] ^ 32u));
+        }
+        bl[TN - 1] = lds_read(ldsB + (fb_pre[0][TN - 1] ^ 32u));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bh[j]), "+v"(bl[j]));
+    }
+
+    unsigned sR_cur = lds_base, sR_nxt = lds_base + RUN_BYTES;        // run buffers of the current / next run
+    unsigned sB_cur = ldsB, sB_nxt = ldsB + B_BYTES;
+    int tap0 = 0;                                                      // tap index of the current run's kw = 0 tile
+    for (int rr = 0; rr < nruns; ++rr) {
+        const int tap0_nxt = (tap0 + 3 == ntaps) ? 0 : tap0 + 3;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {                                  // tile kw = t of the run
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const int kn = kc ^ 1;
+                // the K step being prepared: (this tile, kc = 1), or the next tile's kc = 0 -- kw + 1 of this run or kw = 0 of the next
+                const int nkw = kc == 0 ? t : (t == 2 ? 0 : t + 1);
+                const unsigned srcA = (kc == 1 && t == 2) ? sR_nxt : sR_cur;
+                const int ntap = kc == 0 ? tap0 + t : (t == 2 ? tap0_nxt : tap0 + t + 1);
+                const unsigned srcB = kc == 0 ? sB_cur : sB_nxt;
+                // DMA of this K step: kc = 0 -> the next run's pieces (5 with the first tile, 4 with the second); kc = 1 -> the
+                // weights of tile + 2
+                const int a_first = t == 0 ? 0 : 5, a_count = t == 0 ? 5 : (t == 1 ? 4 : 0);
+                auto dma = [&](int q) {
+                    if (TT_PIPE_DEBUG & 1) return;
+                    asm volatile("" ::: "memory");
+                    if (kc == 0) run_emit(a_first + q);
+                    else b_emit(q);
+                    asm volatile("" ::: "memory");
+                };
+                uint32_t sh[4], sl[4];
+                float st0 = 0.f, st1 = 0.f;
+                auto split_stage = [&](int s) {
+                    const int e = s >> 1;
+                    asm volatile("" : "+v"(ra0), "+v"(ra1));
+                    const float x0 = __uint_as_float(e == 0 ? ra0.x : e == 1 ? ra0.z : e == 2 ? ra1.x : ra1.z);
+                    const float x1 = __uint_as_float(e == 0 ? ra0.y : e == 1 ? ra0.w : e == 2 ? ra1.y : ra1.w);
+                    if ((s & 1) == 0) {
+                        split_a(x0, x1, sh[e], st0, st1);
+                        asm volatile("" : "+v"(sh[e]), "+v"(st0), "+v"(st1));
+                    } else {
+                        asm volatile("" : "+v"(st0), "+v"(st1));
+                        sl[e] = split_b(x0, x1, st0, st1);
+                        asm volatile("" : "+v"(sl[e]));
+                    }
+                };
+#pragma unroll
+                for (int g = 0; g < TN; ++g) {
+                    const int rb = g / NGR;
+                    const bool barw = (kc == 1 && rb == 0);
+                    const bool bar = barw && (g % NGR) == 0;
+                    const bool last = g == TN - 1;
+                    constexpr int R0 = 1, W0 = 4, RB = 4, WB = 7;
+#pragma unroll
+                    for (int m = 0; m < MG; ++m) {
+                        const int tt = m / TM, i = m % TM;
+                        if (tt == 0) TT_MFMA(acc[i][g], al[kc][i], bh[g]);
+                        else if (tt == 1) TT_MFMA(acc[i][g], ah[kc][i], bl[g]);
+                        else TT_MFMA(acc[i][g], ah[kc][i], bh[g]);
+                        const int ws = (g % NGR) * MG + m;
+                        if (m == 0) {
+                            if (g == 0) bh[TN - 1] = lds_read(sB_cur + fb_pre[kc][TN - 1]);
+                            else bh[g - 1] = lds_read(srcB + fb_pre[kn][g - 1]);
+                        }
+                        if (bar && m == 3) {
+                            // the next tile's operands have landed for this wave: its weights, and -- third tile of a run --
+                            // the next run (issued with the first two tiles).  Younger loads = this tile's share of the run
+                            if (t == 0) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                            else if (t == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        }
+                        if (ws == (barw ? RB : R0)) {
+                            // padding: a lane whose (row, tap) is outside the image reads the zero row
+                            const unsigned a0 = ((f_mask[rb] >> ntap) & 1u) ? srcA + fa_run[nkw][kn][rb] : zaddr;
+                            ra0 = lds_read(a0);
+                            ra1 = lds_read(a0 ^ 16u);
+                        }
+                        {
+                            // DMA slots: gaps 2 and 3 of a group (4 and 5 behind the barrier).  Weights: one piece per group;
+                            // run pieces: spread from group 0 on, two per group only where the count needs it (TN = 4)
+                            const int s0 = bar ? (MG >= 8 ? 5 : 4) : 2;
+                            if (kc == 1) {
+                                if (m == s0) dma(g);
+                            } else if (a_count > 0) {
+                                const int per = (a_count + TN - 1) / TN;                    // 1 (TN = 8) or 2 (TN = 4, five pieces)
+                                const int q0 = g * per;
+                                if (m == s0 && q0 < a_count) dma(q0);
+                                if (per == 2 && m == s0 + 1 && q0 + 1 < a_count) dma(q0 + 1);
+                            }
+                        }
+                        if (ws == (barw ? WB : W0)) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            asm volatile("" : "+v"(ra0), "+v"(ra1));
+                            if (g == 0) asm volatile("" : "+v"(bh[TN - 1]));
+                        }
+                        if (m == 2 * TM - 1) bl[g] = lds_read(srcB + (fb_pre[kn][g] ^ 32u));
+                        {
+                            const int first = barw ? WB : W0;
+                            const int avail = WIN - first;
+                            int lastslot;
+                            if (avail >= 16) {
+                                if (ws >= first && ((ws - first) & 1) == 0 && (ws - first) / 2 < 8) split_stage((ws - first) / 2);
+                                lastslot = first + 14;
+                            } else if (avail >= 8) {
+                                if (ws >= first && ws - first < 8) split_stage(ws - first);
+                                lastslot = first + 7;
+                            } else {
+                                if (ws >= first && ws - first < 4) {
+                                    split_stage(2 * (ws - first));
+                                    split_stage(2 * (ws - first) + 1);
+                                }
+                                lastslot = first + 3;
+                            }
+                            if (ws == lastslot) {
+                                ah[kn][rb] = u32x4{sh[0], sh[1], sh[2], sh[3]};
+                                al[kn][rb] = u32x4{sl[0], sl[1], sl[2], sl[3]};
+                                asm volatile("" : "+v"(ah[kn][rb]), "+v"(al[kn][rb]));
+                            }
+                        }
+                        // walkers: the run walker after the run's last piece went out (second tile), the weight walker every tile
+                        if (last && kc == 0 && t == 1 && m == MG - 2) run_walk();     // (a dozen SALU once per run: not pinned)
+                        if (last && kc == 1) {
+                            if (m == MG - 3) {
+                                asm volatile("" : "+s"(b_tap), "+s"(b_off));
+                                b_walk1();
+                                asm volatile("" : "+s"(b_tap), "+s"(b_off));
+                            }
+                            if (m == MG - 2) {
+                                asm volatile("" : "+s"(b_rem), "+s"(b_st));
+                                b_walk2();
+                                asm volatile("" : "+s"(b_rem), "+s"(b_st));
+                            }
+                            if (m == MG - 1) {
+                                asm volatile("" : "+s"(sB_cur), "+s"(sB_nxt));
+                                const unsigned tb = sB_cur;
+                                sB_cur = sB_nxt;
+                                sB_nxt = tb;
+                                asm volatile("" : "+s"(sB_cur), "+s"(sB_nxt));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned tr = sR_cur;
+        sR_cur = sR_nxt;
+        sR_nxt = tr;
+        tap0 = tap0_nxt;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_epilogue<float, 1, TN, 32, WTN>(p, *reinterpret_cast<f32x16(*)[1][TN]>(&acc[0]), smem, wave, lane, wm * TM + 0, 0, m0, n0, Mlim);
+    conv_epilogue<float, 1, TN, 32, WTN>(p, *reinterpret_cast<f32x16(*)[1][TN]>(&acc[1]), smem, wave, lane, wm * TM + 1, 0, m0, n0, Mlim);
+#endif
+}
+
 static bool grid_is_2x2() {
     static const int grid = [] { const char* e = getenv("TT_X3_PIPE"); return e ? atoi(e) : 2; }();
     return grid == 1;
@@ -460,6 +833,29 @@ int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int 
     int tiles_m = div_up(a.M - a.m_begin, 256);
     if (m_tiles_limit > 0 && m_tiles_limit < tiles_m) tiles_m = m_tiles_limit;
     const int tiles_n = a.Cout / bn;
+    // 3 x 3 stride-1 "same" convolutions over a dense batch: the run-staged form (one staged pixel run per filter row serves
+    // its three taps).  TT_X3_RUN3=0: the per-tap form everywhere (A/B knob)
+    static const bool run3 = [] { const char* e = getenv("TT_X3_RUN3"); return e ? atoi(e) != 0 : true; }();
+    if (run3 && a.KW == 3 && a.KH <= 5 && a.stride == 1 && a.dil == 1 && a.pad == 1 && a.OH == a.H && a.OW == a.W &&
+        (a.N == 1 || a.in_nstride == (long long)a.H * a.W * a.in_cstride) && !grid_is_2x2()) {
+        const size_t smem_r = (size_t)2 * 288 * 128 + (size_t)2 * bn * 128 + 256;
+        auto kr = bn == 128 ? conv_x3_run3_kernel<128> : conv_x3_run3_kernel<256>;
+        static bool attr_r = false;
+        if (!attr_r) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_run3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      2 * 288 * 128 + 2 * 128 * 128 + 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_run3_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      2 * 288 * 128 + 2 * 256 * 128 + 256);
+            attr_r = true;
+        }
+        a.tiles_n = tiles_n;
+        a.splits = 1;
+        a.ws = nullptr;
+        if (a.m_begin == 0)
+            snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_x3_run3_kernel<%d>%s", bn, m_tiles_limit > 0 ? " + tail" : "");
+        hipLaunchKernelGGL(kr, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), smem_r, st, a, zp, tiles_m, tiles_n);
+        return 1;
+    }
     // activation ring 3 x 32 KiB + weight ring 2 x (bn x 128 B); the epilogue stages 4 x 32 x (WTN + 4) floats
     size_t smem = (size_t)(3 * 256 + 2 * bn) * 128;
     const size_t epi = (size_t)4 * 32 * ((bn == 128 ? 128 : (grid_is_2x2() ? 128 : 256)) + 4) * 4;
