@@ -714,7 +714,15 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
         return (double)((tiles + kNumCU - 1) / kNumCU) * bn / rate;
     };
     const bool wide = a.Cout % 256 == 0 || a.Cout > 512;
-    const double c256 = wide ? cost(256, 1.0) : 1e30;
+    // 256-wide with a tail split: the main launch's full rounds + the peeled row tiles as 256 x 64 tiles
+    auto cost256 = [&]() {
+        const int main_rows = tail_split_rows(a);
+        if (!main_rows) return cost(256, 1.0);
+        const long long tn = a.Cout / 256;
+        const long long main_tiles = (long long)main_rows * tn, tail_tiles = (long long)(tiles_m - main_rows) * tn * 4;
+        return (double)((main_tiles + kNumCU - 1) / kNumCU) * 256 / 1.0 + (double)((tail_tiles + kNumCU - 1) / kNumCU) * 64 / 0.63;
+    };
+    const double c256 = wide ? cost256() : 1e30;
     // (long-K layers run the 128-wide tile on the hand-pipelined kernel: 404 vs 423 TF/s for the 256-wide one, profiles/r04_run3_ab.txt)
     const double c128 = a.Cout > 64 ? cost(128, (a.K >= 1152 && a.Cout % 128 == 0) ? 0.95 : 0.85) : 1e30;
     const double c64 = cost(64, 0.63);
