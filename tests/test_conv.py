@@ -385,3 +385,78 @@ def test_run_staged_sparse_conv_on_cell_ordered_rulebooks(Cin, Cout, stride, occ
     err = float((got[:live] - ref).abs().max() / ref.abs().max())
     assert err < 1e-4, err
     assert bool((got[live:] == 123.0).all())          # rows beyond the live count are not written
+
+
+# Shapes that take the round-4 hand-pipelined bf16x3 kernels (csrc/conv_x3_pipe.hip): K >= 1152, Cout % 128 == 0, M > 4096.
+# (N, H, W, Cin, Cout, k, stride, act, bn, residuals, in_window, expected kernel)
+PIPE_CASES = [   # (M sized so that the tile cost model picks the wide tile: ~256 tiles of 256 rows)
+    (4, 128, 128, 128, 256, 3, 1, 1, True, 1, False, "conv_x3_run3_kernel<256>"),    # 3x3 "same": run-staged, 256-wide
+    (5, 100, 130, 160, 256, 3, 1, 0, False, 0, False, "conv_x3_run3_kernel<256>"),   # ragged M (253.9 tiles), 5 channel chunks
+    (2, 128, 128, 128, 512, 3, 1, 1, True, 0, False, "conv_x3_run3_kernel<256>"),    # two column tiles
+    (4, 128, 128, 128, 128, 3, 1, 1, True, 2, False, "conv_x3_run3_kernel<128>"),    # 128-wide, two residuals (rolled epilogue)
+    (4, 128, 128, 128, 256, 3, 1, 3, False, 0, True, "conv_x3_run3_kernel<256>"),    # input = channel window of a wider buffer, GELU
+    (4, 256, 256, 128, 256, 3, 2, 1, True, 0, False, "conv_x3_pipe_kernel<4, 1>"),   # stride 2: per-tap pipelined tile
+    (4, 128, 128, 1152, 256, 1, 1, 1, True, 1, False, "conv_x3_pipe_kernel<4, 1>"),  # 1x1 with a long K
+    (4, 256, 256, 128, 128, 3, 2, 0, False, 0, False, "conv_x3_pipe_kernel<4, 1, 128>"),
+    (1, 1, 65536, 128, 256, 3, 1, 1, True, 0, False, "conv_x3_run3_kernel<256>"),    # ONE image row: no vertical neighbours at all
+    (64, 32, 32, 128, 256, 3, 1, 1, False, 0, False, "conv_x3_run3_kernel<256>"),    # 32 x 32 images: 4 images per tile, 8 rows per image row
+]
+
+
+@pytest.mark.parametrize("case", PIPE_CASES, ids=[c[-1] + f"-{i}" for i, c in enumerate(PIPE_CASES)])
+def test_pipelined_bf16x3_tiles_match_torch_f32(case, monkeypatch):
+    """The 4-wave hand-pipelined tiles and their run-staged 3x3 form against torch f32 (1e-4) and against the exact-f32
+    kernel, on shapes with padding on every side, ragged M, image-row boundaries inside a tile, stride 2 and channel-window
+    inputs -- with the kernel that ran asserted (a dispatch change must not silently move these shapes elsewhere)."""
+    from thinktwice_amd import ops, weights
+    N, H, W, Cin, Cout, k, stride, act, use_bn, res, window, kern = case
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + H)
+    pad = k // 2
+    x = _mk((N, Cin, H, W), g)
+    w = _mk((Cout, Cin, k, k), g, (Cin * k * k) ** -0.5)
+    scale = (torch.rand(Cout, generator=g) + 0.5) if use_bn else None
+    shift = _mk((Cout,), g, 0.3)
+    xq = weights.to_channel_last(x, torch.float32)
+    in_coff = 0
+    if window:       # the layer reads channels [32, 32 + Cin) of a (N, H, W, Cin + 64) buffer (torch.cat that never copies)
+        wide = _mk((N, H, W, Cin + 64), g)
+        wide[..., 32:32 + Cin] = xq
+        xq, in_coff = wide, 32
+    xq = xq.cuda()
+    wq = weights.prep_conv_weight(w, torch.float32).cuda()
+    wx = weights.split_pairs_x3(wq)
+    ref = F.conv2d(x, w, None, stride, pad)
+    if scale is not None:
+        ref = ref * scale.view(1, -1, 1, 1)
+    ref = ref + shift.view(1, -1, 1, 1)
+    rs = []
+    for _ in range(res):
+        r = _mk(tuple(ref.shape), g).permute(0, 2, 3, 1).contiguous()
+        ref = ref + r.permute(0, 3, 1, 2)
+        rs.append(r.cuda())
+    ref = {0: lambda t: t, 1: F.relu, 3: F.gelu}[act](ref)
+    kw = dict(stride=stride, pad=pad, scale=None if scale is None else scale.cuda(), shift=shift.cuda(), act=act,
+              res1=rs[0] if res >= 1 else None, res2=rs[1] if res >= 2 else None, in_coff=in_coff, cin=Cin)
+    out = ops.conv2d(xq, wq, w_x3=wx, **kw)
+    assert ops._last_conv_kernel().replace(" + tail", "") == kern, ops._last_conv_kernel()
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+    assert err < 1e-4, err
+    exact = ops.conv2d(xq, wq, **kw)
+    e2 = float((out - exact).abs().max() / exact.abs().max())
+    assert 0 < e2 < 5e-5, e2
+    assert torch.equal(out, ops.conv2d(xq, wq, w_x3=wx, **kw))        # repeatable: no race in the pipeline
+
+
+def test_pipelined_tiles_are_bit_identical_to_the_8wave_tiles():
+    """tools/x3_pipe_ab.py: every arm in its own process (the knobs are read once), outputs compared bit for bit -- 256-wide
+    (8-wave tile vs the pipelined / run-staged kernels) and 128-wide -- plus repeatability and the exact-f32 distance."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for env_extra, arms in (({}, "0,2"), ({"TT_AB_SET": "128"}, "0,1"), ({"TT_X3_RUN3": "0"}, "0,2")):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "x3_pipe_ab.py"), "1", arms], cwd=root,
+                           env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "ALL OK" in r.stdout, (env_extra, r.stdout[-1500:], r.stderr[-500:])
