@@ -693,6 +693,13 @@ int tt_plan_add_reloc(tt_plan* plan, long long blob_offset, int buffer, long lon
 int tt_plan_add_call(tt_plan* plan, const char* entry, int nargs, const int* kinds, const int* buffers, const long long* ivals,
                      const double* fvals, int stream_slot);
 int tt_plan_add_sync(tt_plan* plan, int waiter_stream_slot, int signal_stream_slot);
+/* Builder only.  Declare one allocation of the activation arena (address order, no overlap), then let the plan re-place the
+ * allocations by liveness: tt_plan_compact_arena rewrites every pointer into buffer `arena_buffer` (call arguments, pointers
+ * inside argument blobs, outputs) and returns the arena's new size in bytes (< 0 on error, plan unchanged).  Memory is handed
+ * on only between allocations whose every use is on ONE stream (stream order makes the reuse safe); outputs keep their own.
+ * (replaces the caching allocator torch gives the reference's eager forward, encoder_decoder_framework.py:194-235) */
+int tt_plan_add_arena_alloc(tt_plan* plan, long long offset, long long nbytes);
+long long tt_plan_compact_arena(tt_plan* plan, int arena_buffer, long long align);
 /* outputs: where a host finds a result tensor -- byte offset of element 0 inside `buffer`, shape and ELEMENT strides (f32) */
 int tt_plan_add_output(tt_plan* plan, const char* name, int buffer, long long offset, int ndim, const long long* shape,
                        const long long* stride);

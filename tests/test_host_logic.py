@@ -289,3 +289,79 @@ def test_plan_load_rejects_malformed_files(tmp_path):
         ok, err = load(data)
         assert not ok, f"{what}: a malformed plan loaded"
         assert what.split(" (")[0] in err, (what, err)
+
+
+def test_plan_arena_compaction_reuses_memory_by_liveness_and_stream():
+    """tt_plan_compact_arena (round 4): temporaries of the recorded forward are re-placed by liveness.  Memory moves on only
+    between allocations whose every use is on one stream; buffers seen from two streams and outputs keep their own; pointers
+    inside argument blobs count as uses; a pointer outside every declared allocation leaves the plan untouched."""
+    import ctypes
+    from thinktwice_amd import _lib
+    L = _lib.lib()
+    L.tt_plan_create.restype = ctypes.c_void_p
+    L.tt_plan_compact_arena.restype = ctypes.c_longlong
+    L.tt_plan_add_blob.restype = ctypes.c_longlong
+    ll, ci = ctypes.c_longlong, ctypes.c_int
+
+    def build(allocs, calls, outputs=(), bad_ptr=None):
+        """calls: (stream, [arena offsets used as the dst of a tt_fill_u32])."""
+        p = ctypes.c_void_p(L.tt_plan_create())
+        assert L.tt_plan_set_buffer(p, 0, ll(64), b"weights") == 0 and L.tt_plan_set_buffer(p, 1, ll(1 << 20), b"arena") == 0
+        for off, n in allocs:
+            assert L.tt_plan_add_arena_alloc(p, ll(off), ll(n)) == 0
+        for stream, offs in calls:
+            for off in offs:
+                kinds, bufs = (ci * 3)(2, 0, 0), (ci * 3)(1, 0, 0)
+                iv, fv = (ll * 3)(off, 1, 0), (ctypes.c_double * 3)()
+                assert L.tt_plan_add_call(p, b"tt_fill_u32", ci(3), kinds, bufs, iv, fv, ci(stream)) == 0
+        for name, off in outputs:
+            sh = (ll * 8)(4)
+            assert L.tt_plan_add_output(p, name, ci(1), ll(off), ci(1), sh, sh) == 0
+        if bad_ptr is not None:
+            kinds, bufs = (ci * 3)(2, 0, 0), (ci * 3)(1, 0, 0)
+            assert L.tt_plan_add_call(p, b"tt_fill_u32", ci(3), kinds, bufs, (ll * 3)(bad_ptr, 1, 0), (ctypes.c_double * 3)(), ci(0)) == 0
+        return p
+
+    def arg_offsets(p, tmp):
+        """arena offsets of the calls after compaction, read back through save + the file format."""
+        import struct
+        assert L.tt_plan_save(p, tmp.encode()) == 0
+        raw = open(tmp, "rb").read()
+        offs, i = [], 0
+        needle = struct.pack("<q", len(b"tt_fill_u32")) + b"tt_fill_u32"
+        while True:
+            i = raw.find(needle, i)
+            if i < 0:
+                break
+            j = i + len(needle) + 16            # stream, nargs
+            kind, buf, val = struct.unpack_from("<qqq", raw, j)
+            assert kind == 2 and buf == 1
+            offs.append(val)
+            i = j
+        return offs
+
+    import tempfile
+    tmp = tempfile.mktemp(suffix=".plan")
+    A, B, C, D = (0, 1024), (1024, 1024), (2048, 512), (4096, 1024)
+    # stream 0: A used by ops 0-1, then B (op 2), then C (op 3), D is an output written by op 4: B reuses A's block, C fits too
+    p = build([A, B, C, D], [(0, [0, 512]), (0, [1024]), (0, [2048]), (0, [4096])], outputs=[(b"out", 4096)])
+    nb = L.tt_plan_compact_arena(p, ci(1), ll(256))
+    offs = arg_offsets(p, tmp)
+    assert offs[0] == 0 and offs[1] == 512                      # A at 0 (interior pointer keeps its distance)
+    assert offs[2] == 0                                         # B took A's block (A died at op 1, B born at op 2)
+    assert offs[3] in (0, 1024) and offs[3] != offs[4]          # C reuses B's (or a remainder); never the output's
+    assert nb <= 1024 + 1024 + 256 and nb < 5120                # smaller than the bump layout
+    L.tt_plan_destroy(p)
+    # two streams: B lives on stream 1 -> may not take A's block (A's uses are on stream 0); E touched by both streams keeps its own
+    E = (5120, 1024)
+    p = build([A, B, E], [(0, [0]), (1, [1024]), (0, [5120]), (1, [5120 + 4])])
+    assert L.tt_plan_compact_arena(p, ci(1), ll(256)) == 3 * 1024
+    offs = arg_offsets(p, tmp)
+    assert len({offs[0], offs[1], offs[2]}) == 3 and offs[3] == offs[2] + 4
+    L.tt_plan_destroy(p)
+    # a pointer in no declared allocation: refused, plan unchanged
+    p = build([A], [(0, [0])], bad_ptr=3000)
+    assert L.tt_plan_compact_arena(p, ci(1), ll(256)) < 0
+    assert arg_offsets(p, tmp) == [0, 3000]
+    L.tt_plan_destroy(p)
+    os.remove(tmp)

@@ -377,21 +377,25 @@ class ForwardWorkload:
         out["eager_prev_sweep_cache_ms"] = timed(
             lambda: self.model.forward_inference(b1, channel_last_out=True, prev_bev=key))
         try:
+            # the same tick issued from C: a compiled launch plan (thinktwice_amd/plan.py), tt_encoder_fwd + tt_decoder_fwd.
+            # Timed BEFORE the graph legs: after a HIP graph has been captured and replayed in the process, plain multi-stream
+            # launches of the same kernels measure ~2.5 ms slower per tick (22.6 vs 20.0 ms, profiles/r04_tick_notes.txt)
+            from . import plan as P
+            fp = P.compile_forward(self.model, b1, channel_last_out=True)
+            out["c_plan_ms"] = timed(fp.run)
+            out["c_plan_calls"], out["c_plan_streams"] = fp.calls, fp.nstreams
+            out["c_plan_arena_gb"] = round(fp.arena.numel() / 1e9, 2)
+            out["c_plan_arena_bump_gb"] = round(fp.recorded_arena_bytes / 1e9, 2)
+            del fp
+        except Exception as e:
+            out["c_plan_error"] = f"{type(e).__name__}: {e}"[:300]
+        try:
             g = InferenceGraph(self.model, b1, channel_last_out=True)
             out["graph_ms"] = timed(g.replay)
             gc = InferenceGraph(self.model, b1, channel_last_out=True, prev_bev=key)
             out["graph_prev_sweep_cache_ms"] = timed(gc.replay)
         except Exception as e:
             out["graph_error"] = f"{type(e).__name__}: {e}"
-        try:
-            # the same tick issued from C: a compiled launch plan (thinktwice_amd/plan.py), tt_encoder_fwd + tt_decoder_fwd
-            from . import plan as P
-            fp = P.compile_forward(self.model, b1, channel_last_out=True)
-            out["c_plan_ms"] = timed(fp.run)
-            out["c_plan_calls"], out["c_plan_streams"] = fp.calls, fp.nstreams
-            del fp
-        except Exception as e:
-            out["c_plan_error"] = f"{type(e).__name__}: {e}"[:300]
         return out
 
     def cpu_baseline(self):

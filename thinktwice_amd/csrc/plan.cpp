@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -64,6 +65,11 @@ struct PlanReloc {             // a device pointer stored INSIDE a host blob (de
     long long blob_offset;
     int buffer;
     long long offset;
+    int op = -1;               // builder only: index of the call whose argument blob holds it (arena liveness; not serialised)
+};
+
+struct PlanAlloc {             // builder only: one allocation of the activation arena (tt_plan_add_arena_alloc)
+    long long offset, bytes;
 };
 
 struct PlanOp {
@@ -94,6 +100,7 @@ struct tt_plan {
     std::vector<unsigned char> blob;          // pristine host blob (relocations unresolved)
     std::vector<tt::PlanBuffer> buffers;
     std::vector<tt::PlanOutput> outputs;
+    std::vector<tt::PlanAlloc> allocs;        // builder only (consumed by tt_plan_compact_arena)
     int nstreams = 1;
     // bound state
     std::vector<unsigned char> bound_blob;
@@ -196,9 +203,145 @@ extern "C" long long tt_plan_add_blob(tt_plan* p, const void* bytes, long long n
 
 extern "C" int tt_plan_add_reloc(tt_plan* p, long long blob_offset, int buffer, long long offset) {
     TT_REQUIRE(p && blob_offset >= 0 && blob_offset + 8 <= (long long)p->blob.size(), "tt_plan_add_reloc: outside the blob");
-    p->relocs.push_back(PlanReloc{blob_offset, buffer, offset});
+    // (relocations are declared while the arguments of the NEXT call are assembled: that call's index is ops.size())
+    p->relocs.push_back(PlanReloc{blob_offset, buffer, offset, (int)p->ops.size()});
     p->bound = false;
     return 0;
+}
+
+// ---- arena compaction.  The plan compiler serves every temporary of the recorded forward from a bump arena (no reuse: ~6 GB per
+// full-size frame), which is what the recorded pointers refer to.  Replayed from C that arena is cold memory on every tick -- each
+// temporary a first touch of its pages -- where torch's caching allocator hands the eager forward the same hot blocks again and
+// again (round 3: 23.5 ms from the plan against 21.5 eager).  The compiler therefore also declares the allocations
+// (tt_plan_add_arena_alloc), and tt_plan_compact_arena re-places them by LIVENESS: an allocation is live from the first to the
+// last op that names an address inside it (call arguments and pointers inside argument blobs); outputs stay live to the end.
+// Reuse is by stream order only: a block is handed on only between allocations whose EVERY use sits on one and the same
+// stream (ops of one stream run in plan order); anything touched from two streams keeps its own memory.
+extern "C" int tt_plan_add_arena_alloc(tt_plan* p, long long offset, long long nbytes) {
+    TT_REQUIRE(p && offset >= 0 && nbytes >= 0, "tt_plan_add_arena_alloc: bad argument");
+    TT_REQUIRE(p->allocs.empty() || offset >= p->allocs.back().offset + p->allocs.back().bytes,
+               "tt_plan_add_arena_alloc: allocations must be declared in address order without overlap");
+    p->allocs.push_back(PlanAlloc{offset, nbytes});
+    return 0;
+}
+
+extern "C" long long tt_plan_compact_arena(tt_plan* p, int arena_buffer, long long align) {
+    if (!p || arena_buffer < 0 || arena_buffer >= (int)p->buffers.size() || align <= 0) {
+        set_error("tt_plan_compact_arena: bad argument");
+        return -1;
+    }
+    const size_t n = p->allocs.size();
+    struct Info {
+        int first = 0x7fffffff, last = -1, stream = -2;      // stream: -2 unused, -1 several, >= 0 the one stream of every use
+        bool pinned = false;
+        long long new_off = 0, size = 0;
+    };
+    std::vector<Info> info(n);
+    auto find = [&](long long off) -> long long {            // allocation holding arena offset `off`, or -1
+        size_t lo = 0, hi = n;
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (p->allocs[mid].offset <= off) lo = mid + 1; else hi = mid;
+        }
+        if (lo == 0) return -1;
+        const PlanAlloc& a = p->allocs[lo - 1];
+        return (off < a.offset + (a.bytes > 0 ? a.bytes : 1)) ? (long long)(lo - 1) : -1;
+    };
+    bool all_found = true;
+    auto touch = [&](long long off, int op, int stream) {
+        const long long k = find(off);
+        if (k < 0) { all_found = false; return; }
+        Info& f = info[(size_t)k];
+        if (op < f.first) f.first = op;
+        if (op > f.last) f.last = op;
+        f.stream = f.stream == -2 ? stream : (f.stream == stream ? stream : -1);
+    };
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const PlanOp& o = p->ops[i];
+        if (o.kind != 0) continue;
+        for (int k = 0; k < o.nargs; ++k) {
+            const PlanArgRec& a = p->args[o.first_arg + k];
+            if (a.kind == kDevPtr && a.buffer == arena_buffer) touch(a.value, (int)i, o.stream);
+        }
+    }
+    for (const PlanReloc& r : p->relocs)
+        if (r.buffer == arena_buffer) {
+            if (r.op < 0 || r.op >= (int)p->ops.size() || p->ops[r.op].kind != 0) { all_found = false; continue; }
+            touch(r.offset, r.op, p->ops[r.op].stream);
+        }
+    for (const PlanOutput& o : p->outputs)
+        if (o.buffer == arena_buffer) {
+            const long long k = find(o.offset);
+            if (k < 0) all_found = false; else info[(size_t)k].pinned = true;
+        }
+    if (!all_found) {
+        set_error("tt_plan_compact_arena: an arena pointer of the plan lies in no declared allocation (nothing was changed)");
+        return -1;
+    }
+    auto up = [&](long long v) { return (v + align - 1) / align * align; };
+    std::vector<size_t> order;
+    for (size_t i = 0; i < n; ++i) {
+        info[i].size = up(p->allocs[i].bytes);
+        if (info[i].stream != -2 || info[i].pinned) order.push_back(i);      // (never-referenced allocations get no memory)
+    }
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+        return info[a].first != info[b].first ? info[a].first < info[b].first : a < b;
+    });
+    struct Block { long long off, size; int stream, free_after; };
+    std::vector<Block> free_blocks;
+    std::vector<size_t> active;                               // placed, single-stream, not pinned: released once their last op is past
+    long long top = 0;
+    for (size_t idx : order) {
+        Info& f = info[idx];
+        for (size_t k = 0; k < active.size();) {              // release what died before this allocation's first use
+            const Info& g = info[active[k]];
+            if (g.last < f.first) {
+                free_blocks.push_back(Block{g.new_off, g.size, g.stream, g.last});
+                active[k] = active.back();
+                active.pop_back();
+            } else {
+                ++k;
+            }
+        }
+        long long place = -1;
+        if (f.stream >= 0 && !f.pinned && f.size > 0) {
+            int best = -1;
+            for (size_t k = 0; k < free_blocks.size(); ++k) {
+                const Block& b = free_blocks[k];
+                if (b.stream == f.stream && b.free_after < f.first && b.size >= f.size &&
+                    (best < 0 || b.size < free_blocks[best].size)) best = (int)k;
+            }
+            if (best >= 0) {
+                Block b = free_blocks[best];
+                place = b.off;
+                if (b.size > f.size) free_blocks[best] = Block{b.off + f.size, b.size - f.size, b.stream, b.free_after};
+                else { free_blocks[best] = free_blocks.back(); free_blocks.pop_back(); }
+            }
+        }
+        if (place < 0) { place = top; top += f.size; }
+        f.new_off = place;
+        if (f.stream >= 0 && !f.pinned && f.size > 0) active.push_back(idx);
+    }
+    // rewrite every arena pointer
+    auto moved = [&](long long off) {
+        const long long k = find(off);
+        return info[(size_t)k].new_off + (off - p->allocs[(size_t)k].offset);
+    };
+    for (const PlanOp& o : p->ops) {
+        if (o.kind != 0) continue;
+        for (int k = 0; k < o.nargs; ++k) {
+            PlanArgRec& a = p->args[o.first_arg + k];
+            if (a.kind == kDevPtr && a.buffer == arena_buffer) a.value = moved(a.value);
+        }
+    }
+    for (PlanReloc& r : p->relocs)
+        if (r.buffer == arena_buffer) r.offset = moved(r.offset);
+    for (PlanOutput& o : p->outputs)
+        if (o.buffer == arena_buffer) o.offset = moved(o.offset);
+    p->allocs.clear();
+    p->buffers[arena_buffer].bytes = up(top > 0 ? top : align);
+    p->bound = false;
+    return p->buffers[arena_buffer].bytes;
 }
 
 // kinds[i] / buffers[i] / ivals[i] / fvals[i]: see ArgKind.  The entry's trailing `stream` argument is not listed: the call

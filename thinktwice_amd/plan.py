@@ -158,6 +158,7 @@ class PlanBuilder:
         self.streams = {}            # cuda_stream handle -> slot
         self.calls = 0
         self.marks = {}
+        self.compacted_bytes = None
 
     # ---------------------------------------------------------------- ctypes signatures of the plan API
     def _declare(self):
@@ -165,6 +166,7 @@ class PlanBuilder:
         L.tt_plan_create.restype = ctypes.c_void_p
         L.tt_plan_load.restype = ctypes.c_void_p
         L.tt_plan_add_blob.restype = ctypes.c_longlong
+        L.tt_plan_compact_arena.restype = ctypes.c_longlong
         L.tt_plan_buffer_bytes.restype = ctypes.c_longlong
         L.tt_plan_buffer_name.restype = ctypes.c_char_p
 
@@ -217,6 +219,9 @@ class PlanBuilder:
         if off + nbytes > self.arena.numel():
             raise PlanBuildError(f"activation arena exhausted ({self.arena.numel()} bytes): pass a larger arena_bytes")
         self.arena_top = off + nbytes
+        if nbytes:      # declared to the plan: tt_plan_compact_arena re-places the allocations by liveness after the recording
+            _lib.check(self.L.tt_plan_add_arena_alloc(self.plan, ctypes.c_longlong(off), ctypes.c_longlong(nbytes)),
+                       "tt_plan_add_arena_alloc")
         t = self.arena[off:off + nbytes].view(dtype).view(*shape) if nbytes else torch.empty(shape, dtype=dtype, device=self.device)
         if zero:
             self.emit_fill(t, 0)
@@ -389,7 +394,14 @@ class ForwardPlan:
 
     def __init__(self, builder, outputs, inputs, consts):
         self.L, self.plan, self.device = builder.L, builder.plan, builder.device
-        self.arena = builder.arena[:(builder.arena_top + ALIGN - 1) // ALIGN * ALIGN]
+        self.recorded_arena_bytes = (builder.arena_top + ALIGN - 1) // ALIGN * ALIGN
+        if builder.compacted_bytes is not None:
+            # the plan's arena pointers were re-placed by liveness: a fresh, smaller arena; the outputs move with it
+            self.arena = torch.empty(builder.compacted_bytes, dtype=torch.uint8, device=self.device)
+            outputs = self._outputs_from_plan(outputs)
+            builder.arena = None
+        else:
+            self.arena = builder.arena[:self.recorded_arena_bytes]
         self.weights_blob = torch.zeros(max(builder.weights_bytes, ALIGN), dtype=torch.uint8, device=self.device)
         for view, off in builder.weights:
             self.weights_blob[off:off + view.numel()].copy_(view)
@@ -399,6 +411,25 @@ class ForwardPlan:
         self.calls = int(self.L.tt_plan_num_calls(self.plan))
         self._streams = [torch.cuda.Stream(self.device) for _ in range(self.nstreams)]
         self.bind()
+
+    def _outputs_from_plan(self, recorded):
+        """name -> view of self.arena, from the plan's own output table (buffer, offset, shape, element strides); outputs that
+        do not live in the arena keep the recorded tensor."""
+        L = self.L
+        name, bid, off, nd = ctypes.c_char_p(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_int()
+        shape, stride = (ctypes.c_longlong * 8)(), (ctypes.c_longlong * 8)()
+        out = {}
+        for i in range(L.tt_plan_num_outputs(self.plan)):
+            _lib.check(L.tt_plan_output(self.plan, i, ctypes.byref(name), ctypes.byref(bid), ctypes.byref(off), ctypes.byref(nd),
+                                        shape, stride), "tt_plan_output")
+            k = name.value.decode()
+            if k not in recorded:
+                continue
+            if bid.value != PlanBuilder.ARENA:
+                out[k] = recorded[k]
+                continue
+            out[k] = torch.as_strided(self.arena[off.value:].view(recorded[k].dtype), list(shape)[:nd.value], list(stride)[:nd.value])
+        return out
 
     def bases(self):
         nb = int(self.L.tt_plan_num_buffers(self.plan))
@@ -512,4 +543,10 @@ def compile_forward(model, batch, arena_bytes=None, channel_last_out=False, prev
     first = b.marks.get("decoder", int(L.tt_plan_num_ops(b.plan)))
     _lib.check(L.tt_plan_add_output(b.plan, b"__decoder_first_op", ctypes.c_int(-1), ctypes.c_longlong(first), ctypes.c_int(0),
                                     None, None), "tt_plan_add_output")
+    # liveness-based re-placement of the arena (TT_PLAN_COMPACT=0: keep the bump layout, A/B knob)
+    b.compacted_bytes = None
+    if os.environ.get("TT_PLAN_COMPACT", "1") != "0":
+        nb = int(L.tt_plan_compact_arena(b.plan, ctypes.c_int(PlanBuilder.ARENA), ctypes.c_longlong(ALIGN)))
+        if nb > 0:
+            b.compacted_bytes = nb
     return ForwardPlan(b, outputs, inputs, consts)
