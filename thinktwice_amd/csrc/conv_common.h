@@ -41,7 +41,8 @@ struct ConvArgs {
     int tiles_n;
     int m_begin;         // first output row of this launch (tail-split launches of the LDS-DMA kernel), else 0
     int ws_slices;       // split-K: > 0 = every split stores into its own [M][Cout] slice of ws (ordered finalize)
-    int flags;           // bit 0: s_setprio(1) around the MFMA groups of the LDS-DMA kernel (TT_GLDS_SETPRIO=1, A/B knob)
+    int flags;           // bit 3: whole-tile DMA issue in the x3 256-wide 8-wave tile (TT_GLDS_X3_SPREAD=0); bit 4: non-temporal
+                         // f32 output stores; < 0: split-K query (no launch)
 };
 
 template <typename T> struct Mfma;
@@ -173,9 +174,12 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
         }
         return (long long)n * p.out_nstride + ((long long)oh * OWo + ow) * p.out_cstride + p.out_coff + cc;
     };
+    const bool nt_store = (p.flags & 16) != 0;      // non-temporal f32 output stores (default; TT_CONV_NT_STORE=0 turns them off)
     auto store_row = [&](long long o, const float (&v)[CO]) {
         if constexpr (CO == 4) {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            if (nt_store) __builtin_nontemporal_store(f4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4v*>(reinterpret_cast<float*>(p.out) + o));
+            else *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
             // 16-bit output: the storage type of the operands (f32-compute layers never take the CO == 8 path)
             using T16 = typename std::conditional<sizeof(T) == 2, T, uint16_t>::type;

@@ -377,6 +377,10 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     {
         static const bool spread = [] { const char* e = getenv("TT_GLDS_X3_SPREAD"); return !(e && e[0] == '0'); }();   // A/B knob
         a.flags = spread ? 0 : 8;
+        // f32 outputs are written once and read by a LATER launch: non-temporal stores keep them from displacing the tile operands
+        // in L2 / MALL (+0.3-0.5 % on the forward, profiles/r04_nt_store.txt).  TT_CONV_NT_STORE=0: plain stores (A/B knob)
+        static const bool nt_store = [] { const char* e = getenv("TT_CONV_NT_STORE"); return e ? atoi(e) != 0 : true; }();
+        if (nt_store) a.flags |= 16;
     }
     if (query) a.flags = -1;       // launch_conv returns the split count instead of launching
     {
