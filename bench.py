@@ -179,7 +179,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        import datetime
+        # (a rank that dies inside a collective must not leave the others waiting for the default 10 minutes)
+        dist.init_process_group(backend="nccl", device_id=device, timeout=datetime.timedelta(minutes=4))
 
     name = args.workload
     if name == "auto":

@@ -305,7 +305,7 @@ class ForwardWorkload:
                            "data parallel, one rank per GPU, batch per GPU fixed (weak scaling); value = all ranks' samples / s"}
             if world > 1:
                 leg["value"] = round(self.B * world / dt, 3)
-                leg["all_reduce"] = w.all_reduce_report()
+                leg["all_reduce"] = getattr(w, "_all_reduce", None) or w.all_reduce_report()      # (collect() has timed it)
             del w
             torch.cuda.empty_cache()
             return leg
