@@ -203,6 +203,19 @@ typedef struct tt_chain_stage {
  * the BEV update's broadcast-channel term, 2048 -> 9 x 128) */
 int tt_mlp_chain(const float* x, long long R, int x_stride, int nstages, const tt_chain_stage* stages, int n_split,
                  void* stream);
+/* The same chain for FEW rows (the batch-1 tick: 1 - 32 rows, where a chain's time is the latency of streaming its weights
+ * through one workgroup): the 32-column blocks of every stage are dealt over `n_groups` co-resident workgroups per 32 rows, the
+ * waves of a workgroup split K; stage outputs a later stage reads go through `workspace` (f32, global) and the workgroups of
+ * a row block meet at a ticket barrier between dependent stages.  Same arithmetic per product as tt_mlp_chain (bf16x3), the K
+ * sum is taken in eight interleaved slices added in a fixed order.  Requires (R + 31) / 32 * n_groups <= 256.
+ * tt_mlp_chain_wide_faults(): blocking; non-zero if any launch so far gave up waiting at a barrier (its outputs are invalid). */
+long long tt_mlp_chain_wide_workspace_bytes(long long R, int nstages, const tt_chain_stage* stages);
+int tt_mlp_chain_wide(const float* x, long long R, int x_stride, int nstages, const tt_chain_stage* stages, int n_groups,
+                      void* workspace, long long workspace_bytes, void* stream);
+int tt_mlp_chain_wide_faults(void);
+/* debug: while set, every tt_mlp_chain_wide workgroup writes up to 64 wall-clock stamps (10 ns ticks; kernel entry, then per stage:
+ * entry, barrier passed, first block's K loop + reduction done, stage done) at stamps[(row_group * n_groups + group) * 64] */
+int tt_mlp_chain_wide_set_trace(void* stamps_or_null);
 
 /* ------------------------------------------------------------------------
  * Spatial half of a refinement layer as persistent per-sample kernels (csrc/dec_spatial.hip), bf16x3 arithmetic.

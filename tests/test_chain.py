@@ -13,11 +13,14 @@ def _lin(g, n, k, scale=None):
     return torch.randn(n, k, generator=g) * (scale or k ** -0.5), torch.randn(n, generator=g) * 0.1
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["rows", "wide"])
 @pytest.mark.parametrize("R", [5, 32, 33, 3840])
-def test_look_query_chain_matches_torch(R):
+def test_look_query_chain_matches_torch(R, wide):
     """query_linear.1 (1544 -> 512, GELU) -> .3 (512 -> 256, GELU) -> {sampling_offsets 256 -> 512,
     attention_weights 256 -> 256}: two outputs fanned out of one LDS intermediate, zero-padded input rows."""
     from thinktwice_amd import ops
+    if wide and R > 512:
+        pytest.skip("the wide form is for <= 512 rows")
     g = torch.Generator().manual_seed(R)
     x = torch.zeros(R, 1552)
     x[:, :1543] = torch.randn(R, 1543, generator=g)
@@ -33,14 +36,16 @@ def test_look_query_chain_matches_torch(R):
     off = torch.full((R, 512), float("nan"), device=dev)
     aw = torch.full((R, 300), float("nan"), device=dev)
     ops.mlp_chain(x.to(dev), [{"lin": L1, "src": -1}, {"lin": L3, "src": 0},
-                              {"lin": LO, "src": 1, "out": (off, 0)}, {"lin": LA, "src": 1, "out": (aw, 44)}])
+                              {"lin": LO, "src": 1, "out": (off, 0)}, {"lin": LA, "src": 1, "out": (aw, 44)}], wide=wide)
     torch.cuda.synchronize()
+    assert ops.chain_faults() == 0
     for got, ref in ((off.cpu(), ref_off), (aw.cpu()[:, 44:], ref_aw)):
         assert float((got - ref).abs().max() / ref.abs().max()) < 1e-4
     assert torch.isnan(aw[:, :44]).all()
 
 
-def test_residual_side_input_and_narrow_heads():
+@pytest.mark.parametrize("wide", [False, True], ids=["rows", "wide"])
+def test_residual_side_input_and_narrow_heads(wide):
     """ffn-style residual (out = W2 gelu(W1 x) + x), a side input of 2 leading columns (cat([wp, h]) @ W^T), a 2-wide
     head (traj offset) and a 4-wide head, R not a multiple of 32."""
     from thinktwice_amd import ops
@@ -66,8 +71,9 @@ def test_residual_side_input_and_narrow_heads():
               {"lin": ops.ChainLinear(wt, bt, act=1, side_k=2), "src": 1, "side": wpd},
               {"lin": ops.ChainLinear(wh, bh), "src": 2, "out": (ho, 0)},
               {"lin": ops.ChainLinear(wc, bc, act=4), "src": 2, "out": (co, 0)}]
-    ops.mlp_chain(xd, stages)
+    ops.mlp_chain(xd, stages, wide=wide)
     torch.cuda.synchronize()
+    assert ops.chain_faults() == 0
     for got, ref in ((yo.cpu(), y), (ho.cpu(), ref_h), (co.cpu(), ref_c)):
         assert float((got - ref).abs().max() / ref.abs().max()) < 1e-4, float((got - ref).abs().max() / ref.abs().max())
 
@@ -85,13 +91,22 @@ def test_wide_hidden_chain_and_lds_budget():
     xd = x.cuda()
     y = torch.empty(R, 256, device="cuda")
     L1, L2 = ops.ChainLinear(w1, b1, act=3), ops.ChainLinear(w2, b2)
-    ops.mlp_chain(xd, [{"lin": L1, "src": -1}, {"lin": L2, "src": 0, "res": (xd, 0), "out": (y, 0)}])
-    torch.cuda.synchronize()
-    assert float((y.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
+    for wide in (False, True):
+        y.fill_(float("nan"))
+        ops.mlp_chain(xd, [{"lin": L1, "src": -1}, {"lin": L2, "src": 0, "res": (xd, 0), "out": (y, 0)}], wide=wide)
+        torch.cuda.synchronize()
+        assert float((y.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
     w3, b3 = _lin(g, 8, 256)
     with pytest.raises(_lib.TTError):
         ops.mlp_chain(xd, [{"lin": L1, "src": -1}, {"lin": L2, "src": 0}, {"lin": ops.ChainLinear(w3, b3), "src": 1,
-                                                                          "out": (torch.empty(R, 8, device="cuda"), 0)}])
+                                                                          "out": (torch.empty(R, 8, device="cuda"), 0)}],
+                      wide=False)
+    # the wide form keeps its intermediates in global scratch: the same wiring runs
+    o8 = torch.empty(R, 8, device="cuda")
+    ops.mlp_chain(xd, [{"lin": L1, "src": -1}, {"lin": L2, "src": 0}, {"lin": ops.ChainLinear(w3, b3), "src": 1, "out": (o8, 0)}],
+                  wide=True)
+    ref8 = F.linear(F.linear(F.gelu(F.linear(x, w1, b1)), w2, b2), w3, b3)
+    assert float((o8.cpu() - ref8).abs().max() / ref8.abs().max()) < 1e-4
 
 
 def test_chain_rejects_bad_wiring():
@@ -100,5 +115,64 @@ def test_chain_rejects_bad_wiring():
     w1, b1 = _lin(g, 64, 32)
     w2, b2 = _lin(g, 16, 48)                # K = 48 does not match the 64 outputs of stage 0
     x = torch.zeros(8, 32, device="cuda")
-    with pytest.raises(_lib.TTError):
-        ops.mlp_chain(x, [{"lin": ops.ChainLinear(w1, b1), "src": -1}, {"lin": ops.ChainLinear(w2, b2), "src": 0}])
+    for wide in (False, True):
+        with pytest.raises(_lib.TTError):
+            ops.mlp_chain(x, [{"lin": ops.ChainLinear(w1, b1), "src": -1}, {"lin": ops.ChainLinear(w2, b2), "src": 0}], wide=wide)
+
+
+@pytest.mark.parametrize("R,groups", [(1, 1), (1, 16), (4, 36), (8, 3), (32, 16), (77, 8), (256, 16), (480, 16)])
+def test_wide_form_agrees_with_the_row_form_and_survives_concurrent_launches(R, groups):
+    """The decoder's merge chain (1024 -> 512 -> 512 -> two three-stage heads with side inputs and residuals, stages ordered
+    level by level as decoder_fused issues them): the wide form against the one-workgroup-per-32-rows kernel (same products, a
+    different K summation order: 2e-5 of the output's max), run-to-run bit-identical, and correct when two chains run
+    concurrently on two streams for many launches (tickets claimed round-robin, each barrier counter reset by its launch)."""
+    from thinktwice_amd import ops
+    g = torch.Generator().manual_seed(100 + R)
+    dev = "cuda"
+    x = torch.randn(R, 1024, generator=g).to(dev)
+    wp, ct = torch.randn(R, 2, generator=g).to(dev), torch.randn(R, 4, generator=g).to(dev)
+    m = [ops.ChainLinear(*_lin(g, 512, 1024), act=1), ops.ChainLinear(*_lin(g, 512, 512), act=1),
+         ops.ChainLinear(*_lin(g, 256, 514), act=1, side_k=2), ops.ChainLinear(*_lin(g, 64, 256), act=1),
+         ops.ChainLinear(*_lin(g, 2, 64)),
+         ops.ChainLinear(*_lin(g, 256, 516), act=1, side_k=4), ops.ChainLinear(*_lin(g, 64, 256), act=1),
+         ops.ChainLinear(*_lin(g, 4, 64))]
+
+    def run(wide, stream=None):
+        h = torch.full((R, 512), float("nan"), device=dev)
+        o2 = torch.full((R, 2), float("nan"), device=dev)
+        o4 = torch.full((R, 4), float("nan"), device=dev)
+        if wide:
+            st = [{"lin": m[0], "src": -1}, {"lin": m[1], "src": 0, "out": (h, 0)},
+                  {"lin": m[2], "src": 1, "side": wp}, {"lin": m[5], "src": 1, "side": ct},
+                  {"lin": m[3], "src": 2}, {"lin": m[6], "src": 3},
+                  {"lin": m[4], "src": 4, "res": (wp, 0), "out": (o2, 0)}, {"lin": m[7], "src": 5, "res": (ct, 0), "out": (o4, 0)}]
+        else:                                  # the row form's order in decoder_fused (one head after the other)
+            st = [{"lin": m[0], "src": -1}, {"lin": m[1], "src": 0, "out": (h, 0)},
+                  {"lin": m[2], "src": 1, "side": wp}, {"lin": m[3], "src": 2},
+                  {"lin": m[4], "src": 3, "res": (wp, 0), "out": (o2, 0)},
+                  {"lin": m[5], "src": 1, "side": ct}, {"lin": m[6], "src": 5},
+                  {"lin": m[7], "src": 6, "res": (ct, 0), "out": (o4, 0)}]
+        ops.mlp_chain(x, st, wide=wide, groups=groups)
+        return h, o2, o4
+
+    ref = run(False)
+    got = run(True)
+    again = run(True)
+    torch.cuda.synchronize()
+    for a, b, c in zip(ref, got, again):
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max() / a.abs().max()) < 2e-5, float((a - b).abs().max() / a.abs().max())
+        assert torch.equal(b, c)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1.wait_stream(torch.cuda.current_stream())
+    s2.wait_stream(torch.cuda.current_stream())
+    outs = []
+    for it in range(40):
+        for s in (s1, s2):
+            with torch.cuda.stream(s):
+                outs.append(run(True))
+    torch.cuda.synchronize()
+    assert ops.chain_faults() == 0
+    for o in outs:
+        for b, c in zip(got, o):
+            assert torch.equal(b, c)

@@ -224,6 +224,264 @@ __global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_kernel(const Chain
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The WIDE form (tt_mlp_chain_wide): few rows, so the time of a chain is the latency of streaming its weights -- one workgroup
+// keeps ~128 KiB of loads in flight and gets ~45 GB/s out of the L2 (a 4.4 MB chain: 90-120 us; the batch-1 tick runs 38 of
+// them back to back).  Here the COLUMNS of every stage are dealt over `G` co-resident workgroups per 32 rows (gridDim.y) and
+// the eight waves of a workgroup split the K steps of a column block between them (partial tiles summed through LDS in wave
+// order: deterministic).  Stage outputs a later stage reads go through an f32 scratch in global memory; between dependent
+// stages the G workgroups of a row block meet at a ticket barrier (agent-scope release / acquire: the XCDs' L2s are not
+// coherent with each other for ordinary stores).  The ticket counters live in a library-owned pool, are claimed round-robin per
+// launch and reset themselves with the launch's last arrival.
+constexpr int kWidePF = 8;               // K steps in flight per wave (8 x 4 KiB: weights + activation fragments)
+constexpr int kWideMaxSpin = 1 << 21;    // bail-out of a ticket wait (~1 s): a wrong count must not hang the device
+
+struct WideStage {
+    ChainStage s;
+    const float* in;      // stage input: the chain input rows, or an earlier stage's scratch (fragment-major)
+    int in_stride;        // row stride in floats; fragment-major: 16-column steps per row block
+    int in_frag;
+    float* keep;          // scratch of this stage's output (null: no later stage reads it), fragment-major
+    int keep_stride;      // its steps per row block = N rounded up to 32, / 16
+    int sync_before;      // the row block's workgroups meet before this stage
+};
+
+struct WideArgs {
+    long long R;
+    int nstages, nsync;
+    int rb;               // 32-row blocks per workgroup (1, 2, 4 or 8); its eight waves = rb row blocks x 8 / rb K slices
+    unsigned* tickets;    // one counter (64 B apart) per row group
+    int* fault;           // set to 1 if a ticket wait gave up
+    long long* trace;     // debug (tt_mlp_chain_wide_set_trace): 64 wall-clock stamps (10 ns ticks) per workgroup, or null
+    WideStage st[kChainMaxStages];
+};
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global store (~1 us per
+// stage here), which only the ticket barrier needs
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+__device__ __forceinline__ void ticket_barrier(unsigned* ctr, unsigned target, int* fault) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int spin = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spin > kWideMaxSpin) { *fault = 1; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // one cache invalidate after the wait, not one per poll
+    }
+    __syncthreads();
+}
+
+// One stage of the wide chain with a ring of PF K steps per wave (PF = 2, 4, 8 by the stage's steps per wave: every ring slot
+// is loaded unconditionally, and a workgroup's loads go through one L1 at 64 B / clock -- a ring deeper than the stage has
+// steps would spend more time on duplicate loads than the stage's own weights take).
+template <int PF>
+__device__ __forceinline__ void wide_stage(const WideArgs& a, const WideStage& W, float (*part)[32][32], unsigned* ctr,
+                                           unsigned& arrived, long long* tr, int& tri) {
+    const ChainStage& S = W.s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.y, g = blockIdx.y;
+    const int RB = a.rb, KS = kChainWaves / RB;
+    const int rb = wave & (RB - 1), ks = wave / RB;
+    const long long m0g = (long long)blockIdx.x * RB * 32;       // first row of the workgroup
+    const long long m0 = m0g + rb * 32;                          // first row of this wave's block
+    auto stamp = [&]() {
+        if (tr && tid == 0 && tri < 64) tr[tri++] = (long long)wall_clock64();
+    };
+    const int NB = (S.N + 31) >> 5;
+    const int nsteps = S.Kp >> 4;
+    const int last = nsteps - 1;
+    const int mine = (nsteps - ks + KS - 1) / KS;                // K steps ks, ks + KS, ... (<= 0: none)
+    int r = lane & 31, h = lane >> 5;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(r), "+v"(h));
+#endif
+    // The WEIGHT half of the first block's ring is issued before the barrier: it does not depend on the other workgroups.
+    uint4 bh[PF], bl[PF];
+    float4 a0[PF], a1[PF];
+    const unsigned char* bp = reinterpret_cast<const unsigned char*>(S.w) + (size_t)(g < NB ? g : 0) * nsteps * 2048 +
+                              (h * 32 + r) * 16;
+    auto load_b = [&](int step, int p) {
+        const int kk = step < last ? step : last;
+        const unsigned char* q = bp + (size_t)kk * 2048;
+        bh[p] = *reinterpret_cast<const uint4*>(q);
+        bl[p] = *reinterpret_cast<const uint4*>(q + 1024);
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_b(ks + KS * p, p);
+    if (W.sync_before) {
+        arrived += (unsigned)G;
+        ticket_barrier(ctr, arrived, a.fault);
+    }
+    stamp();
+    // activation fragments: lanes of rows beyond R load nothing (a 1-row chain issues 2 of 64 lanes).  Row-major input (the
+    // chain input): 32 B of row m0 + r per step; an earlier stage's scratch is FRAGMENT-MAJOR (per row block and step two
+    // contiguous KiB indexed by lane), so those loads are fully coalesced.
+    const bool row_live = m0 + r < a.R;
+    const float* ap;
+    int a_step, a_off1;
+    if (W.in_frag) {
+        ap = W.in + ((size_t)(m0 >> 5) * W.in_stride * 128 + (size_t)(h * 32 + r)) * 4;
+        a_step = 512; a_off1 = 256;
+    } else {
+        ap = W.in + (row_live ? m0 + r : 0) * W.in_stride + h * 8;
+        a_step = 16; a_off1 = 4;
+    }
+    auto load_a = [&](int step, int p) {
+        const int kk = step < last ? step : last;
+        if (row_live) {
+            a0[p] = *reinterpret_cast<const float4*>(ap + (size_t)kk * a_step);
+            a1[p] = *reinterpret_cast<const float4*>(ap + (size_t)kk * a_step + a_off1);
+        } else {
+            a0[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            a1[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    for (int nb = g; nb < NB; nb += G) {
+        if (nb != g) {
+            bp += (size_t)G * nsteps * 2048;
+#pragma unroll
+            for (int p = 0; p < PF; ++p) load_b(ks + KS * p, p);
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) load_a(ks + KS * p, p);
+        // epilogue operands, loaded now so that their latency is not exposed after the K loop (first two row slots of the
+        // thread: all of them when the workgroup has one row block)
+        const int col = tid & 31, n = nb * 32 + col;
+        const bool n_ok = n < S.N;
+        const float bias = (S.bias && n_ok) ? S.bias[n] : 0.f;
+        // (straight-line code: clamped addresses + selects under wave-uniform branches, not one branch per element)
+        float sw[8], pre[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sw[j] = 0.f;
+        const int n_c = n_ok ? n : 0;
+        if (S.side) {
+            float wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = S.side_w[n_c * S.side_k + (j < S.side_k ? j : 0)];
+#if defined(__HIP_DEVICE_COMPILE__)
+            // all eight loads issued before the first select (the compiler otherwise sinks each into its own branch: 8 serial
+            // round trips)
+            asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]), "+v"(wv[7]));
+#endif
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sw[j] = (n_ok && j < S.side_k) ? wv[j] : 0.f;
+        }
+        constexpr int kPre = PF < 8 ? 2 : 0;                       // (the deep ring has no registers to spare, and its stages
+                                                                  // are bound by their weight stream, not by this latency)
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+            const long long mr = m0g + (tid >> 5) + 16 * j;
+            const long long mr_c = mr < a.R ? mr : 0;
+            float v = 0.f;
+            if (S.res) v = S.res[mr_c * S.res_stride + S.res_coff + n_c];
+            if (S.side) {
+                const float* sp = S.side + mr_c * S.side_stride;
+                float sv[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) sv[jj] = sp[jj < S.side_k ? jj : 0];
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]), "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]));
+#endif
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v += sv[jj] * sw[jj];
+            }
+            pre[j] = v;                                           // used only where (mr < R && n < N)
+        }
+
+        f32x16 acc, acc2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = acc2[i] = 0.f;
+#pragma unroll 1
+        for (int i = 0; i < mine; i += PF) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const float v[8] = {a0[p].x, a0[p].y, a0[p].z, a0[p].w, a1[p].x, a1[p].y, a1[p].z, a1[p].w};
+                uint4 ah, al;
+                split8(v, ah, al);
+                if (i + p < mine) mfma3(ah, al, bh[p], bl[p], acc, acc2);
+                if (i + PF < mine) {                 // wave-uniform: the last ring round reloads nothing
+                    const int nxt = ks + KS * (i + p + PF);
+                    load_b(nxt, p);
+                    load_a(nxt, p);
+                }
+            }
+        }
+        // this wave's partial tile.  C/D map: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[wave][(i & 3) + 8 * (i >> 2) + 4 * h][r] = acc[i] + acc2[i];
+        lds_barrier();
+        if (nb == g) stamp();
+        // epilogue: thread -> column `col` of rows (tid >> 5) + 16 j of the workgroup's RB * 32 rows; the K slices of a row
+        // block are summed in slice order
+        for (int j = 0; j < 2 * RB; ++j) {
+            const int rg = (tid >> 5) + 16 * j;                   // row within the workgroup
+            const int b = rg >> 5, rr = rg & 31;
+            const long long mr = m0g + rg;
+            const bool ok = n_ok && mr < a.R;
+            float v = part[b][rr][col];
+            for (int q = 1; q < KS; ++q) v += part[q * RB + b][rr][col];
+            v += bias;
+            if (j < kPre) {
+                v += j == 0 ? pre[0] : pre[1];
+            } else {
+                const long long mr_c = ok ? mr : 0;
+                float t = 0.f;
+                if (S.res) t = S.res[mr_c * S.res_stride + S.res_coff + n_c];
+                if (S.side) {
+                    const float* sp = S.side + mr_c * S.side_stride;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) t += sp[jj < S.side_k ? jj : 0] * sw[jj];
+                }
+                v += t;
+            }
+            v = apply_act(v, S.act);
+            if (!ok) v = 0.f;
+            if (S.out && ok) S.out[mr * S.out_stride + S.out_coff + n] = v;
+            if (W.keep && mr < a.R)                              // fragment-major scratch (see load_a); padding columns = 0
+                W.keep[((((size_t)(mr >> 5) * W.keep_stride + (n >> 4)) * 2 + ((n >> 2) & 1)) * 64 + ((n >> 3) & 1) * 32 + rr) * 4 +
+                       (n & 3)] = v;
+        }
+        lds_barrier();      // `part` is free again; the global stores are NOT waited for here (the next ticket barrier does)
+    }
+    stamp();
+}
+
+__global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_wide_kernel(const WideArgs a) {
+    __shared__ float part[kChainWaves][32][32];
+    const int tid = threadIdx.x;
+    const int G = gridDim.y, g = blockIdx.y;
+    unsigned* ctr = a.tickets + (size_t)blockIdx.x * 16;
+    unsigned arrived = 0;
+    long long* tr = a.trace ? a.trace + ((size_t)blockIdx.x * G + g) * 64 : nullptr;
+    int tri = 0;
+    if (tr && tid == 0) tr[tri++] = (long long)wall_clock64();
+    const int KS = kChainWaves / a.rb;
+    for (int s = 0; s < a.nstages; ++s) {
+        const WideStage& W = a.st[s];
+        if (tr && tid == 0 && tri < 64) tr[tri++] = (long long)wall_clock64();
+        const int per_wave = ((W.s.Kp >> 4) + KS - 1) / KS;      // K steps of the busiest wave (uniform over the workgroup)
+        if (per_wave <= 2) wide_stage<2>(a, W, part, ctr, arrived, tr, tri);
+        else if (per_wave <= 4) wide_stage<4>(a, W, part, ctr, arrived, tr, tri);
+        else wide_stage<8>(a, W, part, ctr, arrived, tr, tri);
+    }
+    // the launch's last arrival puts the ticket back to zero for the next launch that claims this slot
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned total = (unsigned)(a.nsync + 1) * (unsigned)G;
+        const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == total) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -315,4 +573,126 @@ extern "C" int tt_mlp_chain(const float* x, long long R, int x_stride, int nstag
     hipLaunchKernelGGL(mlp_chain_kernel, dim3(blocks, (unsigned)n_split), dim3(kChainWaves * 64), total,
                        (hipStream_t)stream, a);
     return check_launch("tt_mlp_chain");
+}
+
+// ---- tt_mlp_chain_wide
+namespace {
+constexpr int kTicketSlots = 4096;       // 64 B each; a launch claims one per row block, round-robin
+unsigned* g_tickets = nullptr;           // + one int after the last slot: the fault flag
+unsigned g_next_ticket = 0;
+long long* g_trace = nullptr;            // tt_mlp_chain_wide_set_trace
+
+int ticket_pool() {
+    if (g_tickets) return 0;
+    void* p = nullptr;
+    const size_t bytes = (size_t)(kTicketSlots + 1) * 64;
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
+        tt::set_error("tt_mlp_chain_wide: cannot allocate the ticket pool");
+        return -2;
+    }
+    g_tickets = static_cast<unsigned*>(p);
+    return 0;
+}
+}  // namespace
+
+static inline long long wide_keep_stride(int N) { return (N + 31) / 32 * 32; }
+// 32-row blocks per workgroup: with several row blocks the waves of a workgroup share the weight stream (same K slice, different
+// rows) instead of every row block streaming all the weights through its own workgroup
+static inline int wide_rb(long long row_blocks) { return row_blocks <= 1 ? 1 : (row_blocks == 2 ? 2 : 4); }
+static inline long long wide_rows(long long R) {
+    const long long row_blocks = (R + 31) / 32;
+    const int rb = wide_rb(row_blocks);
+    return (row_blocks + rb - 1) / rb * rb * 32;
+}
+
+extern "C" long long tt_mlp_chain_wide_workspace_bytes(long long R, int nstages, const tt_chain_stage* st) {
+    if (!st || R <= 0 || nstages < 1 || nstages > kChainMaxStages) return -1;
+    const long long rows = wide_rows(R);
+    long long total = 0;
+    for (int s = 0; s < nstages; ++s) {
+        bool kept = false;
+        for (int t = s + 1; t < nstages; ++t) kept = kept || st[t].in_sel == s;
+        if (kept) total += (rows * wide_keep_stride(st[s].N) * 4 + 255) / 256 * 256;
+    }
+    return total < 256 ? 256 : total;
+}
+
+extern "C" int tt_mlp_chain_wide_set_trace(void* stamps_or_null) {
+    g_trace = static_cast<long long*>(stamps_or_null);
+    return 0;
+}
+
+extern "C" int tt_mlp_chain_wide_faults(void) {
+    if (!g_tickets) return 0;
+    int f = 0;
+    if (hipMemcpy(&f, g_tickets + (size_t)kTicketSlots * 16, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    return f;
+}
+
+extern "C" int tt_mlp_chain_wide(const float* x, long long R, int x_stride, int nstages, const tt_chain_stage* st,
+                                 int n_groups, void* workspace, long long workspace_bytes, void* stream) {
+    TT_REQUIRE(x && st && R > 0 && nstages >= 1 && nstages <= kChainMaxStages, "tt_mlp_chain_wide: bad arguments");
+    TT_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride % 4 == 0, "tt_mlp_chain_wide: x must be 16 B aligned rows");
+    const long long row_blocks = (R + 31) / 32;
+    const int rb = wide_rb(row_blocks);
+    const long long row_groups = (row_blocks + rb - 1) / rb;
+    TT_REQUIRE(n_groups >= 1 && n_groups <= 64 && row_groups * n_groups <= 256,
+               "tt_mlp_chain_wide: %lld row groups x %d column groups must be co-resident (<= 256 workgroups)", row_groups,
+               n_groups);
+    const long long need = tt_mlp_chain_wide_workspace_bytes(R, nstages, st);
+    TT_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+               "tt_mlp_chain_wide: workspace of %lld B needed (%lld given)", need, workspace_bytes);
+    if (ticket_pool() != 0) return -2;
+    WideArgs a;
+    a.R = R; a.nstages = nstages; a.nsync = 0; a.rb = rb;
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    int synced_upto = -1;                 // stages <= this index are complete on every workgroup of the row block
+    for (int s = 0; s < nstages; ++s) {
+        const tt_chain_stage& d = st[s];
+        TT_REQUIRE(d.in_sel < s, "tt_mlp_chain_wide: stage %d reads stage %d", s, d.in_sel);
+        TT_REQUIRE(d.w && d.K > 0 && d.N > 0 && d.Kp % 16 == 0 && d.Kp >= d.K && d.K % 4 == 0,
+                   "tt_mlp_chain_wide: stage %d: K=%d Kp=%d N=%d", s, d.K, d.Kp, d.N);
+        TT_REQUIRE((reinterpret_cast<uintptr_t>(d.w) & 15) == 0, "tt_mlp_chain_wide: stage %d weights unaligned", s);
+        TT_REQUIRE(d.side_k >= 0 && d.side_k <= 8 && (!d.side || d.side_w), "tt_mlp_chain_wide: stage %d side input", s);
+        TT_REQUIRE(d.in_sel >= 0 || x_stride >= d.Kp,
+                   "tt_mlp_chain_wide: stage %d: x rows (stride %d) must cover the padded K = %d (finite padding)", s, x_stride,
+                   d.Kp);
+        TT_REQUIRE(d.in_sel < 0 || st[d.in_sel].N == d.K, "tt_mlp_chain_wide: stage %d: K=%d but stage %d has N=%d", s, d.K,
+                   d.in_sel, d.in_sel >= 0 ? st[d.in_sel].N : 0);
+        WideStage& W = a.st[s];
+        ChainStage& S = W.s;
+        S.w = d.w; S.bias = d.bias; S.res = d.res; S.side = d.side; S.side_w = d.side_w; S.out = d.out;
+        S.K = d.K; S.Kp = d.Kp; S.N = d.N; S.act = d.act; S.in_sel = d.in_sel;
+        S.res_stride = d.res_stride; S.res_coff = d.res_coff; S.side_stride = d.side_stride; S.side_k = d.side_k;
+        S.out_stride = d.out_stride; S.out_coff = d.out_coff;
+        S.lds_off = -1; S.lds_stride = 0;
+        bool kept = false;
+        for (int t = s + 1; t < nstages; ++t) kept = kept || st[t].in_sel == s;
+        W.keep = nullptr; W.keep_stride = 0;
+        if (kept) {
+            W.keep = reinterpret_cast<float*>(ws);
+            W.keep_stride = (int)wide_keep_stride(d.N) / 16;
+            ws += (wide_rows(R) * wide_keep_stride(d.N) * 4 + 255) / 256 * 256;
+        }
+        if (d.in_sel < 0) {
+            W.in = x; W.in_stride = x_stride; W.in_frag = 0; W.sync_before = 0;
+        } else {
+            W.in = a.st[d.in_sel].keep; W.in_stride = a.st[d.in_sel].keep_stride; W.in_frag = 1;
+            // the consumer's padded K (a multiple of 16) lies inside the producer's 32-column blocks: finite (zero) padding
+            W.sync_before = d.in_sel > synced_upto ? 1 : 0;
+            if (W.sync_before) { synced_upto = s - 1; ++a.nsync; }
+        }
+    }
+    if (n_groups == 1) {                   // one workgroup per row block: nobody to wait for
+        for (int s = 0; s < nstages; ++s) a.st[s].sync_before = 0;
+        a.nsync = 0;
+    }
+    if (g_next_ticket + row_groups > (unsigned)kTicketSlots) g_next_ticket = 0;
+    a.tickets = g_tickets + (size_t)g_next_ticket * 16;
+    g_next_ticket += (unsigned)row_groups;
+    a.fault = reinterpret_cast<int*>(g_tickets + (size_t)kTicketSlots * 16);
+    a.trace = g_trace;
+    hipLaunchKernelGGL(mlp_chain_wide_kernel, dim3((unsigned)row_groups, (unsigned)n_groups), dim3(kChainWaves * 64), 0,
+                       (hipStream_t)stream, a);
+    return check_launch("tt_mlp_chain_wide");
 }

@@ -240,11 +240,20 @@ class FusedDecoder:
         wp2, ctrl2 = wp.view(B * 4, 2), ctrl.view(B * 4, 4)
         res_wp = (wp2, 0) if residual_emit else None
         res_ct = (ctrl2, 0) if residual_emit else None
-        ops.mlp_chain(hn, [{"lin": m[0], "src": -1}, {"lin": m[1], "src": 0, "out": (h, 0)},
-                           {"lin": m[2], "src": 1, "side": wp2}, {"lin": m[3], "src": 2},
-                           {"lin": m[4], "src": 3, "res": res_wp, "out": (wp_out.view(B * 4, 2), 0)},
-                           {"lin": m[5], "src": 1, "side": ctrl2}, {"lin": m[6], "src": 5},
-                           {"lin": m[7], "src": 6, "res": res_ct, "out": (ctrl_out.view(B * 4, 4), 0)}])
+        # the trajectory and control heads interleaved level by level: in the wide form of the chain (few rows) dependent
+        # stages are separated by a barrier, and this order needs four of them instead of six
+        if ops.chain_is_wide(B * 4):
+            ops.mlp_chain(hn, [{"lin": m[0], "src": -1}, {"lin": m[1], "src": 0, "out": (h, 0)},
+                               {"lin": m[2], "src": 1, "side": wp2}, {"lin": m[5], "src": 1, "side": ctrl2},
+                               {"lin": m[3], "src": 2}, {"lin": m[6], "src": 3},
+                               {"lin": m[4], "src": 4, "res": res_wp, "out": (wp_out.view(B * 4, 2), 0)},
+                               {"lin": m[7], "src": 5, "res": res_ct, "out": (ctrl_out.view(B * 4, 4), 0)}])
+        else:
+            ops.mlp_chain(hn, [{"lin": m[0], "src": -1}, {"lin": m[1], "src": 0, "out": (h, 0)},
+                               {"lin": m[2], "src": 1, "side": wp2}, {"lin": m[3], "src": 2},
+                               {"lin": m[4], "src": 3, "res": res_wp, "out": (wp_out.view(B * 4, 2), 0)},
+                               {"lin": m[5], "src": 1, "side": ctrl2}, {"lin": m[6], "src": 5},
+                               {"lin": m[7], "src": 6, "res": res_ct, "out": (ctrl_out.view(B * 4, 4), 0)}])
         hb = h.view(B, 2048)
         # ---- state updates: the BEV map (feeds the next layer's GRU) on the prediction stream, the flat feature here
         if branch is not None:
@@ -253,14 +262,17 @@ class FusedDecoder:
                 t.record_stream(branch)
         with (torch.cuda.stream(branch) if branch is not None else _Null()):
             G = torch.empty(B, 1152, dtype=F32, device=dev)
-            ops.mlp_chain(hb, [{"lin": lay.bev["G"], "src": -1, "out": (G, 0)}], n_split=5)
+            ops.mlp_chain(hb, [{"lin": lay.bev["G"], "src": -1, "out": (G, 0)}], n_split=5, groups=36)
             ops.dec_bev_update(lay.bev, cur_bev, G, bev_out)
         fin = torch.empty(B, 2304, dtype=F32, device=dev)
         ops.concat_rows(fin, [(cur_flat, 256, 1, 0), (hb, 2048, 1, 0)])
         f_ = lay.flat
         # 2304 -> 512 over <= 32 rows is a 4.7 MB weight stream: deal its 16 column blocks over 4 workgroups (a single one
         # took 122 us), then the 512 -> 256 tail + residual as its own small launch
-        f1 = torch.empty(B, 512, dtype=F32, device=dev)
-        ops.mlp_chain(fin, [{"lin": f_[0], "src": -1, "out": (f1, 0)}], n_split=4)
-        ops.mlp_chain(f1, [{"lin": f_[1], "src": -1, "res": (cur_flat, 0), "out": (flat_out, 0)}])
+        if ops.chain_is_wide(B):
+            ops.mlp_chain(fin, [{"lin": f_[0], "src": -1}, {"lin": f_[1], "src": 0, "res": (cur_flat, 0), "out": (flat_out, 0)}])
+        else:
+            f1 = torch.empty(B, 512, dtype=F32, device=dev)
+            ops.mlp_chain(fin, [{"lin": f_[0], "src": -1, "out": (f1, 0)}], n_split=4)
+            ops.mlp_chain(f1, [{"lin": f_[1], "src": -1, "res": (cur_flat, 0), "out": (flat_out, 0)}])
         return count, max_len

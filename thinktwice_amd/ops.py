@@ -807,9 +807,26 @@ class ChainLinear:
         self.act = act
 
 
-def mlp_chain(x, stages, n_split=1):
+CHAIN_WIDE = os.environ.get("TT_CHAIN_WIDE", "1") != "0"   # A/B knob: 0 = always the one-workgroup-per-32-rows kernel
+CHAIN_WIDE_MAX_ROW_BLOCKS = 16                               # beyond this the rows alone fill enough workgroups
+
+
+def chain_is_wide(R):
+    """Whether mlp_chain runs R rows on tt_mlp_chain_wide (callers order their stages for the form that runs)."""
+    return CHAIN_WIDE and (R + 31) // 32 <= CHAIN_WIDE_MAX_ROW_BLOCKS
+
+
+def chain_faults():
+    """Blocking: non-zero if a tt_mlp_chain_wide launch ever gave up waiting at its barrier (tests assert 0)."""
+    return int(lib().tt_mlp_chain_wide_faults())
+
+
+def mlp_chain(x, stages, n_split=1, groups=None, wide=None):
     """x (R, >= K0) f32 rows (row-strided ok).  stages: list of dicts {lin: ChainLinear, src: -1 | earlier stage index,
-    res: (tensor (R, *), coff) | None, side: tensor (R, >= side_k) | None, out: (tensor (R, *), coff) | None}."""
+    res: (tensor (R, *), coff) | None, side: tensor (R, >= side_k) | None, out: (tensor (R, *), coff) | None}.
+    Few rows (<= 512) run tt_mlp_chain_wide: the columns of every stage over `groups` workgroups per 32 rows (default: the
+    widest stage's 32-column blocks, at most 16; capped so that all workgroups are co-resident); otherwise tt_mlp_chain
+    (`n_split`: the single-stage column split of that kernel).  `wide`: force one form (tests)."""
     require_cuda(x)
     assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
     R = x.shape[0]
@@ -835,6 +852,19 @@ def mlp_chain(x, stages, n_split=1):
             t, coff = out
             assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] >= R and t.shape[1] >= coff + lin.N
             d.out, d.out_stride, d.out_coff = t.data_ptr(), t.stride(0), coff
+    row_blocks = (R + 31) // 32
+    if chain_is_wide(R) if wide is None else wide:
+        L = lib()
+        if groups is None:
+            groups = min(16, max((st["lin"].N + 31) // 32 for st in stages))
+        row_groups = 1 if row_blocks <= 2 else (row_blocks + 3) // 4       # workgroups take 1, 2 or 4 row blocks
+        groups = max(1, min(groups, 128 // row_groups, 64))      # all workgroups co-resident with room to spare
+        L.tt_mlp_chain_wide_workspace_bytes.restype = ctypes.c_longlong
+        nbytes = int(L.tt_mlp_chain_wide_workspace_bytes(_ll(R), _c(n), arr))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        check(L.tt_mlp_chain_wide(ptr(x), _ll(R), _c(x.stride(0)), _c(n), arr, _c(groups), ptr(ws), _ll(nbytes), _st(x)),
+              "tt_mlp_chain_wide")
+        return
     check(lib().tt_mlp_chain(ptr(x), _ll(R), _c(x.stride(0)), _c(n), arr, _c(n_split), _st(x)), "tt_mlp_chain")
 
 
