@@ -38,6 +38,64 @@ def test_tape_gradient_buffers_mirror_the_activation_storage():
     assert torch.equal(tape.param_grads["w"], torch.full((3,), 2.0))
 
 
+def test_tape_releases_activations_and_gradients_as_the_sweep_passes_their_first_node():
+    """Tape(release=True) (the training step): a = 3 x (node 0), b = a * p (node 1), d loss / d b = 1.  After the backward of the
+    node that FIRST referenced a storage, neither the forward tensor nor its gradient buffer is held any more; parameter
+    gradients survive; the arithmetic equals the retaining tape's."""
+    import gc
+    import weakref
+
+    def run(release):
+        seen = {}
+        p = torch.full((3,), 2.0)
+        autodiff.register_param(p, "p.weight")
+
+        def node0(tape, x, a, keys):
+            def bwd():
+                seen["grads inside node 0"] = set(tape.grads)
+                seen["b alive inside node 0"] = refs["b"]() is not None
+                tape.grad(x).add_(3.0 * tape.grad(a))
+            return bwd
+
+        def node1(tape, a, b):
+            def bwd():
+                tape.grad(a).add_(tape.grad(b) * p)
+                tape.grad(p).add_((tape.grad(b) * a).sum(0))
+            return bwd
+
+        try:
+            with autodiff.Tape(release=release) as tape:
+                x = torch.arange(6, dtype=torch.float32).view(2, 3)
+                a = x * 3.0
+                keys = {"x": x.untyped_storage().data_ptr(), "a": a.untyped_storage().data_ptr()}
+                tape._keep += [x, a]
+                tape.nodes.append(node0(tape, x, a, keys))
+                b = a * p
+                keys["b"] = b.untyped_storage().data_ptr()
+                tape._keep += [a, p, b]
+                tape.nodes.append(node1(tape, a, b))
+                tape.seed(b, torch.ones(2, 3))
+                refs = {"x": weakref.ref(x), "a": weakref.ref(a), "b": weakref.ref(b)}
+                gx = weakref.ref(tape.grad(x).untyped_storage())
+                del x, a, b
+                tape.backward()
+                seen["d p"] = tape.grad(p).clone()      # (Tape.backward collects device parameters into param_grads itself)
+            gc.collect()
+            return tape, refs, keys, seen, gx
+        finally:
+            autodiff.clear_metas()
+
+    tape, refs, keys, seen, gx = run(True)
+    assert torch.equal(seen["d p"], torch.tensor([9.0, 15.0, 21.0]))      # sum over the rows of a = 3 x: parameters are not released
+    assert keys["b"] not in seen["grads inside node 0"] and keys["a"] in seen["grads inside node 0"]
+    assert not seen["b alive inside node 0"]
+    assert all(r() is None for r in refs.values()), "forward tensors outlive the sweep"
+    assert gx() is None, "the gradient buffer of x outlives its first node"
+    tape2, refs2, keys2, seen2, gx2 = run(False)
+    assert torch.equal(seen2["d p"], seen["d p"])
+    assert keys2["b"] in seen2["grads inside node 0"] and seen2["b alive inside node 0"] and gx2() is not None
+
+
 def test_prepared_weight_gradients_return_in_the_reference_layouts():
     """ConvMeta.place_weight_grad: prepared operands are [Cout][KH][KW][cin_pad]; the reference stores Conv2d as
     [Cout, Cin, KH, KW], Linear as [Cout, Cin], spconv as (Cout, kD, kH, kW, Cin), and some prepared convs are channel

@@ -15,6 +15,8 @@ they do not differentiate (row-run stem, unregistered weights, ...); the fused i
 *_ln look kernels) and the NCHW output conversions have no recorder and are not used by the taped forward.  trainer.Trainer drives the tape; tests/test_backward.py checks every sub-network against torch
 autograd through the oracle and tests/test_train_step.py the whole model against the reference's own gradients (golden F13).
 """
+import os
+
 import torch
 
 from . import ops
@@ -187,13 +189,49 @@ def register_param(t, name):
     return t
 
 
+class _Keep(list):
+    """The forward tensors the backward closures read, in recording order.  Remembers, per storage, the index of the FIRST node
+    that referenced it (its producer, or for an input its first reader): once that node's backward has run no remaining node
+    touches the storage, so Tape.backward releases the tensor and its gradient buffer there instead of at the end of the sweep
+    (batch 8 at the thinktwice.py size: every activation AND every gradient buffer alive at once was 189 GB)."""
+
+    def __init__(self, tape):
+        super().__init__()
+        self.tape = tape
+        self.first = {}             # storage data_ptr -> node index
+
+    def _reg(self, t):
+        if isinstance(t, torch.Tensor):
+            self.first.setdefault(t.untyped_storage().data_ptr(), len(self.tape.nodes))
+
+    def append(self, t):
+        self._reg(t)
+        super().append(t)
+
+    def __iadd__(self, items):
+        items = list(items)
+        for t in items:
+            self._reg(t)
+        return super().__iadd__(items)
+
+    def clear(self):
+        super().clear()
+        self.first.clear()
+
+
 class Tape:
-    def __init__(self, x3=True):
+    EAGER_RELEASE = os.environ.get("TT_TAPE_EAGER_RELEASE", "1") != "0"     # A/B knob (memory only; same arithmetic)
+
+    def __init__(self, x3=True, release=False):
+        """`release`: let backward() drop every activation and its gradient buffer as soon as the node that first referenced
+        the storage has run (the training step; only parameter gradients survive the sweep).  Off by default: the sub-network
+        tests read the gradients of graph inputs after backward()."""
+        self.release = release and self.EAGER_RELEASE
         self.nodes = []
         self.grads = {}             # storage data_ptr -> flat f32 gradient buffer covering the whole storage
         self.param_grads = {}
         self.x3 = x3                # input gradients through the bf16x3 kernel (else exact f32)
-        self._keep = []             # forward tensors the closures read: kept alive until backward() returns
+        self._keep = _Keep(self)    # forward tensors the closures read: kept alive until their first node has run backward
 
     def __enter__(self):
         global TAPE
@@ -232,11 +270,28 @@ class Tape:
     def backward(self):
         global TAPE
         active, TAPE = TAPE, None          # the backward closures call forward ops too: nothing of that is recorded
+        # storages to release after node i: those whose first reference is node i -- except parameter storages, whose gradient
+        # buffers are collected below
+        param_keys = {t.untyped_storage().data_ptr() for t, _ in PARAM_TENSORS.items()}
+        release, held = {}, {}
+        if self.release:
+            for key, idx in self._keep.first.items():
+                if key not in param_keys:
+                    release.setdefault(idx, []).append(key)
+            for t in self._keep:           # the references move into a per-storage table (the list is refilled by grad())
+                if isinstance(t, torch.Tensor):
+                    held.setdefault(t.untyped_storage().data_ptr(), []).append(t)
+            list.clear(self._keep)
         try:
-            for fn in reversed(self.nodes):
-                fn()
+            for i in range(len(self.nodes) - 1, -1, -1):
+                self.nodes[i]()
+                self.nodes[i] = None       # the closure holds forward tensors
+                for key in release.get(i, ()):
+                    self.grads.pop(key, None)
+                    held.pop(key, None)
         finally:
             TAPE = active
+            held.clear()
         for t, name in PARAM_TENSORS.items():
             if t.is_cuda and t.untyped_storage().data_ptr() in self.grads:
                 self.add_param_grad(name, self.grad(t).clone())

@@ -102,7 +102,7 @@ class Trainer:
         was_training = self.model.training
         self.model.train(not self.frozen_bn)
         try:
-            with autodiff.Tape(x3=self.x3) as tape:
+            with autodiff.Tape(x3=self.x3, release=True) as tape:
                 out = self.model.train_step(batch, None)
                 tape.backward()
         finally:
