@@ -224,7 +224,7 @@ int tt_mlp_chain_wide_set_trace(void* stamps_or_null);
 /* SpatialGRU (dense_heads/utils.py:53-106): inp6 [B][4][6] (waypoint xy, softplus ctrl), state [B][441][32] f32
  * channel-last -> fut [B][4][441][32].  w0/wx/b0/w2/b2: arrays of 3 (conv_update, conv_reset, conv_state_tilde):
  * w0 = state part of the .0 conv [32][9*32], wx = its constant-input part f32 [9][6][32], w2 = the .2 conv.
- * scratch: [B][2][441][32] f32. */
+ * scratch: [B][2][448][32] f32 (the 441 pixels padded to 14 row blocks of 32). */
 int tt_dec_gru(int B, const float* inp6, const float* state, float* fut, float* scratch, const void* const* w0,
                const float* const* wx, const float* const* b0, const void* const* w2, const float* const* b2,
                const void* wd0, const float* bd0, const void* wd2, const float* bd2, void* stream);
@@ -232,6 +232,8 @@ int tt_dec_gru(int B, const float* inp6, const float* state, float* fut, float* 
  * 17 weight sets in the order documented in dec_spatial.hip; mids (nullable): the three SE-block outputs. */
 int tt_dec_flatten(int maps, const float* in, float* out, float* mids_or_null, const void* const* w,
                    const float* const* b, const float* bn_scale, const float* bn_shift, void* stream);
+/* debug: while set, workgroup 0 of tt_dec_gru / tt_dec_flatten writes a wall-clock stamp (10 ns ticks) after every phase (<= 64) */
+int tt_dec_set_trace(void* stamps_or_null);
 /* BEV_feat_update_module + residual (thinktwice_decoder.py:221-225,257): bev [B][441][32], G [B][9][128] = the
  * broadcast-channel term per tap (tt_mlp_chain over h), w0 [128][9*32] (bev part), w2[4] [32][9*32] per hidden chunk. */
 int tt_dec_bev_update(int B, const float* bev, const float* G, float* out, long long out_bstride, float* out2,

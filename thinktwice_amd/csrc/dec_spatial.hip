@@ -137,6 +137,179 @@ __device__ __forceinline__ void conv_lds(const unsigned char* in_map, int H, int
     }
 }
 
+// The same convolution with MBG 32-row blocks per work item sharing every weight fragment (one 32-column block per item).  The
+// 21 x 21 x 32 -> 32 convolutions of the GRU / BEV update have ONE column block: with a row block per wave, fourteen waves each
+// pulled the whole 36 KiB weight matrix through the workgroup's single L1 (504 KiB at 64 B / clock = 3.8 us per convolution,
+// more than its 2.9 us of MFMA work); two row blocks per wave halve that stream and the number of waves.
+// epi(m, n, v, i) as above; items = (group of MBG row blocks, column block), dealt to the waves round-robin.
+template <int MBG, int PF, typename Epi>
+__device__ __forceinline__ void conv_lds_mb(const unsigned char* in_map, int H, int W, int Cp, int PS,
+                                            const unsigned char* zero, int stride, int pad, int KH, int KW,
+                                            const unsigned char* w, int N, int OH, int OW, int wave, int nwaves, int lane,
+                                            Epi epi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lane));
+#endif
+    const int M = OH * OW, MB = (M + 31) >> 5, NB = (N + 31) >> 5, MG = (MB + MBG - 1) / MBG;
+    const int gpt = Cp >> 4;
+    const int nsteps = KH * KW * gpt;
+    const size_t blk_bytes = (size_t)nsteps * 2048;
+    const int r = lane & 31, h = lane >> 5;
+    for (int item = wave; item < MG * NB; item += nwaves) {
+        const int mg = item / NB, nb = item - mg * NB;
+        int ih0[MBG], iw0[MBG];
+        bool m_ok[MBG];
+        f32x16 acc[MBG], acc2[MBG];
+#pragma unroll
+        for (int q = 0; q < MBG; ++q) {
+            const int m = (mg * MBG + q) * 32 + r;
+            m_ok[q] = m < M;
+            const int oh = m_ok[q] ? m / OW : 0, ow = m_ok[q] ? m - (m / OW) * OW : 0;
+            ih0[q] = oh * stride - pad;
+            iw0[q] = ow * stride - pad;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[q][i] = acc2[q][i] = 0.f;
+        }
+        const unsigned char* bp = w + (size_t)nb * blk_bytes + (h * 32 + r) * 16;
+        uint4 bh[PF], bl[PF];
+        const int last = nsteps - 1;
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int kp = p < last ? p : last;
+            bh[p] = *reinterpret_cast<const uint4*>(bp + (size_t)kp * 2048);
+            bl[p] = *reinterpret_cast<const uint4*>(bp + (size_t)kp * 2048 + 1024);
+        }
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < nsteps; ks0 += PF) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int ks = ks0 + p;
+                if (ks < nsteps) {
+                    const int tap = ks / gpt, g = ks - tap * gpt;
+                    const int kh = tap / KW, kw = tap - kh * KW;
+                    uint4 ah[MBG], al[MBG];
+#pragma unroll
+                    for (int q = 0; q < MBG; ++q) {
+                        const int ih = ih0[q] + kh, iw = iw0[q] + kw;
+                        const bool ok = m_ok[q] && ih >= 0 && ih < H && iw >= 0 && iw < W;
+                        const unsigned char* ap = ok ? in_map + (size_t)(ih * W + iw) * PS + g * 64 + h * 16 : zero + h * 16;
+                        ah[q] = *reinterpret_cast<const uint4*>(ap);
+                        al[q] = *reinterpret_cast<const uint4*>(ok ? ap + 32 : ap);
+                    }
+                    // per accumulator the same sequence of products as conv_lds (bit-identical sums); consecutive MFMAs go to
+                    // different accumulators
+#pragma unroll
+                    for (int q = 0; q < MBG; ++q) Mfma<uint16_t>::run(al[q], bh[p], acc2[q]);
+#pragma unroll
+                    for (int q = 0; q < MBG; ++q) Mfma<uint16_t>::run(ah[q], bh[p], acc[q]);
+#pragma unroll
+                    for (int q = 0; q < MBG; ++q) Mfma<uint16_t>::run(ah[q], bl[p], acc2[q]);
+                }
+                {
+                    const int kn = ks + PF < last ? ks + PF : last;
+                    bh[p] = *reinterpret_cast<const uint4*>(bp + (size_t)kn * 2048);
+                    bl[p] = *reinterpret_cast<const uint4*>(bp + (size_t)kn * 2048 + 1024);
+                }
+            }
+        }
+        const int n = nb * 32 + r;
+#pragma unroll
+        for (int q = 0; q < MBG; ++q) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int mm = (mg * MBG + q) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (mm < M && n < N) epi(mm, n, acc[q][i] + acc2[q][i], i);
+            }
+        }
+    }
+}
+
+// The 3 x 3 / pad 1 / stride 1 convolution of a 21 x 21 x 32 LDS map to 32 channels (every GRU conv, the BEV update) with all
+// shape arithmetic at compile time.  In the generic conv_lds* loops the tap decomposition and the window tests cost ~40 VALU
+// instructions per (row block, K step) beside 3 MFMAs -- at 4 cycles per wave64 VALU instruction that is ~1.7x the MFMA time, so
+// those loops are VALU-bound (9 us per conv against 2.9 us of MFMA work).  Here: the nine window tests of a lane are lane masks
+// computed once per conv, the tap offset is an immediate of the ds_read, and a K step costs one select per row block.
+// Same products in the same order per accumulator as conv_lds (bit-identical results).
+template <int MBG, typename Epi>
+__device__ __forceinline__ void conv3x3_map32(const unsigned char* in_map, const unsigned char* zero, const unsigned char* w,
+                                              int wave, int nwaves, int lane, Epi epi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lane));
+#endif
+    constexpr int HW = 21, M = 441, MB = 14, PS = 144, PF = 6;         // PF = the six K steps (3 taps x 2 channel groups) of a kernel row
+    static_assert(M <= MB * 32, "row blocks");
+    constexpr int MG = (MB + MBG - 1) / MBG;
+    const int r = lane & 31, h = lane >> 5;
+    const unsigned char* zl = zero + h * 16;
+    for (int mg = wave; mg < MG; mg += nwaves) {
+        const unsigned char* base[MBG];          // pixel (oh - 1, ow - 1) of the lane's output pixel (+ its 16 B half)
+        bool rowok[MBG][3], colok[MBG][3];
+        f32x16 acc[MBG], acc2[MBG];
+#pragma unroll
+        for (int q = 0; q < MBG; ++q) {
+            const int m = (mg * MBG + q) * 32 + r;
+            const bool m_ok = m < M;
+            const int oh = m_ok ? m / HW : 0, ow = m_ok ? m - (m / HW) * HW : 0;
+            base[q] = in_map + ((oh - 1) * HW + (ow - 1)) * PS + h * 16;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                rowok[q][t] = m_ok && oh + t - 1 >= 0 && oh + t - 1 < HW;
+                colok[q][t] = ow + t - 1 >= 0 && ow + t - 1 < HW;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[q][i] = acc2[q][i] = 0.f;
+        }
+        // weight ring: the six K steps of a kernel row in flight; the refill for row kh + 1 is issued behind the MFMAs of row kh
+        // (a rolled loop over kh: in a fully unrolled body the compiler sinks every load to just before its use)
+        const unsigned char* bp = w + (h * 32 + r) * 16;
+        uint4 bh[PF], bl[PF];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            bh[p] = *reinterpret_cast<const uint4*>(bp + (size_t)p * 2048);
+            bl[p] = *reinterpret_cast<const uint4*>(bp + (size_t)p * 2048 + 1024);
+        }
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+            const unsigned char* rowbase[MBG];
+            bool rk[MBG];
+#pragma unroll
+            for (int q = 0; q < MBG; ++q) {
+                rowbase[q] = base[q] + kh * (HW * PS);
+                rk[q] = kh == 0 ? rowok[q][0] : (kh == 1 ? rowok[q][1] : rowok[q][2]);
+            }
+            const int knext = kh < 2 ? kh + 1 : 2;                     // (the last row re-reads itself: loads stay unconditional)
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                constexpr int kGpt = 2;
+                const int kw = p / kGpt, g = p % kGpt;
+                const int toff = kw * PS + g * 64;                     // compile-time
+                uint4 ah[MBG], al[MBG];
+#pragma unroll
+                for (int q = 0; q < MBG; ++q) {
+                    const unsigned char* sel = (rk[q] && colok[q][kw]) ? rowbase[q] : zl - toff;
+                    ah[q] = *reinterpret_cast<const uint4*>(sel + toff);
+                    al[q] = *reinterpret_cast<const uint4*>(sel + toff + 32);
+                }
+#pragma unroll
+                for (int q = 0; q < MBG; ++q) Mfma<uint16_t>::run(al[q], bh[p], acc2[q]);
+#pragma unroll
+                for (int q = 0; q < MBG; ++q) Mfma<uint16_t>::run(ah[q], bh[p], acc[q]);
+#pragma unroll
+                for (int q = 0; q < MBG; ++q) Mfma<uint16_t>::run(ah[q], bl[p], acc2[q]);
+                bh[p] = *reinterpret_cast<const uint4*>(bp + (size_t)(knext * PF + p) * 2048);
+                bl[p] = *reinterpret_cast<const uint4*>(bp + (size_t)(knext * PF + p) * 2048 + 1024);
+            }
+        }
+        // epi(mg, q, i, v): accumulator element i of row block mg * MBG + q -- output pixel (mg * MBG + q) * 32 + (i & 3) +
+        // 8 * (i >> 2) + 4 * (lane >> 5), channel lane & 31.  Called for EVERY element, also the rows beyond pixel 440 of the last
+        // block: the caller decides what to guard (its LDS maps are padded to 448 pixels so that it need not)
+#pragma unroll
+        for (int q = 0; q < MBG; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) epi(mg, q, i, acc[q][i] + acc2[q][i]);
+    }
+}
+
 // border class of pixel (y, x) of an H x W map for a 3x3 / pad 1 conv: 3 * row class + column class
 __device__ __forceinline__ int border_class(int y, int x, int H, int W) {
     const int rc = y == 0 ? 0 : (y == H - 1 ? 2 : 1);
@@ -149,16 +322,24 @@ __device__ __forceinline__ bool tap_valid(int cls, int kh, int kw) {
     return !((rc == 0 && kh == 0) || (rc == 2 && kh == 2) || (cc == 0 && kw == 0) || (cc == 2 && kw == 2));
 }
 
+// sigmoid on the hardware exp2 / reciprocal (2 + 1 instructions instead of the ~35 of expf and an IEEE division -- the two gate
+// epilogues of the GRU were 1100-1400 VALU instructions per wave): relative error ~1e-6, below the bf16x3 products feeding it
+__device__ __forceinline__ float sigmoid_fast(float v) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * v));
+}
+
 // ------------------------------------------------------------------------------------------------ conv-GRU
-constexpr int kGruWaves = 14;            // one 32-pixel row block of the 441-pixel map per wave
+constexpr int kGruWaves = 7;             // two 32-pixel row blocks of the 441-pixel map per wave (conv_lds_mb<2>)
+constexpr int kBevWaves = 14;            // BEV update: one row block per wave (its second conv accumulates in the wave's registers)
 constexpr int kMapHW = 21, kMapPix = 441, kMapC = 32;
+constexpr int kMapPixPad = 448;        // 14 row blocks of 32
 constexpr int kPS32 = kMapC * 4 + 16;    // 144 B per pixel
 
 struct GruArgs {
     const float* inp6;        // [B][4][6]   (waypoint xy, softplus(ctrl) x4) per future step
     const float* state;       // [B][441][32] f32 channel-last BEV state
     float* fut;               // [B][4][441][32] f32
-    float* scratch;           // [B][2][441][32] f32: update gate and previous state of the running step (each element
+    float* scratch;           // [B][2][448][32] f32: update gate and previous state of the running step (each element
                               // is written and re-read by the SAME lane, so plain stores / loads need no fence)
     const unsigned char* w0[3];   // conv_update.0 / conv_reset.0 / conv_state_tilde.0: state part, pair [32][9*32]
     const float* wx[3];           // ... constant-input part, f32 [9][6][32]
@@ -167,28 +348,69 @@ struct GruArgs {
     const float* b2[3];
     const unsigned char* wd0; const float* bd0;   // conv_decoder.0 / .2
     const unsigned char* wd2; const float* bd2;
+    long long* trace;         // debug (tt_dec_set_trace): wall-clock stamps of workgroup 0 after every phase, or null
 };
 
 __global__ __launch_bounds__(kGruWaves * 64) void dec_gru_kernel(const GruArgs a) {
+    // LDS: two maps padded to 448 pixels (the epilogues store the 7 rows beyond pixel 440 of the last row block unguarded), the
+    // zero page, the class sums [3 convs][16 class slots][32] (slot 15: rows beyond the map).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Smap = smem;                                   // state (or (1-r)*state) map
-    unsigned char* Hmap = smem + kMapPix * kPS32;                 // hidden map of the current two-conv block
-    unsigned char* zero = Hmap + kMapPix * kPS32;                 // 64 zero bytes
-    float* Gc = reinterpret_cast<float*>(zero + 64);              // [3 convs][9 classes][32]
+    unsigned char* Hmap = smem + kMapPixPad * kPS32;              // hidden map of the current two-conv block
+    unsigned char* zero = Hmap + kMapPixPad * kPS32;              // 64 zero bytes
+    float* Gc = reinterpret_cast<float*>(zero + 64);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
+    int tri = 0;
+    auto stamp = [&]() {
+        if (a.trace && b == 0 && tid == 0 && tri < 64) a.trace[tri++] = (long long)wall_clock64();
+    };
+    stamp();
+    if (a.trace && b == 0 && tid == 0) a.trace[62] = (long long)clock64();      // shader-clock ticks (vs the 100 MHz stamps)
     if (tid < 16) reinterpret_cast<uint32_t*>(zero)[tid] = 0u;
     for (int e = tid; e < kMapPix * kMapC; e += kGruWaves * 64) {
         const int pix = e >> 5, c = e & 31;
         pair_store(Smap, kPS32, pix, c, a.state[(size_t)b * kMapPix * kMapC + e]);
     }
-    float* ug = a.scratch + (size_t)b * 2 * kMapPix * kMapC;
-    float* sg = ug + kMapPix * kMapC;
+    for (int e = tid; e < 3 * 16 * 32; e += kGruWaves * 64)
+        if (((e >> 5) & 15) >= 9) Gc[e] = 0.f;      // slot 15 (rows beyond the map) and the unused slots: finite; 0-8 are written per step
+    // The epilogues were the larger half of a conv (30-44 VALU instructions per accumulator element at 4 cycles each: pixel ->
+    // (y, x) division, border class, guards, addresses).  A lane's 32 output pixels are the same in all 32 convs, so their border
+    // classes are packed once (4 bits each, 15 = beyond the map) and every address below is `lane base + immediate`.
+    const int r = lane & 31, h = lane >> 5;
+    const int m_lane = wave * 64 + 4 * h;                         // + q * 32 + (i & 3) + 8 * (i >> 2)
+    unsigned long long clsp[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        clsp[q] = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m_lane + q * 32 + (i & 3) + 8 * (i >> 2);
+            const int y = m / kMapHW, x = m - y * kMapHW;
+            const unsigned long long c = m < kMapPix ? (unsigned long long)border_class(y, x, kMapHW, kMapHW) : 15ull;
+            clsp[q] |= c << (4 * i);
+        }
+    }
+    auto cls_of = [&](int q, int i) { return (int)((clsp[q] >> (4 * i)) & 15ull); };
+    // `ml`: m_lane laundered before every conv -- the per-element addresses are invariant across the convs and the time steps, and
+    // the compiler would otherwise hoist all of them (32 elements x 5 arrays) out of the loops and spill
+    int ml = m_lane;
+    auto fresh_rows = [&]() {
+        ml = m_lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(ml));
+#endif
+    };
+    auto row_of = [&](int q, int i) { return ml + q * 32 + (i & 3) + 8 * (i >> 2); };
+    stamp();
+    float* ug = a.scratch + (size_t)b * 2 * kMapPixPad * kMapC;   // padded like the maps: written / read unguarded
+    float* sg = ug + kMapPixPad * kMapC;
+    const float b2u = a.b2[0][r], b2r = a.b2[1][r], b2c = a.b2[2][r], bd0 = a.bd0[r], bd2 = a.bd2[r];
     for (int t = 0; t < 4; ++t) {
         // class sums of the constant-input contribution of the three first convs (+ their bias)
         const float* x = a.inp6 + ((size_t)b * 4 + t) * 6;
-        if (tid < 3 * 288) {        // thread = (conv, class, n); the conv index is wave-uniform per 288-thread group
-            const int cv = tid / 288, e = tid - cv * 288, cls = e >> 5, n = e & 31;
+        for (int ge = tid; ge < 3 * 288; ge += kGruWaves * 64) {        // entry = (conv, class, n)
+            const int cv = ge / 288, e = ge - cv * 288, cls = e >> 5, n = e & 31;
             const float* wxc = cv == 0 ? a.wx[0] : (cv == 1 ? a.wx[1] : a.wx[2]);
             const float* b0c = cv == 0 ? a.b0[0] : (cv == 1 ? a.b0[1] : a.b0[2]);
             float xv[6];
@@ -202,52 +424,68 @@ __global__ __launch_bounds__(kGruWaves * 64) void dec_gru_kernel(const GruArgs a
                 for (int j = 0; j < 6; ++j) g += wxc[(tap * 6 + j) * 32 + n] * xv[j];      // 18 independent loads in flight
                 if (tap_valid(cls, tap / 3, tap % 3)) s += g;
             }
-            Gc[tid] = s;
+            Gc[(cv * 16 + cls) * 32 + n] = s;
         }
         __syncthreads();
+        stamp();
         auto first_conv = [&](int cv) {    // H = relu(conv_cv.0([x, S]))
-            conv_lds<1, 4>(Smap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w0[cv], 32, kMapHW, kMapHW, wave,
-                           kGruWaves, lane, [&](int m, int n, float v, int) {
-                               const int y = m / kMapHW, xx = m - y * kMapHW;
-                               v += Gc[(cv * 9 + border_class(y, xx, kMapHW, kMapHW)) * 32 + n];
-                               pair_store(Hmap, kPS32, m, n, v > 0.f ? v : 0.f);
-                           });
+            fresh_rows();
+            fresh_rows();
+        conv3x3_map32<2>(Smap, zero, a.w0[cv], wave, kGruWaves, lane, [&](int, int q, int i, float v) {
+                v += Gc[(cv * 16 + cls_of(q, i)) * 32 + r];
+                pair_store(Hmap, kPS32, row_of(q, i), r, v > 0.f ? v : 0.f);
+            });
         };
         first_conv(0);
         __syncthreads();
-        conv_lds<1, 4>(Hmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w2[0], 32, kMapHW, kMapHW, wave, kGruWaves,
-                       lane, [&](int m, int n, float v, int) { ug[m * kMapC + n] = 1.f / (1.f + expf(-(v + a.b2[0][n]))); });
+        stamp();
+        fresh_rows();
+        conv3x3_map32<2>(Hmap, zero, a.w2[0], wave, kGruWaves, lane, [&](int, int q, int i, float v) {
+            ug[row_of(q, i) * kMapC + r] = sigmoid_fast(v + b2u);
+        });
         __syncthreads();
+        stamp();
         first_conv(1);
         __syncthreads();
-        conv_lds<1, 4>(Hmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w2[1], 32, kMapHW, kMapHW, wave, kGruWaves,
-                       lane, [&](int m, int n, float v, int) {
-                           const float rg = 1.f / (1.f + expf(-(v + a.b2[1][n])));
-                           const float s = pair_load(Smap, kPS32, m, n);
-                           sg[m * kMapC + n] = s;
-                           pair_store(Smap, kPS32, m, n, (1.f - rg) * s);     // own element only: no other reader now
-                       });
+        stamp();
+        fresh_rows();
+        conv3x3_map32<2>(Hmap, zero, a.w2[1], wave, kGruWaves, lane, [&](int, int q, int i, float v) {
+            const int m = row_of(q, i);
+            const float rg = sigmoid_fast(v + b2r);
+            const float s = pair_load(Smap, kPS32, m, r);
+            sg[m * kMapC + r] = s;
+            pair_store(Smap, kPS32, m, r, (1.f - rg) * s);        // own element only: no other reader now
+        });
         __syncthreads();
+        stamp();
         first_conv(2);
         __syncthreads();
-        conv_lds<1, 4>(Hmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w2[2], 32, kMapHW, kMapHW, wave, kGruWaves,
-                       lane, [&](int m, int n, float v, int) {
-                           const float cand = v + a.b2[2][n];
-                           const float u = ug[m * kMapC + n];
-                           pair_store(Smap, kPS32, m, n, (1.f - u) * sg[m * kMapC + n] + u * cand);
-                       });
+        stamp();
+        fresh_rows();
+        conv3x3_map32<2>(Hmap, zero, a.w2[2], wave, kGruWaves, lane, [&](int, int q, int i, float v) {
+            const int m = row_of(q, i);
+            const float cand = v + b2c;
+            const float u = ug[m * kMapC + r];
+            pair_store(Smap, kPS32, m, r, (1.f - u) * sg[m * kMapC + r] + u * cand);
+        });
         __syncthreads();
-        conv_lds<1, 4>(Smap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.wd0, 32, kMapHW, kMapHW, wave, kGruWaves,
-                       lane, [&](int m, int n, float v, int) {
-                           v += a.bd0[n];
-                           pair_store(Hmap, kPS32, m, n, v > 0.f ? v : 0.f);
-                       });
+        stamp();
+        fresh_rows();
+        conv3x3_map32<2>(Smap, zero, a.wd0, wave, kGruWaves, lane, [&](int, int q, int i, float v) {
+            v += bd0;
+            pair_store(Hmap, kPS32, row_of(q, i), r, v > 0.f ? v : 0.f);
+        });
         __syncthreads();
+        stamp();
         float* fo = a.fut + (((size_t)b * 4 + t) * kMapPix) * kMapC;
-        conv_lds<1, 4>(Hmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.wd2, 32, kMapHW, kMapHW, wave, kGruWaves,
-                       lane, [&](int m, int n, float v, int) { fo[(size_t)m * kMapC + n] = v + a.bd2[n]; });
+        fresh_rows();
+        conv3x3_map32<2>(Hmap, zero, a.wd2, wave, kGruWaves, lane, [&](int, int q, int i, float v) {
+            if (cls_of(q, i) != 15) fo[(size_t)row_of(q, i) * kMapC + r] = v + bd2;      // global output: exactly 441 rows
+        });
         __syncthreads();
+        stamp();
     }
+    if (a.trace && b == 0 && tid == 0) a.trace[63] = (long long)clock64();
 }
 
 // ------------------------------------------------------------------------------------------------ grid2feat
@@ -266,6 +504,7 @@ struct FlatArgs {
     const float* b[kFlatSets];
     const float* bn_scale;    // output_fc.2 (eval BatchNorm1d) scale / shift [512]
     const float* bn_shift;
+    long long* trace;         // debug (tt_dec_set_trace), as in GruArgs
 };
 
 __device__ __forceinline__ int ps_of(int C) { return C * 4 + 16; }
@@ -314,6 +553,11 @@ __global__ __launch_bounds__(kFlatWaves * 64) void dec_flatten_kernel(const Flat
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int map = blockIdx.x;
+    int tri = 0;
+    auto stamp = [&]() {
+        if (a.trace && map == 0 && tid == 0 && tri < 64) a.trace[tri++] = (long long)wall_clock64();
+    };
+    stamp();
     // LDS plan (bytes).  Region A [0, 63504): the input map; once conv21_10 has consumed it, MLP10's 128-channel hidden
     // map; after MLP10 the 4x4 and 2x2 maps.  Region B: the 10x10x64 map X10 and MLP10's Y2.  Then zero page, vectors.
     constexpr int kIn = kMapPix * kPS32;                               // 63504
@@ -342,11 +586,14 @@ __global__ __launch_bounds__(kFlatWaves * 64) void dec_flatten_kernel(const Flat
     const float* src = a.in + (size_t)map * kMapPix * kMapC;
     for (int e = tid; e < kMapPix * kMapC; e += kFlatWaves * 64) pair_store(Rin, kPS32, e >> 5, e & 31, src[e]);
     __syncthreads();
+    stamp();
     // conv21_10: 3x3 stride 2, no padding, 32 -> 64, ReLU
     conv_lds<1, 4>(Rin, kMapHW, kMapHW, 32, kPS32, zero, 2, 0, 3, 3, a.w[0], 64, 10, 10, wave, kFlatWaves, lane,
                    [&](int m, int n, float v, int) { v += a.b[0][n]; pair_store(X10, ps_of(64), m, n, v > 0.f ? v : 0.f); });
     __syncthreads();
+    stamp();
     se_block(a, 1, 10, 64, X10, Y10a, Y10b, vec, zero, wave, lane, tid);            // X10 updated in place
+    stamp();
     float* mid = a.mids ? a.mids + (size_t)map * (100 * 64 + 16 * 128 + 4 * 256) : nullptr;
     if (mid)
         for (int e = tid; e < 100 * 64; e += kFlatWaves * 64) mid[e] = pair_load(X10, ps_of(64), e >> 6, e & 63);
@@ -354,14 +601,18 @@ __global__ __launch_bounds__(kFlatWaves * 64) void dec_flatten_kernel(const Flat
     conv_lds<1, 4>(X10, 10, 10, 64, ps_of(64), zero, 2, 0, 3, 3, a.w[5], 128, 4, 4, wave, kFlatWaves, lane,
                    [&](int m, int n, float v, int) { v += a.b[5][n]; pair_store(X4, ps_of(128), m, n, v > 0.f ? v : 0.f); });
     __syncthreads();
+    stamp();
     se_block(a, 6, 4, 128, X4, Y4a, Y4b, vec, zero, wave, lane, tid);
+    stamp();
     if (mid)
         for (int e = tid; e < 16 * 128; e += kFlatWaves * 64) mid[100 * 64 + e] = pair_load(X4, ps_of(128), e >> 7, e & 127);
     // conv4_2: 3x3 stride 1, no padding, 128 -> 256, ReLU
     conv_lds<1, 4>(X4, 4, 4, 128, ps_of(128), zero, 1, 0, 3, 3, a.w[10], 256, 2, 2, wave, kFlatWaves, lane,
                    [&](int m, int n, float v, int) { v += a.b[10][n]; pair_store(X2, ps_of(256), m, n, v > 0.f ? v : 0.f); });
     __syncthreads();
+    stamp();
     se_block(a, 11, 2, 256, X2, Y2a, Y2b, vec, zero, wave, lane, tid);
+    stamp();
     if (mid)
         for (int e = tid; e < 4 * 256; e += kFlatWaves * 64)
             mid[100 * 64 + 16 * 128 + e] = pair_load(X2, ps_of(256), e >> 8, e & 255);
@@ -373,9 +624,11 @@ __global__ __launch_bounds__(kFlatWaves * 64) void dec_flatten_kernel(const Flat
                        pair_store(H512, ps_of(512), 0, n, v * a.bn_scale[n] + a.bn_shift[n]);
                    });
     __syncthreads();
+    stamp();
     float* dst = a.out + (size_t)map * 256;
     conv_lds<1, 4>(H512, 1, 1, 512, ps_of(512), zero, 1, 0, 1, 1, a.w[16], 256, 1, 1, wave, kFlatWaves, lane,
                    [&](int, int n, float v, int) { v += a.b[16][n]; dst[n] = v > 0.f ? v : 0.f; });
+    stamp();
 }
 
 // ------------------------------------------------------------------------------------------------ BEV update
@@ -394,7 +647,7 @@ struct BevArgs {
     const float* b2;          // [32]
 };
 
-__global__ __launch_bounds__(kGruWaves * 64) void dec_bev_update_kernel(const BevArgs a) {
+__global__ __launch_bounds__(kBevWaves * 64) void dec_bev_update_kernel(const BevArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Bmap = smem;
     unsigned char* Hmap = smem + kMapPix * kPS32;
@@ -404,9 +657,9 @@ __global__ __launch_bounds__(kGruWaves * 64) void dec_bev_update_kernel(const Be
     const int b = blockIdx.x;
     if (tid < 16) reinterpret_cast<uint32_t*>(zero)[tid] = 0u;
     const float* src = a.bev + (size_t)b * kMapPix * kMapC;
-    for (int e = tid; e < kMapPix * kMapC; e += kGruWaves * 64) pair_store(Bmap, kPS32, e >> 5, e & 31, src[e]);
+    for (int e = tid; e < kMapPix * kMapC; e += kBevWaves * 64) pair_store(Bmap, kPS32, e >> 5, e & 31, src[e]);
     const float* g = a.G + (size_t)b * 9 * 128;
-    for (int e = tid; e < 9 * 128; e += kGruWaves * 64) {
+    for (int e = tid; e < 9 * 128; e += kBevWaves * 64) {
         const int cls = e >> 7, n = e & 127;
         float s = a.b0[n];
         for (int kh = 0; kh < 3; ++kh)
@@ -420,13 +673,13 @@ __global__ __launch_bounds__(kGruWaves * 64) void dec_bev_update_kernel(const Be
     for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
     for (int c = 0; c < 4; ++c) {
         conv_lds<1, 4>(Bmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w0 + (size_t)c * 32 * (9 * 32 * 4), 32,
-                       kMapHW, kMapHW, wave, kGruWaves, lane, [&](int m, int n, float v, int) {
+                       kMapHW, kMapHW, wave, kBevWaves, lane, [&](int m, int n, float v, int) {
                            const int y = m / kMapHW, x = m - y * kMapHW;
                            v += Gc[border_class(y, x, kMapHW, kMapHW) * 128 + c * 32 + n];
                            pair_store(Hmap, kPS32, m, n, v > 0.f ? v : 0.f);
                        });
         __syncthreads();
-        conv_lds<1, 4>(Hmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w2[c], 32, kMapHW, kMapHW, wave, kGruWaves,
+        conv_lds<1, 4>(Hmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w2[c], 32, kMapHW, kMapHW, wave, kBevWaves,
                        lane, [&](int, int, float v, int i) { acc2[i] += v; });
         __syncthreads();
     }
@@ -446,6 +699,12 @@ __global__ __launch_bounds__(kGruWaves * 64) void dec_bev_update_kernel(const Be
 
 using namespace tt;
 
+static long long* g_dec_trace = nullptr;
+extern "C" int tt_dec_set_trace(void* stamps_or_null) {
+    g_dec_trace = static_cast<long long*>(stamps_or_null);
+    return 0;
+}
+
 extern "C" int tt_dec_gru(int B, const float* inp6, const float* state, float* fut, float* scratch, const void* const* w0,
                           const float* const* wx, const float* const* b0, const void* const* w2, const float* const* b2,
                           const void* wd0, const float* bd0, const void* wd2, const float* bd2, void* stream) {
@@ -458,7 +717,8 @@ extern "C" int tt_dec_gru(int B, const float* inp6, const float* state, float* f
         a.w2[c] = (const unsigned char*)w2[c]; a.b2[c] = b2[c];
     }
     a.wd0 = (const unsigned char*)wd0; a.bd0 = bd0; a.wd2 = (const unsigned char*)wd2; a.bd2 = bd2;
-    const size_t smem = (size_t)2 * kMapPix * kPS32 + 64 + 3 * 9 * 32 * 4;
+    a.trace = g_dec_trace;
+    const size_t smem = (size_t)2 * kMapPixPad * kPS32 + 64 + 3 * 16 * 32 * 4;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gru_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -474,6 +734,7 @@ extern "C" int tt_dec_flatten(int maps, const float* in, float* out, float* mids
     TT_REQUIRE(maps > 0 && in && out && w && b && bn_scale && bn_shift, "tt_dec_flatten: null");
     FlatArgs a;
     a.in = in; a.out = out; a.mids = mids_or_null; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
+    a.trace = g_dec_trace;
     for (int i = 0; i < kFlatSets; ++i) {
         TT_REQUIRE(w[i] && b[i], "tt_dec_flatten: null weight set %d", i);
         a.w[i] = (const unsigned char*)w[i];
@@ -509,6 +770,6 @@ extern "C" int tt_dec_bev_update(int B, const float* bev, const float* G, float*
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr = true;
     }
-    hipLaunchKernelGGL(dec_bev_update_kernel, dim3((unsigned)B), dim3(kGruWaves * 64), smem, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(dec_bev_update_kernel, dim3((unsigned)B), dim3(kBevWaves * 64), smem, (hipStream_t)stream, a);
     return check_launch("tt_dec_bev_update");
 }

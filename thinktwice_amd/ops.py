@@ -1110,7 +1110,7 @@ def dec_gru(wts, inp6, state, fut):
     """wts: dict from decoder_fused.prep_gru; inp6 (B,4,6), state (B,441,32), fut (B,4,441,32) all f32 contiguous."""
     B = state.shape[0]
     assert inp6.is_contiguous() and state.is_contiguous() and fut.is_contiguous()
-    scratch = torch.empty(B, 2, 441, 32, dtype=torch.float32, device=state.device)
+    scratch = torch.empty(B, 2, 448, 32, dtype=torch.float32, device=state.device)       # 441 pixels padded to 14 x 32 rows
     check(lib().tt_dec_gru(_c(B), ptr(inp6), ptr(state), ptr(fut), ptr(scratch), wts["w0"], wts["wx"], wts["b0"],
                            wts["w2"], wts["b2"], ptr(wts["wd0"]), ptr(wts["bd0"]), ptr(wts["wd2"]), ptr(wts["bd2"]),
                            _st(state)), "tt_dec_gru")

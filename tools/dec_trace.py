@@ -1,0 +1,42 @@
+"""Phase timing inside tt_dec_gru / tt_dec_flatten (tools only; tt_dec_set_trace): wall-clock stamps of workgroup 0, us since entry."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from thinktwice_amd import _lib, config, decoder_fused as DF, ops, params  # noqa: E402
+
+cfg = config.model_config(final_dim=(128, 256))
+sd = params.init_params(cfg, seed=0, parts=("fusion", "decoder"))
+L = _lib.lib()
+
+
+def traced(fn, name):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    buf = torch.zeros(64, dtype=torch.int64, device="cuda")
+    L.tt_dec_set_trace(ctypes.c_void_p(buf.data_ptr()))
+    fn()
+    torch.cuda.synchronize()
+    L.tt_dec_set_trace(ctypes.c_void_p(0))
+    t = buf.cpu()
+    clk = (t[63] - t[62]).item() if t[63] > 0 else 0
+    t[62] = t[63] = 0
+    n = int((t > 0).sum())
+    rel = [(t[i] - t[0]).item() / 100 for i in range(n)]
+    print(f"== {name}: {n} stamps, total {rel[-1]:.1f} us")
+    print("   deltas: " + " ".join(f"{rel[i] - rel[i - 1]:.1f}" for i in range(1, n)))
+    if clk:
+        print(f"   s_memtime ticks over the kernel: {clk} -> {clk / rel[-1]:.0f} per us")
+
+
+for B in (1, 8):
+    w = DF.prep_gru(sd, "decoder.decoder_layers.0.prediction_module.spatial_gru", "cuda")
+    inp6, state, fut = torch.randn(B, 4, 6).cuda(), torch.randn(B, 441, 32).cuda(), torch.empty(B, 4, 441, 32).cuda()
+    traced(lambda: ops.dec_gru(w, inp6, state, fut), f"gru B={B} (entry, map load, then per step: class sums + 8 convs)")
+    fw = DF.prep_flatten(sd, "cuda")
+    maps = torch.randn(B * 4, 441, 32).cuda()
+    traced(lambda: ops.dec_flatten(fw, maps), f"flatten maps={B * 4} (load, conv21_10, MLP10, conv10_4, MLP4, conv4_2, MLP2, fc0, fc3)")
