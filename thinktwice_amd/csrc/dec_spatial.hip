@@ -137,93 +137,6 @@ __device__ __forceinline__ void conv_lds(const unsigned char* in_map, int H, int
     }
 }
 
-// The same convolution with MBG 32-row blocks per work item sharing every weight fragment (one 32-column block per item).  The
-// 21 x 21 x 32 -> 32 convolutions of the GRU / BEV update have ONE column block: with a row block per wave, fourteen waves each
-// pulled the whole 36 KiB weight matrix through the workgroup's single L1 (504 KiB at 64 B / clock = 3.8 us per convolution,
-// more than its 2.9 us of MFMA work); two row blocks per wave halve that stream and the number of waves.
-// epi(m, n, v, i) as above; items = (group of MBG row blocks, column block), dealt to the waves round-robin.
-template <int MBG, int PF, typename Epi>
-__device__ __forceinline__ void conv_lds_mb(const unsigned char* in_map, int H, int W, int Cp, int PS,
-                                            const unsigned char* zero, int stride, int pad, int KH, int KW,
-                                            const unsigned char* w, int N, int OH, int OW, int wave, int nwaves, int lane,
-                                            Epi epi) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(lane));
-#endif
-    const int M = OH * OW, MB = (M + 31) >> 5, NB = (N + 31) >> 5, MG = (MB + MBG - 1) / MBG;
-    const int gpt = Cp >> 4;
-    const int nsteps = KH * KW * gpt;
-    const size_t blk_bytes = (size_t)nsteps * 2048;
-    const int r = lane & 31, h = lane >> 5;
-    for (int item = wave; item < MG * NB; item += nwaves) {
-        const int mg = item / NB, nb = item - mg * NB;
-        int ih0[MBG], iw0[MBG];
-        bool m_ok[MBG];
-        f32x16 acc[MBG], acc2[MBG];
-#pragma unroll
-        for (int q = 0; q < MBG; ++q) {
-            const int m = (mg * MBG + q) * 32 + r;
-            m_ok[q] = m < M;
-            const int oh = m_ok[q] ? m / OW : 0, ow = m_ok[q] ? m - (m / OW) * OW : 0;
-            ih0[q] = oh * stride - pad;
-            iw0[q] = ow * stride - pad;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[q][i] = acc2[q][i] = 0.f;
-        }
-        const unsigned char* bp = w + (size_t)nb * blk_bytes + (h * 32 + r) * 16;
-        uint4 bh[PF], bl[PF];
-        const int last = nsteps - 1;
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const int kp = p < last ? p : last;
-            bh[p] = *reinterpret_cast<const uint4*>(bp + (size_t)kp * 2048);
-            bl[p] = *reinterpret_cast<const uint4*>(bp + (size_t)kp * 2048 + 1024);
-        }
-#pragma unroll 1
-        for (int ks0 = 0; ks0 < nsteps; ks0 += PF) {
-#pragma unroll
-            for (int p = 0; p < PF; ++p) {
-                const int ks = ks0 + p;
-                if (ks < nsteps) {
-                    const int tap = ks / gpt, g = ks - tap * gpt;
-                    const int kh = tap / KW, kw = tap - kh * KW;
-                    uint4 ah[MBG], al[MBG];
-#pragma unroll
-                    for (int q = 0; q < MBG; ++q) {
-                        const int ih = ih0[q] + kh, iw = iw0[q] + kw;
-                        const bool ok = m_ok[q] && ih >= 0 && ih < H && iw >= 0 && iw < W;
-                        const unsigned char* ap = ok ? in_map + (size_t)(ih * W + iw) * PS + g * 64 + h * 16 : zero + h * 16;
-                        ah[q] = *reinterpret_cast<const uint4*>(ap);
-                        al[q] = *reinterpret_cast<const uint4*>(ok ? ap + 32 : ap);
-                    }
-                    // per accumulator the same sequence of products as conv_lds (bit-identical sums); consecutive MFMAs go to
-                    // different accumulators
-#pragma unroll
-                    for (int q = 0; q < MBG; ++q) Mfma<uint16_t>::run(al[q], bh[p], acc2[q]);
-#pragma unroll
-                    for (int q = 0; q < MBG; ++q) Mfma<uint16_t>::run(ah[q], bh[p], acc[q]);
-#pragma unroll
-                    for (int q = 0; q < MBG; ++q) Mfma<uint16_t>::run(ah[q], bl[p], acc2[q]);
-                }
-                {
-                    const int kn = ks + PF < last ? ks + PF : last;
-                    bh[p] = *reinterpret_cast<const uint4*>(bp + (size_t)kn * 2048);
-                    bl[p] = *reinterpret_cast<const uint4*>(bp + (size_t)kn * 2048 + 1024);
-                }
-            }
-        }
-        const int n = nb * 32 + r;
-#pragma unroll
-        for (int q = 0; q < MBG; ++q) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int mm = (mg * MBG + q) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (mm < M && n < N) epi(mm, n, acc[q][i] + acc2[q][i], i);
-            }
-        }
-    }
-}
-
 // The 3 x 3 / pad 1 / stride 1 convolution of a 21 x 21 x 32 LDS map to 32 channels (every GRU conv, the BEV update) with all
 // shape arithmetic at compile time.  In the generic conv_lds* loops the tap decomposition and the window tests cost ~40 VALU
 // instructions per (row block, K step) beside 3 MFMAs -- at 4 cycles per wave64 VALU instruction that is ~1.7x the MFMA time, so
@@ -330,7 +243,7 @@ __device__ __forceinline__ float sigmoid_fast(float v) {
 
 // ------------------------------------------------------------------------------------------------ conv-GRU
 constexpr int kGruWaves = 7;             // two 32-pixel row blocks of the 441-pixel map per wave (conv_lds_mb<2>)
-constexpr int kBevWaves = 14;            // BEV update: one row block per wave (its second conv accumulates in the wave's registers)
+constexpr int kBevWaves = 7;             // BEV update: two row blocks per wave too (its second conv accumulates in the wave's registers)
 constexpr int kMapHW = 21, kMapPix = 441, kMapC = 32;
 constexpr int kMapPixPad = 448;        // 14 row blocks of 32
 constexpr int kPS32 = kMapC * 4 + 16;    // 144 B per pixel
@@ -648,49 +561,72 @@ struct BevArgs {
 };
 
 __global__ __launch_bounds__(kBevWaves * 64) void dec_bev_update_kernel(const BevArgs a) {
+    // (maps padded to 448 pixels, 16 class slots, packed border classes: see dec_gru_kernel)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Bmap = smem;
-    unsigned char* Hmap = smem + kMapPix * kPS32;
-    unsigned char* zero = Hmap + kMapPix * kPS32;
-    float* Gc = reinterpret_cast<float*>(zero + 64);              // [9 classes][128], bias included
+    unsigned char* Hmap = smem + kMapPixPad * kPS32;
+    unsigned char* zero = Hmap + kMapPixPad * kPS32;
+    float* Gc = reinterpret_cast<float*>(zero + 64);              // [16 class slots][128], bias included
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     if (tid < 16) reinterpret_cast<uint32_t*>(zero)[tid] = 0u;
     const float* src = a.bev + (size_t)b * kMapPix * kMapC;
     for (int e = tid; e < kMapPix * kMapC; e += kBevWaves * 64) pair_store(Bmap, kPS32, e >> 5, e & 31, src[e]);
     const float* g = a.G + (size_t)b * 9 * 128;
-    for (int e = tid; e < 9 * 128; e += kBevWaves * 64) {
+    for (int e = tid; e < 16 * 128; e += kBevWaves * 64) {
         const int cls = e >> 7, n = e & 127;
-        float s = a.b0[n];
-        for (int kh = 0; kh < 3; ++kh)
-            for (int kw = 0; kw < 3; ++kw)
-                if (tap_valid(cls, kh, kw)) s += g[(kh * 3 + kw) * 128 + n];
+        float s = 0.f;
+        if (cls < 9) {
+            s = a.b0[n];
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw)
+                    if (tap_valid(cls, kh, kw)) s += g[(kh * 3 + kw) * 128 + n];
+        }
         Gc[e] = s;
     }
-    __syncthreads();
-    f32x16 acc2;
+    const int r = lane & 31, h = lane >> 5;
+    const int m_lane = wave * 64 + 4 * h;                         // + q * 32 + (i & 3) + 8 * (i >> 2)
+    unsigned long long clsp[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+    for (int q = 0; q < 2; ++q) {
+        clsp[q] = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m_lane + q * 32 + (i & 3) + 8 * (i >> 2);
+            const int y = m / kMapHW, x = m - y * kMapHW;
+            clsp[q] |= (m < kMapPix ? (unsigned long long)border_class(y, x, kMapHW, kMapHW) : 15ull) << (4 * i);
+        }
+    }
+    __syncthreads();
+    f32x16 out_acc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out_acc[q][i] = 0.f;
     for (int c = 0; c < 4; ++c) {
-        conv_lds<1, 4>(Bmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w0 + (size_t)c * 32 * (9 * 32 * 4), 32,
-                       kMapHW, kMapHW, wave, kBevWaves, lane, [&](int m, int n, float v, int) {
-                           const int y = m / kMapHW, x = m - y * kMapHW;
-                           v += Gc[border_class(y, x, kMapHW, kMapHW) * 128 + c * 32 + n];
-                           pair_store(Hmap, kPS32, m, n, v > 0.f ? v : 0.f);
-                       });
+        int ml = m_lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(ml));
+#endif
+        conv3x3_map32<2>(Bmap, zero, a.w0 + (size_t)c * 32 * (9 * 32 * 4), wave, kBevWaves, lane,
+                         [&](int, int q, int i, float v) {
+                             v += Gc[(int)((clsp[q] >> (4 * i)) & 15ull) * 128 + c * 32 + r];
+                             pair_store(Hmap, kPS32, ml + q * 32 + (i & 3) + 8 * (i >> 2), r, v > 0.f ? v : 0.f);
+                         });
         __syncthreads();
-        conv_lds<1, 4>(Hmap, kMapHW, kMapHW, kMapC, kPS32, zero, 1, 1, 3, 3, a.w2[c], 32, kMapHW, kMapHW, wave, kBevWaves,
-                       lane, [&](int, int, float v, int i) { acc2[i] += v; });
+        conv3x3_map32<2>(Hmap, zero, a.w2[c], wave, kBevWaves, lane, [&](int, int q, int i, float v) { out_acc[q][i] += v; });
         __syncthreads();
     }
-    const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int m = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (m < kMapPix) {
-            const float v = acc2[i] + a.b2[r] + src[(size_t)m * kMapC + r];
-            a.out[(size_t)b * a.out_bstride + (size_t)m * kMapC + r] = v;
-            if (a.out2) a.out2[(size_t)b * a.out2_bstride + (size_t)m * kMapC + r] = v;
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = wave * 64 + q * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (m < kMapPix) {
+                const float v = out_acc[q][i] + a.b2[r] + src[(size_t)m * kMapC + r];
+                a.out[(size_t)b * a.out_bstride + (size_t)m * kMapC + r] = v;
+                if (a.out2) a.out2[(size_t)b * a.out2_bstride + (size_t)m * kMapC + r] = v;
+            }
         }
     }
 }
@@ -763,7 +699,7 @@ extern "C" int tt_dec_bev_update(int B, const float* bev, const float* G, float*
         TT_REQUIRE(w2[c], "tt_dec_bev_update: null w2[%d]", c);
         a.w2[c] = (const unsigned char*)w2[c];
     }
-    const size_t smem = (size_t)2 * kMapPix * kPS32 + 64 + 9 * 128 * 4;
+    const size_t smem = (size_t)2 * kMapPixPad * kPS32 + 64 + 16 * 128 * 4;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bev_update_kernel),

@@ -40,3 +40,22 @@ for B in (1, 8):
     fw = DF.prep_flatten(sd, "cuda")
     maps = torch.randn(B * 4, 441, 32).cuda()
     traced(lambda: ops.dec_flatten(fw, maps), f"flatten maps={B * 4} (load, conv21_10, MLP10, conv10_4, MLP4, conv4_2, MLP2, fc0, fc3)")
+
+
+def timeit(fn, iters=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+bw = DF.prep_bev_update(sd, "decoder.decoder_layers.0", "cuda")
+for B in (1, 8):
+    bev, G, o = torch.randn(B, 441, 32).cuda(), torch.randn(B, 1152).cuda(), torch.empty(B, 441, 32).cuda()
+    print(f"bev_update B={B}: {timeit(lambda: ops.dec_bev_update(bw, bev, G, o)):.1f} us per launch (back to back)")
