@@ -365,3 +365,37 @@ def test_plan_arena_compaction_reuses_memory_by_liveness_and_stream():
     assert arg_offsets(p, tmp) == [0, 3000]
     L.tt_plan_destroy(p)
     os.remove(tmp)
+
+
+def test_wide_chain_workspace_and_argument_checks_are_host_side():
+    """tt_mlp_chain_wide_workspace_bytes is pure host arithmetic: one fragment-major f32 scratch per stage output a later stage
+    reads, rows padded to the workgroup's row blocks (1, 2 or 4 x 32), columns to 32, each rounded to 256 B; and the launch entry
+    refuses a missing / short workspace and an over-wide grid before touching the device."""
+    import ctypes
+    from thinktwice_amd import _lib, ops
+    L = _lib.lib()
+    L.tt_mlp_chain_wide_workspace_bytes.restype = ctypes.c_longlong
+
+    def stages(dims, srcs):
+        arr = (ops._ChainStage * (len(dims) - 1))()
+        for i in range(len(dims) - 1):
+            arr[i].w = 0x1000
+            arr[i].K, arr[i].Kp, arr[i].N = dims[i], (dims[i] + 15) // 16 * 16, dims[i + 1]
+            arr[i].in_sel = srcs[i]
+        return arr
+
+    merge = stages([1024, 512, 512, 256], [-1, 0, 1])                      # outputs of stages 0 and 1 are read later
+    ws = lambda R, arr, n: int(L.tt_mlp_chain_wide_workspace_bytes(ctypes.c_longlong(R), ctypes.c_int(n), arr))
+    assert ws(4, merge, 3) == 2 * 32 * 512 * 4                             # one row block
+    assert ws(33, merge, 3) == 2 * 64 * 512 * 4                            # two row blocks in one workgroup
+    assert ws(480, merge, 3) == 2 * 512 * 512 * 4                          # 15 row blocks -> 4 groups of 4
+    narrow = stages([256, 4, 8], [-1, 0])                                  # a 4-wide intermediate still takes a 32-column block
+    assert ws(1, narrow, 2) == 32 * 32 * 4
+    assert ws(1, stages([256, 256], [-1]), 1) == 256                       # nothing kept: the minimum
+    assert ws(0, merge, 3) == -1 and ws(4, merge, 0) == -1
+    x = ctypes.c_void_p(0x2000)
+    call = lambda R, g, wsp, nbytes: L.tt_mlp_chain_wide(x, ctypes.c_longlong(R), ctypes.c_int(1024), ctypes.c_int(3), merge,
+                                                         ctypes.c_int(g), ctypes.c_void_p(wsp), ctypes.c_longlong(nbytes), None)
+    assert call(4, 16, 0, 1 << 20) != 0 and b"workspace" in L.tt_last_error()
+    assert call(4, 16, 0x4000, 1024) != 0 and b"workspace" in L.tt_last_error()
+    assert call(480, 65, 0x4000, 1 << 24) != 0 and b"co-resident" in L.tt_last_error()
