@@ -341,7 +341,9 @@ int tt_look_query_ln(int B, const int* query_of_slot, const float* ref_packed, c
                      int row_stride, void* stream);
 int tt_msda_sample_ln(int B, const void* value, int value_dtype, int value_cstride, int value_coff,
                       const float* offsets, const float* logits, const float* ref_packed, const int* level_hw,
-                      const float* gamma, const float* beta, float eps, float* out, float* out_ln, void* stream);
+                      const float* gamma, const float* beta, float eps, float* out, float* out_ln,
+                      const int* max_len_or_null, void* stream);   /* max_len (device, from tt_look_project_pack): rows of
+                      slots >= *max_len are skipped and left unwritten -- tt_sca_reduce_ln never reads them */
 int tt_sca_reduce_ln(int B, const float* x, const int* max_len, const float* gamma, const float* beta, float eps,
                      float* out, void* stream);
 /* row (b, t) of the refinement layer's mlp input: LayerNorm(cat([fflat(b,t) | look(b) | 0 | temporal(t) | meas(b)])) */

@@ -83,3 +83,39 @@ def test_bev_update_kernel_matches_oracle(sd_cfg, B):
     torch.cuda.synchronize()
     got = out.cpu().view(B, 21, 21, 32).permute(0, 3, 1, 2)
     assert _rel(got, ref) < 1e-3, _rel(got, ref)
+
+
+def test_msda_sample_ln_skips_only_the_slots_no_one_reads():
+    """tt_msda_sample_ln with the device `max_len` of tt_look_project_pack: rows of slots < max_len are bit-identical to the
+    unskipped launch, rows of slots >= max_len are left untouched (tt_sca_reduce_ln sums k < max_len only, so the look feature
+    is unchanged)."""
+    from thinktwice_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    level_hw = [(16, 32), (8, 16), (4, 8), (2, 4)]
+    S = sum(h * w for h, w in level_hw)
+    value = torch.randn(B * 4, S, 512, generator=g).cuda()                 # two layers' value maps side by side
+    R = B * 4 * 120
+    off = (torch.randn(R, 512, generator=g) * 2).cuda()
+    aw = torch.randn(R, 256, generator=g).cuda()
+    ref = torch.rand(B, 4, 120, 2, generator=g).cuda()
+    gamma, beta = torch.randn(256, generator=g).cuda(), torch.randn(256, generator=g).cuda()
+    full, full_ln = ops.msda_sample_ln(value, off, aw, ref, level_hw, B, 256, gamma, beta)
+    ml = torch.tensor([37], dtype=torch.int32, device="cuda")
+    import thinktwice_amd.ops as O
+    real_empty = torch.empty
+    try:                                                                    # the skipped rows keep whatever the buffers held: NaN
+        torch.empty = lambda *a, **k: real_empty(*a, **k).fill_(float("nan")) if k.get("dtype") == torch.float32 else real_empty(*a, **k)
+        part, part_ln = O.msda_sample_ln(value, off, aw, ref, level_hw, B, 256, gamma, beta, max_len=ml)
+    finally:
+        torch.empty = real_empty
+    torch.cuda.synchronize()
+    slot = torch.arange(R, device="cuda") % 120
+    live = slot < 37
+    assert torch.equal(part[live], full[live]) and torch.equal(part_ln[live], full_ln[live])
+    assert torch.isnan(part[~live]).all() and torch.isnan(part_ln[~live]).all()
+    y = torch.randn(R, 256, generator=g).cuda()
+    a = ops.sca_reduce_ln(torch.where(live[:, None], y, torch.full_like(y, float("nan"))), ml, B, torch.ones(1024).cuda(),
+                          torch.zeros(1024).cuda())
+    b = ops.sca_reduce_ln(y, ml, B, torch.ones(1024).cuda(), torch.zeros(1024).cuda())
+    assert torch.equal(a, b)                                                # the consumer never touches the skipped rows

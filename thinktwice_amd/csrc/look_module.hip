@@ -287,10 +287,14 @@ __global__ __launch_bounds__(256) void msda_sample_ln_kernel(const T* __restrict
                                                              const float* __restrict__ ref, LevelMaps lv, int S, int vcs,
                                                              int vco, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps,
-                                                             float* __restrict__ out, float* __restrict__ out_ln) {
+                                                             float* __restrict__ out, float* __restrict__ out_ln,
+                                                             const int* __restrict__ max_len) {
     __shared__ float red[4];
     const long long row = blockIdx.x;
     const int bc = (int)(row / kQ);
+    // slots at or beyond the longest camera list are never read (tt_sca_reduce_ln sums k < max_len): their rows -- random 128 B
+    // reads of the value maps, the kernel's whole cost -- are skipped and left unwritten
+    if (max_len && (int)(row - (long long)bc * kQ) >= *max_len) return;
     const int t = threadIdx.x, head = t >> 5;
     const float* lg = logits + row * 256 + head * 32;
     float mx = -INFINITY;
@@ -491,7 +495,7 @@ extern "C" int tt_look_query_ln(int B, const int* query_of_slot, const float* re
 extern "C" int tt_msda_sample_ln(int B, const void* value, int value_dtype, int value_cstride, int value_coff,
                                  const float* offsets, const float* logits, const float* ref_packed, const int* level_hw,
                                  const float* gamma, const float* beta, float eps, float* out, float* out_ln,
-                                 void* stream) {
+                                 const int* max_len_or_null, void* stream) {
     TT_REQUIRE(value && offsets && logits && ref_packed && level_hw && gamma && beta && out && out_ln,
                "tt_msda_sample_ln: null");
     TT_REQUIRE(value_cstride >= 256 && value_coff >= 0 && value_coff + 256 <= value_cstride,
@@ -504,7 +508,7 @@ extern "C" int tt_msda_sample_ln(int B, const void* value, int value_dtype, int 
     hipStream_t st = (hipStream_t)stream;
 #define MLN(T)                                                                                                     \
     hipLaunchKernelGGL(msda_sample_ln_kernel<T>, dim3(rows_n), dim3(256), 0, st, (const T*)value, offsets, logits, \
-                       ref_packed, m, S, value_cstride, value_coff, gamma, beta, eps, out, out_ln)
+                       ref_packed, m, S, value_cstride, value_coff, gamma, beta, eps, out, out_ln, max_len_or_null)
     if (value_dtype == TT_F32) MLN(float);
     else if (value_dtype == TT_F16) MLN(f16_t);
     else MLN(uint16_t);

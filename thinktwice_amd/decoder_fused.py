@@ -222,7 +222,7 @@ class FusedDecoder:
                            {"lin": a[3], "src": 1, "out": (aw, 0)}])
         if vready is not None and wait_values:
             torch.cuda.current_stream(dev).wait_stream(vready)
-        att, an = ops.msda_sample_ln(value_all, off, aw, ref, level_hw, B, L * 256, *lay.ffn_ln)
+        att, an = ops.msda_sample_ln(value_all, off, aw, ref, level_hw, B, L * 256, *lay.ffn_ln, max_len=max_len)
         y = torch.empty(R, 256, dtype=F32, device=dev)
         b_ = lay.chain_b
         ops.mlp_chain(an, [{"lin": b_[0], "src": -1}, {"lin": b_[1], "src": 0, "res": (att, 0), "out": (y, 0)}])

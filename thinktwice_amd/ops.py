@@ -1078,15 +1078,16 @@ def look_query_ln(qos, ref, wp, ctrl, raw_ctrl, temporal, static, meas, flat, ma
     return out
 
 
-def msda_sample_ln(value, offsets, logits, ref, level_hw, B, coff, gamma, beta, eps=1e-5):
-    """msda_sample + LayerNorm(256): -> (raw rows, normalised rows), both (B*4*120, 256) f32."""
+def msda_sample_ln(value, offsets, logits, ref, level_hw, B, coff, gamma, beta, eps=1e-5, max_len=None):
+    """msda_sample + LayerNorm(256): -> (raw rows, normalised rows), both (B*4*120, 256) f32.  `max_len` (device int from
+    look_project_pack): the rows of slots >= max_len are skipped and left unwritten (sca_reduce_ln never reads them)."""
     R = B * 4 * 120
     out = torch.empty(R, 256, dtype=torch.float32, device=value.device)
     out_ln = torch.empty(R, 256, dtype=torch.float32, device=value.device)
     hw = (ctypes.c_int * 8)(*[v for pair in level_hw for v in pair])
     check(lib().tt_msda_sample_ln(_c(B), ptr(value), _c(dtype_code(value)), _c(value.shape[-1]), _c(coff), ptr(offsets),
                                   ptr(logits), ptr(ref), hw, ptr(gamma), ptr(beta), _f(eps), ptr(out), ptr(out_ln),
-                                  _st(value)), "tt_msda_sample_ln")
+                                  ptr(max_len), _st(value)), "tt_msda_sample_ln")
     return out, out_ln
 
 
