@@ -460,3 +460,59 @@ def test_pipelined_tiles_are_bit_identical_to_the_8wave_tiles():
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "x3_pipe_ab.py"), "1", arms], cwd=root,
                            env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "ALL OK" in r.stdout, (env_extra, r.stdout[-1500:], r.stderr[-500:])
+
+
+SPLITK_X3_CASES = [   # (N, H, W, Cin, Cout, k, act, use_bn, residuals, window)
+    (8, 14, 28, 512, 512, 3, 1, True, 1, False),     # ResNet layer 4 of a batch-1 tick: M = 3136, 104 tiles x 4 K ranges
+    (8, 14, 28, 2048, 512, 1, 1, True, 1, False),    # its 1x1 with K = 2048
+    (3, 13, 29, 256, 320, 3, 0, False, 0, False),    # ragged M = 1131 (4.4 row tiles), 5 column tiles, 9 ranges of 8 K tiles
+    (8, 14, 28, 512, 96, 3, 3, True, 2, True),       # Cout = 96: half-empty second column tile; channel-window input, GELU, 2 residuals
+    (16, 4, 8, 512, 512, 3, 1, True, 0, False),      # M = 512 (the small-golden trunk): 16 tiles x 16 ranges
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_X3_CASES, ids=[f"M{c[0] * c[1] * c[2]}-K{c[3] * c[5] * c[5]}-N{c[4]}" for c in SPLITK_X3_CASES])
+def test_bf16x3_splitk_tile_matches_torch_f32(case):
+    """Few rows, long K, bf16x3 operand: the 64-wide bf16x3 tile with the K tiles dealt over workgroups (conv_igemm_glds.hip
+    x3_splitk_plan) + the ordered finalize kernel, against torch f32 (1e-4 of the output's max) and the exact-f32 split-K kernel
+    the same layers ran before; the kernel that ran is asserted, and the result is run-to-run bit-identical (ordered slices)."""
+    from thinktwice_amd import ops, weights
+    N, H, W, Cin, Cout, k, act, use_bn, res, window = case
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    pad = k // 2
+    x = _mk((N, Cin, H, W), g)
+    w = _mk((Cout, Cin, k, k), g, (Cin * k * k) ** -0.5)
+    scale = (torch.rand(Cout, generator=g) + 0.5) if use_bn else None
+    shift = _mk((Cout,), g, 0.3)
+    xq = weights.to_channel_last(x, torch.float32)
+    in_coff = 0
+    if window:
+        wide = _mk((N, H, W, Cin + 64), g)
+        wide[..., 32:32 + Cin] = xq
+        xq, in_coff = wide, 32
+    xq = xq.cuda()
+    wq = weights.prep_conv_weight(w, torch.float32).cuda()
+    wx = weights.split_pairs_x3(wq)
+    ref = F.conv2d(x, w, None, 1, pad)
+    if scale is not None:
+        ref = ref * scale.view(1, -1, 1, 1)
+    ref = ref + shift.view(1, -1, 1, 1)
+    rs = []
+    for _ in range(res):
+        r = _mk(tuple(ref.shape), g).permute(0, 2, 3, 1).contiguous()
+        ref = ref + r.permute(0, 3, 1, 2)
+        rs.append(r.cuda())
+    ref = {0: lambda t: t, 1: F.relu, 3: F.gelu}[act](ref)
+    kw = dict(stride=1, pad=pad, scale=None if scale is None else scale.cuda(), shift=shift.cuda(), act=act,
+              res1=rs[0] if res >= 1 else None, res2=rs[1] if res >= 2 else None, in_coff=in_coff, cin=Cin)
+    out = ops.conv2d(xq, wq, w_x3=wx, **kw)
+    assert ops._last_conv_kernel() == "conv_igemm_glds_kernel<float, 64, 8, 1, 128, 2, false, true> split-K", ops._last_conv_kernel()
+    again = ops.conv2d(xq, wq, w_x3=wx, **kw)
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape and torch.equal(out, again)
+    err = float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+    assert err < 1e-4, err
+    exact = ops.conv2d(xq, wq, **kw)
+    assert "split-K" in ops._last_conv_kernel() and "conv_igemm_kernel" in ops._last_conv_kernel(), ops._last_conv_kernel()
+    err = float((out - exact).abs().max() / exact.abs().max().clamp_min(1e-6))
+    assert err < 1e-4, err

@@ -399,3 +399,31 @@ def test_wide_chain_workspace_and_argument_checks_are_host_side():
     assert call(4, 16, 0, 1 << 20) != 0 and b"workspace" in L.tt_last_error()
     assert call(4, 16, 0x4000, 1024) != 0 and b"workspace" in L.tt_last_error()
     assert call(480, 65, 0x4000, 1 << 24) != 0 and b"co-resident" in L.tt_last_error()
+
+
+def test_splitk_query_answers_for_the_bf16x3_tile_when_the_operand_is_there():
+    """tt_conv2d_splitk_slices (host arithmetic only): a few-row long-K layer WITH a bf16x3 operand is planned on the 64-wide
+    bf16x3 tile -- tiles_m x Cout / 64 workgroups, K tiles of 32 dealt over <= 16 ranges of >= 8 tiles until ~512 workgroups; without
+    the operand the exact-f32 register-staged kernel answers as before; many-row layers do not split."""
+    import ctypes
+    from thinktwice_amd import _lib, ops
+    L = _lib.lib()
+
+    def slices(N, H, W, Cin, Cout, k, x3):
+        d = ops._ConvDesc()
+        d.in_, d.weight, d.out = 0x10000, 0x20000, 0x30000
+        d.weight_x3 = 0x40000 if x3 else None
+        d.N, d.H, d.W, d.Cin, d.in_cstride = N, H, W, Cin, Cin
+        d.Cout, d.KH, d.KW, d.stride, d.pad, d.dil = Cout, k, k, 1, k // 2, 1
+        d.OH, d.OW, d.out_cstride = H, W, Cout
+        d.dtype = d.out_dtype = _lib.TT_F32
+        return int(L.tt_conv2d_splitk_slices(ctypes.byref(d)))
+
+    # ResNet layer 4 of a batch-1 tick: 8 images of 14 x 28 -> M = 3136 = 13 row tiles
+    assert slices(8, 14, 28, 512, 512, 3, True) == 4          # 104 tiles x 4 ranges of 36 K tiles
+    assert slices(8, 14, 28, 2048, 512, 1, True) == 4         # K = 2048: 64 K tiles, 4 ranges of 16
+    assert slices(2, 4, 8, 512, 512, 3, True) == slices(2, 4, 8, 512, 512, 3, False)      # M = 64: not the bf16x3 tile's
+    assert slices(16, 4, 8, 512, 512, 3, True) == 16          # the F7-sized trunk: M = 512, 16 tiles x 16 ranges of 9
+    assert slices(8, 56, 112, 512, 512, 3, True) == 0         # M = 50,176: the chip is full without a split
+    f32 = slices(8, 14, 28, 512, 512, 3, False)
+    assert f32 > 0 and f32 != 4                               # the exact-f32 kernel plans its own split

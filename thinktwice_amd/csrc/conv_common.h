@@ -405,6 +405,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st);
 // bf16x3 variant of the same kernel (f32 storage, pre-split weights in a.weight): same contract.
 int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st);
+// split-K form of the 64-wide bf16x3 tile (few rows, long K): workspace slices it would use (0: not eligible) / the tile launch
+int conv_glds_x3_splitk_slices(const ConvArgs& a);
+int launch_conv_glds_x3_splitk(ConvArgs& a, hipStream_t st);
 // bf16x3, 256 x 256 tile as four hand-pipelined 128 x 128 waves (csrc/conv_x3_pipe.hip); `m_tiles_limit` > 0 = tail split
 int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int bn = 256);
 // run-staged sparse 3x3x3 conv (csrc/sp_conv_runs.hip; bf16x3, a.weight = pre-split weights): same contract.

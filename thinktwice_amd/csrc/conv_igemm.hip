@@ -403,6 +403,10 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
         a.ws = nullptr;
         a.row_perm = nullptr;
         a.row_mask = nullptr;
+        if (d->weight_x3 && d->dtype == TT_F32 && a.K % 16 == 0) {      // few rows, long K, bf16x3 operand: the 64-wide x3 tile, K split
+            const int n = conv_glds_x3_splitk_slices(a);
+            if (n > 0) return n;
+        }
         if (d->dtype == TT_F32) return dispatch_conv<float>(a, st);
         if (d->dtype == TT_F16) return dispatch_conv<f16_t>(a, st);
         return dispatch_conv<uint16_t>(a, st);
@@ -410,6 +414,16 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     if (!d->splitk_ws && try_launch_conv_small(a, d->dtype, st)) {
         snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_small_kernel");
         return check_launch("tt_conv2d_fwd(small)");
+    }
+    if (d->splitk_ws && d->weight_x3 && d->dtype == TT_F32 && a.K % 16 == 0 &&
+        (reinterpret_cast<uintptr_t>(d->weight_x3) & 15) == 0) {
+        ConvArgs ax = a;
+        ax.weight = d->weight_x3;
+        if (launch_conv_glds_x3_splitk(ax, st)) {
+            const long long tot = (long long)ax.M * ax.Cout;
+            hipLaunchKernelGGL(splitk_finalize_kernel<float>, dim3((unsigned)div_up(tot, 256)), dim3(256), 0, st, ax);
+            return check_launch("tt_conv2d_fwd(glds x3 split-K)");
+        }
     }
     if (!d->splitk_ws && d->weight_x3 && d->dtype == TT_F32) {
         TT_REQUIRE((reinterpret_cast<uintptr_t>(d->weight_x3) & 15) == 0 && a.K % 16 == 0,

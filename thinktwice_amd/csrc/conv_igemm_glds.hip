@@ -264,6 +264,21 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         int kh, kw, ci;
     };
     KWalk wa{0, 0, 0}, wb{0, 0, 0};
+    if (!GATHER && p.splits > 1) {
+        // split-K (few rows, long K: gridDim.y K ranges): this workgroup owns K tiles [kt0, kt1) of the (channel chunk outer, tap
+        // inner) walk -- both walkers start there, the ring and the loop below count from 0; the epilogue stores the raw partial
+        // sums into slice blockIdx.y of the workspace (conv_epilogue's p.ws branch), splitk_finalize_kernel adds the slices
+        const int per = (nk + p.splits - 1) / p.splits;
+        const int kt0 = (int)blockIdx.y * per;
+        int kt1 = kt0 + per;
+        kt1 = kt1 < nk ? kt1 : nk;
+        const int taps = p.KH * p.KW;
+        const int chunk = kt0 / taps, tap = kt0 - chunk * taps;
+        wa.ci = wb.ci = chunk * BK;
+        wa.kh = wb.kh = tap / p.KW;
+        wa.kw = wb.kw = tap - (tap / p.KW) * p.KW;
+        nk = kt1 > kt0 ? kt1 - kt0 : 0;
+    }
     auto advance = [&](KWalk& w) {
         if (++w.kw == p.KW) {
             w.kw = 0;
@@ -638,7 +653,7 @@ static const void* zero_page() {
 }
 
 template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false>
-static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0) {
+static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0, int splits = 1, int slices = 1) {
     constexpr int BM = 256;
     constexpr int WTN = BN / WAVES_N;
     const void* zp = zero_page();
@@ -658,14 +673,14 @@ static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0) {
         attr_set = true;
     }
     a.tiles_n = tiles_n;
-    a.splits = 1;
-    a.ws = nullptr;
+    a.splits = splits;
+    if (splits <= 1) a.ws = nullptr;       // split-K: a.ws / a.ws_slices are the caller's (ordered slices, `slices` non-empty ranges)
     if (a.m_begin == 0)      // (the tail launch of a split keeps the main launch's label)
         snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_igemm_glds_kernel<%s, %d, %d, %d, %d, %d, %s, %s>%s",
                  sizeof(T) == 4 ? "float" : "16-bit", BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER ? "true" : "false",
-                 X3 ? "true" : "false", m_tiles_limit > 0 ? " + tail" : "");
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(WAVES_M * WAVES_N * 64), smem, st, a, zp,
-                       tiles_m, tiles_n);
+                 X3 ? "true" : "false", splits > 1 ? " split-K" : (m_tiles_limit > 0 ? " + tail" : ""));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n), (unsigned)(splits > 1 ? slices : 1)),
+                       dim3(WAVES_M * WAVES_N * 64), smem, st, a, zp, tiles_m, tiles_n);
     return 1;
 }
 
@@ -688,6 +703,38 @@ static int tail_split_rows(const ConvArgs& a) {
     if (rounds < 2 || rounds > 8 || last > kNumCU / 4) return 0;
     const int peel = div_up(last, tiles_n);            // row tiles moved to the tail launch
     return peel < tiles_m ? tiles_m - peel : 0;
+}
+
+// Split-K form of the 64-wide bf16x3 tile: few rows, long K (batch-1 ticks: ResNet layer 4 at M = 3,136, K = 2048 / 4608 --
+// 13 row tiles are a twentieth of the chip, so those layers ran the exact-f32 register-staged kernel with a K split, 2.0 ms per
+// tick).  Column blocks of 64 give tiles_m x Cout / 64 workgroups; the K tiles are dealt over up to 16 ranges of >= 8 tiles until
+// ~512 workgroups (two per CU) are in flight.  Returns the number of non-empty K ranges (= workspace slices), 0 = not this path.
+static int x3_splitk_plan(const ConvArgs& a, int* splits_out) {
+    static const bool on = [] { const char* e = getenv("TT_X3_SPLITK"); return e ? atoi(e) != 0 : true; }();   // A/B knob
+    if (!on || a.gather || a.m_dev || a.M < 512 || a.M > 8192 || a.Cout < 64 || a.KH * a.KW > 32) return 0;
+    if (a.Cin % 32 != 0 || a.K < 1024 || a.pixel_shuffle2) return 0;
+    const int tiles = div_up(a.M, 256) * div_up(a.Cout, 64);
+    const int nk = a.K / 32;
+    if (tiles >= 256) return 0;
+    int sp = 512 / tiles;
+    if (sp > nk / 8) sp = nk / 8;
+    if (sp > 16) sp = 16;
+    if (sp < 2) return 0;
+    const int per = div_up(nk, sp);
+    if (splits_out) *splits_out = sp;
+    return div_up(nk, per);
+}
+
+int conv_glds_x3_splitk_slices(const ConvArgs& a) { return x3_splitk_plan(a, nullptr); }
+
+// a.weight = the pre-split weights, a.ws = the workspace of >= conv_glds_x3_splitk_slices(a) [M][Cout] f32 slices.  Launches the
+// tiles only; the caller runs splitk_finalize_kernel (a.ws_slices is set to the slices written).
+int launch_conv_glds_x3_splitk(ConvArgs& a, hipStream_t st) {
+    int sp = 0;
+    const int slices = x3_splitk_plan(a, &sp);
+    if (slices < 2 || !a.ws || a.ws_slices < slices) return 0;
+    a.ws_slices = slices;
+    return launch_glds<float, 64, 8, 1, 128, 2, false, true>(a, st, 0, sp, slices);
 }
 
 // bf16x3 arithmetic on f32 storage (see the kernel's template comment).  `a.weight` must already point at the

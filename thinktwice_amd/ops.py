@@ -282,19 +282,29 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     d.res1 = _dp(res1); d.res1_cstride = 0 if res1 is None else res1.shape[-1]; d.res1_coff = res1_coff
     d.res2 = _dp(res2); d.res2_cstride = 0 if res2 is None else res2.shape[-1]; d.res2_coff = res2_coff
     d.act = act; d.dtype = dtype_code(x); d.out_dtype = dtype_code(out)
+    from . import autodiff
+    if w_x3 is not None:       # (before the split-K query: with a bf16x3 operand the query answers for the bf16x3 split-K tile)
+        assert x.dtype == torch.float32 and w_x3.shape == w.shape and w_x3.is_contiguous()
+        # the training step (forward under the tape, and the backward's recomputations / input-gradient convolutions, which
+        # pass _no_tape) keeps the exact-f32 split-K kernel for the few-row long-K layers -- the gradient goldens were taken
+        # with it: the query must not see the bf16x3 operand there
+        x3_splitk = autodiff.TAPE is None and not _no_tape
+        if x3_splitk:
+            d.weight_x3 = w_x3.data_ptr()
     if _AUTO_SPLITK and splitk_ws is None and N * OH * OW <= 4096 and KH * KW * Cin >= 2048:
         # few rows, very long K (BEV-update conv K=18720, flatten MLPs): cross-workgroup split-K with an f32 workspace
         # beats conv_small.hip's in-workgroup split there (277 vs 416 us on the BEV-update conv: the direct 32 B/row
         # operand loads of the small kernel waste L2 sectors on a 10 MB weight matrix).  TT_CONV_AUTO_SPLITK=0 disables.
-        # ordered form (no atomics, no zero fill): one [M][Cout] slice per K split, added in index order by the finalize kernel
+        # ordered form (no atomics, no zero fill): one [M][Cout] slice per K split, added in index order by the finalize kernel.
+        # With a bf16x3 operand the layer runs the 64-wide bf16x3 tile with the K tiles dealt over workgroups
+        # (conv_igemm_glds.hip, x3_splitk_plan) instead of the exact-f32 register-staged kernel
         slices = int(lib().tt_conv2d_splitk_slices(ctypes.byref(d)))
         if slices > 0:
             splitk_ws = torch.empty(slices, N * OH * OW, Cout, dtype=torch.float32, device=x.device)
             d.splitk_slices = slices
     if splitk_ws is not None:
         d.splitk_ws = splitk_ws.data_ptr()
-    if w_x3 is not None:
-        assert x.dtype == torch.float32 and w_x3.shape == w.shape and w_x3.is_contiguous()
+    elif w_x3 is not None:
         d.weight_x3 = w_x3.data_ptr()
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
