@@ -19,9 +19,14 @@ def fake_save(name, **arrays):
         r = ref[k]
         if r.shape != v.shape or r.dtype != v.dtype:
             bad.append(f"{k}: shape/dtype {r.shape}{r.dtype} vs {v.shape}{v.dtype}"); continue
-        if not np.array_equal(r, v, equal_nan=True):
-            d = float(np.max(np.abs(r.astype(np.float64) - v.astype(np.float64)))) if r.dtype.kind in "fiu" else -1
-            bad.append(f"{k}: max abs diff {d}")
+        if not np.array_equal(r, v, equal_nan=(r.dtype.kind in "fc")):
+            if r.dtype.kind in "fiu" and r.size:
+                a, b = r.astype(np.float64), v.astype(np.float64)
+                d = float(np.max(np.abs(a - b)))
+                rel = float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-30)))
+                bad.append(f"{k}: max abs diff {d:.3e}, max rel diff {rel:.3e}, {int(np.sum(a != b))} of {a.size} entries")
+            else:
+                bad.append(f"{k}: differs")
     extra = [k for k in ref.files if k not in arrays]
     out[name] = {"arrays": len(arrays), "mismatch": bad, "only_in_file": extra}
 G._save = fake_save
