@@ -1,7 +1,6 @@
 """Train-mode BatchNorm / dropout kernels (csrc/batchnorm.hip) vs torch: F.batch_norm(training=True) forward
 (batch statistics per row group, running-statistics update), autograd backward (dz, residual gradients, dgamma, dbeta), the
 sparse form with a device row count, and nn.Dropout's scaling with a replayed mask."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
