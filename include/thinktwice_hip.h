@@ -207,12 +207,25 @@ int tt_mlp_chain(const float* x, long long R, int x_stride, int nstages, const t
  * through one workgroup): the 32-column blocks of every stage are dealt over `n_groups` co-resident workgroups per 32 rows, the
  * waves of a workgroup split K; stage outputs a later stage reads go through `workspace` (f32, global) and the workgroups of
  * a row block meet at a ticket barrier between dependent stages.  Same arithmetic per product as tt_mlp_chain (bf16x3), the K
- * sum is taken in eight interleaved slices added in a fixed order.  Requires (R + 31) / 32 * n_groups <= 256.
- * tt_mlp_chain_wide_faults(): blocking; non-zero if any launch so far gave up waiting at a barrier (its outputs are invalid). */
+ * sum is taken in eight interleaved slices added in a fixed order.
+ * Co-residency: the barrier needs every workgroup of the launch running.  The library bounds a launch to
+ * tt_mlp_chain_wide_max_workgroups() = (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs) / 2 workgroups (two launches at a
+ * time: the decoder's main and branch streams) and returns -1 beyond it (callers take tt_mlp_chain instead).  A barrier wait is
+ * bounded; a wait that gives up is LOUD: the workgroup writes NaN from there on, the device's fault word (pinned host memory,
+ * written by the kernel) is set, and from then on tt_mlp_chain_wide, tt_plan_run, tt_encoder_fwd and tt_decoder_fwd return -3
+ * until tt_clear_device_faults().  tt_device_faults(): non-blocking read of that word for the current device (check it after any
+ * synchronisation with the forward's streams -- thinktwice_amd does after the D2H copy of tt_action_post's result and at the
+ * start of every forward); tt_mlp_chain_wide_faults(): the same after a hipDeviceSynchronize().  Ticket counters are per
+ * device; launches recorded into a HIP graph claim theirs permanently (a replay reuses the recorded counter). */
 long long tt_mlp_chain_wide_workspace_bytes(long long R, int nstages, const tt_chain_stage* stages);
 int tt_mlp_chain_wide(const float* x, long long R, int x_stride, int nstages, const tt_chain_stage* stages, int n_groups,
                       void* workspace, long long workspace_bytes, void* stream);
+int tt_mlp_chain_wide_max_workgroups(void);
 int tt_mlp_chain_wide_faults(void);
+int tt_device_faults(void);
+int tt_clear_device_faults(void);
+/* test hook: polls before a barrier wait gives up (default 1 << 21, about a second; 0 forces a time-out; < 0 restores) */
+int tt_mlp_chain_wide_set_max_spin(int polls);
 /* debug: while set, every tt_mlp_chain_wide workgroup writes up to 64 wall-clock stamps (10 ns ticks; kernel entry, then per stage:
  * entry, barrier passed, first block's K loop + reduction done, stage done) at stamps[(row_group * n_groups + group) * 64] */
 int tt_mlp_chain_wide_set_trace(void* stamps_or_null);

@@ -63,3 +63,21 @@ def require_cuda(*tensors):
         if t is not None and not t.is_cuda:
             raise TTError("thinktwice_amd ops need device tensors (MI355X); got a CPU tensor. "
                           "There is no CPU path in the product -- see oracle/ for the checker.")
+
+
+def device_faults():
+    """Non-blocking read of the current device's host-mapped fault word (tt_device_faults): meaningful for work the caller
+    has synchronised with."""
+    return int(lib().tt_device_faults())
+
+
+def clear_device_faults():
+    check(lib().tt_clear_device_faults(), "tt_clear_device_faults")
+
+
+def raise_on_device_fault(where):
+    """The product's check: a barrier time-out of tt_mlp_chain_wide poisons its outputs with NaN and sets the fault word;
+    whoever has just synchronised with the forward (or is about to start the next one) turns it into a TTError."""
+    if device_faults() > 0:
+        raise TTError(f"{where}: a tt_mlp_chain_wide barrier timed out on this device -- the decoder outputs since then are "
+                      f"NaN / invalid (thinktwice_amd.ops.clear_device_faults() re-arms the device)")

@@ -15,7 +15,7 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import check, cur_stream, lib
+from ._lib import check, cur_stream, lib, raise_on_device_fault
 
 PID_WINDOW_MAX = 64
 (ACT_STEER, ACT_THROTTLE, ACT_BRAKE, ACT_STEER_CTRL, ACT_THROTTLE_CTRL, ACT_BRAKE_CTRL, ACT_STEER_TRAJ, ACT_THROTTLE_TRAJ,
@@ -111,6 +111,13 @@ class ActionPost:
                                    cur_stream(self.device)), "tt_action_post")
         self.out_host.copy_(self.out_dev, non_blocking=True)          # the tick's one device -> host copy
         torch.cuda.current_stream(self.device).synchronize()
+        # the forward that produced `pred` is complete here: a wide-chain barrier time-out (NaN outputs) is an error, not a
+        # steering command (tt_device_faults reads host-mapped memory: no copy, no further synchronisation)
+        if self.device.index is None or self.device.index == torch.cuda.current_device():
+            raise_on_device_fault("tt_action_post")
+        else:
+            with torch.cuda.device(self.device):
+                raise_on_device_fault("tt_action_post")
         o = self.out_host.tolist()
         return o[ACT_STEER], o[ACT_THROTTLE], o[ACT_BRAKE], _info(o)
 

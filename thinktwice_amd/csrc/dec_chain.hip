@@ -19,6 +19,10 @@
 // blocks of N round-robin, up to 4 accumulator blocks per wave at a time, so one A fragment feeds up to 12 MFMAs.
 // Weights stream from L2 straight into the B operand registers (each element is used once per workgroup: staging
 // them through LDS would only add a round trip), double-buffered one K step ahead.
+#include <atomic>
+#include <mutex>
+#include <string.h>
+
 #include "conv_common.h"
 
 namespace tt {
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_kernel(const Chain
 // coherent with each other for ordinary stores).  The ticket counters live in a library-owned pool, are claimed round-robin per
 // launch and reset themselves with the launch's last arrival.
 constexpr int kWidePF = 8;               // K steps in flight per wave (8 x 4 KiB: weights + activation fragments)
-constexpr int kWideMaxSpin = 1 << 21;    // bail-out of a ticket wait (~1 s): a wrong count must not hang the device
+constexpr int kWideMaxSpin = 1 << 21;    // default bail-out of a ticket wait (~1 s): a wrong count must not hang the device
 
 struct WideStage {
     ChainStage s;
@@ -252,7 +256,9 @@ struct WideArgs {
     int nstages, nsync;
     int rb;               // 32-row blocks per workgroup (1, 2, 4 or 8); its eight waves = rb row blocks x 8 / rb K slices
     unsigned* tickets;    // one counter (64 B apart) per row group
-    int* fault;           // set to 1 if a ticket wait gave up
+    int* fault;           // HOST-mapped (pinned) word of this device, set with a system-scope store if a ticket wait gave up:
+                          // the host reads it without a copy (tt_device_faults) and every later entry point refuses to run
+    int max_spin;         // polls before a wait gives up (kWideMaxSpin; tests force a time-out with 0)
     long long* trace;     // debug (tt_mlp_chain_wide_set_trace): 64 wall-clock stamps (10 ns ticks) per workgroup, or null
     WideStage st[kChainMaxStages];
 };
@@ -265,18 +271,28 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
-__device__ __forceinline__ void ticket_barrier(unsigned* ctr, unsigned target, int* fault) {
+// Returns true if the wait GAVE UP (the launch's workgroups were not all running within max_spin polls: the chip was
+// oversubscribed beyond what the host-side occupancy check allows for, or a count is wrong).  A time-out is made LOUD, never
+// silent: the device's host-mapped fault word is set (system scope), and the caller poisons every value the workgroup writes
+// from here on with NaN, so the launch's outputs cannot be mistaken for results.  The workgroup still arrives at every later
+// barrier, so the counter reaches its total and resets itself for the slot's next launch.
+__device__ __forceinline__ bool ticket_barrier(unsigned* ctr, unsigned target, int* fault, int max_spin, int* gave_up) {
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         int spin = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spin > max_spin) {
+                __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                *gave_up = 1;
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
-            if (++spin > kWideMaxSpin) { *fault = 1; break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // one cache invalidate after the wait, not one per poll
     }
     __syncthreads();
+    return *gave_up != 0;
 }
 
 // One stage of the wide chain with a ring of PF K steps per wave (PF = 2, 4, 8 by the stage's steps per wave: every ring slot
@@ -284,7 +300,7 @@ __device__ __forceinline__ void ticket_barrier(unsigned* ctr, unsigned target, i
 // steps would spend more time on duplicate loads than the stage's own weights take).
 template <int PF>
 __device__ __forceinline__ void wide_stage(const WideArgs& a, const WideStage& W, float (*part)[32][32], unsigned* ctr,
-                                           unsigned& arrived, long long* tr, int& tri) {
+                                           unsigned& arrived, long long* tr, int& tri, int* gave_up, bool& poisoned) {
     const ChainStage& S = W.s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = gridDim.y, g = blockIdx.y;
@@ -318,7 +334,7 @@ __device__ __forceinline__ void wide_stage(const WideArgs& a, const WideStage& W
     for (int p = 0; p < PF; ++p) load_b(ks + KS * p, p);
     if (W.sync_before) {
         arrived += (unsigned)G;
-        ticket_barrier(ctr, arrived, a.fault);
+        poisoned = ticket_barrier(ctr, arrived, a.fault, a.max_spin, gave_up) || poisoned;
     }
     stamp();
     // activation fragments: lanes of rows beyond R load nothing (a 1-row chain issues 2 of 64 lanes).  Row-major input (the
@@ -444,6 +460,7 @@ __device__ __forceinline__ void wide_stage(const WideArgs& a, const WideStage& W
                 v += t;
             }
             v = apply_act(v, S.act);
+            if (poisoned) v = __builtin_nanf("");                 // a barrier of this workgroup timed out: never a plausible number
             if (!ok) v = 0.f;
             if (S.out && ok) S.out[mr * S.out_stride + S.out_coff + n] = v;
             if (W.keep && mr < a.R)                              // fragment-major scratch (see load_a); padding columns = 0
@@ -457,10 +474,13 @@ __device__ __forceinline__ void wide_stage(const WideArgs& a, const WideStage& W
 
 __global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_wide_kernel(const WideArgs a) {
     __shared__ float part[kChainWaves][32][32];
+    __shared__ int gave_up;
     const int tid = threadIdx.x;
     const int G = gridDim.y, g = blockIdx.y;
     unsigned* ctr = a.tickets + (size_t)blockIdx.x * 16;
     unsigned arrived = 0;
+    bool poisoned = false;
+    if (tid == 0) gave_up = 0;                                   // (published by the first ticket barrier's __syncthreads)
     long long* tr = a.trace ? a.trace + ((size_t)blockIdx.x * G + g) * 64 : nullptr;
     int tri = 0;
     if (tr && tid == 0) tr[tri++] = (long long)wall_clock64();
@@ -469,9 +489,9 @@ __global__ __launch_bounds__(kChainWaves * 64) void mlp_chain_wide_kernel(const 
         const WideStage& W = a.st[s];
         if (tr && tid == 0 && tri < 64) tr[tri++] = (long long)wall_clock64();
         const int per_wave = ((W.s.Kp >> 4) + KS - 1) / KS;      // K steps of the busiest wave (uniform over the workgroup)
-        if (per_wave <= 2) wide_stage<2>(a, W, part, ctr, arrived, tr, tri);
-        else if (per_wave <= 4) wide_stage<4>(a, W, part, ctr, arrived, tr, tri);
-        else wide_stage<8>(a, W, part, ctr, arrived, tr, tri);
+        if (per_wave <= 2) wide_stage<2>(a, W, part, ctr, arrived, tr, tri, &gave_up, poisoned);
+        else if (per_wave <= 4) wide_stage<4>(a, W, part, ctr, arrived, tr, tri, &gave_up, poisoned);
+        else wide_stage<8>(a, W, part, ctr, arrived, tr, tri, &gave_up, poisoned);
     }
     // the launch's last arrival puts the ticket back to zero for the next launch that claims this slot
     __syncthreads();
@@ -576,24 +596,118 @@ extern "C" int tt_mlp_chain(const float* x, long long R, int x_stride, int nstag
 }
 
 // ---- tt_mlp_chain_wide
+// Host state of the wide form, PER DEVICE and behind one mutex (the library may be driven from several host threads / devices):
+//  * the ticket pool: kEagerSlots counters claimed round-robin by plain launches (a collision needs > kEagerSlots row groups in
+//    flight at once), and kCapturedSlots claimed PERMANENTLY by launches recorded into a HIP graph (a captured launch replays
+//    with the slot baked into its arguments, so no later launch may be handed the same counter);
+//  * the fault word: one int in pinned, host-mapped memory per device.  A barrier that gives up sets it from the device with a
+//    system-scope store; the host reads it without a copy or a synchronisation of its own (tt_device_faults), and once it is
+//    set tt_mlp_chain_wide / tt_encoder_fwd / tt_decoder_fwd / tt_plan_run refuse to run until tt_clear_device_faults();
+//  * the co-residency capacity: hipOccupancyMaxActiveBlocksPerMultiprocessor x the device's CU count.  A launch may use at most
+//    capacity / kWideConcurrent workgroups (the decoder runs two chains at a time, on its main and its branch stream), so the
+//    spinning workgroups of concurrent launches can never fill the chip and keep their own peers out.  hipLaunchCooperativeKernel
+//    would give the same guarantee per launch, but it goes through the device's single cooperative queue (the two streams'
+//    chains would serialise) and is not recordable into a HIP graph; the occupancy bound + bounded spin + loud fault is the
+//    form that keeps both.
 namespace {
-constexpr int kTicketSlots = 4096;       // 64 B each; a launch claims one per row block, round-robin
-unsigned* g_tickets = nullptr;           // + one int after the last slot: the fault flag
-unsigned g_next_ticket = 0;
+constexpr int kEagerSlots = 4096;        // 64 B each; a launch claims one per row group
+constexpr int kCapturedSlots = 12288;
+constexpr int kMaxDevices = 64;
+constexpr int kWideConcurrent = 2;
+struct WidePool {
+    unsigned* tickets = nullptr;         // kEagerSlots + kCapturedSlots counters, 64 B apart, device memory
+    unsigned next_eager = 0, next_captured = 0;
+    int capacity = 0;                    // co-resident workgroups of mlp_chain_wide_kernel on this device
+};
+WidePool g_pools[kMaxDevices];
+int* g_fault_words = nullptr;            // pinned host-mapped: one int (64 B apart) per device
+std::mutex g_wide_mutex;
+std::atomic<int> g_wide_max_spin{kWideMaxSpin};
 long long* g_trace = nullptr;            // tt_mlp_chain_wide_set_trace
 
-int ticket_pool() {
-    if (g_tickets) return 0;
-    void* p = nullptr;
-    const size_t bytes = (size_t)(kTicketSlots + 1) * 64;
-    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
-        tt::set_error("tt_mlp_chain_wide: cannot allocate the ticket pool");
-        return -2;
+int* fault_word(int dev) {               // (g_wide_mutex held, or after the first successful call)
+    if (!g_fault_words) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, (size_t)kMaxDevices * 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        memset(p, 0, (size_t)kMaxDevices * 64);
+        g_fault_words = static_cast<int*>(p);
     }
-    g_tickets = static_cast<unsigned*>(p);
-    return 0;
+    return g_fault_words + (size_t)dev * 16;
+}
+
+// (g_wide_mutex held)
+WidePool* wide_pool(int dev) {
+    WidePool& P = g_pools[dev];
+    if (P.tickets) return &P;
+    if (!fault_word(dev)) {
+        tt::set_error("tt_mlp_chain_wide: cannot allocate the host-mapped fault word");
+        return nullptr;
+    }
+    int occ = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tt::mlp_chain_wide_kernel, kChainWaves * 64, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || occ < 1 || cus < 1) {
+        (void)hipGetLastError();
+        tt::set_error("tt_mlp_chain_wide: cannot query the kernel's occupancy on device %d", dev);
+        return nullptr;
+    }
+    void* p = nullptr;
+    const size_t bytes = (size_t)(kEagerSlots + kCapturedSlots) * 64;
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        tt::set_error("tt_mlp_chain_wide: cannot allocate the ticket pool");
+        return nullptr;
+    }
+    P.capacity = occ * cus;
+    P.tickets = static_cast<unsigned*>(p);
+    return &P;
 }
 }  // namespace
+
+// Non-blocking: the fault word of the CURRENT device (0 = no barrier has timed out since the last clear).  Meaningful for the
+// work the caller has already synchronised with; any entry point that synchronises anyway (the D2H copy of tt_action_post's
+// result, the end of a plan run in tools/plan_host.cpp) checks it there.
+extern "C" int tt_device_faults(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -2;
+    if (!g_fault_words) return 0;
+    return __atomic_load_n(g_fault_words + (size_t)dev * 16, __ATOMIC_ACQUIRE);
+}
+
+extern "C" int tt_clear_device_faults(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -2;
+    if (g_fault_words) __atomic_store_n(g_fault_words + (size_t)dev * 16, 0, __ATOMIC_RELEASE);
+    return 0;
+}
+
+// The check every forward entry point makes first: a barrier time-out is sticky (like a device fault), because whatever ran
+// after it consumed poisoned data.
+int tt::refuse_after_fault(const char* what) {
+    const int f = tt_device_faults();
+    if (f > 0) {
+        tt::set_error("%s: refused -- an earlier tt_mlp_chain_wide launch on this device gave up waiting at its barrier (its "
+                      "outputs are NaN); results since then are invalid.  tt_clear_device_faults() re-arms the device", what);
+        return -3;
+    }
+    return 0;
+}
+
+extern "C" int tt_mlp_chain_wide_set_max_spin(int polls) {
+    g_wide_max_spin.store(polls < 0 ? kWideMaxSpin : polls);
+    return 0;
+}
+
+// Workgroups one launch may use on the current device (co-resident capacity / kWideConcurrent), or < 0 on error.
+extern "C" int tt_mlp_chain_wide_max_workgroups(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -2;
+    std::lock_guard<std::mutex> lock(g_wide_mutex);
+    WidePool* P = wide_pool(dev);
+    return P ? P->capacity / kWideConcurrent : -2;
+}
 
 static inline long long wide_keep_stride(int N) { return (N + 31) / 32 * 32; }
 // 32-row blocks per workgroup: with several row blocks the waves of a workgroup share the weight stream (same K slice, different
@@ -622,11 +736,10 @@ extern "C" int tt_mlp_chain_wide_set_trace(void* stamps_or_null) {
     return 0;
 }
 
+// Blocking form (tests): waits for the device, then reads the fault word.
 extern "C" int tt_mlp_chain_wide_faults(void) {
-    if (!g_tickets) return 0;
-    int f = 0;
-    if (hipMemcpy(&f, g_tickets + (size_t)kTicketSlots * 16, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -2;
-    return f;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return tt_device_faults();
 }
 
 extern "C" int tt_mlp_chain_wide(const float* x, long long R, int x_stride, int nstages, const tt_chain_stage* st,
@@ -636,13 +749,19 @@ extern "C" int tt_mlp_chain_wide(const float* x, long long R, int x_stride, int 
     const long long row_blocks = (R + 31) / 32;
     const int rb = wide_rb(row_blocks);
     const long long row_groups = (row_blocks + rb - 1) / rb;
-    TT_REQUIRE(n_groups >= 1 && n_groups <= 64 && row_groups * n_groups <= 256,
-               "tt_mlp_chain_wide: %lld row groups x %d column groups must be co-resident (<= 256 workgroups)", row_groups,
-               n_groups);
+    if (int rc = tt::refuse_after_fault("tt_mlp_chain_wide")) return rc;
+    int dev = 0;
+    TT_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices, "tt_mlp_chain_wide: no current device");
+    std::lock_guard<std::mutex> lock(g_wide_mutex);     // pool creation + slot claim (+ the launch: slots stay in claim order)
+    WidePool* P = wide_pool(dev);
+    if (!P) return -2;
+    TT_REQUIRE(n_groups >= 1 && n_groups <= 64 && row_groups * n_groups * kWideConcurrent <= P->capacity,
+               "tt_mlp_chain_wide: %lld row groups x %d column groups: at most %d workgroups per launch can be guaranteed "
+               "co-resident on this device (%d resident, %d launches at a time)", row_groups, n_groups,
+               P->capacity / kWideConcurrent, P->capacity, kWideConcurrent);
     const long long need = tt_mlp_chain_wide_workspace_bytes(R, nstages, st);
     TT_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
                "tt_mlp_chain_wide: workspace of %lld B needed (%lld given)", need, workspace_bytes);
-    if (ticket_pool() != 0) return -2;
     WideArgs a;
     a.R = R; a.nstages = nstages; a.nsync = 0; a.rb = rb;
     unsigned char* ws = static_cast<unsigned char*>(workspace);
@@ -687,10 +806,23 @@ extern "C" int tt_mlp_chain_wide(const float* x, long long R, int x_stride, int 
         for (int s = 0; s < nstages; ++s) a.st[s].sync_before = 0;
         a.nsync = 0;
     }
-    if (g_next_ticket + row_groups > (unsigned)kTicketSlots) g_next_ticket = 0;
-    a.tickets = g_tickets + (size_t)g_next_ticket * 16;
-    g_next_ticket += (unsigned)row_groups;
-    a.fault = reinterpret_cast<int*>(g_tickets + (size_t)kTicketSlots * 16);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusNone;
+    }
+    if (cap == hipStreamCaptureStatusActive) {          // replayed with these arguments: the slots are this launch's for good
+        TT_REQUIRE(P->next_captured + row_groups <= (unsigned)kCapturedSlots,
+                   "tt_mlp_chain_wide: the %d ticket slots reserved for graph-captured launches are used up", kCapturedSlots);
+        a.tickets = P->tickets + (size_t)(kEagerSlots + P->next_captured) * 16;
+        P->next_captured += (unsigned)row_groups;
+    } else {
+        if (P->next_eager + row_groups > (unsigned)kEagerSlots) P->next_eager = 0;
+        a.tickets = P->tickets + (size_t)P->next_eager * 16;
+        P->next_eager += (unsigned)row_groups;
+    }
+    a.fault = fault_word(dev);
+    a.max_spin = g_wide_max_spin.load();
     a.trace = g_trace;
     hipLaunchKernelGGL(mlp_chain_wide_kernel, dim3((unsigned)row_groups, (unsigned)n_groups), dim3(kChainWaves * 64), 0,
                        (hipStream_t)stream, a);

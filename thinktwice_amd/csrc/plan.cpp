@@ -469,6 +469,7 @@ extern "C" int tt_plan_run_range(tt_plan* p, void* const* streams, int nstreams,
     TT_REQUIRE(streams && nstreams >= p->nstreams, "tt_plan_run: the plan uses %d streams", p->nstreams);
     const int end = num_ops < 0 ? (int)p->ops.size() : first_op + num_ops;
     TT_REQUIRE(first_op >= 0 && end <= (int)p->ops.size(), "tt_plan_run: op range");
+    if (int rc = refuse_after_fault("tt_plan_run")) return rc;     // a barrier time-out of an earlier forward is sticky
     int ev = 0;
     for (int i = first_op; i < end; ++i) {
         const PlanOp& o = p->ops[i];

@@ -10,6 +10,9 @@
 namespace tt {
 
 void set_error(const char* fmt, ...);
+// Non-zero (and the error text set) if a tt_mlp_chain_wide barrier has timed out on the current device since the last
+// tt_clear_device_faults(): forward entry points return it first (csrc/dec_chain.hip).
+int refuse_after_fault(const char* what);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

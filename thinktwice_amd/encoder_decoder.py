@@ -259,6 +259,8 @@ class EncoderDecoder(torch.nn.Module):
         key sweep only.  `pred["_key_bev_cl"]` is this call's key-sweep BEV for the cache."""
         if not self.loaded:
             raise _lib.TTError("EncoderDecoder: load_state_dict() first")
+        # sticky device fault (a tt_mlp_chain_wide barrier that gave up in an EARLIER forward: its outputs were NaN)
+        ops.raise_on_device_fault("EncoderDecoder.forward_inference")
         self.epoch = 10000
         meas = self.measurement_feat(batch)
         cam, cam_bev, lidar = self.extract_sensor_feat(batch["img"], batch["img_metas"], batch.get("points"),
@@ -417,6 +419,7 @@ class InferenceGraph:
             self.batch["img_metas"] = batch["img_metas"]
 
     def replay(self):
+        ops.raise_on_device_fault("InferenceGraph.replay")       # sticky: an earlier forward's barrier time-out
         self.graph.replay()
         return self.out
 

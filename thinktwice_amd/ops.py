@@ -9,7 +9,8 @@ import os
 import torch
 
 from . import _lib
-from ._lib import TT_BF16, TT_F16, TT_F32, check, cur_stream, lib, ptr, require_cuda
+from ._lib import (TT_BF16, TT_F16, TT_F32, TTError, check, clear_device_faults, cur_stream, device_faults, lib, ptr,  # noqa: F401
+                   raise_on_device_fault, require_cuda)
 
 _c = ctypes.c_int
 
@@ -827,8 +828,24 @@ def chain_is_wide(R):
 
 
 def chain_faults():
-    """Blocking: non-zero if a tt_mlp_chain_wide launch ever gave up waiting at its barrier (tests assert 0)."""
+    """Blocking (device synchronise): non-zero if a tt_mlp_chain_wide launch on the current device gave up waiting at its
+    barrier since the last `clear_device_faults()` (tests assert 0)."""
     return int(lib().tt_mlp_chain_wide_faults())
+
+
+_wide_cap = {}
+
+
+def chain_wide_max_workgroups(device):
+    """Workgroups one tt_mlp_chain_wide launch may use on `device` (co-resident capacity / 2 concurrent launches)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _wide_cap:
+        with torch.cuda.device(idx):
+            cap = int(lib().tt_mlp_chain_wide_max_workgroups())
+        if cap < 0:
+            raise TTError(f"tt_mlp_chain_wide_max_workgroups failed: {lib().tt_last_error().decode()}")
+        _wide_cap[idx] = cap
+    return _wide_cap[idx]
 
 
 def mlp_chain(x, stages, n_split=1, groups=None, wide=None):
@@ -863,12 +880,19 @@ def mlp_chain(x, stages, n_split=1, groups=None, wide=None):
             assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] >= R and t.shape[1] >= coff + lin.N
             d.out, d.out_stride, d.out_coff = t.data_ptr(), t.stride(0), coff
     row_blocks = (R + 31) // 32
-    if chain_is_wide(R) if wide is None else wide:
+    use_wide = chain_is_wide(R) if wide is None else wide
+    if use_wide:
+        row_groups = 1 if row_blocks <= 2 else (row_blocks + 3) // 4       # workgroups take 1, 2 or 4 row blocks
+        cap = min(128, chain_wide_max_workgroups(x.device))     # co-resident with room to spare (the library enforces cap)
+        if cap < row_groups:
+            if wide:
+                raise TTError(f"tt_mlp_chain_wide: {row_groups} row groups cannot be co-resident on this device ({cap})")
+            use_wide = False                                       # a small / partitioned device: the per-row-block kernel
+    if use_wide:
         L = lib()
         if groups is None:
             groups = min(16, max((st["lin"].N + 31) // 32 for st in stages))
-        row_groups = 1 if row_blocks <= 2 else (row_blocks + 3) // 4       # workgroups take 1, 2 or 4 row blocks
-        groups = max(1, min(groups, 128 // row_groups, 64))      # all workgroups co-resident with room to spare
+        groups = max(1, min(groups, cap // row_groups, 64))
         L.tt_mlp_chain_wide_workspace_bytes.restype = ctypes.c_longlong
         nbytes = int(L.tt_mlp_chain_wide_workspace_bytes(_ll(R), _c(n), arr))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)

@@ -85,6 +85,10 @@ int main(int argc, char** argv) {
         TT_OK(tt_encoder_fwd(plan, streams.data(), ns));
         TT_OK(tt_decoder_fwd(plan, streams.data(), ns));
         HIP_OK(hipDeviceSynchronize());
+        if (tt_device_faults() != 0) {                 // a wide-chain barrier gave up: the outputs are NaN, say so
+            fprintf(stderr, "forward %d: a tt_mlp_chain_wide barrier timed out (tt_device_faults) -- outputs invalid\n", r);
+            return 6;
+        }
         if (r > 0) ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     printf("forward: %.3f ms (mean of %d, host wall clock)\n", ms / (repeats > 0 ? repeats : 1), repeats);
