@@ -440,6 +440,13 @@ int tt_grad_norm_clip(const float* grad, long long n, float max_norm, float* wor
 int tt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step,
                   const float* grad_scale_or_null, void* stream);
+/* The same update with the step count ON THE DEVICE: the bias corrections use *good_steps_dev + 1; tt_adamw_advance, issued once
+ * after the launches of one optimizer step, increments the count unless the clip factor is NaN (non-finite gradient norm: the
+ * update was skipped, and the count stays with the moments whatever the host does meanwhile). */
+int tt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, const int* good_steps_dev,
+                      const float* grad_scale_or_null, void* stream);
+int tt_adamw_advance(int* good_steps_dev, const float* grad_scale_or_null, void* stream);
 
 /* ----------------------------------------------------------------------
  * SURVEY 8f-4 / row A24, loss half of the training forward: device reductions for every term of

@@ -96,6 +96,52 @@ def test_tape_releases_activations_and_gradients_as_the_sweep_passes_their_first
     assert keys2["b"] in seen2["grads inside node 0"] and seen2["b alive inside node 0"] and gx2() is not None
 
 
+def test_tape_release_covers_gradients_created_during_the_sweep():
+    """x0 -(n0)-> x -(n1)-> a -(n2)-> b.  Only b's gradient exists before the sweep (the loss seeds it); grad(a) and
+    grad(x) are created INSIDE the closures of n2 / n1.  In release mode `a` (first referenced by n1) must be dead -- tensor and
+    gradient buffer -- by the time n0's backward runs; the retaining tape keeps it."""
+    import gc
+    import weakref
+
+    def run(release):
+        seen = {}
+        try:
+            with autodiff.Tape(release=release) as tape:
+                x0 = torch.arange(4, dtype=torch.float32)
+                x = x0 * 2.0
+                tape._keep += [x0, x]
+
+                def n0(x0_, x_):
+                    def bwd():
+                        gc.collect()
+                        seen["a alive in n0"] = refs["a"]() is not None
+                        seen["grad(a) alive in n0"] = keys["a"] in tape.grads
+                        tape.grad(x0_).add_(2.0 * tape.grad(x_))
+                    return bwd
+                tape.nodes.append(n0(x0, x))
+                a = x + 1.0
+                tape._keep += [x, a]
+                tape.nodes.append((lambda x_, a_: lambda: tape.grad(x_).add_(tape.grad(a_)))(x, a))
+                b = a * 3.0
+                tape._keep += [a, b]
+                tape.nodes.append((lambda a_, b_: lambda: tape.grad(a_).add_(3.0 * tape.grad(b_)))(a, b))
+                tape.seed(b, torch.ones(4))
+                refs = {"a": weakref.ref(a)}
+                keys = {"a": a.untyped_storage().data_ptr()}
+                gx0 = tape.grad(x0)                      # (a graph input: its gradient is what the test reads)
+                del x, a, b
+                tape.backward()
+                seen["d x0"] = gx0.clone()
+            return seen
+        finally:
+            autodiff.clear_metas()
+
+    rel, keep = run(True), run(False)
+    assert torch.equal(rel["d x0"], torch.full((4,), 6.0)) and torch.equal(keep["d x0"], rel["d x0"])
+    assert not rel["a alive in n0"] and not rel["grad(a) alive in n0"]
+    assert keep["a alive in n0"] and keep["grad(a) alive in n0"]
+
+
 def test_prepared_weight_gradients_return_in_the_reference_layouts():
     """ConvMeta.place_weight_grad: prepared operands are [Cout][KH][KW][cin_pad]; the reference stores Conv2d as
     [Cout, Cin, KH, KW], Linear as [Cout, Cin], spconv as (Cout, kD, kH, kW, Cin), and some prepared convs are channel

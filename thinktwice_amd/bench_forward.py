@@ -233,8 +233,16 @@ class ForwardWorkload:
             out["tick_latency"] = self.tick_latency()
         if os.environ.get("TT_BENCH_H2D", "1") != "0":
             out["h2d_inclusive"] = self.h2d_inclusive()
+        def guarded(fn):       # a failing side leg must not take the headline line down with it
+            try:
+                return fn()
+            except Exception as e:
+                return {"error": f"{type(e).__name__}: {e}"[:300]}
+        if os.environ.get("TT_BENCH_RAW", "1") != "0":
+            out["raw_inclusive"] = guarded(self.raw_inclusive)
         if os.environ.get("TT_BENCH_VOXEL", "1") != "0" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
             out["voxel_pool_op"] = self.voxel_pool_op()
+            out["lift_splat"] = guarded(self.lift_splat_op)
         single = int(os.environ.get("WORLD_SIZE", "1")) == 1
         # the same workload in the other precision modes, a few timed steps each: the exact-f32 parity mode and the
         # bf16-storage speed mode (whose outputs are NOT inside the 1e-3 tolerance: tests/test_forward.py MODES)
@@ -335,6 +343,77 @@ class ForwardWorkload:
         return {"value": round(self.B / dt, 3), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3),
                 "h2d_bytes_per_step": nbytes, "note": "pinned host batch -> device copy inside the timed step"}
 
+    def raw_inclusive(self, steps=5):
+        """north_star's input: "synthetic 4 x 900 x 1600 RGB ... frames".  The same batch-8 step started from the RAW uint8
+        camera frames resident in HBM (B x 2 sweeps x 4 cams x 900 x 1600 x 3 = 276 MB): tt_preprocess_images (undistort +
+        resize + crop + normalise, thinktwice_agent.py's test_pipeline) inside the timed step, then the forward.  Reported
+        beside the headline, whose timed region starts at the network input like the reference's forward_inference."""
+        from .preprocess import ImagePreprocessor
+        dev = self.batch["img"].device
+        B, T = self.batch["img"].shape[:2]
+        base = torch.from_numpy(synth.raw_camera_frames(seed=31, T=T)).to(dev)          # (T, 4, 900, 1600, 3) uint8
+        raw = torch.stack([torch.roll(base, shifts=13 * b, dims=3) for b in range(B)]).contiguous()
+        pre = ImagePreprocessor(final_dim=tuple(self.batch["img"].shape[-2:]), device=dev)
+
+        def one():
+            b = dict(self.batch)
+            b["img"] = pre(raw)                                                         # (B, T, 4, 3, 448, 896) f32
+            return self.model.forward_inference(b, channel_last_out=True)
+        one()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            pre(raw)
+        e1.record()
+        torch.cuda.synchronize()
+        pre_ms = e0.elapsed_time(e1) / steps
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        nb = raw.numel()
+        out_b = B * T * 4 * 3 * self.batch["img"].shape[-2] * self.batch["img"].shape[-1] * 4
+        return {"value": round(B / dt, 3), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3),
+                "raw_bytes_per_step": nb, "preprocess_ms": round(pre_ms, 3),
+                "preprocess_gbps": round((nb + out_b) / (pre_ms * 1e-3) / 1e9, 1),
+                "note": "uint8 4 x 900 x 1600 frames resident in HBM -> tt_preprocess_images -> forward, per step"}
+
+    def lift_splat_op(self, launches=20):
+        """The splat that actually runs inside the forward (tt_lift_splat_fwd_ws: softmax (x) context, permute and voxel pooling
+        fused -- the reference's 514 MB / sample lift volume is never materialised), one launch per sweep, timed on its own
+        with HIP events at the bench shape: HBM roofline on its ALGORITHMIC bytes (depth logits + context + geom + out)."""
+        dev = self.batch["img"].device
+        lss = self.model.img_encoder
+        B, N = self.B, self.batch["img"].shape[2]
+        D = lss.depth_channels
+        fH, fW = lss.final_dim[0] // lss.downsample_factor, lss.final_dim[1] // lss.downsample_factor
+        C = lss.output_channels
+        g = torch.Generator(device="cpu").manual_seed(3)
+        depth = (torch.randn(B * N, fH, fW, D, generator=g) * 2).to(dev)
+        ctx = torch.randn(B * N, fH, fW, C, generator=g).to(dev)
+        consts = lss.host_constants(self.batch["img_metas"], N)
+        geom = lss.geometry(consts["gm"].to(dev), B, N)               # the forward's own frustum -> voxel index (int32 [B, Np, 3])
+        vn = tuple(int(v) for v in lss.voxel_num)
+        out = torch.zeros(B, vn[1], vn[0], C, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            ops.lift_splat(depth, ctx, geom, vn, B, N, out=out, record=False)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
+        ev[0].record()
+        for i in range(launches):
+            ops.lift_splat(depth, ctx, geom, vn, B, N, out=out, record=False)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(launches))[launches // 2]
+        nbytes = depth.numel() * 4 + ctx.numel() * 4 + geom.numel() * 4 + out.numel() * 4
+        ach = nbytes / (ms * 1e-3) / 1e9
+        return {"kernel": "lift_splat_strip_kernel + lift_splat_cells_kernel (tt_lift_splat_fwd_ws)", "bound": "hbm",
+                "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes),
+                "note": "one launch per sweep of the forward (B x 4 cams); 119 MB per launch: a latency / LDS-bound fusion, not a "
+                        "stream -- the materialised formulation it replaces moves 4.1 GB per launch"}
+
     def voxel_pool_op(self, launches=20):
         """The B1 operator boundary (`voxel_pooling_forward_wrapper`, f32 rows) at the thinktwice.py size, next to the
         forward: HBM roofline on COMPULSORY bytes (SURVEY 8d target >= 60 % of 8 TB/s)."""
@@ -390,6 +469,28 @@ class ForwardWorkload:
         except Exception as e:
             out["c_plan_error"] = f"{type(e).__name__}: {e}"[:300]
         try:
+            # the WHOLE model-side tick from the raw sensors (thinktwice_agent.py:362-529, thinktwice_amd/agent_tick.py): H2D of the
+            # four uint8 900 x 1600 frames + tt_preprocess_images + half-sweep merge + forward + tt_action_post + D2H of the control
+            import numpy as np
+            from .agent_tick import AgentTick
+            raw = synth.raw_camera_frames(seed=41, T=1)[0]                               # (4, 900, 1600, 3) uint8, host
+            raw_pinned = torch.from_numpy(raw).pin_memory()
+            rng = np.random.default_rng(2)
+            half = np.concatenate([rng.uniform(-8, 30, (32768, 1)), rng.uniform(-19, 19, (32768, 1)),
+                                   rng.uniform(-4.5, 0.5, (32768, 1)), rng.uniform(0, 1, (32768, 1))], 1).astype(np.float32)
+            for cache, key_ in ((False, "raw_ms"), (True, "raw_prev_sweep_cache_ms")):
+                at = AgentTick(self.model, lag=2, queue_len=3, use_cache=cache)
+                pos = np.array([3.0, 1.0])
+                tick = lambda: at.run_step(raw_pinned, half, pos, 0.2, 4.0, pos + np.array([5.0, 20.0]), 2)   # noqa: E731
+                for _ in range(6):
+                    tick()                       # fills the queue (and the BEV ring); run_step synchronises itself (D2H copy)
+                out[key_] = timed(tick)
+                del at
+            out["raw_note"] = ("host uint8 frames (17.3 MB, pinned) + 32,768-point half sweep per tick -> control: H2D, preprocess, "
+                               "merge (65,536 points), eager forward, tt_action_post, D2H")
+        except Exception as e:
+            out["raw_error"] = f"{type(e).__name__}: {e}"[:300]
+        try:
             g = InferenceGraph(self.model, b1, channel_last_out=True)
             out["graph_ms"] = timed(g.replay)
             gc = InferenceGraph(self.model, b1, channel_last_out=True, prev_bev=key)
@@ -399,12 +500,13 @@ class ForwardWorkload:
         return out
 
     def cpu_baseline(self):
-        """The oracle on ONE frame in a bounded subprocess (bench_cpu_baseline.py beside bench.py: <= 32 threads, 2 warm-ups
-        + 5 timed passes, per-stage medians, CPU model string; TT_BENCH_CPU_PASSES=n for fewer timed passes)."""
+        """The oracle on ONE frame in a bounded subprocess (bench_cpu_baseline.py beside bench.py: one thread per PHYSICAL core
+        of the host -- SURVEY 8(d) --, 2 warm-ups + 5 timed passes, per-stage medians, CPU model string, one 32-thread pass
+        beside it; TT_BENCH_CPU_PASSES=n for fewer timed passes, TT_BENCH_CPU_THREADS=n to fix the thread count)."""
         import json
         import subprocess
         import sys
-        threads = min(os.cpu_count() or 1, 32)
+        threads = int(os.environ.get("TT_BENCH_CPU_THREADS", "0"))       # 0: all physical cores (counted in the subprocess)
         timed = os.environ.get("TT_BENCH_CPU_PASSES", "5")
         root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
         try:

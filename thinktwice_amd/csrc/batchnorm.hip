@@ -208,7 +208,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, int 
         shift[g * C + c] = beta ? beta[c] : 0.f;      // NOT folded with the mean: tt_bn_apply centres first (see there)
         mean[g * C + c] = (float)mu;
         invstd[g * C + c] = is;
-        if (n > 0) {
+        // a non-finite forward (overflow / NaN in this channel) must not reach the running statistics: the optimizer skips
+        // the update of such an iteration on the device (tt_grad_norm_clip's NaN factor), and the buffers stay those of the
+        // last good step too
+        const bool finite = mu == mu && var == var && fabs(mu) <= 3.0e38 && var <= 3.0e38;
+        if (n > 0 && finite) {
             rm = (1.f - momentum) * rm + momentum * (float)mu;
             rv = (1.f - momentum) * rv + momentum * (float)(n > 1 ? var * n / (n - 1.0) : var);
         }

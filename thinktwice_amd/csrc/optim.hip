@@ -71,6 +71,38 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// The same update with the STEP COUNT on the device: `*good_steps` counts the updates that were actually applied, so a skipped
+// iteration (NaN clip factor) leaves the bias corrections, like p / m / v, at the last good step -- whatever the host does
+// meanwhile.  Every launch of one optimizer step (one per live parameter range) reads the same count; adamw_advance_kernel,
+// issued once after them, increments it when the factor was finite.
+__global__ void adamw_dev_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                      float* __restrict__ v, long long n, float lr, float beta1, float beta2, float eps,
+                                      float weight_decay, const int* __restrict__ good_steps,
+                                      const float* __restrict__ grad_scale) {
+    const float gs = grad_scale ? *grad_scale : 1.f;
+    if (gs != gs) return;
+    const double step = (double)(*good_steps + 1);
+    const float bias_c1 = (float)(1.0 - pow((double)beta1, step));
+    const float bias_c2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+    const float step_size = lr / bias_c1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gs;
+        float pi = p[i] * (1.f - lr * weight_decay);
+        const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+        const float vi = v[i] * beta2 + gi * gi * (1.f - beta2);
+        const float denom = sqrtf(vi) / bias_c2_sqrt + eps;
+        pi = pi - step_size * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+__global__ void adamw_advance_kernel(int* good_steps, const float* __restrict__ grad_scale) {
+    const float gs = grad_scale ? *grad_scale : 1.f;
+    if (gs == gs) *good_steps += 1;
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -101,4 +133,23 @@ extern "C" int tt_adamw_step(float* param, const float* grad, float* exp_avg, fl
                        exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)b1, (float)sqrt(b2),
                        grad_scale_or_null);
     return check_launch("tt_adamw_step");
+}
+
+extern "C" int tt_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, const int* good_steps_dev,
+                                 const float* grad_scale_or_null, void* stream) {
+    TT_REQUIRE(param && grad && exp_avg && exp_avg_sq && good_steps_dev && n > 0, "tt_adamw_step_dev: bad args");
+    TT_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f,
+               "tt_adamw_step_dev: bad hyper-parameters");
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256LL * 32) blocks = 256LL * 32;
+    hipLaunchKernelGGL(adamw_dev_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, good_steps_dev, grad_scale_or_null);
+    return check_launch("tt_adamw_step_dev");
+}
+
+extern "C" int tt_adamw_advance(int* good_steps_dev, const float* grad_scale_or_null, void* stream) {
+    TT_REQUIRE(good_steps_dev, "tt_adamw_advance: null");
+    hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, good_steps_dev, grad_scale_or_null);
+    return check_launch("tt_adamw_advance");
 }

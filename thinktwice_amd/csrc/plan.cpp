@@ -97,6 +97,7 @@ struct tt_plan {
     std::vector<tt::PlanOp> ops;
     std::vector<tt::PlanArgRec> args;
     std::vector<tt::PlanReloc> relocs;
+    int pending_relocs = 0;      // relocations declared since the last op was added: they belong to the NEXT call
     std::vector<unsigned char> blob;          // pristine host blob (relocations unresolved)
     std::vector<tt::PlanBuffer> buffers;
     std::vector<tt::PlanOutput> outputs;
@@ -205,6 +206,7 @@ extern "C" int tt_plan_add_reloc(tt_plan* p, long long blob_offset, int buffer, 
     TT_REQUIRE(p && blob_offset >= 0 && blob_offset + 8 <= (long long)p->blob.size(), "tt_plan_add_reloc: outside the blob");
     // (relocations are declared while the arguments of the NEXT call are assembled: that call's index is ops.size())
     p->relocs.push_back(PlanReloc{blob_offset, buffer, offset, (int)p->ops.size()});
+    ++p->pending_relocs;
     p->bound = false;
     return 0;
 }
@@ -356,6 +358,7 @@ extern "C" int tt_plan_add_call(tt_plan* p, const char* entry, int nargs, const 
     PlanOp op{0, th, stream, 0, 0, (int)p->args.size(), nargs};
     for (int i = 0; i < nargs; ++i) p->args.push_back(PlanArgRec{kinds[i], buffers[i], ivals[i], fvals[i]});
     p->ops.push_back(op);
+    p->pending_relocs = 0;       // (they were recorded against this op's index)
     if (stream + 1 > p->nstreams) p->nstreams = stream + 1;
     p->bound = false;
     return 0;
@@ -364,6 +367,10 @@ extern "C" int tt_plan_add_call(tt_plan* p, const char* entry, int nargs, const 
 extern "C" int tt_plan_add_sync(tt_plan* p, int waiter_stream, int signal_stream) {
     TT_REQUIRE(p && waiter_stream >= 0 && signal_stream >= 0 && waiter_stream < kMaxPlanStreams && signal_stream < kMaxPlanStreams,
                "tt_plan_add_sync: bad argument");
+    // the liveness analysis of tt_plan_compact_arena attributes a blob's pointers to the op index current when they were
+    // declared: a sync slipped in between a call's relocations and the call itself would silently mis-attribute them
+    TT_REQUIRE(p->pending_relocs == 0, "tt_plan_add_sync: %d relocation(s) were declared for a call that has not been added yet",
+               p->pending_relocs);
     p->ops.push_back(PlanOp{1, -1, 0, waiter_stream, signal_stream, 0, 0});
     const int m = (waiter_stream > signal_stream ? waiter_stream : signal_stream) + 1;
     if (m > p->nstreams) p->nstreams = m;

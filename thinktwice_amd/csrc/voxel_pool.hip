@@ -1036,24 +1036,33 @@ __global__ __launch_bounds__(1024) void vp_plan_segments_kernel(const int* __res
     if (tid == 0) seg_off[nkeys] = carry_sh;
 }
 
+// Segments are numbered per GROUP of `cpg` cells: group `grp` owns segment ids [grp * segcap, (grp + 1) * segcap) and the
+// entries [grp * (cpg + 1), (grp + 1) * (cpg + 1)) of cell_start (absolute positions in `order`) and seg_off (segments of the
+// group's cells before cell k).  The static plan is ONE group of batch x cells keys (a global scan at build time); the
+// per-launch sort of the generic path (vp_cs_*) makes one group per sample, so that no scan crosses samples.
 template <int NV, int RF, bool NT>
-__global__ __launch_bounds__(256) void vp_planned_segments_kernel(int C, int nkeys, const int* __restrict__ order,
+__global__ __launch_bounds__(256) void vp_planned_segments_kernel(int C, int cpg, int segcap, int ngroups,
+                                                                  const int* __restrict__ order,
                                                                   const int* __restrict__ cell_start,
                                                                   const int* __restrict__ seg_off,
                                                                   const float* __restrict__ feats,
                                                                   float* __restrict__ partial) {
     const int lane = threadIdx.x & 63;
     const int g = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);      // segment
-    const int nseg = seg_off[nkeys];
-    if (g >= nseg) return;
-    // the cell of segment g: last k with seg_off[k] <= g (binary search over a few thousand entries)
-    int lo = 0, hi = nkeys;
+    const int grp = g / segcap;
+    if (grp >= ngroups) return;
+    const int gl = g - grp * segcap;
+    seg_off += (long long)grp * (cpg + 1);
+    cell_start += (long long)grp * (cpg + 1);
+    if (gl >= seg_off[cpg]) return;
+    // the cell of segment gl: last k with seg_off[k] <= gl (binary search over the group's cells)
+    int lo = 0, hi = cpg;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (seg_off[mid] <= g) lo = mid;
+        if (seg_off[mid] <= gl) lo = mid;
         else hi = mid;
     }
-    const int beg = cell_start[lo] + (g - seg_off[lo]) * kSeg;
+    const int beg = cell_start[lo] + (gl - seg_off[lo]) * kSeg;
     const int end = min(beg + kSeg, cell_start[lo + 1]);
     const int my = (beg + lane < end) ? order[beg + lane] : 0;
     const int c4 = C >> 2;
@@ -1094,11 +1103,13 @@ __global__ __launch_bounds__(256) void vp_planned_segments_kernel(int C, int nke
 // One workgroup of 4 waves per (sample, cell): wave w sums segments s0 + w, s0 + w + 4, ... with 4 partial rows in flight,
 // then the four wave sums are combined in a fixed order through LDS (deterministic).
 template <int NV>
-__global__ __launch_bounds__(256) void vp_planned_cells_kernel(int C, const int* __restrict__ seg_off,
+__global__ __launch_bounds__(256) void vp_planned_cells_kernel(int C, int cpg, int segcap, const int* __restrict__ seg_off,
                                                                const float* __restrict__ partial, float* __restrict__ out) {
     __shared__ float4 red[3][NV * 64];
     const int key = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s0 = seg_off[key], s1 = seg_off[key + 1];
+    const int grp = key / cpg, cell = key - grp * cpg;
+    seg_off += (long long)grp * (cpg + 1);
+    const int s0 = grp * segcap + seg_off[cell], s1 = grp * segcap + seg_off[cell + 1];
     if (s0 == s1) return;
     const int c4 = C >> 2;
     float4 acc[NV];
@@ -1148,6 +1159,161 @@ __global__ __launch_bounds__(256) void vp_planned_cells_kernel(int C, const int*
     }
 }
 
+// ---------------------------------------------------------------------------
+// v3 (round 5): the planned path for ARBITRARY geometry.  The static plan above needs the in-range points sorted by
+// (sample, cell); a general radix sort of 4 M (key, point) pairs takes 2.2 ms -- nine times the operator.  But the keys are
+// only `cells` (441) wide per sample, so the sort is a counting sort in three small kernels per launch:
+//   vp_cs_count   : one workgroup per 8192 points.  Every wave ranks its 512 points by cell with wave ballots (a slice of 64
+//                   consecutive frustum points falls into 1-4 cells: 1-4 ballots), per-(wave, cell) counts in LDS (u16), a
+//                   column scan over the 16 waves, and out go one packed (cell, rank within the chunk) word per point and the
+//                   chunk's count per cell.  pos_memo is written here.
+//   vp_cs_scan    : one workgroup per SAMPLE: per cell the prefix over the sample's <= 64 chunks (held in registers), the
+//                   exclusive scans of the cell totals (positions in `order`) and of ceil(total / 64) (segments); rewrites the
+//                   table as absolute start positions per (chunk, cell).  Nothing crosses samples: sample b's rows live at
+//                   order[b * Np ...) and its segments at [b * segcap, ...).
+//   vp_cs_scatter : one thread per point: order[table[chunk][cell] + rank] = point.
+// The order inside a cell is ascending point index -- what the stable radix sort of the static plan produces -- so the two paths
+// add the same rows in the same order: bit-identical outputs.  Then the planned streaming kernels run as they are.
+// Traffic on top of the rows: geom 12 B + 4 B written + 4 B read per point, 4 B per in-range point, < 1 MB of tables.
+// ---------------------------------------------------------------------------
+constexpr int kCsChunk = 8192;
+constexpr int kCsWaves = 16;
+constexpr int kCsMaxCells = 1024;
+constexpr int kCsMaxChunksPerSample = 64;
+constexpr int kCsRankBits = 13;          // rank within a chunk < 8192
+
+__global__ __launch_bounds__(kCsWaves * 64) void vp_cs_count_kernel(int num_points, int X, int Y, int Z, int cps,
+                                                                    const int32_t* __restrict__ geom,
+                                                                    int32_t* __restrict__ pos_memo,
+                                                                    unsigned* __restrict__ keyrank, int* __restrict__ table) {
+    extern __shared__ unsigned short cs_cnt[];      // [kCsWaves][cells_p]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cells = X * Y, cells_p = (cells + 63) & ~63;
+    const int chunk = blockIdx.x;
+    const int b = chunk / cps, cis = chunk - b * cps;
+    const long long p0 = (long long)b * num_points + (long long)cis * kCsChunk;
+    const int npts = min(kCsChunk, num_points - cis * kCsChunk);
+    for (int i = tid; i < kCsWaves * cells_p; i += kCsWaves * 64) cs_cnt[i] = 0;
+    constexpr int kSlices = kCsChunk / kCsWaves / 64;        // 8 slices of 64 consecutive points per wave
+    const VpPoint* gp = reinterpret_cast<const VpPoint*>(geom) + p0;
+    VpPoint pt[kSlices];
+#pragma unroll
+    for (int sl = 0; sl < kSlices; ++sl) {               // one round trip for all of a lane's points
+        const int i = wave * (kSlices * 64) + sl * 64 + lane;
+        pt[sl].x = -1; pt[sl].y = -1; pt[sl].z = -1;
+        if (i < npts) pt[sl] = gp[i];
+    }
+    __syncthreads();
+    unsigned short* mine = cs_cnt + wave * cells_p;
+    unsigned kr[kSlices];
+#pragma unroll
+    for (int sl = 0; sl < kSlices; ++sl) {
+        const int i = wave * (kSlices * 64) + sl * 64 + lane;
+        const int x = pt[sl].x, y = pt[sl].y, z = pt[sl].z;
+        int key = -1;
+        if (i < npts && x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) {
+            key = y * X + x;
+            if (pos_memo) {
+                const long long p = p0 + i;
+                pos_memo[p * 3] = b;
+                pos_memo[p * 3 + 1] = y;
+                pos_memo[p * 3 + 2] = x;
+            }
+        }
+        int rank = 0;
+        bool pending = key >= 0;
+        while (__ballot(pending)) {
+            if (pending) {                                  // exec = the lanes still to be ranked
+                const int k = __builtin_amdgcn_readfirstlane(key);
+                const unsigned long long m = __ballot(key == k);
+                const int base = mine[k];                   // (the wave's own row: LDS operations of one wave are in order)
+                if (key == k) {
+                    rank = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    pending = false;
+                    if ((int)__builtin_ctzll(m) == lane) mine[k] = (unsigned short)(base + __popcll(m));
+                }
+            }
+        }
+        kr[sl] = key >= 0 ? (((unsigned)key << kCsRankBits) | (unsigned)rank) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    // column scan over the waves: count of (wave, cell) -> rows of the cell in the waves before; the chunk's total to the table
+    for (int c = tid; c < cells; c += kCsWaves * 64) {
+        int run = 0;
+#pragma unroll
+        for (int w = 0; w < kCsWaves; ++w) {
+            const int v = cs_cnt[w * cells_p + c];
+            cs_cnt[w * cells_p + c] = (unsigned short)run;
+            run += v;
+        }
+        table[(long long)chunk * cells + c] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sl = 0; sl < kSlices; ++sl) {
+        const int i = wave * (kSlices * 64) + sl * 64 + lane;
+        if (i < npts) {
+            unsigned v = kr[sl];
+            if (v != 0xFFFFFFFFu) v += mine[v >> kCsRankBits];
+            keyrank[p0 + i] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void vp_cs_scan_kernel(int num_points, int cells, int cps, int* __restrict__ table,
+                                                          int* __restrict__ cell_start, int* __restrict__ seg_off) {
+    __shared__ int wsum[2][16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int v[kCsMaxChunksPerSample];
+    int total = 0;
+    int* tab = table + (long long)b * cps * cells + t;
+#pragma unroll
+    for (int c = 0; c < kCsMaxChunksPerSample; ++c) v[c] = (t < cells && c < cps) ? tab[(long long)c * cells] : 0;
+#pragma unroll
+    for (int c = 0; c < kCsMaxChunksPerSample; ++c) total += v[c];
+    const int segs = (total + kSeg - 1) / kSeg;
+    // exclusive scans over the sample's cells (thread = cell): rows and segments
+    int irow = total, iseg = segs;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int a = __shfl_up(irow, o), s2 = __shfl_up(iseg, o);
+        if (lane >= o) { irow += a; iseg += s2; }
+    }
+    if (lane == 63) { wsum[0][wave] = irow; wsum[1][wave] = iseg; }
+    __syncthreads();
+    int brow = 0, bseg = 0;
+    for (int w = 0; w < wave; ++w) { brow += wsum[0][w]; bseg += wsum[1][w]; }
+    const int row0 = b * num_points + brow + irow - total;        // absolute position in `order` of this cell's first row
+    if (t < cells) {
+        cell_start[(long long)b * (cells + 1) + t] = row0;
+        seg_off[(long long)b * (cells + 1) + t] = bseg + iseg - segs;
+        int run = row0;
+#pragma unroll
+        for (int c = 0; c < kCsMaxChunksPerSample; ++c)
+            if (c < cps) {
+                tab[(long long)c * cells] = run;
+                run += v[c];
+            }
+    }
+    if (t == cells - 1) {
+        cell_start[(long long)b * (cells + 1) + cells] = row0 + total;
+        seg_off[(long long)b * (cells + 1) + cells] = bseg + iseg;
+    }
+}
+
+__global__ __launch_bounds__(256) void vp_cs_scatter_kernel(long long total, int num_points, int cells, int cps,
+                                                            const unsigned* __restrict__ keyrank,
+                                                            const int* __restrict__ table, int* __restrict__ order) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const unsigned v = keyrank[p];
+    if (v == 0xFFFFFFFFu) return;
+    const int b = (int)(p / num_points);
+    const int cis = (int)((p - (long long)b * num_points) / kCsChunk);
+    const int key = (int)(v >> kCsRankBits), rank = (int)(v & ((1u << kCsRankBits) - 1u));
+    order[table[((long long)b * cps + cis) * cells + key] + rank] = (int)p;
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -1194,6 +1360,29 @@ extern "C" int tt_voxel_pool_fwd(int batch_size, int num_points, int num_channel
 }
 
 
+// The two streaming kernels of the planned forward over `ngroups` groups of `cpg` cells (see vp_planned_segments_kernel).
+static void launch_planned(int C, int cpg, int segcap, int ngroups, const int* order, const int* cell_start, const int* seg_off,
+                           const float* input_features, float* output_features, float* partial, hipStream_t st) {
+    const unsigned blocks = (unsigned)div_up((long long)segcap * ngroups, 4);          // 4 waves per workgroup
+    static const int rf = [] { const char* e = getenv("TT_VP_PLAN_ROWS_IN_FLIGHT"); return e ? atoi(e) : 32; }();
+    static const bool nt = [] { const char* e = getenv("TT_VP_NT"); return e ? atoi(e) != 0 : true; }();
+#define TT_VP_SEG(NV_, RF_, NT_)                                                                                          \
+    hipLaunchKernelGGL((vp_planned_segments_kernel<NV_, RF_, NT_>), dim3(blocks), dim3(256), 0, st, C, cpg, segcap, ngroups, \
+                       order, cell_start, seg_off, input_features, partial)
+    if (C <= 256) {
+        if (rf >= 32) { if (nt) TT_VP_SEG(1, 32, true); else TT_VP_SEG(1, 32, false); }
+        else if (rf >= 16) { if (nt) TT_VP_SEG(1, 16, true); else TT_VP_SEG(1, 16, false); }
+        else { if (nt) TT_VP_SEG(1, 8, true); else TT_VP_SEG(1, 8, false); }
+        hipLaunchKernelGGL(vp_planned_cells_kernel<1>, dim3((unsigned)(cpg * ngroups)), dim3(256), 0, st, C, cpg, segcap, seg_off,
+                           partial, output_features);
+    } else {
+        if (nt) TT_VP_SEG(4, 4, true); else TT_VP_SEG(4, 4, false);
+        hipLaunchKernelGGL(vp_planned_cells_kernel<4>, dim3((unsigned)(cpg * ngroups)), dim3(256), 0, st, C, cpg, segcap, seg_off,
+                           partial, output_features);
+    }
+#undef TT_VP_SEG
+}
+
 static int v2_smax(int C) {
     (void)C;
     return 64;   // workspace rows per chunk (Lift-Splat chunks touch <= ~40 cells)
@@ -1203,15 +1392,60 @@ static bool v2_ok(long long total, int C, int X, int Y) {
     return C % 4 == 0 && C <= 1024 && (long long)X * Y <= kMaxCells && v2_smax(C) >= 8 && total >= 4 * kChunk;
 }
 
+// ---- v3: per-launch counting sort + the planned streaming kernels (vp_cs_* above)
+static bool v3_ok(long long total, int num_points, int C, int X, int Y) {
+    static const bool on = [] { const char* e = getenv("TT_VP_SORT"); return e ? atoi(e) != 0 : true; }();   // A/B knob
+    const long long cps = ((long long)num_points + kCsChunk - 1) / kCsChunk;
+    return on && C % 4 == 0 && C <= 1024 && (long long)X * Y <= kCsMaxCells && cps <= kCsMaxChunksPerSample &&
+           total >= 4 * kCsChunk && total < (1ll << 31);
+}
+
+struct V3Layout {
+    size_t keyrank, table, order, cell_start, seg_off, partial, bytes;
+    int cps, segcap;
+};
+
+static V3Layout v3_layout(int B, int num_points, int C, int cells) {
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    V3Layout L;
+    const size_t total = (size_t)B * num_points;
+    L.cps = (num_points + kCsChunk - 1) / kCsChunk;
+    L.segcap = num_points / kSeg + cells + 1;             // a sample's segments: <= floor(rows / 64) + one ragged one per cell
+    size_t off = 0;
+    L.keyrank = off; off += al(4 * total);
+    L.table = off; off += al(4 * (size_t)B * L.cps * cells);
+    L.order = off; off += al(4 * total);
+    L.cell_start = off; off += al(4 * (size_t)B * (cells + 1));
+    L.seg_off = off; off += al(4 * (size_t)B * (cells + 1));
+    L.partial = off; off += al(4 * (size_t)B * L.segcap * C);
+    L.bytes = off;
+    return L;
+}
+
 extern "C" long long tt_voxel_pool_workspace_bytes(int batch_size, int num_points, int num_channels,
                                                    int num_voxel_x, int num_voxel_y) {
+    const long long total = (long long)batch_size * num_points;
+    long long need = 0;
+    if (v2_ok(total, num_channels, num_voxel_x, num_voxel_y)) {
+        const long long cps = (num_points + kChunk - 1) / kChunk;
+        const long long nchunks = cps * batch_size;
+        const long long part = nchunks * v2_smax(num_channels) * num_channels * 4;
+        const long long tab = (long long)batch_size * num_voxel_x * num_voxel_y * cps * 4;
+        need = part + tab + 256;
+    }
+    if (v3_ok(total, num_points, num_channels, num_voxel_x, num_voxel_y)) {
+        const long long n3 = (long long)v3_layout(batch_size, num_points, num_channels, num_voxel_x * num_voxel_y).bytes;
+        if (n3 > need) need = n3;
+    }
+    return need;
+}
+
+static long long v2_workspace_bytes(int batch_size, int num_points, int num_channels, int num_voxel_x, int num_voxel_y) {
     const long long total = (long long)batch_size * num_points;
     if (!v2_ok(total, num_channels, num_voxel_x, num_voxel_y)) return 0;
     const long long cps = (num_points + kChunk - 1) / kChunk;
     const long long nchunks = cps * batch_size;
-    const long long part = nchunks * v2_smax(num_channels) * num_channels * 4;
-    const long long tab = (long long)batch_size * num_voxel_x * num_voxel_y * cps * 4;
-    return part + tab + 256;
+    return nchunks * v2_smax(num_channels) * num_channels * 4 + (long long)batch_size * num_voxel_x * num_voxel_y * cps * 4 + 256;
 }
 
 extern "C" int tt_voxel_pool_fwd_ws(int batch_size, int num_points, int num_channels, int num_voxel_x,
@@ -1219,7 +1453,35 @@ extern "C" int tt_voxel_pool_fwd_ws(int batch_size, int num_points, int num_chan
                                     const float* input_features, float* output_features, int32_t* pos_memo,
                                     void* workspace, long long workspace_bytes, void* stream) {
     const long long total = (long long)batch_size * num_points;
-    const long long need = tt_voxel_pool_workspace_bytes(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y);
+    const bool aligned = !(reinterpret_cast<uintptr_t>(input_features) & 15) && !(reinterpret_cast<uintptr_t>(output_features) & 15) &&
+                         !(reinterpret_cast<uintptr_t>(workspace) & 15);
+    if (workspace && aligned && v3_ok(total, num_points, num_channels, num_voxel_x, num_voxel_y)) {
+        const int cells = num_voxel_x * num_voxel_y;
+        const V3Layout L = v3_layout(batch_size, num_points, num_channels, cells);
+        if (workspace_bytes >= (long long)L.bytes) {
+            TT_REQUIRE(geom_xyz && input_features && output_features, "tt_voxel_pool_fwd_ws: null pointer");
+            hipStream_t st = (hipStream_t)stream;
+            char* w = static_cast<char*>(workspace);
+            unsigned* keyrank = reinterpret_cast<unsigned*>(w + L.keyrank);
+            int* table = reinterpret_cast<int*>(w + L.table);
+            int* order = reinterpret_cast<int*>(w + L.order);
+            int* cell_start = reinterpret_cast<int*>(w + L.cell_start);
+            int* seg_off = reinterpret_cast<int*>(w + L.seg_off);
+            float* partial = reinterpret_cast<float*>(w + L.partial);
+            const int nchunks = L.cps * batch_size;
+            const size_t lds = (size_t)kCsWaves * ((cells + 63) & ~63) * sizeof(unsigned short);
+            hipLaunchKernelGGL(vp_cs_count_kernel, dim3((unsigned)nchunks), dim3(kCsWaves * 64), lds, st, num_points, num_voxel_x,
+                               num_voxel_y, num_voxel_z, L.cps, geom_xyz, pos_memo, keyrank, table);
+            hipLaunchKernelGGL(vp_cs_scan_kernel, dim3((unsigned)batch_size), dim3(1024), 0, st, num_points, cells, L.cps, table,
+                               cell_start, seg_off);
+            hipLaunchKernelGGL(vp_cs_scatter_kernel, dim3((unsigned)div_up(total, 256)), dim3(256), 0, st, total, num_points, cells,
+                               L.cps, keyrank, table, order);
+            launch_planned(num_channels, cells, L.segcap, batch_size, order, cell_start, seg_off, input_features, output_features,
+                           partial, st);
+            return check_launch("tt_voxel_pool_fwd_ws");
+        }
+    }
+    const long long need = v2_workspace_bytes(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y);
     if (need == 0 || !workspace || workspace_bytes < need ||
         (reinterpret_cast<uintptr_t>(input_features) & 15) || (reinterpret_cast<uintptr_t>(output_features) & 15))
         return tt_voxel_pool_fwd(batch_size, num_points, num_channels, num_voxel_x, num_voxel_y, num_voxel_z,
@@ -1469,26 +1731,8 @@ extern "C" int tt_voxel_pool_fwd_planned(int batch_size, int num_points, int num
     const int* order = (const int*)pl;
     const int* cell_start = (const int*)(pl + vp_align(4 * total));
     const int* seg_off = (const int*)(pl + vp_align(4 * total) + vp_align(4 * (nkeys + 1)));
-    hipStream_t st = (hipStream_t)stream;
     const long long max_seg = total / kSeg + nkeys + 1;
-    float* partial = (float*)workspace;
-    const unsigned blocks = (unsigned)div_up(max_seg, 4);          // 4 waves per workgroup
-    static const int rf = [] { const char* e = getenv("TT_VP_PLAN_ROWS_IN_FLIGHT"); return e ? atoi(e) : 32; }();
-    static const bool nt = [] { const char* e = getenv("TT_VP_NT"); return e ? atoi(e) != 0 : true; }();
-#define TT_VP_SEG(NV_, RF_, NT_)                                                                                        \
-    hipLaunchKernelGGL((vp_planned_segments_kernel<NV_, RF_, NT_>), dim3(blocks), dim3(256), 0, st, C, (int)nkeys, order, \
-                       cell_start, seg_off, input_features, partial)
-    if (C <= 256) {
-        if (rf >= 32) { if (nt) TT_VP_SEG(1, 32, true); else TT_VP_SEG(1, 32, false); }
-        else if (rf >= 16) { if (nt) TT_VP_SEG(1, 16, true); else TT_VP_SEG(1, 16, false); }
-        else { if (nt) TT_VP_SEG(1, 8, true); else TT_VP_SEG(1, 8, false); }
-        hipLaunchKernelGGL(vp_planned_cells_kernel<1>, dim3((unsigned)nkeys), dim3(256), 0, st, C, seg_off, partial,
-                           output_features);
-    } else {
-        if (nt) TT_VP_SEG(4, 4, true); else TT_VP_SEG(4, 4, false);
-        hipLaunchKernelGGL(vp_planned_cells_kernel<4>, dim3((unsigned)nkeys), dim3(256), 0, st, C, seg_off, partial,
-                           output_features);
-    }
-#undef TT_VP_SEG
+    launch_planned(C, (int)nkeys, (int)max_seg, 1, order, cell_start, seg_off, input_features, output_features,
+                   (float*)workspace, (hipStream_t)stream);
     return check_launch("tt_voxel_pool_fwd_planned");
 }

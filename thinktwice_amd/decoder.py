@@ -154,8 +154,9 @@ class ThinkTwiceDecoder:
         # value_proj(feat + cam_embed + level_embed) = value_proj(feat) + per-(level, cam) shift  (DEC:392-393)
         for lay in self.layers:
             emb = cams.view(1, 4, 256) + lvls.view(4, 1, 256)                       # (lvl, cam, 256)
-            lay.vshift = [torch.addmm(lay.vproj_b.new_zeros(256), emb[l], lay.vproj_w.t()).contiguous()
-                          for l in range(4)]                                         # W e (bias added by shift)
+            # W e (bias added by shift): 4 rows through the library's exact-f32 linear (tt_conv2d_fwd), not a torch GEMM
+            w_e = conv_from_weight(lay.vproj_w.view(256, 1, 1, 256).contiguous(), F32)
+            lay.vshift = [unrows(w_e(rows(emb[l].contiguous()))).contiguous() for l in range(4)]
         self.vproj_all_shift = torch.cat([lay.vproj.shift for lay in self.layers], 0).contiguous()  # (L*256,)
         self.vproj_all = conv_from_weight(torch.cat([lay.vproj.w for lay in self.layers], 0).contiguous(),
                                           self.wdtype, shift=self.vproj_all_shift)                  # (L*256,1,1,256)

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib, camera, layers, ops, weights
 from .layers import conv_from_sd, conv_from_weight, deconv2x2_from_sd, linear_from_sd, rows, unrows
-from .registry import BACKBONES
+from .registry import BACKBONES, NECKS, build_neck
 
 
 class _ResNet50:
@@ -88,6 +88,64 @@ class _ResNet50:
         return outs
 
 
+@NECKS.register_module(name="PAFPN")
+@NECKS.register_module()
+class PAFPN_fp32:
+    """mmdet PAFPN / the reference's `PAFPN_fp32` (backbones/lss.py:284-348, built by `build_neck(img_neck_conf)` at
+    lss.py:402 from `dict(type='PAFPN', in_channels=[256, 512, 1024, 2048], num_outs=4, out_channels=256)`): lateral 1x1
+    convs, top-down nearest-upsample adds, 3x3 fpn convs, bottom-up stride-2 adds, 3x3 pafpn convs.  Same constructor
+    arguments and state_dict names (`lateral_convs.i.conv`, `fpn_convs.i.conv`, `downsample_convs.i.conv`,
+    `pafpn_convs.i.conv`); channel-last tensors.  `targets`: optional [(buffer, channel offset) | None] per output level --
+    the consumer's concat buffer an output is produced in (LSS writes the FPN maps straight into the UNet's inputs)."""
+
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
+                 dtype=torch.float32, device="cuda", **unused):
+        assert start_level == 0 and end_level in (-1, len(in_channels)) and not add_extra_convs and \
+            num_outs == len(in_channels), "PAFPN: only the thinktwice.py form (all levels, no extra convs) is built"
+        self.in_channels, self.out_channels, self.num_outs = list(in_channels), out_channels, num_outs
+        self.wdtype, self.device = dtype, torch.device(device)
+        self.loaded = False
+
+    def load_state_dict(self, sd, prefix):
+        n, dt, dev, L = prefix, self.wdtype, self.device, self.num_outs
+        self.lat = [conv_from_sd(sd, f"{n}.lateral_convs.{i}.conv", dt, dev) for i in range(L)]
+        self.fpn = [conv_from_sd(sd, f"{n}.fpn_convs.{i}.conv", dt, dev, pad=1) for i in range(L)]
+        self.down = [conv_from_sd(sd, f"{n}.downsample_convs.{i}.conv", dt, dev, stride=2, pad=1) for i in range(L - 1)]
+        self.paf = [conv_from_sd(sd, f"{n}.pafpn_convs.{i}.conv", dt, dev, pad=1) for i in range(L - 1)]
+        self.loaded = True
+        return self
+
+    def __call__(self, inputs, targets=None):
+        """inputs: the backbone's maps (channel-last).  Returns [(tensor, channel offset, channels)] per level."""
+        L = self.num_outs
+        assert len(inputs) == len(self.in_channels)
+        targets = list(targets) if targets is not None else [None] * L
+        C = self.out_channels
+        lat = [self.lat[i](inputs[i]) for i in range(L)]
+        for i in range(L - 1, 0, -1):
+            ops.upsample_nearest_add_(lat[i - 1], lat[i])
+        # out[0] == inter[0] (pafpn.py: outs = [inter_outs[0]] + ...): produced where its consumer wants it
+        if targets[0] is not None:
+            buf0, off0 = targets[0]
+            self.fpn[0](lat[0], out=buf0, out_coff=off0)
+        else:
+            buf0, off0 = self.fpn[0](lat[0]), 0
+        inter = [None] + [self.fpn[i](lat[i]) for i in range(1, L)]
+        if L > 1:
+            self.down[0](buf0, in_coff=off0, cin=C, res1=inter[1], out=inter[1])
+        for i in range(1, L - 1):
+            self.down[i](inter[i], res1=inter[i + 1], out=inter[i + 1])
+        outs = [(buf0, off0, C)]
+        for i in range(1, L):
+            if targets[i] is not None:
+                buf, off = targets[i]
+                self.paf[i - 1](inter[i], out=buf, out_coff=off)
+            else:
+                buf, off = self.paf[i - 1](inter[i]), 0
+            outs.append((buf, off, C))
+        return outs
+
+
 @BACKBONES.register_module()
 class LSS:
     def __init__(self, x_bound, y_bound, z_bound, d_bound, final_dim, downsample_factor, output_channels,
@@ -99,6 +157,8 @@ class LSS:
         self.downsample_factor = downsample_factor
         self.output_channels = output_channels
         self.queue_len = queue_len
+        self.img_neck_conf = dict(img_neck_conf) if img_neck_conf else dict(type="PAFPN", in_channels=[256, 512, 1024, 2048],
+                                                                              num_outs=4, out_channels=256)
         self.wdtype = dtype                               # precision mode of the conv weights (may be weights.X3)
         self.dtype = weights.storage_dtype(dtype)         # storage type of the activations
         self.device = torch.device(device)
@@ -114,11 +174,8 @@ class LSS:
         dt, dev, p = self.wdtype, self.device, prefix
         f32 = torch.float32
         self.backbone = _ResNet50(sd, p + ".img_backbone", dt, dev)
-        n = p + ".img_neck"
-        self.lat = [conv_from_sd(sd, f"{n}.lateral_convs.{i}.conv", dt, dev) for i in range(4)]
-        self.fpn = [conv_from_sd(sd, f"{n}.fpn_convs.{i}.conv", dt, dev, pad=1) for i in range(4)]
-        self.down = [conv_from_sd(sd, f"{n}.downsample_convs.{i}.conv", dt, dev, stride=2, pad=1) for i in range(3)]
-        self.paf = [conv_from_sd(sd, f"{n}.pafpn_convs.{i}.conv", dt, dev, pad=1) for i in range(3)]
+        # lss.py:402 `self.img_neck = build_neck(img_neck_conf)`: the NECKS registry ('PAFPN' / 'PAFPN_fp32')
+        self.img_neck = build_neck(self.img_neck_conf, dtype=dt, device=dev).load_state_dict(sd, p + ".img_neck")
         self.neck_conv = conv_from_sd(sd, p + ".neck_conv", dt, dev)
         d = p + ".depth_net"
         self.bn22 = layers.bn_affine(sd, d + ".bn", dev)
@@ -190,24 +247,14 @@ class LSS:
         inside the UNet concat buffers (torch.cat of lss.py:256 becomes a channel offset)."""
         NI = x.shape[0]
         c = self.backbone(x, bordered=bordered)
-        lat = [self.lat[i](c[i]) for i in range(4)]
-        for i in range(3, 0, -1):
-            ops.upsample_nearest_add_(lat[i - 1], lat[i])
-        H0, W0 = lat[0].shape[1:3]
+        H0, W0 = c[0].shape[1:3]
         dt, dev = self.dtype, x.device
         cat2 = torch.empty(NI, H0, W0, 384, dtype=dt, device=dev)            # [up(d3) 128 | e1 256]
         cat3 = torch.empty(NI, H0 // 2, W0 // 2, 512, dtype=dt, device=dev)  # [up(d4) 256 | e2 256]
         cat4 = torch.empty(NI, H0 // 4, W0 // 4, 512, dtype=dt, device=dev)  # [up(e4) 256 | e3 256]
-        # PAFPN out[0] == inter[0]: produced in place inside the UNet concat buffer
-        self.fpn[0](lat[0], out=cat2, out_coff=128)
-        inter = [None] + [self.fpn[i](lat[i]) for i in range(1, 4)]
-        self.down[0](cat2, in_coff=128, cin=256, res1=inter[1], out=inter[1])
-        for i in range(1, 3):
-            self.down[i](inter[i], res1=inter[i + 1], out=inter[i + 1])
-        self.paf[0](inter[1], out=cat3, out_coff=256)
-        self.paf[1](inter[2], out=cat4, out_coff=256)
-        e4 = self.paf[2](inter[3])
-        return (cat2, cat3, cat4, e4)
+        # the PAFPN outputs are produced in place inside the UNet concat buffers
+        outs = self.img_neck(c, targets=[(cat2, 128), (cat3, 256), (cat4, 256), None])
+        return (cat2, cat3, cat4, outs[3][0])
 
     def _fpn_views(self, bufs):
         """[(tensor, channel offset, channels)] of the 4 FPN maps."""

@@ -19,9 +19,26 @@ class FlatAdamW:
         self.m = torch.zeros_like(flat_param)
         self.v = torch.zeros_like(flat_param)
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
-        self.steps = 0
+        # the count of APPLIED updates lives on the device (tt_adamw_advance): an iteration whose gradient norm is not finite
+        # is skipped there, and the bias corrections / the checkpointed `step` must stay with the untouched moments
+        self.steps_dev = torch.zeros(1, dtype=torch.int32, device=flat_param.device)
+        self.issued, self._base = 0, 0   # optimizer steps issued by the host since the count was set (>= the applied ones)
         self._ws = torch.empty(1024, dtype=torch.float32, device=flat_param.device)
         self.norm_scale = torch.zeros(2, dtype=torch.float32, device=flat_param.device)   # [||g||, clip factor]
+
+    @property
+    def steps(self):
+        """Updates actually applied (one blocking 4-byte read: checkpoints and tests, not the training loop)."""
+        return int(self.steps_dev.item())
+
+    @steps.setter
+    def steps(self, n):
+        self.steps_dev.fill_(int(n))
+        self._base, self.issued = int(n), 0
+
+    def skipped(self):
+        """Issued optimizer steps the device did NOT apply (non-finite gradient norm) since the count was last set.  Blocking."""
+        return self.issued - (self.steps - self._base)
 
     def state_dict(self):
         """Adam moments + step count (what an mmcv checkpoint's `optimizer` entry carries for a resume)."""
@@ -44,13 +61,14 @@ class FlatAdamW:
             check(lib().tt_grad_norm_clip(ptr(self.g), n, _f(self.max_norm), ptr(self._ws), ptr(self.norm_scale), st),
                   "tt_grad_norm_clip")
             scale = ctypes.c_void_p(self.norm_scale.data_ptr() + 4)
-        self.steps += 1
+        self.issued += 1
+        sc = scale if scale is not None else ctypes.c_void_p(0)
         for off, cnt in (live_ranges if live_ranges is not None else [(0, self.p.numel())]):
             at = lambda t: ctypes.c_void_p(t.data_ptr() + 4 * off)
-            check(lib().tt_adamw_step(at(self.p), at(self.g), at(self.m), at(self.v), ctypes.c_longlong(cnt),
-                                      _f(self.lr if lr is None else lr), _f(self.betas[0]), _f(self.betas[1]),
-                                      _f(self.eps), _f(self.wd), ctypes.c_int(self.steps),
-                                      scale if scale is not None else ctypes.c_void_p(0), st), "tt_adamw_step")
+            check(lib().tt_adamw_step_dev(at(self.p), at(self.g), at(self.m), at(self.v), ctypes.c_longlong(cnt),
+                                          _f(self.lr if lr is None else lr), _f(self.betas[0]), _f(self.betas[1]),
+                                          _f(self.eps), _f(self.wd), ptr(self.steps_dev), sc, st), "tt_adamw_step_dev")
+        check(lib().tt_adamw_advance(ptr(self.steps_dev), sc, st), "tt_adamw_advance")
         return self.norm_scale
 
 
@@ -64,8 +82,11 @@ def warmup_cosine_lr(base_lr, it, total_iters, warmup_iters=1000, warmup_ratio=1
     `iters_per_epoch` gives the epoch of an iteration (epoch = it // iters_per_epoch, max_epochs = ceil(total_iters /
     iters_per_epoch)); without it -- or with by_epoch=False -- the cosine is evaluated per iteration (mmcv's by_epoch=False)."""
     import math
+    if by_epoch and not iters_per_epoch:
+        raise ValueError("warmup_cosine_lr(by_epoch=True) -- the reference's schedule -- needs iters_per_epoch; pass "
+                         "by_epoch=False for mmcv's per-iteration cosine")
     target = base_lr * min_lr_ratio
-    if by_epoch and iters_per_epoch:
+    if by_epoch:
         progress = min(it, total_iters) // iters_per_epoch
         max_progress = max(1, -(-total_iters // iters_per_epoch))
     else:

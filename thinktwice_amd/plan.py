@@ -18,6 +18,7 @@ call per half (`tt_encoder_fwd`, `tt_decoder_fwd`); `plan.save(dir)` writes plan
 (tools/plan_host.cpp)."""
 import ctypes
 import os
+import sys
 
 import torch
 from torch.overrides import TorchFunctionMode
@@ -549,4 +550,10 @@ def compile_forward(model, batch, arena_bytes=None, channel_last_out=False, prev
         nb = int(L.tt_plan_compact_arena(b.plan, ctypes.c_int(PlanBuilder.ARENA), ctypes.c_longlong(ALIGN)))
         if nb > 0:
             b.compacted_bytes = nb
+        else:
+            # not fatal (the bump layout is valid, only ~3x larger and cold), but never silent: the usual causes are an arena
+            # pointer outside every declared allocation or a relocation recorded against the wrong op
+            b.compact_error = L.tt_last_error().decode()
+            print(f"[plan] tt_plan_compact_arena failed (rc={nb}): {b.compact_error}; keeping the bump arena of "
+                  f"{b.arena_top if hasattr(b, 'arena_top') else '?'} bytes", file=sys.stderr, flush=True)
     return ForwardPlan(b, outputs, inputs, consts)

@@ -38,6 +38,10 @@ def build_backbone(cfg, **extra):
     return BACKBONES.build(cfg, **extra)
 
 
+def build_neck(cfg, **extra):
+    return NECKS.build(cfg, **extra)
+
+
 def build_head(cfg, **extra):
     return HEADS.build(cfg, **extra)
 

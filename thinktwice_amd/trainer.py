@@ -63,6 +63,8 @@ class Trainer:
         self.param_grads = None
         self._stepped = set()          # names of the parameters the optimizer has updated at least once (torch: those with state)
         self.iteration, self.epoch, self._bn_steps = 0, 0, 0
+        self._skips_accounted = 0      # device-skipped updates already taken out of iteration / _bn_steps (reconcile())
+        self.schedule = None           # set_schedule(): the reference's lr_config
         self._prepare_on_device = os.environ.get("TT_TRAIN_PREPARE", "device") != "host"
         # BatchNorm running statistics: device copies the prepared layers alias (train mode updates them in place)
         self.buffers = {k: v.to(dev, torch.float32).contiguous() for k, v in self.sd.items()
@@ -126,22 +128,58 @@ class Trainer:
             self.sd[k].grad.copy_(g.reshape(self.sd[k].shape))
         return out
 
+    def set_schedule(self, total_iters, iters_per_epoch, warmup_iters=1000, warmup_ratio=1.0 / 3, min_lr_ratio=1e-3):
+        """The reference's `lr_config` (configs/thinktwice.py:286-291: cosine annealing BY EPOCH with a per-iteration linear
+        warm-up, optim.warmup_cosine_lr): from now on step() without an explicit `lr` uses the rate of `self.iteration`, and
+        `self.epoch` follows the iteration count (EpochBasedRunner)."""
+        if not iters_per_epoch or iters_per_epoch < 1:
+            raise ValueError("set_schedule: iters_per_epoch (len(data_loader)) is required for the by-epoch cosine")
+        self.schedule = dict(total_iters=int(total_iters), iters_per_epoch=int(iters_per_epoch), warmup_iters=int(warmup_iters),
+                             warmup_ratio=float(warmup_ratio), min_lr_ratio=float(min_lr_ratio))
+
+    def current_lr(self):
+        if self.schedule is None:
+            return self.opt.lr
+        from .optim import warmup_cosine_lr
+        return warmup_cosine_lr(self.opt.lr, self.iteration, **self.schedule)
+
+    def reconcile(self):
+        """Blocking.  With check_finite=False the host runs ahead of the device, which skips the update of an iteration whose
+        gradient norm is not finite (p, m, v and the applied-step count untouched; non-finite batch statistics never reach
+        the BatchNorm running buffers either, tt_bn_finalize).  This takes those skipped iterations back out of the host's
+        counters (`iteration`, the BatchNorm call count) so that checkpoints agree with the device; called by state_dict() /
+        optimizer_state_dict() / checkpoint().  Returns the number of skipped updates found."""
+        k = self.opt.skipped() - self._skips_accounted
+        if k > 0:
+            self.iteration -= k
+            if not self.frozen_bn:
+                self._bn_steps -= k
+            self._skips_accounted += k
+            if self.schedule is not None:
+                self.epoch = self.iteration // self.schedule["iters_per_epoch"]
+        return max(k, 0)
+
     def step(self, batch, lr=None, check_finite=True):
         """One iteration; adds `grad_norm` (device tensor [norm, clip factor]) to train_step's dict.  A non-finite gradient
-        norm never reaches the weights: tt_grad_norm_clip hands the update a NaN factor and tt_adamw_step skips (p, m, v
-        untouched).  `check_finite` (one host sync per iteration) additionally raises here; pass False to stay asynchronous
-        and look at `grad_norm` whenever convenient."""
+        norm never reaches the weights: tt_grad_norm_clip hands the update a NaN factor and tt_adamw_step_dev skips (p, m, v
+        and the device-side step count untouched).  `check_finite` (one host sync per iteration) additionally raises here;
+        pass False to stay asynchronous and look at `grad_norm` whenever convenient (reconcile() squares the host counters
+        with what the device applied).  Without `lr`, the rate of set_schedule() (else the constructor's)."""
+        if lr is None and self.schedule is not None:
+            lr = self.current_lr()
         out = self.backward(batch)
         self.grads.all_reduce_mean()
         out["grad_norm"] = self.opt.step(lr, live_ranges=self.live_ranges)
         if check_finite and not bool(torch.isfinite(out["grad_norm"][0])):
-            self.opt.steps -= 1                     # the device skipped the update: the step count stays with the moments
+            self._skips_accounted += 1              # nothing below runs: iteration / BatchNorm counters never saw this step
             raise FloatingPointError("Trainer.step: non-finite gradient norm; the update was skipped on the device (weights, "
                                      "Adam moments and running statistics of the optimizer are those of the last good step)")
         self._stepped.update(self.param_grads.keys())
         self.iteration += 1
         if not self.frozen_bn:
             self._bn_steps += 1
+        if self.schedule is not None:
+            self.epoch = self.iteration // self.schedule["iters_per_epoch"]
         self._prepare()
         return out
 
@@ -159,6 +197,7 @@ class Trainer:
     def state_dict(self):
         """Reference-format weights (own copies: the master tensors are views of one flat buffer), BatchNorm running
         statistics and `num_batches_tracked` as they stand now."""
+        self.reconcile()
         out = {}
         for k, v in self.sd.items():
             if k in self._trainable:
@@ -176,13 +215,15 @@ class Trainer:
         resume, train.py:238 / EpochBasedRunner.resume): per-parameter state keyed by the parameter's index in
         model.parameters() order (= state_dict order without the buffers), plus one param_group.  Parameters that never
         received a gradient carry no state, exactly like torch's `grad is None` ones (the reference's 90 dead parameters)."""
+        self.reconcile()
         o = self.opt
+        steps = o.steps
         state, off = {}, 0
         for idx, k in enumerate(self.names):
             n = self.sd[k].numel()
             if k in self._stepped:
                 shape = self.sd[k].shape
-                state[idx] = {"step": torch.tensor(float(o.steps)),
+                state[idx] = {"step": torch.tensor(float(steps)),
                               "exp_avg": o.m[off:off + n].view(shape).detach().clone().cpu(),
                               "exp_avg_sq": o.v[off:off + n].view(shape).detach().clone().cpu()}
             off += n
@@ -192,6 +233,7 @@ class Trainer:
 
     def load_optimizer_state_dict(self, osd):
         o = self.opt
+        self._skips_accounted = 0                  # (setting the step count restarts the issued / applied bookkeeping)
         if "exp_avg" in osd:                       # round-3 flat layout (whole-buffer moments)
             o.load_state_dict(osd)
             self._stepped = set(self.names)
@@ -218,6 +260,7 @@ class Trainer:
     def checkpoint(self, epoch=None):
         """What an mmcv checkpoint holds for a resume (configs/thinktwice.py:292 checkpoint_config, mmcv save_checkpoint):
         `meta` (epoch / iter), `state_dict` (reference key names), `optimizer` (torch AdamW layout)."""
+        self.reconcile()
         return {"meta": {"epoch": self.epoch if epoch is None else epoch, "iter": self.iteration},
                 "state_dict": self.state_dict(), "optimizer": self.optimizer_state_dict()}
 
@@ -232,7 +275,7 @@ class Trainer:
             for k, v in sd.items():
                 if k.endswith("num_batches_tracked") and k in self.sd:
                     self.sd[k] = v.clone()
-        self._bn_steps = 0
+        self._bn_steps, self._skips_accounted = 0, 0
         meta = ckpt.get("meta") or {}
         self.epoch, self.iteration = int(meta.get("epoch", 0) or 0), int(meta.get("iter", 0) or 0)
         if "optimizer" in ckpt:
