@@ -38,6 +38,9 @@ const char* tt_last_error(void);
 /* measurement aid: name (template arguments spelled like rocprofv3 prints them) of the kernel that the last
  * tt_conv2d_fwd call of this thread launched; "" before the first call */
 const char* tt_conv_last_kernel(void);
+/* measurement aid: while set, every workgroup of the LDS-DMA conv kernel writes 4 wall-clock stamps (10 ns ticks: entry, first K tile
+ * landed, K loop done, epilogue done) at stamps[blockIdx.x * 4]; null (default) = off */
+int tt_conv_set_trace(void* stamps_or_null);
 int tt_version(void);
 
 /* ------------------------------------------------------------------------

@@ -173,7 +173,11 @@ class AgentChain:
         self.speed = PID(c["speed_KP"], c["speed_KI"], c["speed_KD"], c["speed_n"])
         self.step = -1
 
-    def run_step(self, frames_u8, lidar_half, pos, compass, speed, next_wp, next_cmd):
+    def run_step(self, frames_u8, lidar_half, pos, compass, speed, next_wp, next_cmd, device_img=None, device_cloud=None):
+        """`device_img` / `device_cloud`: the product's own stage outputs (preprocessed frames (4, 3, fh, fw), merged cloud (n, 4)).
+        The chain always computes its own (kept in `self.last` for the caller's stage-level comparison at that stage's tolerance);
+        when given, the DOWNSTREAM oracle stages consume the product's -- a 1e-4 difference in a point coordinate can move a
+        point across a voxel boundary, a discrete change that no tolerance on the network outputs would describe."""
         import torch
         from . import model_ref, preprocess_ref
         self.step += 1
@@ -190,6 +194,11 @@ class AgentChain:
         one_hot = [0] * 6
         one_hot[command] = 1
         img = preprocess_ref.preprocess(torch.from_numpy(np.asarray(frames_u8)), self.maps[0], self.maps[1], self.final_dim)
+        self.last = dict(img=img, cloud=lidar)
+        if device_img is not None:
+            img = torch.as_tensor(device_img).float()
+        if device_cloud is not None:
+            lidar = np.asarray(device_cloud, dtype=np.float32)
         self.queue.append(dict(img=img, lidar=lidar))
         if self.step < self.queue_len:
             return 0.0, 0.0, 0.0, None

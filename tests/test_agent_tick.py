@@ -76,6 +76,18 @@ def _tick_inputs(n_ticks, seed=5):
         compass += float(rng.uniform(-0.05, 0.05))
 
 
+def _check_stage_outputs(info, chain):
+    """The tick's two input stages against the oracle's, each at its own tolerance: the image pipeline at golden F17's bounds
+    (2e-3 max / 2e-5 mean on the normalised pixels; tests/test_preprocess.py), the merged cloud at 2e-4 m.  The oracle's later
+    stages then consume the device's stage outputs (AgentChain.run_step)."""
+    d = (info["img"].float().cpu() - chain.last["img"]).abs()
+    assert float(d.max()) < 2e-3 and float(d.mean()) < 2e-5, (float(d.max()), float(d.mean()))
+    got, want = info["cloud"].cpu().numpy(), chain.last["cloud"]
+    assert got.shape == want.shape
+    if len(want):
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-4)
+
+
 class _OracleHeads:
     """oracle.agent_ref's process_action + control_pid + Arbitration (pinned by F9 / F15) as one stateful object."""
 
@@ -100,7 +112,7 @@ class _OracleHeads:
 def test_agent_tick_end_to_end_matches_the_oracle_chain(use_cache):
     """VERDICT r4 missing #2: the whole model-side tick (thinktwice_agent.py:362-529) chained -- uint8 4 x 900 x 1600 frames ->
     tt_preprocess_images -> half-sweep merge -> queue / sweep selection -> forward_inference (bf16x3, with and without the
-    previous-sweep BEV cache) -> tt_action_post -- against the ORACLE chain (oracle.agent_ref.AgentChain: preprocess_ref (F17)
+    previous-sweep BEV cache) -> tt_action_post -- stage by stage against the ORACLE chain (oracle.agent_ref.AgentChain: preprocess_ref (F17)
     -> SweepMerge (F15) -> model_ref (F7 / F8) -> process_action / control_pid (F9) -> Arbitration (F15)) over 12 ticks.
     Shortened queue (lag 2, 4 frames) and a 128 x 256 network input so that the CPU oracle finishes in seconds per tick;
     the full-size tick is below."""
@@ -118,7 +130,8 @@ def test_agent_tick_end_to_end_matches_the_oracle_chain(use_cache):
     live, agree = 0, 0
     for t, args in enumerate(_tick_inputs(12)):
         s, th, b, info = tick.run_step(*args)
-        rs, rth, rb, rpred = chain.run_step(*args)
+        rs, rth, rb, rpred = chain.run_step(*args, device_img=info["img"].cpu(), device_cloud=info["cloud"].cpu().numpy())
+        _check_stage_outputs(info, chain)
         if t < 4:
             assert (s, th, b) == (0.0, 0.0, 0.0) and rpred is None
             continue
@@ -150,7 +163,8 @@ def test_agent_tick_full_size_one_live_tick():
     chain = R.AgentChain(sd, cfg, mx, my, (calib.FINAL_H, calib.FINAL_W), tick.img_metas, lag=1, queue_len=2)
     for t, args in enumerate(_tick_inputs(3, seed=8)):
         s, th, b, info = tick.run_step(*args)
-        rs, rth, rb, rpred = chain.run_step(*args)
+        rs, rth, rb, rpred = chain.run_step(*args, device_img=info["img"].cpu(), device_cloud=info["cloud"].cpu().numpy())
+        _check_stage_outputs(info, chain)
     for k in ("pred_wp", "mu_branches", "sigma_branches", "pred_speed"):
         got, want = info["pred"][k].float().cpu(), rpred[k]
         e = float((got - want).abs().max() / want.abs().max().clamp_min(1e-6))

@@ -146,7 +146,7 @@ class AgentTick:
         img = self.pre(raw.contiguous())                                 # (4, 3, fh, fw) f32
         cloud = self.merger.merge(lidar_half, pos, compass)              # (n_prev + n_now, 4)
         self.frames.append(img)
-        info = {"step": self.step, "pred": None}
+        info = {"step": self.step, "pred": None, "img": img, "cloud": cloud}
         live = self.step >= self.queue_len                               # AGENT:430-436: zero control while the queue fills
         # the previous-sweep cache needs the key-sweep BEVs of the `lag` ticks before the first live one
         warm = self.cache is not None and self.step >= self.queue_len - self.lag and len(self.frames) == self.lag + 1

@@ -99,11 +99,17 @@ class ActionPost:
         if self.device is None:
             return self.tick_host(pred["mu_branches"][0, -1].float().cpu().numpy(), pred["sigma_branches"][0, -1].float().cpu().numpy(),
                                   pred["pred_wp"][0, -1].float().cpu().numpy(), speed, target, stuck_desired_speed)
-        mu, sg, wp = pred["mu_branches"], pred["sigma_branches"], pred["pred_wp"]
-        for t in (mu, sg, wp):
-            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] == 1, "batch-1 f32 outputs"
-        assert mu.shape[-1] == 2 and sg.shape[-1] == 2 and tuple(wp.shape[-2:]) == (4, 2)
-        last = lambda t, n: ctypes.c_void_p(t.data_ptr() + (t.numel() - n) * 4)      # [0, -1, ...]: the trailing n floats
+        # the LAST stage's rows of the three heads, where they are: [0, -1] of (1, stages, ...) tensors (views of larger output
+        # buffers are fine as long as that row is dense)
+        rows = []
+        for t, n in ((pred["mu_branches"], 2), (pred["sigma_branches"], 2), (pred["pred_wp"], 8)):
+            assert t.is_cuda and t.dtype == torch.float32 and t.shape[0] == 1, "batch-1 f32 outputs"
+            r = t[0, -1]
+            assert r.numel() == n and r.is_contiguous(), "the last stage's row of a head must be dense"
+            rows.append(r)
+        assert tuple(pred["pred_wp"].shape[-2:]) == (4, 2)
+        last = lambda r, n: ctypes.c_void_p(r.data_ptr())                # noqa: E731
+        mu, sg, wp = rows
         tg = _f32(target, 2)
         check(lib().tt_action_post(last(mu, 2), last(sg, 2), last(wp, 8), ctypes.c_float(float(speed)), ctypes.c_float(tg[0]),
                                    ctypes.c_float(tg[1]), ctypes.c_float(stuck_desired_speed), ctypes.byref(self.cfg),

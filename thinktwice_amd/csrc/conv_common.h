@@ -5,6 +5,7 @@
 
 namespace tt {
 extern thread_local char g_conv_kernel[96];   // common.cpp: label of the kernel the last conv launch used
+extern long long* g_conv_trace;               // common.cpp: tt_conv_set_trace (measurement aid; null in the product)
 
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -43,6 +44,10 @@ struct ConvArgs {
     int ws_slices;       // split-K: > 0 = every split stores into its own [M][Cout] slice of ws (ordered finalize)
     int flags;           // bit 3: whole-tile DMA issue in the x3 256-wide 8-wave tile (TT_GLDS_X3_SPREAD=0); bit 4: non-temporal
                          // f32 output stores; < 0: split-K query (no launch)
+    int stagger_ticks;   // LDS-DMA kernel, HBM-shaped (short-K) layers: the workgroups of the launch's FIRST round start
+    int stagger_blocks;  // phase (blockIdx / 8) % 4 x stagger_ticks (10 ns wall-clock ticks) late -- see conv_igemm_glds.hip
+    long long* trace;    // measurement aid (tt_conv_set_trace): 4 wall-clock stamps (10 ns ticks) per workgroup of the LDS-DMA kernel
+                         // -- entry, first K tile landed, K loop done, epilogue done -- at trace[blockIdx.x * 4]; null in the product
 };
 
 template <typename T> struct Mfma;

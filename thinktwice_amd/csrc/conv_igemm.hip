@@ -374,6 +374,8 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     TT_REQUIRE(!(d->pixel_shuffle2 && (d->res1 || d->res2)),
                "tt_conv2d_fwd: residuals are not supported with pixel_shuffle2");
     a.tiles_n = 1; a.cin_fast = 0; a.m_begin = 0;
+    a.stagger_ticks = 0; a.stagger_blocks = 0;
+    a.trace = g_conv_trace;
     {
         static const bool spread = [] { const char* e = getenv("TT_GLDS_X3_SPREAD"); return !(e && e[0] == '0'); }();   // A/B knob
         a.flags = spread ? 0 : 8;

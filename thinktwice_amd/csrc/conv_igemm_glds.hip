@@ -104,6 +104,22 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     const int tile_n = L % tiles_n, tile_m = L / tiles_n;
     const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
     if (m0 >= Mlim) return;            // block-uniform, before any barrier
+    // Phase stagger (short-K, HBM-shaped layers).  Every tile of such a launch costs the same, so the 256 CUs run in lock
+    // step: all in their K loops (HBM idle), then all in their epilogues (one chip-wide burst of output stores and residual
+    // reads, matrix pipes idle) -- a round takes loop + burst.  Starting the first round's workgroups in four phases a
+    // quarter of a tile apart keeps a quarter of the CUs in their epilogue at any time: HBM is busy continuously, a CU's
+    // burst meets a quarter of the contention, and the later rounds inherit the offsets (a finished workgroup's CU is handed
+    // the next tile at once).  Costs 3/4 of a tile time once per launch; the dispatcher enables it from a few rounds up.
+    long long* const tr = (p.trace && tid == 0 && blockIdx.y == 0) ? p.trace + (long long)blockIdx.x * 4 : nullptr;
+    if (tr) tr[0] = (long long)wall_clock64();
+    if (!GATHER && p.stagger_ticks > 0 && p.m_begin == 0 && (int)blockIdx.x < p.stagger_blocks) {
+        const int phase = ((int)blockIdx.x >> 3) & 3;                  // blockIdx % 8 = XCD: four phases inside every XCD
+        if (phase) {
+            const unsigned long long t0 = wall_clock64();
+            const unsigned long long want = (unsigned long long)phase * (unsigned long long)p.stagger_ticks;
+            while (wall_clock64() - t0 < want) __builtin_amdgcn_s_sleep(16);
+        }
+    }
 
     const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
     const T* __restrict__ wgt = reinterpret_cast<const T*>(p.weight);
@@ -472,6 +488,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
         }
         asm volatile("s_barrier" ::: "memory");   // publishes tile kt; everyone is done reading tile kt-1
 #endif
+        if (tr && kt == 0) tr[1] = (long long)wall_clock64();
 
         // fragment offsets carry the activation / weight split of a symmetric stage (weights at + A_BYTES): the two bases
         // below make the same offsets address the asymmetric ring
@@ -639,7 +656,13 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     // barrier (to cover the prologue bubble) changed nothing, and skipping either DMA stream after the first tile
     // (TT_GLDS_DEBUG) did not shorten the loop either: at ~1.0 PF the loop is neither L2->LDS- nor bubble-bound.
     __syncthreads();   // all waves done with the last stage before the epilogue reuses LDS
+    if (tr) tr[2] = (long long)wall_clock64();
     conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, smem, wave, lane, wm, wn, m0, n0, Mlim);
+    if (tr) {
+        __syncthreads();                                                            // (trace only) the slowest wave's epilogue
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr[3] = (long long)wall_clock64();
+    }
 #endif
 }
 
@@ -751,6 +774,7 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
     }
     if (a.m_dev || a.M < 2048 || a.Cout < 64 || a.KH * a.KW > 32) return 0;
     if (a.Cin % 32 != 0 || a.K < 64) return 0;       // 128 B rows = 32 f32 of one tap per K tile, >= 2 tiles
+    a.stagger_ticks = a.stagger_blocks = 0;
     // Tile width along N.  The widest wave tile the layer allows is the most efficient per tile (the operand split costs
     // 8/TN VALU per MFMA; measured ~1.0 / 0.85 / 0.63 relative MFMA rate for the 256 / 128 / 64 wide tiles), but a
     // launch with fewer workgroups than the chip holds (batch-1 ticks: 49 row tiles x 2 on 256 CUs) is bound by its
@@ -779,6 +803,17 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
     if (force == 128 && a.Cout > 64) bn = 128;
     if (force == 64) bn = 64;
     if (force == 1) bn = wide ? 256 : (a.Cout > 64 ? 128 : 64);          // the pre-cost-model rule
+    // phase stagger of the first round (kernel comment): HBM-shaped layers = 1 x 1, K <= 1024, at least three rounds of tiles.
+    // TT_GLDS_STAGGER_US: total spread over the four phases in microseconds (A/B knob; 0 = off)
+    {
+        static const double stagger_us = [] { const char* e = getenv("TT_GLDS_STAGGER_US"); return e ? atof(e) : 0.0; }();
+        const long long tiles = (long long)tiles_m * div_up(a.Cout, bn);
+        const int per_cu = bn == 64 ? 2 : 1;                   // resident workgroups per CU of the tile
+        if (stagger_us > 0.0 && a.KH * a.KW == 1 && a.K <= 1024 && tiles >= 3LL * kNumCU * per_cu && a.m_begin == 0) {
+            a.stagger_ticks = (int)(stagger_us * 100.0 / 4.0);
+            a.stagger_blocks = kNumCU * per_cu;
+        }
+    }
     if (bn == 256) {                                                                                           // 8 x (64 x 128)
         // TT_GLDS_X3_ASYM=0: symmetric 2-stage ring instead of 3 activation + 2 weight stages (A/B knob)
         static const bool asym = [] { const char* e = getenv("TT_GLDS_X3_ASYM"); return e ? atoi(e) != 0 : true; }();

@@ -1186,14 +1186,20 @@ __global__ __launch_bounds__(kCsWaves * 64) void vp_cs_count_kernel(int num_poin
                                                                     const int32_t* __restrict__ geom,
                                                                     int32_t* __restrict__ pos_memo,
                                                                     unsigned* __restrict__ keyrank, int* __restrict__ table) {
-    extern __shared__ unsigned short cs_cnt[];      // [kCsWaves][cells_p]
+    // LDS: per wave a running count per cell (u16) and a 64-bit LANE MASK per cell (which lanes of the current slice fall into it)
+    extern __shared__ unsigned long long cs_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cells = X * Y, cells_p = (cells + 63) & ~63;
+    unsigned long long* cs_mask = cs_lds;                                                     // [kCsWaves][cells_p]
+    unsigned short* cs_cnt = reinterpret_cast<unsigned short*>(cs_lds + kCsWaves * cells_p);  // [kCsWaves][cells_p]
     const int chunk = blockIdx.x;
     const int b = chunk / cps, cis = chunk - b * cps;
     const long long p0 = (long long)b * num_points + (long long)cis * kCsChunk;
     const int npts = min(kCsChunk, num_points - cis * kCsChunk);
-    for (int i = tid; i < kCsWaves * cells_p; i += kCsWaves * 64) cs_cnt[i] = 0;
+    for (int i = tid; i < kCsWaves * cells_p; i += kCsWaves * 64) {
+        cs_cnt[i] = 0;
+        cs_mask[i] = 0ull;
+    }
     constexpr int kSlices = kCsChunk / kCsWaves / 64;        // 8 slices of 64 consecutive points per wave
     const VpPoint* gp = reinterpret_cast<const VpPoint*>(geom) + p0;
     VpPoint pt[kSlices];
@@ -1205,6 +1211,7 @@ __global__ __launch_bounds__(kCsWaves * 64) void vp_cs_count_kernel(int num_poin
     }
     __syncthreads();
     unsigned short* mine = cs_cnt + wave * cells_p;
+    unsigned long long* mmask = cs_mask + wave * cells_p;
     unsigned kr[kSlices];
 #pragma unroll
     for (int sl = 0; sl < kSlices; ++sl) {
@@ -1220,18 +1227,25 @@ __global__ __launch_bounds__(kCsWaves * 64) void vp_cs_count_kernel(int num_poin
                 pos_memo[p * 3 + 2] = x;
             }
         }
+        // Rank of a point among the EARLIER points of the same cell in this wave's 512, without a loop over the slice's
+        // distinct cells (a slice of 64 consecutive frustum points falls into ~20 cells: the ballot-per-cell form took 40 us per
+        // launch, profiles/r05_voxel_pool_kernel_stats_a.csv): every lane ORs its bit into the cell's lane mask (an atomic OR is
+        // order-independent: deterministic), reads the mask back -- the lanes of its cell -- and the cell's running count; the
+        // lowest lane of each cell then advances the count and clears the mask.  A wave's LDS operations execute in program
+        // order, and the region is the wave's own: no barrier.
         int rank = 0;
-        bool pending = key >= 0;
-        while (__ballot(pending)) {
-            if (pending) {                                  // exec = the lanes still to be ranked
-                const int k = __builtin_amdgcn_readfirstlane(key);
-                const unsigned long long m = __ballot(key == k);
-                const int base = mine[k];                   // (the wave's own row: LDS operations of one wave are in order)
-                if (key == k) {
-                    rank = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    pending = false;
-                    if ((int)__builtin_ctzll(m) == lane) mine[k] = (unsigned short)(base + __popcll(m));
-                }
+        if (key >= 0) {
+            __hip_atomic_fetch_or(&mmask[key], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (key >= 0) {
+            const unsigned long long m = mmask[key];
+            const int base = mine[key];
+            rank = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every lane has its mask and base before anyone rewrites them
+            if ((int)__builtin_ctzll(m) == lane) {
+                mine[key] = (unsigned short)(base + __popcll(m));
+                mmask[key] = 0ull;
             }
         }
         kr[sl] = key >= 0 ? (((unsigned)key << kCsRankBits) | (unsigned)rank) : 0xFFFFFFFFu;
@@ -1469,7 +1483,12 @@ extern "C" int tt_voxel_pool_fwd_ws(int batch_size, int num_points, int num_chan
             int* seg_off = reinterpret_cast<int*>(w + L.seg_off);
             float* partial = reinterpret_cast<float*>(w + L.partial);
             const int nchunks = L.cps * batch_size;
-            const size_t lds = (size_t)kCsWaves * ((cells + 63) & ~63) * sizeof(unsigned short);
+            const size_t lds = (size_t)kCsWaves * ((cells + 63) & ~63) * (sizeof(unsigned short) + sizeof(unsigned long long));
+            static const bool lds_attr = [] {           // > 64 KiB of dynamic LDS needs the opt-in (441 cells: 70 KiB, 1024: 160 KiB)
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(vp_cs_count_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            }();
+            TT_REQUIRE(lds_attr, "tt_voxel_pool_fwd_ws: cannot raise the dynamic LDS limit of vp_cs_count_kernel");
             hipLaunchKernelGGL(vp_cs_count_kernel, dim3((unsigned)nchunks), dim3(kCsWaves * 64), lds, st, num_points, num_voxel_x,
                                num_voxel_y, num_voxel_z, L.cps, geom_xyz, pos_memo, keyrank, table);
             hipLaunchKernelGGL(vp_cs_scan_kernel, dim3((unsigned)batch_size), dim3(1024), 0, st, num_points, cells, L.cps, table,
