@@ -749,6 +749,12 @@ extern "C" int tt_mlp_chain_wide(const float* x, long long R, int x_stride, int 
     const long long row_blocks = (R + 31) / 32;
     const int rb = wide_rb(row_blocks);
     const long long row_groups = (row_blocks + rb - 1) / rb;
+    // host-side argument checks first (no device is touched until they pass)
+    TT_REQUIRE(n_groups >= 1 && n_groups <= 64, "tt_mlp_chain_wide: %d column groups: 1 - 64 workgroups per row group can be "
+               "co-resident", n_groups);
+    const long long need = tt_mlp_chain_wide_workspace_bytes(R, nstages, st);
+    TT_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+               "tt_mlp_chain_wide: workspace of %lld B needed (%lld given)", need, workspace_bytes);
     if (int rc = tt::refuse_after_fault("tt_mlp_chain_wide")) return rc;
     int dev = 0;
     TT_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices, "tt_mlp_chain_wide: no current device");
@@ -759,9 +765,6 @@ extern "C" int tt_mlp_chain_wide(const float* x, long long R, int x_stride, int 
                "tt_mlp_chain_wide: %lld row groups x %d column groups: at most %d workgroups per launch can be guaranteed "
                "co-resident on this device (%d resident, %d launches at a time)", row_groups, n_groups,
                P->capacity / kWideConcurrent, P->capacity, kWideConcurrent);
-    const long long need = tt_mlp_chain_wide_workspace_bytes(R, nstages, st);
-    TT_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
-               "tt_mlp_chain_wide: workspace of %lld B needed (%lld given)", need, workspace_bytes);
     WideArgs a;
     a.R = R; a.nstages = nstages; a.nsync = 0; a.rb = rb;
     unsigned char* ws = static_cast<unsigned char*>(workspace);
