@@ -12,7 +12,7 @@ from . import ops, params, synth
 MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0}
 TORCH_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "bf16x3": "f32x3"}
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = "r04"            # profiles/<tag>_forward_<dtype>_{kernel_stats.csv,pmc.json}: the committed rocprofv3 passes of this build
+PROFILE_TAG = "r05"            # profiles/<tag>_forward_<dtype>_{kernel_stats.csv,pmc.json}: the committed rocprofv3 passes of this build
 
 
 def mfma_per_product(kernel_label, dtype):
