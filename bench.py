@@ -104,9 +104,12 @@ class VoxelPoolWorkload:
                    "plan_build_ms": round(self.plan_build_ms, 3),
                    "note": "static camera rig: geom_xyz is identical every frame, so the (sample, cell) sort is built once "
                            "(tt_voxel_pool_plan_build, excluded) and a forward streams in-range rows + 4 B index per row + out"}
-        return {"kernel": "voxel_pool_p1_kernel + voxel_pool_p2_kernel", "bound": "hbm", "static_geometry_plan": planned,
+        sort = os.environ.get("TT_VP_SORT", "1") != "0"
+        kern = ("vp_cs_count + vp_cs_scan + vp_cs_scatter (per-launch counting sort) + vp_planned_segments_kernel + "
+                "vp_planned_cells_kernel") if sort else "voxel_pool_p1_kernel + voxel_pool_p2_kernel"
+        return {"kernel": kern, "bound": "hbm", "static_geometry_plan": planned,
                 "achieved": round(comp, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(comp / HBM_PEAK_GBS, 4),
-                "traffic": None, "avg_launch_ms": round(avg, 4),
+                "traffic": self._pmc_traffic(), "avg_launch_ms": round(avg, 4),
                 "compulsory_bytes_per_launch": self.compulsory_bytes_per_launch,
                 "in_range_rows": self.in_range_rows, "rows": self.B * self.Np,
                 "op_boundary_algorithmic": {"bytes_per_launch": self.alg_bytes_per_launch, "gbs": round(ach, 1),
@@ -114,6 +117,26 @@ class VoxelPoolWorkload:
                 "note": "achieved/frac count COMPULSORY bytes (geom of every point + feature rows of in-range points "
                         "+ out); op_boundary_algorithmic is SURVEY 8(d)'s geom+feats+out figure, which exceeds what "
                         "HBM delivers because out-of-range rows are never fetched"}
+
+    def _pmc_traffic(self):
+        """HBM bytes per launch of the op's kernels from the committed rocprofv3 counter passes of this workload
+        (profiles/r05_voxel_pool_pmc.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KB), if they were taken from this build."""
+        import json
+        try:
+            from thinktwice_amd import build
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_voxel_pool_pmc.json")
+            data = json.load(open(path))
+            if data.get("_stamp", {}).get("csrc_sha") != build.source_fingerprint() or self.B != 8:
+                return None
+            kb = 0.0                        # one dispatch of each of the five kernels = one launch of the operator
+            seen = 0
+            for name, c in data.items():
+                if name != "_stamp" and ("vp_cs_" in name or "vp_planned" in name):
+                    kb += 2.0 * c.get("FETCH_SIZE", {}).get("per_dispatch", 0.0) + c.get("WRITE_SIZE", {}).get("per_dispatch", 0.0)
+                    seen += 1
+            return int(kb * 1024) if seen == 5 else None
+        except Exception:
+            return None
 
     def cpu_baseline(self):
         """oracle C restatement, 1 thread, one (sample, sweep) repeated for ~10 s."""

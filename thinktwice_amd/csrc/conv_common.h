@@ -417,6 +417,8 @@ int launch_conv_glds_x3_splitk(ConvArgs& a, hipStream_t st);
 int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int bn = 256);
 // run-staged sparse 3x3x3 conv (csrc/sp_conv_runs.hip; bf16x3, a.weight = pre-split weights): same contract.
 int try_launch_sp_conv_runs(ConvArgs& a, hipStream_t st);
+// conv_x3_persist.hip: short-K 1 x 1 layers on persistent workgroups that store tile i under the K loop of tile i + 1
+int try_launch_gemm_x3_persist(ConvArgs& a, hipStream_t st);
 // latency-bound small-M variant (32x32 tile, intra-block split-K): same contract.
 int try_launch_conv_small(ConvArgs& a, int dtype, hipStream_t st);
 

@@ -775,6 +775,12 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
     if (a.m_dev || a.M < 2048 || a.Cout < 64 || a.KH * a.KW > 32) return 0;
     if (a.Cin % 32 != 0 || a.K < 64) return 0;       // 128 B rows = 32 f32 of one tap per K tile, >= 2 tiles
     a.stagger_ticks = a.stagger_blocks = 0;
+    // short-K 1 x 1 layers with at least two 256 x 128 tiles per CU: persistent workgroups that store tile i under the K loop of
+    // tile i + 1 (csrc/conv_x3_persist.hip).  TT_X3_PERSIST=0/1 (A/B knob)
+    {
+        static const bool persist = [] { const char* e = getenv("TT_X3_PERSIST"); return e ? atoi(e) != 0 : false; }();
+        if (persist && try_launch_gemm_x3_persist(a, st)) return 1;
+    }
     // Tile width along N.  The widest wave tile the layer allows is the most efficient per tile (the operand split costs
     // 8/TN VALU per MFMA; measured ~1.0 / 0.85 / 0.63 relative MFMA rate for the 256 / 128 / 64 wide tiles), but a
     // launch with fewer workgroups than the chip holds (batch-1 ticks: 49 row tiles x 2 on 256 CUs) is bound by its

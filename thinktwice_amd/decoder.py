@@ -155,7 +155,8 @@ class ThinkTwiceDecoder:
         for lay in self.layers:
             emb = cams.view(1, 4, 256) + lvls.view(4, 1, 256)                       # (lvl, cam, 256)
             # W e (bias added by shift): 4 rows through the library's exact-f32 linear (tt_conv2d_fwd), not a torch GEMM
-            w_e = conv_from_weight(lay.vproj_w.view(256, 1, 1, 256).contiguous(), F32)
+            w_e = conv_from_weight(lay.vproj_w.reshape(256, 1, 1, 256).clone(), F32)    # (a 16 B aligned copy: under the trainer
+            # vproj_w is a view into the flat master buffer at an arbitrary offset)
             lay.vshift = [unrows(w_e(rows(emb[l].contiguous()))).contiguous() for l in range(4)]
         self.vproj_all_shift = torch.cat([lay.vproj.shift for lay in self.layers], 0).contiguous()  # (L*256,)
         self.vproj_all = conv_from_weight(torch.cat([lay.vproj.w for lay in self.layers], 0).contiguous(),
