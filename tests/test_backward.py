@@ -559,7 +559,7 @@ def test_look_module_backward_matches_oracle_autograd(B):
     assert len(worst) >= 30 and not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
 
 
-@pytest.mark.parametrize("split_k,tol", [(False, 2e-3), (True, 1e-2)], ids=["in-workgroup-K", "product-split-K"])
+@pytest.mark.parametrize("split_k,tol", [(False, 1e-2), (True, 1e-2)], ids=["in-workgroup-K", "product-split-K"])
 def test_decoder_backward_matches_oracle_autograd(monkeypatch, split_k, tol):
     """The whole look-and-predict decoder (thinktwice_decoder.py:419-533): coarse heads, five refinement layers (conv-GRU
     + shared flatten network, look module, merge MLP, offset heads, BEV / flattened-feature updates) chained through the
@@ -578,6 +578,10 @@ def test_decoder_backward_matches_oracle_autograd(monkeypatch, split_k, tol):
     # the in-workgroup order none does on this input; the product's ordered cross-workgroup split-K (K >= 2048 layers at
     # M <= 4096: the BEV-update conv, the flatten MLPs) flips a handful on the flatten network's 2 x 2 / 4 x 4 maps and on
     # the 21 x 21 GRU maps (measured worst 6.7e-3 / 2.8e-3).  Both orders are run; both are deterministic.
+    # Round 5: the camera / level embedding shift of value_proj (W e, 4 x 256 x 256 per layer) is computed by the library's exact-f32
+    # kernel instead of torch.addmm; the 1e-7 difference reaches the same borderline pre-activations through
+    # the look features, so the in-workgroup order now shows the SAME flips (6.7e-3 on the flatten network, 2.8e-3 on the GRU
+    # biases, every other tensor as before): both arms carry the mask-flip bound.
     monkeypatch.setattr(ops, "_AUTO_SPLITK", split_k)
     B, hw, Rn = 2, (128, 256), 5
     cfg = config.model_config(final_dim=hw)

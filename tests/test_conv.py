@@ -462,6 +462,21 @@ def test_pipelined_tiles_are_bit_identical_to_the_8wave_tiles():
         assert r.returncode == 0 and "ALL OK" in r.stdout, (env_extra, r.stdout[-1500:], r.stderr[-500:])
 
 
+def test_persistent_shortk_gemm_is_bit_identical_to_the_8wave_tile():
+    """csrc/conv_x3_persist.hip (TT_X3_PERSIST=1; persistent workgroups, tile i drained behind the K loop of tile i + 1; eight or
+    four waves) against the default kernels on the forward's twelve short-K 1 x 1 shapes (residual + ReLU, plain, K = 128 / 256 take
+    the persistent kernel, the others fall through): tools/shortk_ab.py runs every arm in its own process and compares the outputs
+    bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "shortk_ab.py"), "base", "pers", "pers4"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "BIT-IDENTICAL across arms" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
+    assert "gemm_x3_persist_kernel<8, false, 8 waves>" in r.stdout and "gemm_x3_persist_kernel<4, true, 4 waves>" in r.stdout, r.stdout[-800:]
+
+
 SPLITK_X3_CASES = [   # (N, H, W, Cin, Cout, k, act, use_bn, residuals, window)
     (8, 14, 28, 512, 512, 3, 1, True, 1, False),     # ResNet layer 4 of a batch-1 tick: M = 3136, 104 tiles x 4 K ranges
     (8, 14, 28, 2048, 512, 1, 1, True, 1, False),    # its 1x1 with K = 2048

@@ -46,26 +46,39 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 namespace persist {
 constexpr int BM = 256, BN = 128, BKB = 128, BK = 32;
-constexpr int NW = 4;                       // waves: wave w owns rows [64 w, 64 w + 64) x all 128 columns
-constexpr int TM = 2, TN = 4;
+constexpr int TM = 2;
 constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;          // 32 KiB, 16 KiB per stage
 constexpr int OFF_B = 2 * A_BYTES;                              // ring: A stages at 0 / 32 KiB, B stages at 64 / 80 KiB
-constexpr int OFF_STG = 2 * A_BYTES + 2 * B_BYTES;              // staging: 16 KiB per wave from 96 KiB
-constexpr int STG_BYTES = 32 * BN * 4;
-constexpr int LDS_BYTES = OFF_STG + NW * STG_BYTES;             // 160 KiB
-constexpr int NIA = BM * 8 / 64 / NW, NIB = BN * 8 / 64 / NW;   // 1 KiB DMA pieces per wave per K tile: 8 + 4
-constexpr int NPASS = 32;                   // passes per wave and tile: 2 row blocks x 16 (two rows of 128 floats per pass)
+constexpr int OFF_STG = 2 * A_BYTES + 2 * B_BYTES;              // staging from 96 KiB: 64 KiB whatever the wave count
+constexpr int LDS_BYTES = OFF_STG + 64 * 1024;                  // 160 KiB
 }  // namespace persist
 
-template <int NK, bool RES>
-__global__ __launch_bounds__(256, 1) void gemm_x3_persist_kernel(const ConvArgs p, int tiles_m, int tiles_n) {
+// Two wave geometries on the 256 x 128 tile (W8 template flag):
+//   false: FOUR waves, one per SIMD, 64 rows x 128 columns each (TN = 4: the cheapest LDS traffic per MFMA and 512 registers per lane --
+//          but a lone wave's stalls are the matrix pipe's stalls: this body is compiler-scheduled, not hand-placed);
+//   true : EIGHT waves as 4 x 2, two per SIMD, 64 x 64 each (TN = 2; 256 registers per lane): the second wave covers the first one's
+//          LDS / VMEM waits, like the 8-wave tile of conv_igemm_glds.hip.
+
+template <int NK, bool RES, bool W8>
+__global__ __launch_bounds__(W8 ? 512 : 256, 1) void gemm_x3_persist_kernel(const ConvArgs p, int tiles_m, int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using namespace persist;
     static_assert(NK == 4 || NK == 8, "K = 128, 256 (NK = 16 compiles, but its unrolled body leaves the accumulators in scratch)");
-    constexpr int P = NPASS / NK;             // passes per K tile: 16, 8, 4, 2
+    constexpr int NW = W8 ? 8 : 4;            // waves
+    constexpr int WNN = W8 ? 2 : 1;           // waves along N; wave (wm, wn) owns rows [64 wm, +64) x columns [WTN wn, +WTN)
+    constexpr int WTN = BN / WNN, TN = WTN / 32;
+    constexpr int LPR = WTN / 4;              // lanes per staged row (16 B each): 32 or 16
+    constexpr int RPP = 64 / LPR;             // rows per pass: 2 or 4
+    constexpr int BPASS = 32 / RPP;           // passes per 32-row block: 16 or 8
+    constexpr int NPASS = TM * BPASS;         // passes per wave and tile: 32 or 16
+    constexpr int STG_BYTES = 32 * WTN * 4;   // staging per wave: one 32 x WTN f32 block (16 or 8 KiB)
+    constexpr int NIA = BM * 8 / 64 / NW, NIB = BN * 8 / 64 / NW;   // 1 KiB DMA pieces per wave per K tile: 8 + 4, or 4 + 2
+    constexpr int P = NPASS / NK;             // passes per K tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / WNN, wn = wave % WNN;
+    const int wm_s = wave_s / WNN, wn_s = wave_s % WNN;
     const int T = tiles_m * tiles_n, G = (int)gridDim.x, w = (int)blockIdx.x;
     const float* __restrict__ in = reinterpret_cast<const float*>(p.in);
     const float* __restrict__ wgt = reinterpret_cast<const float*>(p.weight);
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x3_persist_kernel(const ConvArgs 
         const float* ab = in + (long long)m0 * p.in_cstride + p.in_coff + kt * BK + a_lane;
         const float* bb = wgt + (long long)n0 * p.K + kt * BK + b_lane;
         const unsigned sa = lds_base + (unsigned)stage * A_BYTES, sb = lds_base + OFF_B + (unsigned)stage * B_BYTES;
-        const long long a_step = 32ll * p.in_cstride, b_step = 32ll * p.K;          // wave-uniform
+        const long long a_step = (long long)(NW * 8) * p.in_cstride, b_step = (long long)(NW * 8) * p.K;   // wave-uniform
 #pragma unroll
         for (int j = 0; j < NIA; ++j)
             __builtin_amdgcn_global_load_lds(ab + j * a_step, (lds_ptr_t)(uintptr_t)(sa + (unsigned)(wave_s + NW * j) * 1024u), 16, 0, 0);
@@ -111,8 +124,8 @@ __global__ __launch_bounds__(256, 1) void gemm_x3_persist_kernel(const ConvArgs 
     // block, so a block is a constant away (4 KiB); K step 1 flips chunk bit 2 (offset ^ 64); the second half of an A fragment is
     // ^ 16, the lo half of a B fragment ^ 32.
     const unsigned hi = lane >> 5;
-    const unsigned fa0 = (wave * 64 + (lane & 31)) * BKB + (((2u * hi) ^ (unsigned)swz(lane & 31)) << 4);
-    const unsigned fb0 = (lane & 31) * BKB + ((hi ^ (unsigned)swz(lane & 31)) << 4);
+    const unsigned fa0 = (wm * 64 + (lane & 31)) * BKB + (((2u * hi) ^ (unsigned)swz(lane & 31)) << 4);
+    const unsigned fb0 = (wn * WTN + (lane & 31)) * BKB + ((hi ^ (unsigned)swz(lane & 31)) << 4);
     auto fa_at = [&](int kc, int i) __attribute__((always_inline)) { return (fa0 ^ (kc ? 64u : 0u)) + (unsigned)i * 32u * BKB; };
     auto fb_at = [&](int kc, int j) __attribute__((always_inline)) { return (fb0 ^ (kc ? 64u : 0u)) + (unsigned)j * 32u * BKB; };
     auto lds_read = [](unsigned addr) __attribute__((always_inline)) {
@@ -121,11 +134,11 @@ __global__ __launch_bounds__(256, 1) void gemm_x3_persist_kernel(const ConvArgs 
         return v;
     };
 
-    // ---- epilogue state.  Staging: this wave's 32 x 128 f32 block, row-major, 512 B rows (a row is read by 32 consecutive lanes).
+    // ---- epilogue state.  Staging: this wave's 32 x WTN f32 block, row-major (a row is read by LPR consecutive lanes).
     const unsigned stg = lds_base + OFF_STG + (unsigned)wave * STG_BYTES;
-    unsigned stg_w = stg + (((lane >> 5) * 4) * BN + (lane & 31)) * 4;       // + ((r & 3) + 8 (r >> 2)) * 512 + j * 128
-    unsigned stg_r = stg + ((lane >> 5) * BN + (lane & 31) * 4) * 4;         // + pass * 1024
-    const int col_l = (lane & 31) * 4, row_l = lane >> 5;
+    unsigned stg_w = stg + (((lane >> 5) * 4) * WTN + (lane & 31)) * 4;      // + ((r & 3) + 8 (r >> 2)) * WTN * 4 + j * 128
+    unsigned stg_r = stg + ((lane / LPR) * WTN + (lane % LPR) * 4) * 4;       // + pass * 1024 (a pass = RPP rows of WTN floats = 1 KiB)
+    const int col_l = (lane % LPR) * 4, row_l = lane / LPR;
     const int ohw = p.OH * p.OW;
     const bool relu = p.act == TT_ACT_RELU;
     const bool nt_store = (p.flags & 16) != 0;
@@ -136,28 +149,28 @@ __global__ __launch_bounds__(256, 1) void gemm_x3_persist_kernel(const ConvArgs 
     auto load_affine = [&](Tile& o) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = o.n0 + j * 32 + (lane & 31);
+            const int col = o.n0 + wn * WTN + j * 32 + (lane & 31);
             o.sc[j] = p.scale ? p.scale[col] : 1.f;
             o.sh[j] = p.shift ? p.shift[col] : 0.f;
         }
     };
-    // residual pointer of pass 0 of a tile for this lane (row m0 + 64 wave + (lane >> 5), 4 columns from col_l); pass q is
-    // 2 q rows further (the 64 rows of a wave are contiguous)
+    // residual pointer of pass 0 of a tile for this lane (row m0 + 64 wm + row_l, 4 columns from col_l); pass q is RPP q rows
+    // further (the 64 rows of a wave are contiguous)
     auto res_base = [&](const Tile& o) __attribute__((always_inline)) {
-        return res + (long long)(o.m0 + wave_s * 64 + row_l) * p.res1_cstride + p.res1_coff + o.n0 + col_l;
+        return res + (long long)(o.m0 + wm_s * 64 + row_l) * p.res1_cstride + p.res1_coff + o.n0 + wn_s * WTN + col_l;
     };
-    const long long res_step = 2ll * p.res1_cstride, out_step = 2ll * p.out_cstride;             // wave-uniform, per pass
+    const long long res_step = (long long)RPP * p.res1_cstride, out_step = (long long)RPP * p.out_cstride;     // wave-uniform, per pass
     // stage row block b (0, 1) of `acc` (tile o) with the folded affine (+ the per-image shift: the block lies in one image);
     // returns the output pointer of the block's first pass for this lane
     auto stage_block = [&](const Tile& o, f32x16 (&acc)[TM][TN], auto b_t) -> float* {
         constexpr int b = decltype(b_t)::value;
-        const int mb = o.m0 + wave_s * 64 + b * 32;                   // wave-uniform: the division below is scalar
+        const int mb = o.m0 + wm_s * 64 + b * 32;                     // wave-uniform: the division below is scalar
         const int img = (p.out_fast && !p.shift_n) ? 0 : mb / ohw;
         float shb[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) shb[j] = o.sh[j];
         if (p.shift_n) {
-            const float* sn = p.shift_n + (long long)(img % p.shift_n_mod) * p.Cout + o.n0 + (lane & 31);
+            const float* sn = p.shift_n + (long long)(img % p.shift_n_mod) * p.Cout + o.n0 + wn * WTN + (lane & 31);
 #pragma unroll
             for (int j = 0; j < TN; ++j) shb[j] += sn[j * 32];
         }
@@ -169,14 +182,14 @@ __global__ __launch_bounds__(256, 1) void gemm_x3_persist_kernel(const ConvArgs 
                 const float v = acc[b][j][r] * o.sc[j] + shb[j];
                 const unsigned base = stg_w;        // (named here: an asm operand alone does not capture in a generic lambda)
                 // (the address is ONE register + an immediate: computed addresses are loop-invariant, get hoisted, and spill)
-                asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(base), "v"(v), "n"(((r & 3) + 8 * (r >> 2)) * BN * 4 + j * 128) : "memory");
+                asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(base), "v"(v), "n"(((r & 3) + 8 * (r >> 2)) * WTN * 4 + j * 128) : "memory");
             });
             __builtin_amdgcn_sched_barrier(0);                        // one column block's 16 values live at a time
         });
         const long long obase = p.out_fast ? 0 : (long long)img * (p.out_nstride - (long long)ohw * p.out_cstride);
-        return outp + (long long)(mb + row_l) * p.out_cstride + obase + p.out_coff + o.n0 + col_l;
+        return outp + (long long)(mb + row_l) * p.out_cstride + obase + p.out_coff + o.n0 + wn_s * WTN + col_l;
     };
-    // one pass: staged row -> (+ residual) -> ReLU -> 16 B store.  ql: pass inside its row block (0 .. 15)
+    // one pass: staged row -> (+ residual) -> ReLU -> 16 B store.  ql: pass inside its row block (0 .. BPASS - 1)
     auto do_pass = [&](float* out_blk, auto ql_t, const float4& rv) __attribute__((always_inline)) {
         constexpr int ql = decltype(ql_t)::value;
         u32x4 t;
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x3_persist_kernel(const ConvArgs 
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             // drain: a row block is staged when its first pass comes up
-            if constexpr (HAS_OLD && (kt * P) % 16 == 0) out_blk = stage_block(o, old, std::integral_constant<int, (kt * P) / 16>{});
+            if constexpr (HAS_OLD && (kt * P) % BPASS == 0) out_blk = stage_block(o, old, std::integral_constant<int, (kt * P) / BPASS>{});
             // residual reads of the NEXT K tile's passes (this tile's own first passes when kt is its last K tile).  Every vector
             // read here is consumed (the counted waits above rely on the number of operations issued): without a tile to
             // drain only the last K tile reads
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x3_persist_kernel(const ConvArgs 
             }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            // ---- bf16x3 K tile: 2 K steps x 4 column blocks = 8 sub-steps of 6 MFMAs, reads one sub-step ahead
+            // ---- bf16x3 K tile: 2 K steps x TN column blocks = 2 TN sub-steps of 6 MFMAs, reads one sub-step ahead
             const unsigned sA = lds_base + (unsigned)stage * A_BYTES, sB = lds_base + OFF_B + (unsigned)stage * B_BYTES;
             u32x4 ra0[TM], ra1[TM], bh[2], bl[2];
             uint4 ah[2][TM], al[2][TM];
@@ -278,7 +291,9 @@ __global__ __launch_bounds__(256, 1) void gemm_x3_persist_kernel(const ConvArgs 
             constexpr int NS = 2 * TN;
             static_for<NS>([&](auto ss_t) __attribute__((always_inline)) {
                 constexpr int ss = decltype(ss_t)::value;
-                constexpr int kc = ss / TN, j = ss % TN, buf = ss & 1, ab = kc & 1;
+                // (eight waves: ONE set of split fragments -- 16 registers the residual vectors need; the K steps of a wave then
+                // serialise on the split, which the SIMD's other wave covers)
+                constexpr int kc = ss / TN, j = ss % TN, buf = ss & 1, ab = W8 ? 0 : (kc & 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(bh[buf]));
                 asm volatile("" : "+v"(bl[buf]));
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x3_persist_kernel(const ConvArgs 
                     constexpr int q0 = (ss * P) / NS, q1 = ((ss + 1) * P) / NS;
                     static_for<q1 - q0>([&](auto dq_t) __attribute__((always_inline)) {
                         constexpr int q = q0 + decltype(dq_t)::value;
-                        do_pass(out_blk, std::integral_constant<int, (kt * P + q) & 15>{}, rbuf[kt & 1][q]);
+                        do_pass(out_blk, std::integral_constant<int, (kt * P + q) % BPASS>{}, rbuf[kt & 1][q]);
                     });
                 }
             });
@@ -363,13 +378,13 @@ __global__ __launch_bounds__(256, 1) void gemm_x3_persist_kernel(const ConvArgs 
         const float* rb = RES ? res_base(t_prev) : nullptr;
         static_for<TM>([&](auto b_t) __attribute__((always_inline)) {
             constexpr int b = decltype(b_t)::value;
-            float4 rv[16];
+            float4 rv[BPASS];
             if (RES) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) rv[q] = load_res(rb, b * 16 + q);
+                for (int q = 0; q < BPASS; ++q) rv[q] = load_res(rb, b * BPASS + q);
             }
             float* ob = stage_block(t_prev, acc, b_t);
-            static_for<16>([&](auto q_t) __attribute__((always_inline)) {
+            static_for<BPASS>([&](auto q_t) __attribute__((always_inline)) {
                 constexpr int q = decltype(q_t)::value;
                 do_pass(ob, q_t, RES ? rv[q] : make_float4(0.f, 0.f, 0.f, 0.f));
             });
@@ -396,9 +411,11 @@ int try_launch_gemm_x3_persist(ConvArgs& a, hipStream_t st) {
     if (T < 2LL * kNumCU) return 0;                                  // fewer than two tiles per CU: nothing to overlap
     const int nk = a.K / BK;
     const bool has_res = a.res1 != nullptr;
+    static const bool w8 = [] { const char* e = getenv("TT_X3_PERSIST_WAVES"); return e ? atoi(e) == 8 : true; }();   // A/B knob
     void (*kern)(const ConvArgs, int, int) = nullptr;
 #define TT_PICK(NK_)                                                                                      \
-    kern = has_res ? gemm_x3_persist_kernel<NK_, true> : gemm_x3_persist_kernel<NK_, false>
+    kern = w8 ? (has_res ? gemm_x3_persist_kernel<NK_, true, true> : gemm_x3_persist_kernel<NK_, false, true>) \
+              : (has_res ? gemm_x3_persist_kernel<NK_, true, false> : gemm_x3_persist_kernel<NK_, false, false>)
     switch (nk) {
         case 4: TT_PICK(4); break;
         default: TT_PICK(8); break;
@@ -406,8 +423,11 @@ int try_launch_gemm_x3_persist(ConvArgs& a, hipStream_t st) {
 #undef TT_PICK
     static bool attr_set = false;
     if (!attr_set) {
-#define TT_ATTR(NK_, R_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_persist_kernel<NK_, R_>), \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)
+#define TT_ATTR(NK_, R_)                                                                                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_persist_kernel<NK_, R_, true>),                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_persist_kernel<NK_, R_, false>),                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)
         TT_ATTR(4, true); TT_ATTR(4, false);
         TT_ATTR(8, true); TT_ATTR(8, false);
 #undef TT_ATTR
@@ -415,8 +435,8 @@ int try_launch_gemm_x3_persist(ConvArgs& a, hipStream_t st) {
     }
     a.tiles_n = tiles_n;
     a.splits = 1;
-    snprintf(g_conv_kernel, sizeof(g_conv_kernel), "gemm_x3_persist_kernel<%d, %s>", nk, has_res ? "true" : "false");
-    hipLaunchKernelGGL(kern, dim3((unsigned)kNumCU), dim3(256), LDS_BYTES, st, a, tiles_m, tiles_n);
+    snprintf(g_conv_kernel, sizeof(g_conv_kernel), "gemm_x3_persist_kernel<%d, %s, %s>", nk, has_res ? "true" : "false", w8 ? "8 waves" : "4 waves");
+    hipLaunchKernelGGL(kern, dim3((unsigned)kNumCU), dim3(w8 ? 512 : 256), LDS_BYTES, st, a, tiles_m, tiles_n);
     return 1;
 }
 

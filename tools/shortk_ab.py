@@ -38,7 +38,8 @@ ARMS = {
     "stg20": {"TT_GLDS_STAGGER_US": "20"},
     "stg40": {"TT_GLDS_STAGGER_US": "40"},
     "stg80": {"TT_GLDS_STAGGER_US": "80"},
-    "pers": {"TT_X3_PERSIST": "1"},
+    "pers": {"TT_X3_PERSIST": "1"},                                      # persistent 256 x 128 tiles, eight waves (default geometry)
+    "pers4": {"TT_X3_PERSIST": "1", "TT_X3_PERSIST_WAVES": "4"},         # ... four waves, one per SIMD
 }
 
 
