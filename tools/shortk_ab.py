@@ -105,7 +105,7 @@ def main():
         print(row + f"   {b['tb_s']:.2f} TB/s  x{b['calls']}")
     print(f"{'per forward (calls weighted)':34s} " + " ".join(f"{tot[a]:9.3f}" for a in results))
     for a, rs in results.items():
-        print(f"  {a}: " + "; ".join(sorted({r['kernel'].split('<')[0] + '<' + r['kernel'].split('<')[1][:22] for r in rs})))
+        print(f"  {a}: " + "; ".join(sorted({r['kernel'].split('<')[0] + '<' + r['kernel'].split('<')[1][:40] for r in rs})))
     bad = [(a, rs[i]["shape"]) for a, rs in results.items() for i in range(len(base)) if rs[i]["hash"] != base[i]["hash"]]
     print("BIT-IDENTICAL across arms" if not bad else f"MISMATCH: {bad}")
 
