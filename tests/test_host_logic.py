@@ -427,3 +427,50 @@ def test_splitk_query_answers_for_the_bf16x3_tile_when_the_operand_is_there():
     assert slices(8, 56, 112, 512, 512, 3, True) == 0         # M = 50,176: the chip is full without a split
     f32 = slices(8, 14, 28, 512, 512, 3, False)
     assert f32 > 0 and f32 != 4                               # the exact-f32 kernel plans its own split
+
+
+def test_round5_host_side_contracts():
+    """Host-only pieces of round 5: (1) the by-epoch cosine refuses to degrade silently; (2) tt_plan_add_sync refuses
+    while relocations of a not-yet-added call are pending (the liveness analysis attributes a blob's pointers to the op index
+    current when they were declared); (3) tt_voxel_pool_workspace_bytes covers the per-launch counting sort's layout (packed key /
+    rank words, per-(chunk, cell) table, order, per-sample cell / segment tables, one partial row per segment) and answers 0 only
+    for shapes no workspace path takes; (4) the agent tick's world -> ego target point equals the oracle's restatement of
+    thinktwice_agent.py:354-360; (5) the fault entries answer without a device."""
+    import ctypes
+    import numpy as np
+    from oracle import agent_ref as R
+    from thinktwice_amd import _lib, agent_tick
+    from thinktwice_amd.optim import warmup_cosine_lr
+    with pytest.raises(ValueError, match="iters_per_epoch"):
+        warmup_cosine_lr(1e-4, 10, 1000)
+    assert warmup_cosine_lr(1e-4, 10, 1000, by_epoch=False) > 0
+    L = _lib.lib()
+    L.tt_plan_create.restype = ctypes.c_void_p
+    plan = ctypes.c_void_p(L.tt_plan_create())
+    try:
+        L.tt_plan_add_blob.restype = ctypes.c_longlong
+        blob = (ctypes.c_char * 64)()
+        off = L.tt_plan_add_blob(plan, blob, ctypes.c_longlong(64))
+        assert off >= 0
+        assert L.tt_plan_add_reloc(plan, ctypes.c_longlong(off), ctypes.c_int(1), ctypes.c_longlong(0)) == 0
+        assert L.tt_plan_add_sync(plan, ctypes.c_int(0), ctypes.c_int(1)) != 0
+        assert b"relocation" in L.tt_last_error()
+    finally:
+        L.tt_plan_destroy(plan)
+    ws = lambda B, Np, C, X, Y: int(L.tt_voxel_pool_workspace_bytes(ctypes.c_int(B), ctypes.c_int(Np), ctypes.c_int(C),
+                                                                    ctypes.c_int(X), ctypes.c_int(Y)))
+    B, Np, C, cells = 8, 501760, 256, 441
+    al = lambda v: (v + 255) // 256 * 256
+    cps, segcap = (Np + 8191) // 8192, Np // 64 + cells + 1
+    want = al(4 * B * Np) + al(4 * B * cps * cells) + al(4 * B * Np) + 2 * al(4 * B * (cells + 1)) + al(4 * B * segcap * C)
+    two_phase = B * ((Np + 2047) // 2048) * 64 * C * 4 + B * cells * ((Np + 2047) // 2048) * 4 + 256
+    assert ws(B, Np, C, 21, 21) == max(want, two_phase)
+    assert ws(1, 100, 256, 21, 21) == 0                      # tiny inputs: the single-pass kernel
+    assert ws(1, 600000, 256, 21, 21) > 0                    # > 524,288 points per sample: the two-phase kernel still answers
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        pos, yaw, tgt = rng.uniform(-50, 50, 2), float(rng.uniform(-4, 4)), rng.uniform(-50, 50, 2)
+        want_t = R.offset_then_rotate(np.array([[tgt[1], -tgt[0]]]), np.stack([pos[1], -pos[0]], axis=-1), yaw).squeeze(0)
+        got_t = agent_tick.offset_then_rotate((tgt[1], -tgt[0]), (pos[1], -pos[0]), yaw)
+        np.testing.assert_allclose(got_t, want_t, rtol=0, atol=1e-12)
+    assert L.tt_clear_device_faults() in (0, -2) and L.tt_device_faults() in (0, -2)
