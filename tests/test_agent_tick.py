@@ -113,7 +113,7 @@ def test_agent_tick_end_to_end_matches_the_oracle_chain(use_cache):
     """VERDICT r4 missing #2: the whole model-side tick (thinktwice_agent.py:362-529) chained -- uint8 4 x 900 x 1600 frames ->
     tt_preprocess_images -> half-sweep merge -> queue / sweep selection -> forward_inference (bf16x3, with and without the
     previous-sweep BEV cache) -> tt_action_post -- stage by stage against the ORACLE chain (oracle.agent_ref.AgentChain: preprocess_ref (F17)
-    -> SweepMerge (F15) -> model_ref (F7 / F8) -> process_action / control_pid (F9) -> Arbitration (F15)) over 9 ticks (5 live).
+    -> SweepMerge (F15) -> model_ref (F7 / F8) -> process_action / control_pid (F9) -> Arbitration (F15)) over 7 ticks (3 live).
     Shortened queue (lag 2, 4 frames) and a 128 x 256 network input so that the CPU oracle finishes in seconds per tick;
     the full-size tick is below."""
     from oracle import agent_ref as R
@@ -128,7 +128,7 @@ def test_agent_tick_end_to_end_matches_the_oracle_chain(use_cache):
     chain = R.AgentChain(sd, cfg, mx, my, hw, tick.img_metas, lag=2, queue_len=4, stuck_threshold=5)
     heads = _OracleHeads(cfg, stuck_threshold=5)
     live, agree = 0, 0
-    for t, args in enumerate(_tick_inputs(9)):
+    for t, args in enumerate(_tick_inputs(7)):
         s, th, b, info = tick.run_step(*args)
         rs, rth, rb, rpred = chain.run_step(*args, device_img=info["img"].cpu(), device_cloud=info["cloud"].cpu().numpy())
         _check_stage_outputs(info, chain)
@@ -145,7 +145,7 @@ def test_agent_tick_end_to_end_matches_the_oracle_chain(use_cache):
         os_, oth, ob = heads.step(info["pred"], args[4], info["target_point"])
         assert abs(s - os_) < 1e-5 and abs(th - oth) < 1e-5 and b == ob, (t, (s, th, b), (os_, oth, ob))
         agree += int(abs(s - rs) < 5e-3 and abs(th - rth) < 5e-3 and b == rb)
-    assert live == 5 and agree >= 4, agree
+    assert live == 3 and agree >= 2, agree
 
 
 @pytest.mark.gpu
