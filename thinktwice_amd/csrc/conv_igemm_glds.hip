@@ -853,6 +853,10 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
         return launch_glds<float, 128, 8, 1, 128, 2, false, true>(a, st);
     }
     if (stages == 3) return launch_glds<float, 64, 8, 1, 128, 3, false, true>(a, st);                          // 8 x (32 x 64)
+    // TT_GLDS_X3_64_WAVES=4 (A/B knob): four waves of 64 x 64 instead of eight of 32 x 64 -- every wave of the 8-wave form reads the
+    // whole 64-column weight tile from LDS (64 of the tile's 136 KiB of LDS traffic per K tile against 768 cycles of MFMAs per CU)
+    static const int waves64 = [] { const char* e = getenv("TT_GLDS_X3_64_WAVES"); return e ? atoi(e) : 8; }();
+    if (waves64 == 4) return launch_glds<float, 64, 4, 1, 128, 2, false, true>(a, st);                         // 4 x (64 x 64)
     return launch_glds<float, 64, 8, 1, 128, 2, false, true>(a, st);
 }
 
