@@ -87,6 +87,7 @@ X3_CASES = [
     (2, 50, 60, 64, 256, 1, 1, 0, 1, 2, True, 1),     # 2 K tiles only, sigmoid
     (2, 36, 64, 256, 1280, 1, 1, 0, 1, 0, False, 0),  # value_proj-like N = 1280
     (2, 21, 21, 512, 256, 3, 1, 1, 1, 1, True, 0),    # M = 882 <= 4096: the exact f32 small-M kernel on `w`
+    (3, 300, 300, 64, 12, 3, 1, 1, 1, 0, False, 0),   # 256x32 tile: few output channels over >= 2^18 rows (the fused seg head)
 ]
 
 

@@ -60,6 +60,11 @@ class ForwardWorkload:
         # TT_BENCH_GRAPH=1 replays one captured HIP graph per forward.  The graph pays at batch 1: see tick_latency.
         self.graph = None
         self.launch_note = "eager launches"
+        # TT_BENCH_PIPELINE=n: batches in flight (n streams, round-robin); 1 = one batch at a time on the current stream
+        self.pipeline = int(os.environ.get("TT_BENCH_PIPELINE", "1"))
+        self._streams, self._tick = None, 0
+        if self.pipeline > 1:
+            self.launch_note = f"eager launches, {self.pipeline} batches in flight on alternating streams"
         if os.environ.get("TT_BENCH_GRAPH", "0") != "0":
             try:
                 from .encoder_decoder import InferenceGraph
@@ -75,6 +80,18 @@ class ForwardWorkload:
     def step(self):
         if self.graph is not None:
             self.last = self.graph.replay()
+        elif self.pipeline > 1:
+            # consecutive batches on alternating streams: the latency-bound tail of batch i (the decoder's per-sample kernels:
+            # 8 - 64 workgroups on 256 CUs) runs under the camera trunk of batch i + 1.  Every forward is complete inside the
+            # timed region (device-wide synchronise at its end); activations of the two batches come from separate allocator pools
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(self.batch["img"].device) for _ in range(self.pipeline)]
+                for st in self._streams:
+                    st.wait_stream(torch.cuda.current_stream())
+            st = self._streams[self._tick % self.pipeline]
+            self._tick += 1
+            with torch.cuda.stream(st):
+                self.last = self.model.forward_inference(self.batch, channel_last_out=True)
         else:
             self.last = self.model.forward_inference(self.batch, channel_last_out=True)
         return self.last

@@ -772,9 +772,15 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
         if (a.Cout <= 64) return launch_glds<float, 64, 8, 1, 128, 2, true, true>(a, st);
         return launch_glds<float, 128, 8, 1, 128, 2, true, true>(a, st);
     }
-    if (a.m_dev || a.M < 2048 || a.Cout < 64 || a.KH * a.KW > 32) return 0;
+    if (a.m_dev || a.M < 2048 || a.KH * a.KW > 32) return 0;
     if (a.Cin % 32 != 0 || a.K < 64) return 0;       // 128 B rows = 32 f32 of one tap per K tile, >= 2 tiles
     a.stagger_ticks = a.stagger_blocks = 0;
+    // few output channels over very many rows (the segmentation head: 3 x 3, 64 -> 12 at 224 x 448 per image): a 256 x 32 tile,
+    // two workgroups per CU; below that row count the exact-f32 register-staged kernel is as fast
+    if (a.Cout < 64) {
+        if (a.Cout > 32 || a.Cout < 8 || a.M < (1 << 18) || a.K < 256) return 0;
+        return launch_glds<float, 32, 8, 1, 128, 2, false, true>(a, st);
+    }
     // short-K 1 x 1 layers with at least two 256 x 128 tiles per CU: persistent workgroups that store tile i under the K loop of
     // tile i + 1 (csrc/conv_x3_persist.hip).  TT_X3_PERSIST=0/1 (A/B knob)
     {

@@ -229,6 +229,21 @@ class LSS:
         self.u0b = conv_from_sd(sd, s + ".unet_layer0.3", dt, dev, pad=1)
         self.seg_cp = 12 if self.dtype == f32 else 16
         self.conv_last = conv_from_sd(sd, s + ".conv_last", dt, dev)
+        # Inference: `conv_last` (1 x 1, 64 -> n_class, lss.py:272,281) follows `unet_layer0.3` (3 x 3, 64 -> 64, no bias,
+        # lss.py:271) with nothing in between, and the 64-channel map between them has no other reader: the two linear maps are ONE
+        # 3 x 3 convolution 64 -> n_class with W = W_last . W_3 (composed in f64), which neither writes nor re-reads the
+        # (NI, 224, 448, 64) f32 intermediate (1.6 GB at B = 8).  The training tape keeps the two layers (their own gradients).
+        w3 = sd[s + ".unet_layer0.3.weight"].double()
+        wl = sd[s + ".conv_last.weight"].double()[:, :, 0, 0]
+        wm = torch.einsum("om,mckl->ockl", wl.to(w3.device), w3).float().contiguous()
+        bl = sd.get(s + ".conv_last.bias")
+        b3 = sd.get(s + ".unet_layer0.3.bias")
+        bm = None if (bl is None and b3 is None) else \
+            ((0 if bl is None else bl.double()) + (0 if b3 is None else wl.to(b3.device) @ b3.double())).float()
+        fused = {"w.weight": wm}
+        if bm is not None:
+            fused["w.bias"] = bm
+        self.seg_fused = conv_from_sd(fused, "w", dt, dev, pad=1)
         r = p + ".seg_res_to_image_feature"
         self.seg2feat = []
         for idx, (st, pd) in zip((0, 3, 6, 9, 12, 15, 18), ((1, 0), (1, 0), (2, 1), (1, 0), (2, 1), (1, 0), (2, 1))):
@@ -322,10 +337,14 @@ class LSS:
         d3 = self.upc["unet_layer3"](cat3)
         self.up["unet_layer2"](d3, out=cat2, out_coff=0)
         d2 = self.upc["unet_layer2"](cat2)
-        d0 = self.u0b(self.u0a(ops.bilinear_up2(d2)))
-        NI, H, W, _ = d0.shape
-        seg = torch.zeros(NI, H, W, self.seg_cp, dtype=self.dtype, device=d0.device)
-        self.conv_last(d0, out=seg)
+        from . import autodiff
+        d1 = self.u0a(ops.bilinear_up2(d2))
+        NI, H, W, _ = d1.shape
+        seg = torch.zeros(NI, H, W, self.seg_cp, dtype=self.dtype, device=d1.device)
+        if autodiff.TAPE is None and not layers.BN_TRAIN and self.dtype == torch.float32:
+            self.seg_fused(d1, out=seg)          # conv_last o unet_layer0.3 as one convolution (load_state_dict)
+        else:
+            self.conv_last(self.u0b(d1), out=seg)
         return seg
 
     def geometry(self, gm, batch_size, num_cams):
@@ -371,7 +390,9 @@ class LSS:
         border = self.backbone.stem_border() if (H % 2 == 0 and W % 2 == 0 and autodiff.TAPE is None) else None
         if border is not None:
             # zero-bordered image buffer for the row-run stem; the border is written once, the interior every call
-            key = (NI, H, W, str(img.device))
+            # (one per stream: with batches pipelined on alternating streams the next forward's image upload must not overwrite
+            # a buffer the previous forward's stem may still be reading)
+            key = (NI, H, W, str(img.device), int(torch.cuda.current_stream(img.device).cuda_stream))
             x = self._xpad.get(key)
             if x is None:
                 x = torch.zeros(NI, H + border[0] + border[2], W + border[1] + border[3], self.backbone.cin_pad,
