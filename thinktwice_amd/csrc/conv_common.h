@@ -46,8 +46,6 @@ struct ConvArgs {
                          // f32 output stores; < 0: split-K query (no launch)
     int stagger_ticks;   // LDS-DMA kernel, HBM-shaped (short-K) layers: the workgroups of the launch's FIRST round start
     int stagger_blocks;  // phase (blockIdx / 8) % 4 x stagger_ticks (10 ns wall-clock ticks) late -- see conv_igemm_glds.hip
-    float* out2;         // optional second, f32, row-linear copy of the output (tt_conv_desc.out2): [M][out2_cstride] at out2_coff
-    int out2_cstride, out2_coff;
     long long* trace;    // measurement aid (tt_conv_set_trace): 4 wall-clock stamps (10 ns ticks) per workgroup of the LDS-DMA kernel
                          // -- entry, first K tile landed, K loop done, epilogue done -- at trace[blockIdx.x * 4]; null in the product
 };
@@ -188,36 +186,15 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
             if (nt_store) __builtin_nontemporal_store(f4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4v*>(reinterpret_cast<float*>(p.out) + o));
             else *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-            // 16-bit output: the storage type of the operands, or (f32 operands: a bf16x3 layer feeding a half-storage stage of
-            // the mixed mode) the type out_dtype names
+            // 16-bit output: the storage type of the operands (f32-compute layers never take the CO == 8 path)
+            using T16 = typename std::conditional<sizeof(T) == 2, T, uint16_t>::type;
             uint4 pk;
-            if constexpr (sizeof(T) == 2) {
-                pk.x = Pair16<T>::pack(v[0], v[1]);
-                pk.y = Pair16<T>::pack(v[2], v[3]);
-                pk.z = Pair16<T>::pack(v[4], v[5]);
-                pk.w = Pair16<T>::pack(v[6], v[7]);
-            } else if (p.out_dtype == TT_F16) {
-                pk.x = pack_f16x2(v[0], v[1]);
-                pk.y = pack_f16x2(v[2], v[3]);
-                pk.z = pack_f16x2(v[4], v[5]);
-                pk.w = pack_f16x2(v[6], v[7]);
-            } else {
-                pk.x = pack_bf16x2(v[0], v[1]);
-                pk.y = pack_bf16x2(v[2], v[3]);
-                pk.z = pack_bf16x2(v[4], v[5]);
-                pk.w = pack_bf16x2(v[6], v[7]);
-            }
+            pk.x = Pair16<T16>::pack(v[0], v[1]);
+            pk.y = Pair16<T16>::pack(v[2], v[3]);
+            pk.z = Pair16<T16>::pack(v[4], v[5]);
+            pk.w = Pair16<T16>::pack(v[6], v[7]);
             *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.out) + o) = pk;
         }
-    };
-    // second, f32, row-linear copy (tt_conv_desc.out2)
-    float* const out2 = p.out2 ? p.out2 + p.out2_coff + co : nullptr;
-    auto store_row2 = [&](long long row, const float (&v)[CO]) {
-        typedef float f4v __attribute__((ext_vector_type(4)));
-        float* q2 = out2 + row * p.out2_cstride;
-#pragma unroll
-        for (int e = 0; e < CO; e += 4)
-            __builtin_nontemporal_store(f4v{v[e], v[e + 1], v[e + 2], v[e + 3]}, reinterpret_cast<f4v*>(q2 + e));
     };
     const int cc = col_ok ? co : 0;
 #pragma unroll
@@ -293,7 +270,6 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                             for (int e = 0; e < CO; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                         }
                         store_row((long long)mr * p.out_cstride + obase, v);
-                        if (out2) store_row2(mr, v);
                     }
                 }
             };
@@ -338,7 +314,6 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
 #pragma unroll
                 for (int e = 0; e < CO; ++e) v[e] = apply_act(v[e], act);
                 store_row(o, v);
-                if (out2) store_row2(mo, v);
             }
         }
     }
@@ -427,7 +402,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                 reinterpret_cast<float*>(p.out)[o] = v;
             else
                 store16(p.out, o, v, p.out_dtype);
-            if (p.out2) p.out2[(long long)mo * p.out2_cstride + p.out2_coff + co] = v;
         }
     }
 }
@@ -445,9 +419,6 @@ int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int 
 int try_launch_sp_conv_runs(ConvArgs& a, hipStream_t st);
 // conv_x3_persist.hip: short-K 1 x 1 layers on persistent workgroups that store tile i under the K loop of tile i + 1
 int try_launch_gemm_x3_persist(ConvArgs& a, hipStream_t st);
-// "h2" arithmetic (csrc/conv_h2.hip): IEEE-half activations x f16 (hi, lo) weight pairs in a.weight, two MFMAs per product.
-// Returns 1 if it took the launch, 0 if the shape is outside its contract (dense, Cin % 64 == 0, KH*KW <= 31).
-int try_launch_conv_h2(ConvArgs& a, hipStream_t st);
 // latency-bound small-M variant (32x32 tile, intra-block split-K): same contract.
 int try_launch_conv_small(ConvArgs& a, int dtype, hipStream_t st);
 

@@ -116,7 +116,6 @@ class _ConvDesc(ctypes.Structure):
         ("gather_idx", ctypes.c_void_p), ("m_dev", ctypes.c_void_p), ("splitk_ws", ctypes.c_void_p),
         ("weight_x3", ctypes.c_void_p), ("row_perm", ctypes.c_void_p), ("row_mask", ctypes.c_void_p),
         ("splitk_slices", _c),
-        ("weight_h2", ctypes.c_void_p), ("out2", ctypes.c_void_p), ("out2_cstride", _c), ("out2_coff", _c),
     ]
 
 
@@ -244,14 +243,12 @@ def sp_from_dense(gdense, coords, rows, max_rows, dims, grows):
 def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=None, res1_coff=0,
            res2=None, res2_coff=0, out=None, out_coff=0, in_coff=0, cin=None, pixel_shuffle2=False,
            shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None, splitk_ws=None,
-           in_cstride=None, w_x3=None, _no_tape=False, stop_grad=False, bn_raw=False, w_h2=None, out2=None, out2_coff=0):
+           in_cstride=None, w_x3=None, _no_tape=False, stop_grad=False, bn_raw=False):
     """Channel-last implicit-GEMM convolution on MFMA (tt_conv2d_fwd).
 
     x   [N,H,W,Cs]  (f32 or bf16); channels [in_coff, in_coff+cin) are convolved
     w   [Cout,KH,KW,cin] same dtype (for pixel_shuffle2: [4*Cout_real,1,1,cin])
     out [N,OH,OW,Ct] written at channel offset out_coff (allocated if None)
-    w_h2: (x, w half) the f16 (hi, lo) weight pair of weights.split_pairs_h2 -- the layer runs the two-MFMA "h2" product
-    out2 / out2_coff: optional second, f32, copy of the output rows at channel offset out2_coff of a [.., Ct2] tensor
     in_cstride / out_hw: "row-run" form -- the kernel reads `cin` CONTIGUOUS elements starting at pixel (ih, iw) of a
     tensor whose pixels are only Cs < cin elements apart (a run of cin/Cs pixels along W), with the output size given
     explicitly; used for the 7x7/2 stem (lss.py).
@@ -287,15 +284,6 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     d.res2 = _dp(res2); d.res2_cstride = 0 if res2 is None else res2.shape[-1]; d.res2_coff = res2_coff
     d.act = act; d.dtype = dtype_code(x); d.out_dtype = dtype_code(out)
     from . import autodiff
-    if w_h2 is not None:
-        assert x.dtype == torch.float16 and w.dtype == torch.float16 and w_h2.dtype == torch.float16 and w_h2.is_contiguous() \
-            and w_h2.numel() == 2 * w.numel() and w_x3 is None and splitk_ws is None
-        if autodiff.TAPE is not None:
-            raise _lib.TTError("conv2d: half-storage (h2) layers have no backward; train in dtype torch.float32 or 'f32x3'")
-        d.weight_h2 = w_h2.data_ptr()
-    if out2 is not None:
-        assert out2.dtype == torch.float32 and out2.is_contiguous() and out2.numel() // out2.shape[-1] == N * OH * OW
-        d.out2 = out2.data_ptr(); d.out2_cstride = out2.shape[-1]; d.out2_coff = out2_coff
     if w_x3 is not None:       # (before the split-K query: with a bf16x3 operand the query answers for the bf16x3 split-K tile)
         assert x.dtype == torch.float32 and w_x3.shape == w.shape and w_x3.is_contiguous()
         # the training step (forward under the tape, and the backward's recomputations / input-gradient convolutions, which
@@ -304,7 +292,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
         x3_splitk = autodiff.TAPE is None and not _no_tape
         if x3_splitk:
             d.weight_x3 = w_x3.data_ptr()
-    if _AUTO_SPLITK and splitk_ws is None and w_h2 is None and N * OH * OW <= 4096 and KH * KW * Cin >= 2048:
+    if _AUTO_SPLITK and splitk_ws is None and N * OH * OW <= 4096 and KH * KW * Cin >= 2048:
         # few rows, very long K (BEV-update conv K=18720, flatten MLPs): cross-workgroup split-K with an f32 workspace
         # beats conv_small.hip's in-workgroup split there (277 vs 416 us on the BEV-update conv: the direct 32 B/row
         # operand loads of the small kernel waste L2 sectors on a 10 MB weight matrix).  TT_CONV_AUTO_SPLITK=0 disables.
@@ -334,10 +322,8 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
             esz, osz = x.element_size(), out.element_size()
             m_out = N * OH * OW
             in_px = min(N * H * W, m_out * KH * KW)           # a strided 1x1 layer only touches the pixels it samples
-            wsz = w.numel() * w.element_size() * (2 if w_h2 is not None else 1)
-            CONV_BYTES.append(in_px * (in_cstride or Cin) * esz + m_out * Cout * osz + wsz +
-                              m_out * Cout * esz * ((res1 is not None) + (res2 is not None)) +
-                              (m_out * Cout * 4 if out2 is not None else 0))
+            CONV_BYTES.append(in_px * (in_cstride or Cin) * esz + m_out * Cout * osz + w.numel() * w.element_size() +
+                              m_out * Cout * esz * ((res1 is not None) + (res2 is not None)))
     if not _no_tape:
         from . import autodiff
         if autodiff.TAPE is not None:

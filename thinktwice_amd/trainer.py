@@ -227,8 +227,11 @@ class Trainer:
                               "exp_avg": o.m[off:off + n].view(shape).detach().clone().cpu(),
                               "exp_avg_sq": o.v[off:off + n].view(shape).detach().clone().cpu()}
             off += n
-        group = {"lr": o.lr, "betas": tuple(o.betas), "eps": o.eps, "weight_decay": o.wd, "amsgrad": False, "maximize": False,
-                 "foreach": None, "capturable": False, "params": list(range(len(self.names)))}
+        # mmcv's LrUpdaterHook stores the BASE rate under 'initial_lr' and overwrites 'lr' with the scheduled (warmed-up /
+        # annealed) one every iteration: write both, so a resume by either side takes the schedule's base from 'initial_lr'
+        group = {"lr": self.current_lr(), "initial_lr": o.lr, "betas": tuple(o.betas), "eps": o.eps, "weight_decay": o.wd,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                 "params": list(range(len(self.names)))}
         return {"state": state, "param_groups": [group]}
 
     def load_optimizer_state_dict(self, osd):
@@ -253,7 +256,9 @@ class Trainer:
             off += n
         o.steps = steps
         g = (osd.get("param_groups") or [{}])[0]
-        o.lr = g.get("lr", o.lr)
+        # the schedule's BASE rate: mmcv checkpoints carry it as 'initial_lr' ('lr' there is the already scheduled rate of the
+        # iteration the checkpoint was written at -- using it as the base would apply the schedule twice)
+        o.lr = g.get("initial_lr", g.get("lr", o.lr))
         o.betas = tuple(g.get("betas", o.betas))
         o.eps, o.wd = g.get("eps", o.eps), g.get("weight_decay", o.wd)
 
@@ -275,9 +280,14 @@ class Trainer:
             for k, v in sd.items():
                 if k.endswith("num_batches_tracked") and k in self.sd:
                     self.sd[k] = v.clone()
-        self._bn_steps, self._skips_accounted = 0, 0
+        self._bn_steps = 0
         meta = ckpt.get("meta") or {}
         self.epoch, self.iteration = int(meta.get("epoch", 0) or 0), int(meta.get("iter", 0) or 0)
         if "optimizer" in ckpt:
             self.load_optimizer_state_dict(ckpt["optimizer"])
+        else:
+            # no optimizer state: rebase the issued / applied step bookkeeping where it stands, so that updates skipped BEFORE
+            # this load are not taken out of the freshly loaded iteration count by the next reconcile()
+            self.opt.steps = self.opt.steps
+            self._skips_accounted = 0
         self._prepare()
