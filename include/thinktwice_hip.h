@@ -177,6 +177,14 @@ typedef struct tt_conv_desc {
      * zero fill needed); every K split stores its partial tile into its own slice and the finalize kernel adds the slices
      * in index order -- bit-reproducible.  0: the legacy form (one zero-filled slice, f32 atomics) */
     int splitk_slices;
+    /* bf16x3 layers (weight_x3 given) whose activation tensor has no reader but bf16x3 convolutions can move the operand split
+     * from the consumer's K loop (once per USE: nine times per element per column tile in a 3 x 3 layer) to the producer (once per
+     * element).  "Pair format": per 16 channels 64 B = [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15] in bf16, hi = rne(v),
+     * lo = rne(v - hi) -- the weights' format along the channel axis, f32-sized.  The sums are bit-identical to the f32 form.
+     *   out_pair: write `out` (out_dtype TT_F32, no residuals, Cout / out_cstride / out_coff multiples of 16) in pair format;
+     *   in_pair : `in` is in pair format (in_cstride / in_coff multiples of 16, Cin % 32 == 0, N*OH*OW > 4096, Cout <= 32 or
+     *             >= 64): the launch is refused if the layer is outside the LDS-DMA kernel's contract. */
+    int in_pair, out_pair;
 } tt_conv_desc;
 
 int tt_conv2d_fwd(const tt_conv_desc* d, void* stream);
@@ -278,6 +286,8 @@ int tt_upsample_nearest_add(void* dst, const void* src, int N, int H, int W, int
                             int dtype, void* stream);
 /* nn.Upsample(scale_factor=2, bilinear, align_corners=True): UNet (lss.py:267) */
 int tt_bilinear_up2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
+/* the same, f32 in -> bf16x3 pair format out (tt_conv_desc.in_pair of the consuming convolution; C % 16 == 0) */
+int tt_bilinear_up2_pair(const float* in, float* out, int N, int H, int W, int C, void* stream);
 /* mode 0: AdaptiveAvgPool2d(1) (lss.py:80); mode 1: 0.5*mean+0.5*max (code/utils.py:91-92); out f32 [N,C] */
 int tt_spatial_pool(const void* in, float* out, int N, int HW, int C, int cstride, int coff, int mode,
                     int dtype, void* stream);

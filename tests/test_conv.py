@@ -457,25 +457,10 @@ def test_pipelined_tiles_are_bit_identical_to_the_8wave_tiles():
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    for env_extra, arms in (({}, "0,2"), ({"TT_AB_SET": "128"}, "0,1"), ({"TT_X3_RUN3": "0"}, "0,2")):
+    for env_extra, arms in (({}, "0,1"), ({"TT_AB_SET": "128"}, "0,1"), ({"TT_X3_RUN3": "0"}, "0,1")):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "x3_pipe_ab.py"), "1", arms], cwd=root,
                            env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "ALL OK" in r.stdout, (env_extra, r.stdout[-1500:], r.stderr[-500:])
-
-
-def test_persistent_shortk_gemm_is_bit_identical_to_the_8wave_tile():
-    """csrc/conv_x3_persist.hip (TT_X3_PERSIST=1; persistent workgroups, tile i drained behind the K loop of tile i + 1; eight or
-    four waves) against the default kernels on the forward's twelve short-K 1 x 1 shapes (residual + ReLU, plain, K = 128 / 256 take
-    the persistent kernel, the others fall through): tools/shortk_ab.py runs every arm in its own process and compares the outputs
-    bit for bit."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "shortk_ab.py"), "base", "pers", "pers4"], cwd=root,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "BIT-IDENTICAL across arms" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
-    assert "gemm_x3_persist_kernel<8, false, 8 waves>" in r.stdout and "gemm_x3_persist_kernel<4, true, 4 waves>" in r.stdout, r.stdout[-800:]
 
 
 SPLITK_X3_CASES = [   # (N, H, W, Cin, Cout, k, act, use_bn, residuals, window)
@@ -532,3 +517,56 @@ def test_bf16x3_splitk_tile_matches_torch_f32(case):
     assert "split-K" in ops._last_conv_kernel() and "conv_igemm_kernel" in ops._last_conv_kernel(), ops._last_conv_kernel()
     err = float((out - exact).abs().max() / exact.abs().max().clamp_min(1e-6))
     assert err < 1e-4, err
+
+
+PAIR_CASES = [
+    # N, H, W, Cin, Cout, k, stride, act   (M > 4096: the compiler-scheduled LDS-DMA bf16x3 tiles, 32 / 64 / 128 / 256 wide)
+    (3, 40, 48, 64, 64, 3, 1, 1),        # layer1's 3 x 3 (64-wide tile), ragged M
+    (2, 64, 64, 128, 64, 3, 1, 1),       # unet_layer0.1
+    (3, 300, 300, 64, 12, 3, 1, 0),      # fused seg head (32-wide tile)
+    (2, 50, 60, 64, 256, 1, 1, 0),       # 256-wide 8-wave tile
+    (4, 56, 100, 96, 128, 3, 2, 1),      # stride 2, three channel chunks (96 = 3 x 32), M = 5600
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_conv_pair_format_activations_are_bit_identical(case):
+    """tt_conv_desc.in_pair / out_pair: moving the bf16 (hi, lo) operand split from the consumer's K loop to the producer changes
+    nothing in the sums -- a convolution reading the pre-split tensor equals the one reading f32 bit for bit, and a convolution
+    writing pair format writes exactly the split of what it would have written."""
+    from thinktwice_amd import ops, weights
+    N, H, W, Cin, Cout, k, stride, act = case
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    x = _mk((N, Cin, H, W), g)
+    w = _mk((Cout, Cin, k, k), g, (Cin * k * k) ** -0.5)
+    shift = _mk((Cout,), g, 0.3).cuda()
+    xq = weights.to_channel_last(x, torch.float32).cuda()
+    wq = weights.prep_conv_weight(w, torch.float32).cuda()
+    wx = weights.split_pairs_x3(wq)
+    xp = weights.split_pairs_x3(xq)                       # per 16 channels: [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15]
+    ref = ops.conv2d(xq, wq, stride=stride, pad=k // 2, shift=shift, act=act, w_x3=wx)
+    got = ops.conv2d(xp, wq, stride=stride, pad=k // 2, shift=shift, act=act, w_x3=wx, in_pair=True)
+    assert "pre-split A" in ops._last_conv_kernel()
+    assert torch.equal(got, ref)
+    if Cout % 16 == 0:
+        outp = ops.conv2d(xq, wq, stride=stride, pad=k // 2, shift=shift, act=act, w_x3=wx, out_pair=True)
+        assert torch.equal(outp.view(torch.int32), weights.split_pairs_x3(ref.contiguous()).view(torch.int32))
+        both = ops.conv2d(xp, wq, stride=stride, pad=k // 2, shift=shift, act=act, w_x3=wx, in_pair=True, out_pair=True)
+        assert torch.equal(both.view(torch.int32), outp.view(torch.int32))
+
+
+def test_bilinear_up2_pair_format_is_the_split_of_the_f32_result():
+    from thinktwice_amd import ops, weights
+    g = torch.Generator().manual_seed(9)
+    x = _mk((3, 17, 23, 128), g).cuda()
+    ref = ops.bilinear_up2(x)
+    got = ops.bilinear_up2(x, out_pair=True)
+    assert torch.equal(got.view(torch.int32), weights.split_pairs_x3(ref).view(torch.int32))
+
+
+def test_pair_format_is_refused_outside_the_kernel_contract():
+    from thinktwice_amd import _lib, ops, weights
+    x = torch.zeros(1, 8, 8, 64).cuda()                      # 64 rows: below the LDS-DMA kernel's row count
+    w = torch.zeros(64, 1, 1, 64).cuda()
+    with pytest.raises(_lib.TTError):
+        ops.conv2d(x, w, w_x3=weights.split_pairs_x3(w), in_pair=True)

@@ -42,10 +42,8 @@ struct ConvArgs {
     int tiles_n;
     int m_begin;         // first output row of this launch (tail-split launches of the LDS-DMA kernel), else 0
     int ws_slices;       // split-K: > 0 = every split stores into its own [M][Cout] slice of ws (ordered finalize)
-    int flags;           // bit 3: whole-tile DMA issue in the x3 256-wide 8-wave tile (TT_GLDS_X3_SPREAD=0); bit 4: non-temporal
-                         // f32 output stores; < 0: split-K query (no launch)
-    int stagger_ticks;   // LDS-DMA kernel, HBM-shaped (short-K) layers: the workgroups of the launch's FIRST round start
-    int stagger_blocks;  // phase (blockIdx / 8) % 4 x stagger_ticks (10 ns wall-clock ticks) late -- see conv_igemm_glds.hip
+    int flags;           // bit 4: non-temporal f32 output stores (every launch of the product); bit 5: the activations are pre-split bf16 (hi, lo) pairs (tt_conv_desc.in_pair);
+                         // bit 6: write the output in that pair format (tt_conv_desc.out_pair); < 0: split-K query (no launch)
     long long* trace;    // measurement aid (tt_conv_set_trace): 4 wall-clock stamps (10 ns ticks) per workgroup of the LDS-DMA kernel
                          // -- entry, first K tile landed, K loop done, epilogue done -- at trace[blockIdx.x * 4]; null in the product
 };
@@ -179,12 +177,28 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
         }
         return (long long)n * p.out_nstride + ((long long)oh * OWo + ow) * p.out_cstride + p.out_coff + cc;
     };
-    const bool nt_store = (p.flags & 16) != 0;      // non-temporal f32 output stores (default; TT_CONV_NT_STORE=0 turns them off)
+    const bool nt_store = (p.flags & 16) != 0;      // non-temporal f32 output stores (+0.3-0.5 % on the forward, profiles/r04_nt_store.txt)
     auto store_row = [&](long long o, const float (&v)[CO]) {
         if constexpr (CO == 4) {
             typedef float f4v __attribute__((ext_vector_type(4)));
             if (nt_store) __builtin_nontemporal_store(f4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4v*>(reinterpret_cast<float*>(p.out) + o));
             else *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (sizeof(T) == 4 && (p.flags & 64)) {
+            // pair-format output (tt_conv_desc.out_pair): the eight channels' bf16 hi halves go to the first 32 B of their 16-channel
+            // group (second 16 B for channels 8-15 of the group), the lo halves 32 B further -- hi = rne(v), lo = rne(v - hi), the
+            // consumer kernel's own split (conv_igemm_glds.hip split_frag), done once per element here
+            uint4 hi, lo;
+            uint32_t* hp = reinterpret_cast<uint32_t*>(&hi);
+            uint32_t* lp = reinterpret_cast<uint32_t*>(&lo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t h = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                hp[e] = h;
+                lp[e] = pack_bf16x2(v[2 * e] - __uint_as_float(h << 16), v[2 * e + 1] - __uint_as_float(h & 0xffff0000u));
+            }
+            float* g = reinterpret_cast<float*>(p.out) + (o & ~15ll) + ((o & 8) ? 4 : 0);
+            *reinterpret_cast<uint4*>(g) = hi;
+            *reinterpret_cast<uint4*>(g + 8) = lo;
         } else {
             // 16-bit output: the storage type of the operands (f32-compute layers never take the CO == 8 path)
             using T16 = typename std::conditional<sizeof(T) == 2, T, uint16_t>::type;
@@ -349,7 +363,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
     float* sC = reinterpret_cast<float*>(smem) + wave * (32 * (WTN + 4));
     __syncthreads();   // every wave is done with the K-loop tiles before LDS is reused
     if (p.vec_epi) {
-        if (p.out_dtype == TT_F32)
+        if (p.out_dtype == TT_F32 && !(p.flags & 64))
             conv_epilogue_vec<T, 4, TM, TN, WTM, WTN>(p, acc, sC, lane, wm, wn, m0, n0, Mlim);
         else
             conv_epilogue_vec<T, 8, TM, TN, WTM, WTN>(p, acc, sC, lane, wm, wn, m0, n0, Mlim);
@@ -417,8 +431,6 @@ int launch_conv_glds_x3_splitk(ConvArgs& a, hipStream_t st);
 int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int bn = 256);
 // run-staged sparse 3x3x3 conv (csrc/sp_conv_runs.hip; bf16x3, a.weight = pre-split weights): same contract.
 int try_launch_sp_conv_runs(ConvArgs& a, hipStream_t st);
-// conv_x3_persist.hip: short-K 1 x 1 layers on persistent workgroups that store tile i under the K loop of tile i + 1
-int try_launch_gemm_x3_persist(ConvArgs& a, hipStream_t st);
 // latency-bound small-M variant (32x32 tile, intra-block split-K): same contract.
 int try_launch_conv_small(ConvArgs& a, int dtype, hipStream_t st);
 

@@ -374,27 +374,29 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     TT_REQUIRE(!(d->pixel_shuffle2 && (d->res1 || d->res2)),
                "tt_conv2d_fwd: residuals are not supported with pixel_shuffle2");
     a.tiles_n = 1; a.cin_fast = 0; a.m_begin = 0;
-    a.stagger_ticks = 0; a.stagger_blocks = 0;
     a.trace = g_conv_trace;
-    {
-        static const bool spread = [] { const char* e = getenv("TT_GLDS_X3_SPREAD"); return !(e && e[0] == '0'); }();   // A/B knob
-        a.flags = spread ? 0 : 8;
-        // f32 outputs are written once and read by a LATER launch: non-temporal stores keep them from displacing the tile operands
-        // in L2 / MALL (+0.3-0.5 % on the forward, profiles/r04_nt_store.txt).  TT_CONV_NT_STORE=0: plain stores (A/B knob)
-        static const bool nt_store = [] { const char* e = getenv("TT_CONV_NT_STORE"); return e ? atoi(e) != 0 : true; }();
-        if (nt_store) a.flags |= 16;
+    // f32 outputs are written once and read by a LATER launch: non-temporal stores keep them from displacing the tile operands in
+    // L2 / MALL (+0.3-0.5 % on the forward, profiles/r04_nt_store.txt)
+    a.flags = 16;
+    if (d->in_pair || d->out_pair) {
+        TT_REQUIRE(d->dtype == TT_F32 && d->out_dtype == TT_F32 && d->weight_x3 && !d->gather_idx && !d->splitk_ws && !d->pixel_shuffle2,
+                   "tt_conv2d_fwd: in_pair / out_pair go with dense bf16x3 layers (f32 containers, weight_x3, no split-K workspace)");
+        TT_REQUIRE(!d->out_pair || (!d->res1 && !d->res2 && !d->shift_n && d->Cout % 16 == 0 && d->out_cstride % 16 == 0 &&
+                                    d->out_coff % 16 == 0 && (reinterpret_cast<uintptr_t>(d->out) & 63) == 0),
+                   "tt_conv2d_fwd: out_pair needs Cout / out_cstride / out_coff multiples of 16, a 64-byte aligned output and no "
+                   "residual / per-image shift");
+        if (d->in_pair) a.flags |= 32;
+        if (d->out_pair) a.flags |= 64;
     }
     if (query) a.flags = -1;       // launch_conv returns the split count instead of launching
     {
-        const int co_vec = d->out_dtype == TT_F32 ? 4 : 8;
+        const int co_vec = (d->out_dtype == TT_F32 && !d->out_pair) ? 4 : 8;
         const int osz = d->out_dtype == TT_F32 ? 4 : 2;
         const int cr = d->pixel_shuffle2 ? d->Cout / 4 : d->Cout;
         bool ok = (cr % co_vec == 0) && (d->out_cstride % co_vec == 0) && (d->out_coff % co_vec == 0) &&
                   (a.out_nstride % co_vec == 0) && ((reinterpret_cast<uintptr_t>(d->out) & 15) == 0);
         (void)osz;
         a.vec_epi = ok ? 1 : 0;
-        static const bool scalar_epi = getenv("TT_CONV_SCALAR_EPI") != nullptr;   // A/B knob
-        if (scalar_epi) a.vec_epi = 0;
         auto res_ok = [&](const void* r, int cs, int co_) {
             return !r || ((cs % co_vec == 0) && (co_ % co_vec == 0) && ((reinterpret_cast<uintptr_t>(r) & 15) == 0));
         };
@@ -402,6 +404,7 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     }
     hipStream_t st = (hipStream_t)stream;
     if (query) {
+        if (d->in_pair || d->out_pair) return 0;
         a.ws = nullptr;
         a.row_perm = nullptr;
         a.row_mask = nullptr;
@@ -412,6 +415,15 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
         if (d->dtype == TT_F32) return dispatch_conv<float>(a, st);
         if (d->dtype == TT_F16) return dispatch_conv<f16_t>(a, st);
         return dispatch_conv<uint16_t>(a, st);
+    }
+    if (d->in_pair || d->out_pair) {
+        TT_REQUIRE(a.vec_epi && (reinterpret_cast<uintptr_t>(d->weight_x3) & 15) == 0 && a.K % 16 == 0,
+                   "tt_conv2d_fwd: in_pair / out_pair need the vector epilogue and a 16-byte aligned weight_x3");
+        ConvArgs ax = a;
+        ax.weight = d->weight_x3;
+        TT_REQUIRE(try_launch_conv_glds_x3(ax, st), "tt_conv2d_fwd: pair-format layer outside the LDS-DMA bf16x3 kernel's contract "
+                   "(M=%d Cin=%d Cout=%d)", a.M, d->Cin, d->Cout);
+        return check_launch("tt_conv2d_fwd(glds x3, pair)");
     }
     if (!d->splitk_ws && try_launch_conv_small(a, d->dtype, st)) {
         snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_small_kernel");

@@ -40,7 +40,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // footprint as f32).  Each product is three v_mfma_f32_32x32x16_bf16: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with f32
 // accumulation -- 16 mantissa bits per operand (relative error ~1e-5 per dot product instead of bf16's 4e-3) at
 // 16/3 of the exact-f32 MFMA rate.  This is the precision mode whose outputs meet the 1e-3 tolerance.
-template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false>
+// APAIR (X3 only): the ACTIVATIONS arrive pre-split too -- the tensor holds, per 16 channels, 64 B = [hi c0-7 | hi c8-15 | lo c0-7 |
+// lo c8-15] in bf16 (the weights' pair format along the channel axis, same footprint as f32), written by the producer's epilogue
+// (tt_conv_desc.out_pair) or by an elementwise producer (tt_bilinear_up2_pair).  The hi / lo values are the ones split_frag computes,
+// so the sums are bit-identical; what disappears is the split itself: 6 VALU per element pair per USE (a 3 x 3 layer splits every
+// input element 9 x per column tile) against once per element at the producer.  For tensors whose ONLY readers are bf16x3 convolutions.
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false, bool APAIR = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64,
                              ((256 / WAVES_M / 32) * (BN / WAVES_N / 32) >= 16)  ? 1      // 128x128 per wave: 512 regs
                              : ((256 / WAVES_M / 32) * (BN / WAVES_N / 32) >= 8) ? 2      // 128x64 per wave: 256 regs
@@ -76,6 +81,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(!X3 || (sizeof(T) == 4 && BKB == 128), "x3: f32 storage, 128 B rows");
+    static_assert(!APAIR || (X3 && !GATHER), "pre-split activations: dense bf16x3 only");
     static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
     static_assert(NA_INSTR % NW == 0 && NIA >= 1 && NIB >= 1, "tile too small for the wave count");
 
@@ -104,22 +110,8 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     const int tile_n = L % tiles_n, tile_m = L / tiles_n;
     const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
     if (m0 >= Mlim) return;            // block-uniform, before any barrier
-    // Phase stagger (short-K, HBM-shaped layers).  Every tile of such a launch costs the same, so the 256 CUs run in lock
-    // step: all in their K loops (HBM idle), then all in their epilogues (one chip-wide burst of output stores and residual
-    // reads, matrix pipes idle) -- a round takes loop + burst.  Starting the first round's workgroups in four phases a
-    // quarter of a tile apart keeps a quarter of the CUs in their epilogue at any time: HBM is busy continuously, a CU's
-    // burst meets a quarter of the contention, and the later rounds inherit the offsets (a finished workgroup's CU is handed
-    // the next tile at once).  Costs 3/4 of a tile time once per launch; the dispatcher enables it from a few rounds up.
     long long* const tr = (p.trace && tid == 0 && blockIdx.y == 0) ? p.trace + (long long)blockIdx.x * 4 : nullptr;
     if (tr) tr[0] = (long long)wall_clock64();
-    if (!GATHER && p.stagger_ticks > 0 && p.m_begin == 0 && (int)blockIdx.x < p.stagger_blocks) {
-        const int phase = ((int)blockIdx.x >> 3) & 3;                  // blockIdx % 8 = XCD: four phases inside every XCD
-        if (phase) {
-            const unsigned long long t0 = wall_clock64();
-            const unsigned long long want = (unsigned long long)phase * (unsigned long long)p.stagger_ticks;
-            while (wall_clock64() - t0 < want) __builtin_amdgcn_s_sleep(16);
-        }
-    }
 
     const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
     const T* __restrict__ wgt = reinterpret_cast<const T*>(p.weight);
@@ -444,12 +436,12 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     constexpr int NKC_ = X3 ? BKB / 64 : BKB / 32;
     // spread DMA issue (below): 256-wide tiles only -- a 64 x 128 wave tile has 6 MFMAs (192 cycles) per sub-step to put one
     // 16-cycle DMA piece behind; the narrow tiles' 3-MFMA sub-steps do not cover the texture path's time for 8 waves' pieces
-    // (measured +3 % on them).  TT_GLDS_X3_SPREAD=0 (A/B knob): whole-tile issue after the barrier everywhere
-    const bool spread = BN == 256 && (p.flags & 8) == 0;
+    // (measured +3 % on them)
+    const bool spread = BN == 256;
     unsigned fa_pre[NKC_][TM], fb_pre[NKC_][TN];
 #pragma unroll
     for (int kc = 0; kc < NKC_; ++kc) {
-        const unsigned ca = X3 ? 4u * kc + 2u * hi : 2u * kc + hi;
+        const unsigned ca = X3 ? (APAIR ? 4u * kc + hi : 4u * kc + 2u * hi) : 2u * kc + hi;    // APAIR: hi chunk; lo chunk = ^ 32
         const unsigned cb = X3 ? 4u * kc + hi : 2u * kc + hi;
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa_pre[kc][i] = fa_off[i] + ((ca ^ fa_s[i]) << 4);
@@ -507,7 +499,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
             auto split_frag = [&](int i, uint4& hi_out, uint4& lo_out) {
                 asm volatile("" : "+v"(ra0[i]));
                 asm volatile("" : "+v"(ra1[i]));
-                if (TT_GLDS_DEBUG && p.act == 96) {          // debug: no operand split (raw bits as operands)
+                if (APAIR || (TT_GLDS_DEBUG && p.act == 96)) {   // pre-split activations: ra0 = hi, ra1 = lo (debug 96: raw bits)
                     hi_out = __builtin_bit_cast(uint4, ra0[i]);
                     lo_out = __builtin_bit_cast(uint4, ra1[i]);
                     return;
@@ -529,7 +521,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ra0[i] = lds_read(sbase + fa_pre[0][i]);
-                ra1[i] = lds_read(sbase + (fa_pre[0][i] ^ 16u));
+                ra1[i] = lds_read(sbase + (fa_pre[0][i] ^ (APAIR ? 32u : 16u)));
             }
             bh[0] = lds_read(sbase_b + fb_pre[0][0]);
             bl[0] = lds_read(sbase_b + (fb_pre[0][0] ^ 32u));
@@ -584,7 +576,7 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         ra0[i] = lds_read(sbase + fa_pre[kc + 1][i]);
-                        ra1[i] = lds_read(sbase + (fa_pre[kc + 1][i] ^ 16u));
+                        ra1[i] = lds_read(sbase + (fa_pre[kc + 1][i] ^ (APAIR ? 32u : 16u)));
                     }
                 }
                 if (ss + 1 < NS) {
@@ -675,7 +667,7 @@ static const void* zero_page() {
     return z;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false>
+template <typename T, int BN, int WAVES_M, int WAVES_N, int BKB, int STAGES = 3, bool GATHER = false, bool X3 = false, bool APAIR = false>
 static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0, int splits = 1, int slices = 1) {
     constexpr int BM = 256;
     constexpr int WTN = BN / WAVES_N;
@@ -688,7 +680,7 @@ static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0, int s
     size_t smem = STAGES == 23 ? (size_t)(3 * BM + 2 * BN) * BKB : (size_t)STAGES * (BM + BN) * BKB;
     const size_t epi = (size_t)(WAVES_M * WAVES_N) * 32 * (WTN + 4) * 4;
     if (smem < epi) smem = epi;
-    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER, X3>;
+    auto kern = conv_igemm_glds_kernel<T, BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER, X3, APAIR>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -699,9 +691,9 @@ static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0, int s
     a.splits = splits;
     if (splits <= 1) a.ws = nullptr;       // split-K: a.ws / a.ws_slices are the caller's (ordered slices, `slices` non-empty ranges)
     if (a.m_begin == 0)      // (the tail launch of a split keeps the main launch's label)
-        snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_igemm_glds_kernel<%s, %d, %d, %d, %d, %d, %s, %s>%s",
+        snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_igemm_glds_kernel<%s, %d, %d, %d, %d, %d, %s, %s>%s%s",
                  sizeof(T) == 4 ? "float" : "16-bit", BN, WAVES_M, WAVES_N, BKB, STAGES, GATHER ? "true" : "false",
-                 X3 ? "true" : "false", splits > 1 ? " split-K" : (m_tiles_limit > 0 ? " + tail" : ""));
+                 X3 ? "true" : "false", APAIR ? " pre-split A" : "", splits > 1 ? " split-K" : (m_tiles_limit > 0 ? " + tail" : ""));
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n), (unsigned)(splits > 1 ? slices : 1)),
                        dim3(WAVES_M * WAVES_N * 64), smem, st, a, zp, tiles_m, tiles_n);
     return 1;
@@ -713,12 +705,7 @@ static int launch_glds(ConvArgs& a, hipStream_t st, int m_tiles_limit = 0, int s
 // peeled off into a second launch of 256x64 tiles (4x as many, 1/4 the work each) that fills the chip.
 // Returns the number of row tiles the MAIN launch should cover (0: no split).
 static int tail_split_rows(const ConvArgs& a) {
-    static int enabled = -1;
-    if (enabled < 0) {
-        const char* e = getenv("TT_CONV_TAIL_SPLIT");   // A/B knob
-        enabled = e ? atoi(e) : 1;
-    }
-    if (!enabled || a.Cout % 256 != 0) return 0;
+    if (a.Cout % 256 != 0) return 0;
     const int tiles_m = div_up(a.M, 256), tiles_n = a.Cout / 256;
     const long long T = (long long)tiles_m * tiles_n;
     const int rounds = (int)((T + kNumCU - 1) / kNumCU);
@@ -733,8 +720,7 @@ static int tail_split_rows(const ConvArgs& a) {
 // tick).  Column blocks of 64 give tiles_m x Cout / 64 workgroups; the K tiles are dealt over up to 16 ranges of >= 8 tiles until
 // ~512 workgroups (two per CU) are in flight.  Returns the number of non-empty K ranges (= workspace slices), 0 = not this path.
 static int x3_splitk_plan(const ConvArgs& a, int* splits_out) {
-    static const bool on = [] { const char* e = getenv("TT_X3_SPLITK"); return e ? atoi(e) != 0 : true; }();   // A/B knob
-    if (!on || a.gather || a.m_dev || a.M < 512 || a.M > 8192 || a.Cout < 64 || a.KH * a.KW > 32) return 0;
+    if (a.gather || a.m_dev || a.M < 512 || a.M > 8192 || a.Cout < 64 || a.KH * a.KW > 32) return 0;
     if (a.Cin % 32 != 0 || a.K < 1024 || a.pixel_shuffle2) return 0;
     const int tiles = div_up(a.M, 256) * div_up(a.Cout, 64);
     const int nk = a.K / 32;
@@ -774,18 +760,17 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
     }
     if (a.m_dev || a.M < 2048 || a.KH * a.KW > 32) return 0;
     if (a.Cin % 32 != 0 || a.K < 64) return 0;       // 128 B rows = 32 f32 of one tap per K tile, >= 2 tiles
-    a.stagger_ticks = a.stagger_blocks = 0;
+    // pre-split activations (tt_conv_desc.in_pair): 16-channel pair groups must line up with the 32-channel K tiles; the
+    // compiler-scheduled tiles only (the hand-pipelined kernels weave the split into their MFMA gaps)
+    const bool apair = (a.flags & 32) != 0;
+    if (apair && (a.in_coff % 16 != 0 || a.in_cstride % 16 != 0)) return 0;
     // few output channels over very many rows (the segmentation head: 3 x 3, 64 -> 12 at 224 x 448 per image): a 256 x 32 tile,
     // two workgroups per CU; below that row count the exact-f32 register-staged kernel is as fast
     if (a.Cout < 64) {
-        if (a.Cout > 32 || a.Cout < 8 || a.M < (1 << 18) || a.K < 256) return 0;
+        if (a.Cout > 32 || a.Cout < 8) return 0;
+        if (apair) return launch_glds<float, 32, 8, 1, 128, 2, false, true, true>(a, st);
+        if (a.M < (1 << 18) || a.K < 256) return 0;
         return launch_glds<float, 32, 8, 1, 128, 2, false, true>(a, st);
-    }
-    // short-K 1 x 1 layers with at least two 256 x 128 tiles per CU: persistent workgroups that store tile i under the K loop of
-    // tile i + 1 (csrc/conv_x3_persist.hip).  TT_X3_PERSIST=0/1 (A/B knob)
-    {
-        static const bool persist = [] { const char* e = getenv("TT_X3_PERSIST"); return e ? atoi(e) != 0 : false; }();
-        if (persist && try_launch_gemm_x3_persist(a, st)) return 1;
     }
     // Tile width along N.  The widest wave tile the layer allows is the most efficient per tile (the operand split costs
     // 8/TN VALU per MFMA; measured ~1.0 / 0.85 / 0.63 relative MFMA rate for the 256 / 128 / 64 wide tiles), but a
@@ -809,61 +794,40 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
     // (long-K layers run the 128-wide tile on the hand-pipelined kernel: 404 vs 423 TF/s for the 256-wide one, profiles/r04_run3_ab.txt)
     const double c128 = a.Cout > 64 ? cost(128, (a.K >= 1152 && a.Cout % 128 == 0) ? 0.95 : 0.85) : 1e30;
     const double c64 = cost(64, 0.63);
-    static const int force = [] { const char* e = getenv("TT_GLDS_X3_TILE"); return e ? atoi(e) : 0; }();   // A/B knob
-    int bn = (c256 <= c128 && c256 <= c64) ? 256 : (c128 <= c64 ? 128 : 64);
-    if (force == 256 && wide) bn = 256;
-    if (force == 128 && a.Cout > 64) bn = 128;
-    if (force == 64) bn = 64;
-    if (force == 1) bn = wide ? 256 : (a.Cout > 64 ? 128 : 64);          // the pre-cost-model rule
-    // phase stagger of the first round (kernel comment): HBM-shaped layers = 1 x 1, K <= 1024, at least three rounds of tiles.
-    // TT_GLDS_STAGGER_US: total spread over the four phases in microseconds (A/B knob; 0 = off)
-    {
-        static const double stagger_us = [] { const char* e = getenv("TT_GLDS_STAGGER_US"); return e ? atof(e) : 0.0; }();
-        const long long tiles = (long long)tiles_m * div_up(a.Cout, bn);
-        const int per_cu = bn == 64 ? 2 : 1;                   // resident workgroups per CU of the tile
-        if (stagger_us > 0.0 && a.KH * a.KW == 1 && a.K <= 1024 && tiles >= 3LL * kNumCU * per_cu && a.m_begin == 0) {
-            a.stagger_ticks = (int)(stagger_us * 100.0 / 4.0);
-            a.stagger_blocks = kNumCU * per_cu;
-        }
-    }
+    const int bn = (c256 <= c128 && c256 <= c64) ? 256 : (c128 <= c64 ? 128 : 64);
+    // Long-K layers (K >= 1152: every 3 x 3 of the trunks) on the 256- and 128-wide tiles: four hand-pipelined waves, one per SIMD
+    // (csrc/conv_x3_pipe.hip: MFMA pipe 77 % busy against 58 %, profiles/r04_conv_sq_counters_noepilogue.txt).  Short K keeps the
+    // 8-wave tile: there the tile's prologue + epilogue dominate and eight waves issue the output stores faster than four
+    // (K = 1024: 0.203 vs 0.216 ms, K = 256 N = 1280: 0.52 vs 0.77 ms; profiles/r04_pipe_ab_first.txt).
+    // TT_X3_PIPE=0 (test hook: tests/test_conv.py compares the two families bit for bit): the compiler-scheduled tiles everywhere
+    static const bool pipe = [] { const char* e = getenv("TT_X3_PIPE"); return e ? atoi(e) != 0 : true; }();
+    const bool hand = pipe && !apair && a.K >= 1152;
     if (bn == 256) {                                                                                           // 8 x (64 x 128)
-        // TT_GLDS_X3_ASYM=0: symmetric 2-stage ring instead of 3 activation + 2 weight stages (A/B knob)
-        static const bool asym = [] { const char* e = getenv("TT_GLDS_X3_ASYM"); return e ? atoi(e) != 0 : true; }();
         const int main_rows = tail_split_rows(a);
-        // Long-K layers (every 3x3 of the trunks): four hand-pipelined waves, one per SIMD (csrc/conv_x3_pipe.hip): MFMA pipe 77 %
-        // busy against 58 % (profiles/r04_conv_sq_counters_noepilogue.txt).  Short K keeps the 8-wave tile: there the
-        // tile's prologue + epilogue dominate and eight waves issue the output stores faster than four (K = 1024: 0.203 vs
-        // 0.216 ms, K = 256 N = 1280: 0.52 vs 0.77 ms; profiles/r04_pipe_ab_first.txt).  TT_X3_PIPE=0: never; TT_X3_PIPE_MINK=k.
-        static const bool pipe = [] { const char* e = getenv("TT_X3_PIPE"); return e ? atoi(e) != 0 : true; }();
-        static const int pipe_mink = [] { const char* e = getenv("TT_X3_PIPE_MINK"); return e ? atoi(e) : 1152; }();
-        if (pipe && a.K >= pipe_mink && try_launch_conv_x3_pipe(a, st, main_rows)) { /* taken */ }
-        else if (asym) launch_glds<float, 256, 4, 2, 128, 23, false, true>(a, st, main_rows);
-        else launch_glds<float, 256, 4, 2, 128, 2, false, true>(a, st, main_rows);
+        if (hand && try_launch_conv_x3_pipe(a, st, main_rows)) { /* taken */ }
+        else if (apair) launch_glds<float, 256, 4, 2, 128, 23, false, true, true>(a, st, main_rows);
+        else launch_glds<float, 256, 4, 2, 128, 23, false, true>(a, st, main_rows);      // 3 activation + 2 weight stages = 160 KiB
         if (main_rows) {
             ConvArgs t = a;
             t.m_begin = main_rows * 256;
-            return launch_glds<float, 64, 8, 1, 128, 2, false, true>(t, st);
+            return apair ? launch_glds<float, 64, 8, 1, 128, 2, false, true, true>(t, st)
+                         : launch_glds<float, 64, 8, 1, 128, 2, false, true>(t, st);
         }
         return 1;
     }
-    // TT_GLDS_X3_STAGES=3: three LDS stages for the narrow tiles (two K tiles in flight per workgroup).  Measured and NOT
-    // the default: the 64-wide tile then holds 120 KiB and loses its second workgroup per CU (N=64 K=576: 2.13 -> 2.66 ms,
-    // K=64: 0.73 -> 0.86 ms); the 128-wide tile is unchanged (1.79 / 1.84 ms).
-    static const int stages = [] { const char* e = getenv("TT_GLDS_X3_STAGES"); return e ? atoi(e) : 2; }();   // A/B knob
+    // Narrow tiles: two LDS stages (a third costs the 64-wide tile its second workgroup per CU: N=64 K=576 2.13 -> 2.66 ms), eight
+    // waves (four waves of 64 x 64 on the 64-wide tile: 3-15 % slower, profiles/r05_x3_64wide_waves_ab.txt)
     if (bn == 128) {                                                                                           // 8 x (32 x 128)
-        // long-K layers: four hand-pipelined 64 x 128 waves (csrc/conv_x3_pipe.hip); TT_X3_PIPE128=0: never
-        static const bool pipe128 = [] { const char* e = getenv("TT_X3_PIPE128"); return e ? atoi(e) != 0 : true; }();
-        static const int pipe_mink128 = [] { const char* e = getenv("TT_X3_PIPE_MINK"); return e ? atoi(e) : 1152; }();
-        if (pipe128 && a.Cout % 128 == 0 && a.K >= pipe_mink128 && try_launch_conv_x3_pipe(a, st, 0, 128)) return 1;
-        if (stages == 3) return launch_glds<float, 128, 8, 1, 128, 3, false, true>(a, st);
-        return launch_glds<float, 128, 8, 1, 128, 2, false, true>(a, st);
+        if (hand && a.Cout % 128 == 0 && try_launch_conv_x3_pipe(a, st, 0, 128)) return 1;
+        return apair ? launch_glds<float, 128, 8, 1, 128, 2, false, true, true>(a, st)
+                     : launch_glds<float, 128, 8, 1, 128, 2, false, true>(a, st);
     }
-    if (stages == 3) return launch_glds<float, 64, 8, 1, 128, 3, false, true>(a, st);                          // 8 x (32 x 64)
-    // TT_GLDS_X3_64_WAVES=4 (A/B knob): four waves of 64 x 64 instead of eight of 32 x 64 -- every wave of the 8-wave form reads the
-    // whole 64-column weight tile from LDS (64 of the tile's 136 KiB of LDS traffic per K tile against 768 cycles of MFMAs per CU)
-    static const int waves64 = [] { const char* e = getenv("TT_GLDS_X3_64_WAVES"); return e ? atoi(e) : 8; }();
-    if (waves64 == 4) return launch_glds<float, 64, 4, 1, 128, 2, false, true>(a, st);                         // 4 x (64 x 64)
-    return launch_glds<float, 64, 8, 1, 128, 2, false, true>(a, st);
+    if (apair) {
+        static const int w64 = [] { const char* e = getenv("TT_PAIR64_WAVES"); return e ? atoi(e) : 8; }();   // (A/B, round 6)
+        if (w64 == 4) return launch_glds<float, 64, 4, 1, 128, 2, false, true, true>(a, st);                  // 4 x (64 x 64)
+        return launch_glds<float, 64, 8, 1, 128, 2, false, true, true>(a, st);
+    }
+    return launch_glds<float, 64, 8, 1, 128, 2, false, true>(a, st);                                           // 8 x (32 x 64)
 }
 
 // T16 = uint16_t (bf16) or f16_t (IEEE half): same tiles, same MFMA rate.
@@ -871,20 +835,11 @@ template <typename T16>
 static int launch_glds16(ConvArgs& a, int dtype, hipStream_t st, int min_tiles);
 
 int try_launch_conv_glds(ConvArgs& a, int dtype, hipStream_t st) {
-    static int min_tiles = -1;
-    if (min_tiles < 0) {
-        const char* e = getenv("TT_GLDS_MIN_KTILES");
-        min_tiles = e ? atoi(e) : 2;   // K = 64 1x1 layers: 0.43 -> 0.27 ms against the register-staged kernel
-    }
+    constexpr int min_tiles = 2;      // K = 64 1x1 layers: 0.43 -> 0.27 ms against the register-staged kernel
     if (a.gather) {
         // sparse 3D conv as a gathered GEMM (rulebook rows): whole 128 B+ activation rows per DMA lane group
-        static int sp = -1;
-        if (sp < 0) {
-            const char* e = getenv("TT_GLDS_GATHER");   // 0: register-staged gather kernel (A/B knob)
-            sp = e ? atoi(e) : 1;
-        }
         const bool cin_ok = a.Cin >= 16 && (a.Cin & (a.Cin - 1)) == 0;   // power of two: taps tile the 128 B rows
-        if (!sp || dtype == TT_F32 || !cin_ok || a.M < 2048 || a.Cout < 16 || a.Cout > 128) return 0;
+        if (dtype == TT_F32 || !cin_ok || a.M < 2048 || a.Cout < 16 || a.Cout > 128) return 0;
         return dtype == TT_F16 ? launch_glds16<f16_t>(a, dtype, st, min_tiles) : launch_glds16<uint16_t>(a, dtype, st, min_tiles);
     }
     if (a.m_dev || a.M < 2048 || a.Cout < 64 || a.KH * a.KW > 32) return 0;
@@ -914,15 +869,10 @@ static int launch_glds16(ConvArgs& a, int dtype, hipStream_t st, int min_tiles) 
     // Auto: Cout % 256 == 0 -> 256x256 tile of eight 128x64 waves (128 B rows if Cin % 64 == 0); short K -> four
     // 128x64 waves on 256x128; Cout <= 64 -> 256x64 tile with 128 B rows; else eight 64x64 waves on 256x128.
     // Retired after measurement (same file): 16-wave 256x256, 8x1 wave grid, 128 B rows x 3 stages (1 workgroup/CU),
-    // 128 B x 2 stages on the 256x128 tile.  TT_GLDS_VARIANT forces 0 / 1 / 2 / 6 (Cout > 64) for A/B runs.
-    static int variant = -2;
-    if (variant == -2) {
-        const char* e = getenv("TT_GLDS_VARIANT");
-        variant = e ? atoi(e) : -1;
-    }
+    // 128 B x 2 stages on the 256x128 tile.
     if (a.Cout > 64) {
-        int v = variant;
-        if (v < 0) {
+        int v;
+        {
             const long long tiles256 = (long long)div_up(a.M, 256) * (a.Cout / 256);
             if (a.Cout % 256 == 0 && tiles256 >= 200) v = (a.Cin % 64 == 0) ? 6 : 2;
             else if (a.K <= 512) v = 1;
@@ -943,7 +893,7 @@ static int launch_glds16(ConvArgs& a, int dtype, hipStream_t st, int min_tiles) 
     }
     // Cout <= 64 (the 224x448 UNet / stem-level layers): 128 B rows in 2 stages (80 KiB, 2 workgroups / CU)
     // measured +17 % over 64 B rows x 3 stages (1.61 vs 1.89 ms on M=6.4M K=1152)
-    if (a.Cin % 64 == 0 && variant != 0) return launch_glds<T16, 64, 8, 1, 128, 2>(a, st);
+    if (a.Cin % 64 == 0) return launch_glds<T16, 64, 8, 1, 128, 2>(a, st);
     return launch_glds<T16, 64, 8, 1, 64>(a, st);
 }
 

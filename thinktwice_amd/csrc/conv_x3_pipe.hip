@@ -811,11 +811,6 @@ __global__ __launch_bounds__(256, 1) void conv_x3_run3_kernel(const ConvArgs p, 
 #endif
 }
 
-static bool grid_is_2x2() {
-    static const int grid = [] { const char* e = getenv("TT_X3_PIPE"); return e ? atoi(e) : 2; }();
-    return grid == 1;
-}
-
 static const void* pipe_zero_page() {
     static void* z = nullptr;
     if (!z) {
@@ -834,10 +829,10 @@ int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int 
     if (m_tiles_limit > 0 && m_tiles_limit < tiles_m) tiles_m = m_tiles_limit;
     const int tiles_n = a.Cout / bn;
     // 3 x 3 stride-1 "same" convolutions over a dense batch: the run-staged form (one staged pixel run per filter row serves
-    // its three taps).  TT_X3_RUN3=0: the per-tap form everywhere (A/B knob)
+    // its three taps).  TT_X3_RUN3=0 (test hook: tests/test_conv.py compares the two forms bit for bit): the per-tap form everywhere
     static const bool run3 = [] { const char* e = getenv("TT_X3_RUN3"); return e ? atoi(e) != 0 : true; }();
     if (run3 && a.KW == 3 && a.KH <= 5 && a.stride == 1 && a.dil == 1 && a.pad == 1 && a.OH == a.H && a.OW == a.W &&
-        (a.N == 1 || a.in_nstride == (long long)a.H * a.W * a.in_cstride) && !grid_is_2x2()) {
+        (a.N == 1 || a.in_nstride == (long long)a.H * a.W * a.in_cstride)) {
         const size_t smem_r = (size_t)2 * 288 * 128 + (size_t)2 * bn * 128 + 256;
         auto kr = bn == 128 ? conv_x3_run3_kernel<128> : conv_x3_run3_kernel<256>;
         static bool attr_r = false;
@@ -858,15 +853,14 @@ int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int 
     }
     // activation ring 3 x 32 KiB + weight ring 2 x (bn x 128 B); the epilogue stages 4 x 32 x (WTN + 4) floats
     size_t smem = (size_t)(3 * 256 + 2 * bn) * 128;
-    const size_t epi = (size_t)4 * 32 * ((bn == 128 ? 128 : (grid_is_2x2() ? 128 : 256)) + 4) * 4;
+    const size_t epi = (size_t)4 * 32 * ((bn == 128 ? 128 : 256) + 4) * 4;
     if (smem < epi) smem = epi;
-    // wave grid: 4 x 1 (64 x 256 per wave: every activation fragment is split by ONE wave) or 2 x 2 (128 x 128); TT_X3_PIPE=2 / 1
-    static const int grid = [] { const char* e = getenv("TT_X3_PIPE"); return e ? atoi(e) : 2; }();
-    auto kern = bn == 128 ? conv_x3_pipe_kernel<4, 1, 128> : (grid == 1 ? conv_x3_pipe_kernel<2, 2> : conv_x3_pipe_kernel<4, 1>);
+    // wave grid 4 x 1: 64 x 256 (64 x 128 on the 128-wide tile) per wave -- every activation fragment is split by ONE wave (the
+    // 2 x 2 grid of 128 x 128 waves measured slower, profiles/r04_pipe_ab_grids.txt)
+    auto kern = bn == 128 ? conv_x3_pipe_kernel<4, 1, 128> : conv_x3_pipe_kernel<4, 1>;
     static bool attr_set = false;
     if (!attr_set) {
         const int full = (3 * 256 + 2 * 256) * 128;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pipe_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, full);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pipe_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, full);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pipe_kernel<4, 1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, full);
         attr_set = true;
@@ -875,7 +869,7 @@ int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int 
     a.splits = 1;
     a.ws = nullptr;
     if (a.m_begin == 0)
-        snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_x3_pipe_kernel<%s>%s", bn == 128 ? "4, 1, 128" : (grid == 1 ? "2, 2" : "4, 1"),
+        snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_x3_pipe_kernel<%s>%s", bn == 128 ? "4, 1, 128" : "4, 1",
                  m_tiles_limit > 0 ? " + tail" : "");
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), smem, st, a, zp, tiles_m, tiles_n);
     return 1;

@@ -179,6 +179,52 @@ __global__ void bilinear_up2_ac_kernel(const T* __restrict__ in, T* __restrict__
     }
 }
 
+// ---- the same, f32 -> bf16x3 PAIR format (tt_conv_desc.in_pair): a thread owns 8 channels and writes their bf16 hi halves into
+// the first 32 B of the 16-channel group (second 16 B for channels 8-15), the lo halves 32 B further -- hi = rne(v),
+// lo = rne(v - hi): the split the consuming convolution would otherwise redo for every tap and column tile
+__global__ void bilinear_up2_ac_pair_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C) {
+    const int cv = C / 8, OH = 2 * H, OW = 2 * W;
+    const float sh = (OH > 1) ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+    const float sw = (OW > 1) ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    const long long total = (long long)N * OH * OW * cv;
+    TT_GRID_STRIDE(i, total) {
+        const int c = (int)(i % cv);
+        long long r = i / cv;
+        const int ox = (int)(r % OW); r /= OW;
+        const int oy = (int)(r % OH);
+        const long long n = r / OH;
+        const float fy = sh * oy, fx = sw * ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = fy - y0, lx = fx - x0;
+        const float* base = in + n * H * W * C + c * 8;
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            Vec<float> a, b, cc, d;
+            a.load(base + ((long long)y0 * W + x0) * C + 4 * h);
+            b.load(base + ((long long)y0 * W + x1) * C + 4 * h);
+            cc.load(base + ((long long)y1 * W + x0) * C + 4 * h);
+            d.load(base + ((long long)y1 * W + x1) * C + 4 * h);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float top = (1.f - lx) * a.v[k] + lx * b.v[k];
+                const float bot = (1.f - lx) * cc.v[k] + lx * d.v[k];
+                v[4 * h + k] = (1.f - ly) * top + ly * bot;
+            }
+        }
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            lo[e] = pack_bf16x2(v[2 * e] - __uint_as_float(hi[e] << 16), v[2 * e + 1] - __uint_as_float(hi[e] & 0xffff0000u));
+        }
+        float* g = out + (i / cv) * C + (c >> 1) * 16 + (c & 1) * 4;        // pixel row, 16-channel group, 8-channel half
+        *reinterpret_cast<uint4*>(g) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(g + 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
 // ---- per-(image, channel) spatial reductions: mode 0 = mean (AdaptiveAvgPool2d(1), lss.py:80),
 //      mode 1 = 0.5*mean + 0.5*max (SEModule pooling, code/utils.py:91-92).  One block per image
 //      and 64-channel slab; out f32 [N, C].
@@ -454,6 +500,13 @@ extern "C" int tt_bilinear_up2(const void* in, void* out, int N, int H, int W, i
     TT_DISPATCH(dtype, hipLaunchKernelGGL(bilinear_up2_ac_kernel<T>, dim3(grid_for(total)), dim3(256), 0,
                                           (hipStream_t)stream, (const T*)in, (T*)out, N, H, W, C));
     return check_launch("tt_bilinear_up2");
+}
+
+extern "C" int tt_bilinear_up2_pair(const float* in, float* out, int N, int H, int W, int C, void* stream) {
+    TT_REQUIRE(in && out && C % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 63) == 0, "tt_bilinear_up2_pair: C %% 16, 64 B aligned out");
+    const long long total = (long long)N * 4 * H * W * (C / 8);
+    hipLaunchKernelGGL(bilinear_up2_ac_pair_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, N, H, W, C);
+    return check_launch("tt_bilinear_up2_pair");
 }
 
 extern "C" int tt_spatial_pool(const void* in, float* out, int N, int HW, int C, int cstride, int coff, int mode,

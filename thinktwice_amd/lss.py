@@ -82,7 +82,13 @@ class _ResNet50:
         for stage in self.blocks:
             for blk in stage:
                 idt = blk["ds"](x) if blk["ds"] is not None else x
-                y = blk["c2"](blk["c1"](x))
+                # conv1's output has one reader, the 3 x 3 conv2: pre-split (pair format) where conv2 runs on the compiler-scheduled
+                # LDS-DMA tile (64 output channels: layer1 -- the hand-pipelined kernels of the wider stages split in their MFMA gaps)
+                c2 = blk["c2"]
+                rows2 = x.shape[0] * (x.shape[1] // c2.stride) * (x.shape[2] // c2.stride)
+                pr = (c2.w_x3 is not None and not layers.BN_TRAIN and c2.w.shape[0] == 64 and
+                      ops.pair_ok(rows2, c2.w.shape[-1], c2.w.shape[0]))
+                y = c2(blk["c1"](x, out_pair=pr), in_pair=pr)
                 x = blk["c3"](y, res1=idt)          # relu(bn3(conv3) + identity)
             outs.append(x)
         return outs
@@ -338,11 +344,18 @@ class LSS:
         self.up["unet_layer2"](d3, out=cat2, out_coff=0)
         d2 = self.upc["unet_layer2"](cat2)
         from . import autodiff
-        d1 = self.u0a(ops.bilinear_up2(d2))
-        NI, H, W, _ = d1.shape
+        NI, h2, w2, _ = d2.shape
+        H, W = 2 * h2, 2 * w2
+        fused = autodiff.TAPE is None and not layers.BN_TRAIN and self.dtype == torch.float32
+        # the upsampled map and unet_layer0.1's output have ONE reader each, a bf16x3 convolution: they are produced pre-split
+        # (pair format, tt_conv_desc.in_pair) -- same sums, the operand split once per element instead of once per tap
+        x3 = self.u0a.w_x3 is not None
+        p_up = x3 and ops.pair_ok(NI * H * W, 128, 64)
+        p_mid = fused and x3 and self.seg_fused.w_x3 is not None and ops.pair_ok(NI * H * W, 64, self.seg_fused.w.shape[0])
+        d1 = self.u0a(ops.bilinear_up2(d2, out_pair=p_up), in_pair=p_up, out_pair=p_mid)
         seg = torch.zeros(NI, H, W, self.seg_cp, dtype=self.dtype, device=d1.device)
-        if autodiff.TAPE is None and not layers.BN_TRAIN and self.dtype == torch.float32:
-            self.seg_fused(d1, out=seg)          # conv_last o unet_layer0.3 as one convolution (load_state_dict)
+        if fused:
+            self.seg_fused(d1, out=seg, in_pair=p_mid)   # conv_last o unet_layer0.3 as one convolution (load_state_dict)
         else:
             self.conv_last(self.u0b(d1), out=seg)
         return seg

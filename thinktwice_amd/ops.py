@@ -115,7 +115,7 @@ class _ConvDesc(ctypes.Structure):
         ("act", _c), ("dtype", _c), ("out_dtype", _c),
         ("gather_idx", ctypes.c_void_p), ("m_dev", ctypes.c_void_p), ("splitk_ws", ctypes.c_void_p),
         ("weight_x3", ctypes.c_void_p), ("row_perm", ctypes.c_void_p), ("row_mask", ctypes.c_void_p),
-        ("splitk_slices", _c),
+        ("splitk_slices", _c), ("in_pair", _c), ("out_pair", _c),
     ]
 
 
@@ -243,12 +243,15 @@ def sp_from_dense(gdense, coords, rows, max_rows, dims, grows):
 def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=None, res1_coff=0,
            res2=None, res2_coff=0, out=None, out_coff=0, in_coff=0, cin=None, pixel_shuffle2=False,
            shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None, splitk_ws=None,
-           in_cstride=None, w_x3=None, _no_tape=False, stop_grad=False, bn_raw=False):
+           in_cstride=None, w_x3=None, _no_tape=False, stop_grad=False, bn_raw=False, in_pair=False, out_pair=False):
     """Channel-last implicit-GEMM convolution on MFMA (tt_conv2d_fwd).
 
     x   [N,H,W,Cs]  (f32 or bf16); channels [in_coff, in_coff+cin) are convolved
     w   [Cout,KH,KW,cin] same dtype (for pixel_shuffle2: [4*Cout_real,1,1,cin])
     out [N,OH,OW,Ct] written at channel offset out_coff (allocated if None)
+    in_pair / out_pair (bf16x3 layers only): x is / out becomes a PAIR-format tensor (an f32-typed container holding, per 16
+    channels, the bf16 hi and lo halves the kernel's operand split would produce: tt_conv_desc.in_pair).  Only for tensors whose
+    every reader is a bf16x3 convolution (`pair_ok(rows)` says whether a layer of that many output rows takes one).
     in_cstride / out_hw: "row-run" form -- the kernel reads `cin` CONTIGUOUS elements starting at pixel (ih, iw) of a
     tensor whose pixels are only Cs < cin elements apart (a run of cin/Cs pixels along W), with the output size given
     explicitly; used for the 7x7/2 stem (lss.py).
@@ -284,6 +287,11 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     d.res2 = _dp(res2); d.res2_cstride = 0 if res2 is None else res2.shape[-1]; d.res2_coff = res2_coff
     d.act = act; d.dtype = dtype_code(x); d.out_dtype = dtype_code(out)
     from . import autodiff
+    if in_pair or out_pair:
+        assert w_x3 is not None and x.dtype == torch.float32 and out.dtype == torch.float32 and splitk_ws is None
+        if autodiff.TAPE is not None:
+            raise _lib.TTError("conv2d: pair-format activations are an inference-path layout (the tape reads f32 tensors)")
+        d.in_pair, d.out_pair = int(bool(in_pair)), int(bool(out_pair))
     if w_x3 is not None:       # (before the split-K query: with a bf16x3 operand the query answers for the bf16x3 split-K tile)
         assert x.dtype == torch.float32 and w_x3.shape == w.shape and w_x3.is_contiguous()
         # the training step (forward under the tape, and the backward's recomputations / input-gradient convolutions, which
@@ -292,7 +300,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
         x3_splitk = autodiff.TAPE is None and not _no_tape
         if x3_splitk:
             d.weight_x3 = w_x3.data_ptr()
-    if _AUTO_SPLITK and splitk_ws is None and N * OH * OW <= 4096 and KH * KW * Cin >= 2048:
+    if _AUTO_SPLITK and splitk_ws is None and not (in_pair or out_pair) and N * OH * OW <= 4096 and KH * KW * Cin >= 2048:
         # few rows, very long K (BEV-update conv K=18720, flatten MLPs): cross-workgroup split-K with an f32 workspace
         # beats conv_small.hip's in-workgroup split there (277 vs 416 us on the BEV-update conv: the direct 32 B/row
         # operand loads of the small kernel waste L2 sectors on a 10 MB weight matrix).  TT_CONV_AUTO_SPLITK=0 disables.
@@ -524,9 +532,24 @@ def upsample_nearest_add_(dst, src):
     return dst
 
 
-def bilinear_up2(x):
+PAIR = os.environ.get("TT_X3_PAIR", "1") != "0"     # A/B knob: 0 = every activation tensor stays plain f32
+
+
+def pair_ok(rows, cin=32, cout=64):
+    """Whether a bf16x3 convolution with this many output rows / these channel counts accepts a pair-format input
+    (tt_conv_desc.in_pair: the LDS-DMA kernel's contract; up to 4096 rows a layer runs the exact-f32 latency kernel, which a
+    pair-format layer could not take).  Producer and consumer of a tensor ask with the CONSUMER's numbers."""
+    from . import autodiff
+    return PAIR and autodiff.TAPE is None and rows > 4096 and cin % 32 == 0 and (8 <= cout <= 32 or cout >= 64)
+
+
+def bilinear_up2(x, out_pair=False):
     N, H, W, C = x.shape
     out = torch.empty(N, 2 * H, 2 * W, C, dtype=x.dtype, device=x.device)
+    if out_pair:      # f32 -> bf16x3 pair format for a consumer that is a bf16x3 convolution (conv2d(in_pair=True))
+        assert x.dtype == torch.float32 and x.is_contiguous() and C % 16 == 0
+        check(lib().tt_bilinear_up2_pair(ptr(x), ptr(out), _c(N), _c(H), _c(W), _c(C), _st(x)), "tt_bilinear_up2_pair")
+        return out
     check(lib().tt_bilinear_up2(ptr(x), ptr(out), _c(N), _c(H), _c(W), _c(C), _c(dtype_code(x)), _st(x)),
           "tt_bilinear_up2")
     from . import autodiff

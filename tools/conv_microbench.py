@@ -24,8 +24,10 @@ def main():
     res = torch.randn(N, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, Cout, device="cuda").to(dt) \
         if os.environ.get("TT_MB_RES") else None
     from thinktwice_amd import weights
-    wx = weights.split_pairs_x3(w) if mode == "x3" else None
-    conv = lambda: ops.conv2d(x, w, stride=stride, pad=pad, act=act, res1=res, w_x3=wx)
+    wx = weights.split_pairs_x3(w) if mode in ("x3", "x3p") else None
+    if mode == "x3p":       # pre-split (pair-format) activations: tt_conv_desc.in_pair
+        x = weights.split_pairs_x3(x)
+    conv = lambda: ops.conv2d(x, w, stride=stride, pad=pad, act=act, res1=res, w_x3=wx, in_pair=mode == "x3p")
     for _ in range(3):
         y = conv()
     torch.cuda.synchronize()
@@ -38,7 +40,7 @@ def main():
     ms = e0.elapsed_time(e1) / iters
     M = y.shape[0] * y.shape[1] * y.shape[2]
     fl = 2.0 * M * Cout * k * k * Cin
-    print(f"M={M} N={Cout} K={k*k*Cin} {mode}: {ms:.3f} ms  {fl/ms/1e9:.1f} TF/s  env SETPRIO={os.environ.get('TT_GLDS_SETPRIO')} VARIANT={os.environ.get('TT_GLDS_VARIANT')} MINK={os.environ.get('TT_GLDS_MIN_KTILES')} ACT={act} RES={res is not None} SCALAR_EPI={os.environ.get('TT_CONV_SCALAR_EPI')}")
+    print(f"M={M} N={Cout} K={k*k*Cin} {mode}: {ms:.3f} ms  {fl/ms/1e9:.1f} TF/s  ACT={act} RES={res is not None}  {ops._last_conv_kernel()}")
     # reference point: a plain device copy of the output-sized tensor (read + write M*N elements)
     src = torch.empty_like(y)
     for _ in range(3):

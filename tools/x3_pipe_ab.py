@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""A/B of the bf16x3 256x256 conv tile: four hand-pipelined 128x128 waves (TT_X3_PIPE=1, csrc/conv_x3_pipe.hip) against the
-8-wave tile (TT_X3_PIPE=0, conv_igemm_glds.hip X3 body).  Each arm runs in its own process (the knob is read once); the
+"""A/B of the bf16x3 conv tiles: the hand-pipelined kernels of the long-K layers (product, csrc/conv_x3_pipe.hip) against the
+compiler-scheduled 8-wave tiles everywhere (TT_X3_PIPE=0, conv_igemm_glds.hip X3 body).  Each arm runs in its own process (the knob is read once); the
 outputs of the two arms must be BIT-IDENTICAL (same operand split, same K order, same term order), and both are checked
 against the exact-f32 kernel.  Usage:  python tools/x3_pipe_ab.py [rounds]     (needs a GPU)"""
 import json
@@ -78,16 +78,13 @@ def main():
         worker(sys.argv[2])
         return
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    arms = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 2]      # 0: 8-wave tile, 1: 2 x 2 pipe, 2: 4 x 1 pipe
-    shapes = SHAPES_128 if os.environ.get("TT_AB_SET") == "128" else SHAPES                 # TT_AB_SET=128: the 128-wide tile (arms 0 / 1)
+    arms = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1]      # TT_X3_PIPE: 0 = 8-wave tiles only, 1 = product
+    shapes = SHAPES_128 if os.environ.get("TT_AB_SET") == "128" else SHAPES                 # TT_AB_SET=128: shapes that take the 128-wide tile
     outs = {a: [] for a in arms}
     for rd in range(rounds):
         for arm in arms:
             f = tempfile.mktemp(suffix=".json")
-            if os.environ.get("TT_AB_SET") == "128":
-                env = dict(os.environ, TT_X3_PIPE128=str(arm), TT_GLDS_X3_TILE="128", TT_X3_PIPE_MINK="1152")
-            else:
-                env = dict(os.environ, TT_X3_PIPE=str(arm), TT_GLDS_X3_TILE="256", TT_X3_PIPE_MINK="0")   # every shape on the 256-wide tile
+            env = dict(os.environ, TT_X3_PIPE=str(arm))
             subprocess.run([sys.executable, __file__, "worker", f], check=True, env=env)
             outs[arm].append(json.load(open(f)))
     ok = True
