@@ -227,7 +227,8 @@ int tt_mlp_chain(const float* x, long long R, int x_stride, int nstages, const t
  * until tt_clear_device_faults().  tt_device_faults(): non-blocking read of that word for the current device (check it after any
  * synchronisation with the forward's streams -- thinktwice_amd does after the D2H copy of tt_action_post's result and at the
  * start of every forward); tt_mlp_chain_wide_faults(): the same after a hipDeviceSynchronize().  Ticket counters are per
- * device; launches recorded into a HIP graph claim theirs permanently (a replay reuses the recorded counter). */
+ * device; launches recorded into a HIP graph claim theirs permanently (a replay reuses the recorded counter); when those
+ * are used up the call returns -4 (nothing launched): record tt_mlp_chain instead. */
 long long tt_mlp_chain_wide_workspace_bytes(long long R, int nstages, const tt_chain_stage* stages);
 int tt_mlp_chain_wide(const float* x, long long R, int x_stride, int nstages, const tt_chain_stage* stages, int n_groups,
                       void* workspace, long long workspace_bytes, void* stream);

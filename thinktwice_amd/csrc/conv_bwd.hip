@@ -812,24 +812,12 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_finish_kernel(const flo
 // TT_WGRAD_XCD=1: XCD-contiguous workgroup -> tile order.  Measured (MI355X, 3x3 layers of the camera trunk at batch 8): no gain
 // where the grid is large (256 -> 256: 65.0 vs 63.8 TF/s) and a loss where it is small (64 -> 64: 36.3 vs 55.1 TF/s; a
 // training iteration 1701 vs 1368 ms), so the default is the identity mapping.
-static bool wgrad_xcd_remap() {
-    static const bool on = [] {
-        const char* e = getenv("TT_WGRAD_XCD");
-        return e && e[0] == '1';
-    }();
-    return on;
-}
-
 // tile of one wave in 32-channel blocks per side: 4 (128 channels) where the side has >= 128, 1 where it has <= 32 (the
 // segmentation / depth heads, the stem's 3 input channels: a 64-wide tile would multiply mostly zeros), else 2.  2 x 2 is the
 // 64 x 64 workgroup-tile kernel, everything else the per-wave-tile kernel.  TT_WGRAD_WIDE=0: always 2 x 2.
 static void wgrad_blocks(int Cout, int Cin, int* bi, int* bj) {
-    static const bool wide = [] {
-        const char* e = getenv("TT_WGRAD_WIDE");
-        return !(e && e[0] == '0');
-    }();
-    *bi = !wide ? 2 : (Cout >= 128 ? 4 : (Cout <= 32 ? 1 : 2));
-    *bj = !wide ? 2 : (Cin >= 128 ? 4 : (Cin <= 32 ? 1 : 2));
+    *bi = Cout >= 128 ? 4 : (Cout <= 32 ? 1 : 2);
+    *bj = Cin >= 128 ? 4 : (Cin <= 32 ? 1 : 2);
 }
 
 static int wgrad_splits(int N, int OH, int Cout, int Cin, int taps) {
@@ -888,9 +876,8 @@ static int wgrad_run(const float* x, int N, int H, int W, int Cin, int x_cstride
     a.OH = OH; a.OW = OW; a.Cout = Cout; a.dy_cstride = dy_cstride; a.dy_coff = dy_coff;
     a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil; a.cin_p = cin_pad;
     hipStream_t st = (hipStream_t)stream;
-    // >= 64 channels on both sides: the LDS-staged bf16x3 kernel (TT_WGRAD_LDS=0: A/B knob, the f32-MFMA wave-tile form)
-    static const bool lds_on = [] { const char* e = getenv("TT_WGRAD_LDS"); return !(e && e[0] == '0'); }();
-    if (x3 && lds_on && Cout >= 64 && Cin >= 64 && Cout % 4 == 0 && Cin % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0 &&
+    // >= 64 channels on both sides: the LDS-staged bf16x3 kernel (iteration 962 -> 820 ms against the f32-MFMA wave-tile form)
+    if (x3 && Cout >= 64 && Cin >= 64 && Cout % 4 == 0 && Cin % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0 &&
         dy_cstride % 4 == 0 && dy_coff % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
         const float* zp = wgrad_zero_page();
         // the kernel walks image rows in 32-pixel segments: a 1x1 / stride-1 / unpadded layer (linear layers over rows: OW = 1)
@@ -960,9 +947,9 @@ static int wgrad_run(const float* x, int N, int H, int W, int Cin, int x_cstride
     const unsigned tiles = (unsigned)(div_up(Cout, 32 * bi) * a.ci_tiles * taps);
     int slices = splits;
     if (bi == 2 && bj == 2) {
-        const bool remap = wgrad_xcd_remap() && taps > 1;
-        a.xcd_tiles = remap ? (int)tiles : 0;
-        hipLaunchKernelGGL(conv_wgrad_kernel, dim3(remap ? (tiles + 7u) / 8u * 8u : tiles, (unsigned)splits), dim3(256), 0, st, a);
+        // (an XCD-contiguous tile order measured slower here: 36 vs 55 TF/s on 64 -> 64; identity mapping)
+        a.xcd_tiles = 0;
+        hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, st, a);
     } else {
         a.xcd_tiles = 0;
         slices = splits * 4;
@@ -1067,16 +1054,12 @@ extern "C" int tt_gather_conv_wgrad(const float* x, int x_cstride, int Cin, cons
     hipStream_t st = (hipStream_t)stream;
     const unsigned tiles = (unsigned)(div_up(Cout, 32 * bi) * a.ci_tiles * taps);
     if (bi == 2 && bj == 2) {
-        const bool remap = wgrad_xcd_remap() && taps > 1;
-        a.xcd_tiles = remap ? (int)tiles : 0;
-        hipLaunchKernelGGL(gather_wgrad_kernel, dim3(remap ? (tiles + 7u) / 8u * 8u : tiles, (unsigned)splits), dim3(256), 0, st, a);
-    } else {
-        static const bool skip = [] {
-            const char* e = getenv("TT_GATHER_WGRAD_SKIP");
-            return !(e && e[0] == '0');
-        }();
+        // (an XCD-contiguous tile order measured slower here: 36 vs 55 TF/s on 64 -> 64; identity mapping)
         a.xcd_tiles = 0;
-        a.skip_empty = skip ? 1 : 0;
+        hipLaunchKernelGGL(gather_wgrad_kernel, dim3(tiles, (unsigned)splits), dim3(256), 0, st, a);
+    } else {
+        a.xcd_tiles = 0;
+        a.skip_empty = 1;
         const dim3 grid(tiles, (unsigned)splits);
         switch (bi * 8 + bj) {
 #define TT_GW(BI_, BJ_) \

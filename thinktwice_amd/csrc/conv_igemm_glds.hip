@@ -650,10 +650,10 @@ void conv_igemm_glds_kernel(const ConvArgs p, const void* zero_page,
     __syncthreads();   // all waves done with the last stage before the epilogue reuses LDS
     if (tr) tr[2] = (long long)wall_clock64();
     conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, smem, wave, lane, wm, wn, m0, n0, Mlim);
-    if (tr) {
-        __syncthreads();                                                            // (trace only) the slowest wave's epilogue
+    if (p.trace && blockIdx.y == 0) {                                               // block-uniform: every wave takes the barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tr[3] = (long long)wall_clock64();
+        __syncthreads();                                                            // (trace only) the slowest wave's epilogue
+        if (tr) tr[3] = (long long)wall_clock64();
     }
 #endif
 }
@@ -822,12 +822,9 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
         return apair ? launch_glds<float, 128, 8, 1, 128, 2, false, true, true>(a, st)
                      : launch_glds<float, 128, 8, 1, 128, 2, false, true>(a, st);
     }
-    if (apair) {
-        static const int w64 = [] { const char* e = getenv("TT_PAIR64_WAVES"); return e ? atoi(e) : 8; }();   // (A/B, round 6)
-        if (w64 == 4) return launch_glds<float, 64, 4, 1, 128, 2, false, true, true>(a, st);                  // 4 x (64 x 64)
-        return launch_glds<float, 64, 8, 1, 128, 2, false, true, true>(a, st);
-    }
-    return launch_glds<float, 64, 8, 1, 128, 2, false, true>(a, st);                                           // 8 x (32 x 64)
+    // (pre-split activations: four waves of 64 x 64 measured 1-5 % slower than eight of 32 x 64 here too, profiles/r06_pair_format.txt)
+    return apair ? launch_glds<float, 64, 8, 1, 128, 2, false, true, true>(a, st)                              // 8 x (32 x 64)
+                 : launch_glds<float, 64, 8, 1, 128, 2, false, true>(a, st);
 }
 
 // T16 = uint16_t (bf16) or f16_t (IEEE half): same tiles, same MFMA rate.

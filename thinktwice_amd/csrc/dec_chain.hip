@@ -815,8 +815,12 @@ extern "C" int tt_mlp_chain_wide(const float* x, long long R, int x_stride, int 
         cap = hipStreamCaptureStatusNone;
     }
     if (cap == hipStreamCaptureStatusActive) {          // replayed with these arguments: the slots are this launch's for good
-        TT_REQUIRE(P->next_captured + row_groups <= (unsigned)kCapturedSlots,
-                   "tt_mlp_chain_wide: the %d ticket slots reserved for graph-captured launches are used up", kCapturedSlots);
+        if (P->next_captured + row_groups > (unsigned)kCapturedSlots) {
+            // a process that keeps re-capturing graphs: captured launches own their slots for good.  Distinct code: the caller
+            // records the one-workgroup-per-row-block chain (tt_mlp_chain) instead (ops.mlp_chain does)
+            tt::set_error("tt_mlp_chain_wide: the %d ticket slots reserved for graph-captured launches are used up", kCapturedSlots);
+            return -4;
+        }
         a.tickets = P->tickets + (size_t)(kEagerSlots + P->next_captured) * 16;
         P->next_captured += (unsigned)row_groups;
     } else {

@@ -26,6 +26,10 @@
 
 #include "conv_common.h"
 
+#ifndef TT_SP_DEBUG
+#define TT_SP_DEBUG 0
+#endif
+
 namespace tt {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -201,11 +205,11 @@ __global__ __launch_bounds__(WR * WC * 64, 1) void sp_conv_runs_kernel(const Con
 
     // per-lane constants of the DMA slots: instruction i covers stage rows 8i .. 8i+7, lane = (row, 16 B position)
     const int d_row = lane >> 3, d_pos = lane & 7;
-    // measurement knobs (TT_SP_DEBUG, tools only; 0 in the product): bit 4 = no activation DMA after the first stage,
-    // bit 5 = no weight DMA after the first stage, bit 6 = no MFMA phase
-    const bool dbg_no_a = (p.flags & 16) != 0, dbg_no_b = (p.flags & 32) != 0, dbg_no_mfma = (p.flags & 64) != 0;
-    // bit 7 = no operand split (raw bits as bf16), bit 8 = every lane reads the zero row (no gather bank conflicts)
-    const bool dbg_no_split = (p.flags & 128) != 0, dbg_zero_a = (p.flags & 256) != 0;
+    // ablations (compile-time: -DTT_SP_DEBUG=bits, profiles/r03_sparse_runs_ablation.txt; 0 in the product): 1 = no activation DMA
+    // after the first stage, 2 = no weight DMA after the first stage, 4 = no MFMA phase, 8 = no operand split (raw bits as bf16),
+    // 16 = every lane reads the zero row (no gather bank conflicts)
+    constexpr bool dbg_no_a = (TT_SP_DEBUG & 1) != 0, dbg_no_b = (TT_SP_DEBUG & 2) != 0, dbg_no_mfma = (TT_SP_DEBUG & 4) != 0;
+    constexpr bool dbg_no_split = (TT_SP_DEBUG & 8) != 0, dbg_zero_a = (TT_SP_DEBUG & 16) != 0;
     bool first_issue = true;
     // Address diet: everything about a DMA slot that does not change from stage to stage is a per-lane 32-bit element
     // offset computed once (weights: row n, tap t, swizzled chunk; activations: swizzled chunk); per stage a slot costs a
@@ -413,8 +417,6 @@ static int launch_sp_runs(ConvArgs& a, hipStream_t st) {
     a.splits = 1;
     a.ws = nullptr;
     a.m_begin = 0;
-    static const int dbg = [] { const char* e = getenv("TT_SP_DEBUG"); return e ? atoi(e) : 0; }();
-    a.flags = (a.flags & 15) | (dbg << 4);
     snprintf(g_conv_kernel, sizeof(g_conv_kernel), "sp_conv_runs_kernel<%d, %d, %d>", NCB, WR, WC);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles_m), dim3(NW * 64), smem, st, a, tiles_m);
     return 1;
@@ -423,8 +425,7 @@ static int launch_sp_runs(ConvArgs& a, hipStream_t st) {
 // bf16x3 gathered conv with 27 taps in [kz][ky][kx] order (3x3x3 SubM / strided sparse conv), Cin a multiple of 32,
 // Cout 32 / 64 / 128.  `a.weight` = pre-split pair-format weights.  Returns 0 when the shape is not covered.
 int try_launch_sp_conv_runs(ConvArgs& a, hipStream_t st) {
-    static const int enabled = [] { const char* e = getenv("TT_SP_RUNS"); return e ? atoi(e) : 1; }();   // A/B knob
-    if (!enabled || !a.gather || a.row_perm || a.KH != 1 || a.KW != kG * kNG) return 0;
+    if (!a.gather || a.row_perm || a.KH != 1 || a.KW != kG * kNG) return 0;
     // strided sparse convs (the caller states stride 2): the inputs of a (dz, dy) group sit on every other line, the
     // contiguous range is ~4x the tile and is walked in mostly-empty chunks (measured 0.74 -> 4.1 ms): gather kernel
     if (a.stride != 1) return 0;

@@ -1378,19 +1378,16 @@ extern "C" int tt_voxel_pool_fwd(int batch_size, int num_points, int num_channel
 static void launch_planned(int C, int cpg, int segcap, int ngroups, const int* order, const int* cell_start, const int* seg_off,
                            const float* input_features, float* output_features, float* partial, hipStream_t st) {
     const unsigned blocks = (unsigned)div_up((long long)segcap * ngroups, 4);          // 4 waves per workgroup
-    static const int rf = [] { const char* e = getenv("TT_VP_PLAN_ROWS_IN_FLIGHT"); return e ? atoi(e) : 32; }();
-    static const bool nt = [] { const char* e = getenv("TT_VP_NT"); return e ? atoi(e) != 0 : true; }();
+    // 32 rows in flight per wave, non-temporal row loads (measured against 8 / 16 rows and plain loads: profiles/r02_voxel_pool_*)
 #define TT_VP_SEG(NV_, RF_, NT_)                                                                                          \
     hipLaunchKernelGGL((vp_planned_segments_kernel<NV_, RF_, NT_>), dim3(blocks), dim3(256), 0, st, C, cpg, segcap, ngroups, \
                        order, cell_start, seg_off, input_features, partial)
     if (C <= 256) {
-        if (rf >= 32) { if (nt) TT_VP_SEG(1, 32, true); else TT_VP_SEG(1, 32, false); }
-        else if (rf >= 16) { if (nt) TT_VP_SEG(1, 16, true); else TT_VP_SEG(1, 16, false); }
-        else { if (nt) TT_VP_SEG(1, 8, true); else TT_VP_SEG(1, 8, false); }
+        TT_VP_SEG(1, 32, true);
         hipLaunchKernelGGL(vp_planned_cells_kernel<1>, dim3((unsigned)(cpg * ngroups)), dim3(256), 0, st, C, cpg, segcap, seg_off,
                            partial, output_features);
     } else {
-        if (nt) TT_VP_SEG(4, 4, true); else TT_VP_SEG(4, 4, false);
+        TT_VP_SEG(4, 4, true);
         hipLaunchKernelGGL(vp_planned_cells_kernel<4>, dim3((unsigned)(cpg * ngroups)), dim3(256), 0, st, C, cpg, segcap, seg_off,
                            partial, output_features);
     }
@@ -1412,6 +1409,24 @@ static bool v3_ok(long long total, int num_points, int C, int X, int Y) {
     const long long cps = ((long long)num_points + kCsChunk - 1) / kCsChunk;
     return on && C % 4 == 0 && C <= 1024 && (long long)X * Y <= kCsMaxCells && cps <= kCsMaxChunksPerSample &&
            total >= 4 * kCsChunk && total < (1ll << 31);
+}
+
+// > 64 KiB of dynamic LDS needs the opt-in (441 cells: 70 KiB, 1024: 160 KiB = the whole CU).  Decided once PER DEVICE; a device
+// that refuses the attribute, or whose limit is below what this launch needs, takes the two-phase kernel below instead
+static bool v3_lds_ready(size_t lds_needed) {
+    static int state[64] = {0};                 // 0 unknown, > 0: the granted limit in bytes, -1 refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (state[dev] == 0) {
+        int lim = 0;
+        const bool ok = hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess;
+        int want = 160 * 1024;
+        if (ok && lim > 0 && lim < want) want = lim;
+        state[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(vp_cs_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         want) == hipSuccess ? want : -1;
+        (void)hipGetLastError();
+    }
+    return state[dev] > 0 && lds_needed <= (size_t)state[dev];
 }
 
 struct V3Layout {
@@ -1469,7 +1484,8 @@ extern "C" int tt_voxel_pool_fwd_ws(int batch_size, int num_points, int num_chan
     const long long total = (long long)batch_size * num_points;
     const bool aligned = !(reinterpret_cast<uintptr_t>(input_features) & 15) && !(reinterpret_cast<uintptr_t>(output_features) & 15) &&
                          !(reinterpret_cast<uintptr_t>(workspace) & 15);
-    if (workspace && aligned && v3_ok(total, num_points, num_channels, num_voxel_x, num_voxel_y)) {
+    if (workspace && aligned && v3_ok(total, num_points, num_channels, num_voxel_x, num_voxel_y) &&
+        v3_lds_ready((size_t)kCsWaves * ((num_voxel_x * num_voxel_y + 63) & ~63) * (sizeof(unsigned short) + sizeof(unsigned long long)))) {
         const int cells = num_voxel_x * num_voxel_y;
         const V3Layout L = v3_layout(batch_size, num_points, num_channels, cells);
         if (workspace_bytes >= (long long)L.bytes) {
@@ -1484,11 +1500,6 @@ extern "C" int tt_voxel_pool_fwd_ws(int batch_size, int num_points, int num_chan
             float* partial = reinterpret_cast<float*>(w + L.partial);
             const int nchunks = L.cps * batch_size;
             const size_t lds = (size_t)kCsWaves * ((cells + 63) & ~63) * (sizeof(unsigned short) + sizeof(unsigned long long));
-            static const bool lds_attr = [] {           // > 64 KiB of dynamic LDS needs the opt-in (441 cells: 70 KiB, 1024: 160 KiB)
-                return hipFuncSetAttribute(reinterpret_cast<const void*>(vp_cs_count_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-            }();
-            TT_REQUIRE(lds_attr, "tt_voxel_pool_fwd_ws: cannot raise the dynamic LDS limit of vp_cs_count_kernel");
             hipLaunchKernelGGL(vp_cs_count_kernel, dim3((unsigned)nchunks), dim3(kCsWaves * 64), lds, st, num_points, num_voxel_x,
                                num_voxel_y, num_voxel_z, L.cps, geom_xyz, pos_memo, keyrank, table);
             hipLaunchKernelGGL(vp_cs_scan_kernel, dim3((unsigned)batch_size), dim3(1024), 0, st, num_points, cells, L.cps, table,
@@ -1515,28 +1526,13 @@ extern "C" int tt_voxel_pool_fwd_ws(int batch_size, int num_points, int num_chan
     float* partial = reinterpret_cast<float*>(workspace);
     const long long part_bytes = (long long)nchunks * smax * C * 4;
     int* slot_table = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + ((part_bytes + 255) / 256) * 256);
-    static int rf = -1;
-    if (rf < 0) {
-        const char* e = getenv("TT_VP_ROWS_IN_FLIGHT");     // A/B knob: 4 / 8 / 16 rows per wave (C <= 256 only)
-        rf = e ? atoi(e) : 16;   // measured 0.302 / 0.287 / 0.277 ms per launch for 4 / 8 / 16 (profiles/r02_voxel_pool_*)
-    }
-    static const bool nt = [] { const char* e = getenv("TT_VP_NT"); return e ? atoi(e) != 0 : true; }();
+    // 16 rows in flight per wave (0.302 / 0.287 / 0.277 ms per launch for 4 / 8 / 16, profiles/r02_voxel_pool_*), non-temporal loads
 #define TT_P1(NV, RF)                                                                                              \
-    do {                                                                                                           \
-        if (nt)                                                                                                    \
-            hipLaunchKernelGGL((voxel_pool_p1_kernel<NV, RF, true>), dim3((unsigned)nchunks), dim3(512), 0, st,    \
-                               num_points, C, num_voxel_x, num_voxel_y, num_voxel_z, cps, smax, geom_xyz,          \
-                               input_features, output_features, pos_memo, partial, slot_table);                    \
-        else                                                                                                       \
-            hipLaunchKernelGGL((voxel_pool_p1_kernel<NV, RF, false>), dim3((unsigned)nchunks), dim3(512), 0, st,   \
-                               num_points, C, num_voxel_x, num_voxel_y, num_voxel_z, cps, smax, geom_xyz,          \
-                               input_features, output_features, pos_memo, partial, slot_table);                    \
-    } while (0)
+    hipLaunchKernelGGL((voxel_pool_p1_kernel<NV, RF, true>), dim3((unsigned)nchunks), dim3(512), 0, st,            \
+                       num_points, C, num_voxel_x, num_voxel_y, num_voxel_z, cps, smax, geom_xyz,                  \
+                       input_features, output_features, pos_memo, partial, slot_table)
     if (C <= 256) {
-        if (rf >= 32) TT_P1(1, 32);
-        else if (rf >= 16) TT_P1(1, 16);
-        else if (rf >= 8) TT_P1(1, 8);
-        else TT_P1(1, 4);
+        TT_P1(1, 16);
     } else {
         TT_P1(4, 4);
     }

@@ -919,9 +919,12 @@ def mlp_chain(x, stages, n_split=1, groups=None, wide=None):
         L.tt_mlp_chain_wide_workspace_bytes.restype = ctypes.c_longlong
         nbytes = int(L.tt_mlp_chain_wide_workspace_bytes(_ll(R), _c(n), arr))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        check(L.tt_mlp_chain_wide(ptr(x), _ll(R), _c(x.stride(0)), _c(n), arr, _c(groups), ptr(ws), _ll(nbytes), _st(x)),
-              "tt_mlp_chain_wide")
-        return
+        rc = L.tt_mlp_chain_wide(ptr(x), _ll(R), _c(x.stride(0)), _c(n), arr, _c(groups), ptr(ws), _ll(nbytes), _st(x))
+        if rc != -4 or wide:
+            check(rc, "tt_mlp_chain_wide")
+            return
+        # -4: the ticket slots of graph-captured launches are used up (a process that re-captures over and over): the
+        # one-workgroup-per-row-block chain computes the same stages without a cross-workgroup barrier
     check(lib().tt_mlp_chain(ptr(x), _ll(R), _c(x.stride(0)), _c(n), arr, _c(n_split), _st(x)), "tt_mlp_chain")
 
 
