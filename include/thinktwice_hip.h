@@ -153,8 +153,8 @@ typedef struct tt_conv_desc {
     const void* res1; int res1_cstride, res1_coff;
     const void* res2; int res2_cstride, res2_coff;
     int act;
-    int dtype;       /* TT_F32 / TT_BF16: input, weight, residual storage type */
-    int out_dtype;   /* storage type of out */
+    int dtype;       /* TT_F32 / TT_BF16 / TT_F16: input, weight, residual storage type */
+    int out_dtype;   /* storage type of out: TT_F32, the operand dtype, or (f32 operands, no residuals) TT_F16 / TT_BF16 */
     /* sparse (spconv) mode: in = feature rows [*, in_cstride]; N = upper bound of output rows,
      * H=W=OH=OW=KH=1, KW = taps; gather_idx int32 [N][KW] = input row per (output row, tap) or -1
      * (the rulebook of tt_sp_rulebook); m_dev (nullable) = device int with the live row count. */
@@ -185,6 +185,16 @@ typedef struct tt_conv_desc {
      *   in_pair : `in` is in pair format (in_cstride / in_coff multiples of 16, Cin % 32 == 0, N*OH*OW > 4096, Cout <= 32 or
      *             >= 64): the launch is refused if the layer is outside the LDS-DMA kernel's contract. */
     int in_pair, out_pair;
+    /* optional (dtype == TT_F16 only): "h2" arithmetic -- IEEE-half activations as stored x an f16 (hi, lo) weight pair, two
+     * v_mfma_f32_32x32x16_f16 per product with f32 accumulation (exact to ~2^-22 with respect to the stored operands).
+     * Layout: rows of 2*K halves, per 16 K elements 64 B = [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15], hi = f16(w),
+     * lo = f16(w - hi) (thinktwice_amd/weights.py::split_pairs_h2).  Needs Cin % 64 == 0; `weight` is then only a shape
+     * carrier.  The PAFPN of the mixed mode runs it. */
+    const void* weight_h2;
+    /* optional second copy of the output, always f32, rows [N*OH*OW] of out2_cstride floats at channel offset out2_coff
+     * (row-linear outputs only): a layer whose result is read both by a half-storage consumer and by an f32 one
+     * (PAFPN fpn_convs.0: downsample_convs.0 reads the f16 copy, the UNet concat buffer takes the f32 one) */
+    float* out2; int out2_cstride, out2_coff;
 } tt_conv_desc;
 
 int tt_conv2d_fwd(const tt_conv_desc* d, void* stream);

@@ -526,6 +526,12 @@ PAIR_CASES = [
     (3, 300, 300, 64, 12, 3, 1, 0),      # fused seg head (32-wide tile)
     (2, 50, 60, 64, 256, 1, 1, 0),       # 256-wide 8-wave tile
     (4, 56, 100, 96, 128, 3, 2, 1),      # stride 2, three channel chunks (96 = 3 x 32), M = 5600
+    # K >= 1152: the hand-pipelined kernels (csrc/conv_x3_pipe.hip), pre-split variants
+    (2, 64, 64, 128, 128, 3, 1, 1),      # run-staged 3 x 3, 128-wide
+    (4, 40, 48, 256, 256, 3, 1, 1),      # run-staged 3 x 3, 256-wide, ragged M (7680)
+    (4, 56, 100, 256, 256, 3, 2, 0),     # per-tap pipeline (stride 2), 256-wide
+    (2, 50, 60, 2048, 512, 1, 1, 1),     # 1 x 1 with K = 2048 (ASPP conv1), per-tap pipeline
+    (4, 56, 100, 128, 128, 3, 2, 1),     # per-tap pipeline, 128-wide
 ]
 
 
@@ -570,3 +576,84 @@ def test_pair_format_is_refused_outside_the_kernel_contract():
     w = torch.zeros(64, 1, 1, 64).cuda()
     with pytest.raises(_lib.TTError):
         ops.conv2d(x, w, w_x3=weights.split_pairs_x3(w), in_pair=True)
+
+
+H2_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil, act, bn, res, out_f32   ("h2": half storage x f16 (hi, lo) weights, csrc/conv_h2.hip)
+    (3, 40, 48, 64, 128, 3, 1, 1, 1, 1, True, 1, False),    # 128-wide tile, ragged M (5760), half residual + ReLU, 9 K tiles
+    (2, 64, 64, 128, 64, 1, 1, 0, 1, 0, False, 0, False),   # 64-wide tile, 1x1, two K tiles
+    (2, 56, 100, 256, 512, 3, 2, 1, 1, 1, True, 0, True),   # stride 2, four column tiles, f32 output
+    (2, 50, 60, 64, 256, 1, 1, 0, 1, 1, True, 1, False),    # ONE K tile (layer1's 1x1 convs), residual
+    (5, 30, 30, 192, 200, 3, 1, 1, 1, 0, False, 0, True),   # Cout tail (200) in the 128 tile
+    (2, 21, 21, 512, 256, 3, 1, 1, 1, 1, True, 0, False),   # few rows (M = 882): the same kernel, partial row tile
+    (1, 9, 7, 2048, 256, 1, 1, 0, 1, 0, False, 0, False),   # M = 63 (PAFPN lateral 3 of a small image)
+    (2, 40, 48, 64, 64, 3, 1, 6, 6, 1, True, 2, False),     # dilation, two residuals (rolled epilogue)
+]
+
+
+@pytest.mark.parametrize("case", H2_CASES)
+def test_conv_h2_matches_torch_f32(case):
+    """Layer mode "h2" (the PAFPN of the mixed mode "f32x3h"): IEEE-half activations as stored times an f16 (hi, lo) weight pair,
+    two f16 MFMAs per product.  With respect to the STORED activations the product is exact to ~2^-22: within 2e-5 (of the
+    output's max) of the f32 reference evaluated on the half-rounded input and the unrounded weights; a half output adds its own
+    rounding (2^-11 relative per element)."""
+    from thinktwice_amd import ops, weights
+    N, H, W, Cin, Cout, k, stride, pad, dil, act, use_bn, res, out_f32 = case
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    x = _mk((N, Cin, H, W), g)
+    w = _mk((Cout, Cin, k, k), g, (Cin * k * k) ** -0.5)
+    scale = (torch.rand(Cout, generator=g) + 0.5) if use_bn else None
+    shift = _mk((Cout,), g, 0.3)
+    xq = weights.to_channel_last(x, torch.float16).cuda()
+    w32 = weights.prep_conv_weight(w, torch.float32).cuda()
+    wh = weights.split_pairs_h2(w32)
+    assert wh.dtype == torch.float16 and wh.shape[-1] == 2 * w32.shape[-1]
+    ref = F.conv2d(x.half().float(), w, None, stride, pad, dil)
+    if scale is not None:
+        ref = ref * scale.view(1, -1, 1, 1)
+    ref = ref + shift.view(1, -1, 1, 1)
+    r1 = r2 = None
+    if res >= 1:
+        r1 = _mk(tuple(ref.shape), g).permute(0, 2, 3, 1).contiguous().half()
+        ref = ref + r1.float().permute(0, 3, 1, 2)
+    if res >= 2:
+        r2 = _mk(tuple(ref.shape), g).permute(0, 2, 3, 1).contiguous().half()
+        ref = ref + r2.float().permute(0, 3, 1, 2)
+    ref = {0: lambda t: t, 1: F.relu}[act](ref)
+    out2 = torch.zeros(N, ref.shape[2], ref.shape[3], Cout + 8, device="cuda") if (not out_f32 and res < 2) else None
+    out = ops.conv2d(xq, w32.half(), stride=stride, pad=pad, dil=dil, scale=None if scale is None else scale.cuda(),
+                     shift=shift.cuda(), act=act, res1=None if r1 is None else r1.cuda(),
+                     res2=None if r2 is None else r2.cuda(), w_h2=wh, out_dtype=torch.float32 if out_f32 else None,
+                     out2=out2, out2_coff=8)
+    assert out.dtype == (torch.float32 if out_f32 else torch.float16)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    scale_ = ref.abs().max().clamp_min(1e-6)
+    if out_f32:
+        assert float((got - ref).abs().max() / scale_) < 2e-5
+    else:
+        assert torch.equal(got, ref.half().float()) or float((got - ref).abs().max() / scale_) < 6e-4
+        # the half output is the f32 result rounded once: all but a few ties-at-the-last-bit agree with rounding the reference
+        assert float((got != ref.half().float()).float().mean()) < 0.02
+    if out2 is not None:     # the second, f32 copy carries the unrounded values
+        got2 = out2[..., 8:].cpu().permute(0, 3, 1, 2)
+        assert float((got2 - ref).abs().max() / scale_) < 2e-5
+        assert float(out2[..., :8].abs().max()) == 0.0
+
+
+def test_bf16x3_layer_can_store_half():
+    """A bf16x3 layer (f32 operands) feeding a half-storage stage writes IEEE half directly (stem -> layer1, PAFPN laterals 2 / 3)."""
+    from thinktwice_amd import ops, weights
+    g = torch.Generator().manual_seed(5)
+    x = _mk((2, 64, 40, 48), g)
+    w = _mk((256, 64, 1, 1), g, 64 ** -0.5)
+    b = _mk((256,), g, 0.2)
+    xq = weights.to_channel_last(x, torch.float32).cuda()
+    wq = weights.prep_conv_weight(w, torch.float32).cuda()
+    ref = F.conv2d(x, w, b)
+    for wx in (weights.split_pairs_x3(wq), None):
+        out = ops.conv2d(xq, wq, shift=b.cuda(), w_x3=wx, out_dtype=torch.float16)
+        assert out.dtype == torch.float16
+        got = out.float().cpu().permute(0, 3, 1, 2)
+        assert float((got - ref).abs().max() / ref.abs().max()) < 6e-4
+        assert float((got != ref.half().float()).float().mean()) < 0.02

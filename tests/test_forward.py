@@ -79,7 +79,7 @@ def test_forward_small_matches_reference_golden_and_oracle(golden_dir):
     assert l2 < 1e-3, l2
 
 
-@pytest.mark.parametrize("dt", [torch.float32, "f32x3"], ids=["f32", "bf16x3"])
+@pytest.mark.parametrize("dt", [torch.float32, "f32x3", "f32x3h"], ids=["f32", "bf16x3", "bf16x3h"])
 def test_forward_is_bit_reproducible(dt):
     """Two forwards of the same batch are torch.equal in every output: no floating-point atomics on the inference path
     (ordered split-K slices, lift-splat partial rows reduced in strip order)."""
@@ -102,13 +102,16 @@ def test_forward_full_size_matches_reference_golden(golden_dir):
     _check_look_counts(out, pack, strict=True, tag="f8 f32")
 
 
-def test_forward_full_size_headline_mode_integer_parity(golden_dir):
-    """F8 in the bf16x3 headline mode: the 14 outputs within 1e-3 AND the look module's integer work bit-equal."""
+@pytest.mark.parametrize("dt", ["f32x3", "f32x3h"], ids=["bf16x3", "bf16x3h"])
+def test_forward_full_size_headline_mode_integer_parity(golden_dir, dt):
+    """F8 in the bf16x3 headline mode and in the opt-in bf16x3 + half-storage-PAFPN mode: the 14 outputs within 1e-3 AND the look
+    module's integer work bit-equal."""
     pack = np.load(os.path.join(golden_dir, "f8_forward_full_b1.npz"))
     B, H, W, npts, seed = (int(v) for v in pack["meta"])
-    out, *_ = _run_model(B, (H, W), npts, seed, dtype="f32x3")
-    _check_against_pack(pack, out, 1e-3)
-    _check_look_counts(out, pack, strict=True, tag="f8 bf16x3")
+    out, *_ = _run_model(B, (H, W), npts, seed, dtype=dt)
+    errs = _check_against_pack(pack, out, 1e-3)
+    print(f"f8 {dt}: rel errs", errs, "inter", _inter_errs(pack, out) if "inter__seg__idx" in pack.files else None)
+    _check_look_counts(out, pack, strict=True, tag=f"f8 {dt}")
 
 
 def _inter_errs(pack, out):
@@ -129,12 +132,20 @@ def _inter_errs(pack, out):
 # STORAGE modes are held to their measured level (gpurun_out/r2_pytest_b_model.log, B=8): bf16, 8 mantissa bits ->
 # pred_wp 1.8e-2, value head 6.3e-2, seg 9.7e-3; IEEE half, 11 bits -> pred_wp 2.3e-3, value head 9.6e-3, seg 1.2e-3:
 # 8x below bf16 but not inside 1e-3.  bf16x3 measures pred_wp 3.2e-5, worst key 1.2e-4.
-MODES = [(torch.float32, 1e-3, 1e-3), ("f32x3", 1e-3, 1e-3), (torch.float16, 2e-2, 5e-3), (torch.bfloat16, 0.15, 4e-2)]
+# "f32x3h" (round 6; an opt-in mode, NOT the bench headline): bf16x3 with the PAFPN's own tensors in IEEE half and its 3 x 3 layers on
+# the two-MFMA h2 product -- the one stage whose half STORAGE the storage-level emulation clears
+# (profiles/r06_precision_mix_storage.txt).  Measured on the GPU (profiles/r06_x3h_mode.txt): every output key <= 4.6e-4 of its
+# max, seg 3.9e-4, camera BEV 7.4e-5, integer work bit-equal -- inside the relative 1e-3 -- but the ABSOLUTE waypoint distance at
+# B = 8 is 1.19 mm against the 1 mm this suite asks of a parity mode: that is why it is not the headline, and its own bound below
+# is 2 mm.
+MODES = [(torch.float32, 1e-3, 1e-3), ("f32x3", 1e-3, 1e-3), ("f32x3h", 1e-3, 1e-3), (torch.float16, 2e-2, 5e-3),
+         (torch.bfloat16, 0.15, 4e-2)]
 # pred_wp (relative to its max) and the waypoint L2 distance in metres (BASELINE metric "waypoint L2 vs ref")
-WP_TOL = {torch.float32: (1e-3, 1e-3), "f32x3": (1e-3, 1e-3), torch.float16: (5e-3, 3e-2), torch.bfloat16: (4e-2, 0.25)}
+WP_TOL = {torch.float32: (1e-3, 1e-3), "f32x3": (1e-3, 1e-3), "f32x3h": (1e-3, 2e-3), torch.float16: (5e-3, 3e-2),
+          torch.bfloat16: (4e-2, 0.25)}
 
 
-@pytest.mark.parametrize("dt,tol,tol_inter", MODES, ids=["f32", "bf16x3", "f16", "bf16"])
+@pytest.mark.parametrize("dt,tol,tol_inter", MODES, ids=["f32", "bf16x3", "bf16x3h", "f16", "bf16"])
 def test_forward_batch8_full_size_matches_reference_golden(golden_dir, dt, tol, tol_inter):
     """BASELINE configs 2 / 3: batch 8 at the thinktwice.py size against the REFERENCE's forward_inference (f14).  The
     SCA batch coupling (multi_scale_deformable_attn_function.py:338-341: first `bs` slots zeroed, divide by `bs`)
@@ -156,17 +167,17 @@ def test_forward_batch8_full_size_matches_reference_golden(golden_dir, dt, tol, 
     assert errs["pred_wp"] < WP_TOL[dt][0] and l2 < WP_TOL[dt][1], (errs["pred_wp"], l2)
     # integer work bit-exact in the exact-f32 mode and in the bf16x3 HEADLINE mode (a 16-bit STORAGE trunk may move a
     # projected waypoint across an image edge: there the flip rate is printed)
-    _check_look_counts(out, pack, strict=dt in (torch.float32, "f32x3"), tag=f"f14 {dt}")
+    _check_look_counts(out, pack, strict=dt in (torch.float32, "f32x3", "f32x3h"), tag=f"f14 {dt}")
 
 
-@pytest.mark.parametrize("dt,tol,tol_inter", MODES[1:], ids=["bf16x3", "f16", "bf16"])
+@pytest.mark.parametrize("dt,tol,tol_inter", MODES[1:], ids=["bf16x3", "bf16x3h", "f16", "bf16"])
 def test_forward_16bit_modes_small(golden_dir, dt, tol, tol_inter):
     pack = np.load(os.path.join(golden_dir, "f7_forward_small_b2.npz"))
     B, H, W, npts, seed = (int(v) for v in pack["meta"])
     out, *_ = _run_model(B, (H, W), npts, seed, dtype=dt)
     errs = _check_against_pack(pack, out, tol)
     print(f"{dt} trunk: rel errs vs reference golden", errs)
-    _check_look_counts(out, pack, strict=dt == "f32x3", tag=f"f7 {dt}")
+    _check_look_counts(out, pack, strict=dt in ("f32x3", "f32x3h"), tag=f"f7 {dt}")
 
 
 def test_mmcv_style_checkpoint_loading_through_the_module_shell(golden_dir):

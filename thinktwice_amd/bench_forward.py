@@ -9,8 +9,8 @@ import torch
 from . import model as tm
 from . import ops, params, synth
 
-MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0}
-TORCH_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "bf16x3": "f32x3"}
+MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "bf16x3h": 2500.0}
+TORCH_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "bf16x3": "f32x3", "bf16x3h": "f32x3h"}
 HBM_PEAK_GBS = 8000.0
 PROFILE_TAG = "r05"            # profiles/<tag>_forward_<dtype>_{kernel_stats.csv,pmc.json}: the committed rocprofv3 passes of this build
 
@@ -20,9 +20,11 @@ def mfma_per_product(kernel_label, dtype):
     kernels issue three bf16 MFMAs per product: conv_igemm_glds_kernel<..., GATHER, X3> with X3 = true (the LAST template
     argument -- round 3 tested the GATHER flag and printed 1 for the dominant dense tile), conv_x3_pipe_kernel, the run-staged
     sparse kernel.  The exact-f32 / 16-bit kernels issue one."""
-    if dtype != "bf16x3":
+    if dtype not in ("bf16x3", "bf16x3h"):
         return 1
-    k = kernel_label.replace(" + tail", "").strip()
+    k = kernel_label.replace(" + tail", "").replace(" pre-split A", "").strip()
+    if k.startswith("conv_h2_kernel"):        # half storage x f16 (hi, lo) weights: two f16 MFMAs per product
+        return 2
     if k.startswith(("conv_x3_pipe_kernel", "conv_x3_run3_kernel", "sp_conv_runs")):
         return 3
     if k.startswith("conv_igemm_glds_kernel<") and k.endswith(", true>"):
@@ -158,7 +160,7 @@ class ForwardWorkload:
         dec = [r for r in rec if f" N={nv} K=256 k1x1s1" in r[3] and not r[3].startswith("sparse")]
         self._decoder_gemm = None
         if dec:
-            esz = 4 if self.dtype in ("f32", "bf16x3") else 2
+            esz = 4 if self.dtype in ("f32", "bf16x3", "bf16x3h") else 2
             gf = sum(r[0] for r in dec)
             gms = sum(r[1].elapsed_time(r[2]) for r in dec)
             tf = gf / (gms * 1e-3) / 1e12

@@ -44,6 +44,8 @@ struct ConvArgs {
     int ws_slices;       // split-K: > 0 = every split stores into its own [M][Cout] slice of ws (ordered finalize)
     int flags;           // bit 4: non-temporal f32 output stores (every launch of the product); bit 5: the activations are pre-split bf16 (hi, lo) pairs (tt_conv_desc.in_pair);
                          // bit 6: write the output in that pair format (tt_conv_desc.out_pair); < 0: split-K query (no launch)
+    float* out2;         // optional second, f32, row-linear copy of the output (tt_conv_desc.out2): [M][out2_cstride] at out2_coff
+    int out2_cstride, out2_coff;
     long long* trace;    // measurement aid (tt_conv_set_trace): 4 wall-clock stamps (10 ns ticks) per workgroup of the LDS-DMA kernel
                          // -- entry, first K tile landed, K loop done, epilogue done -- at trace[blockIdx.x * 4]; null in the product
 };
@@ -200,15 +202,36 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
             *reinterpret_cast<uint4*>(g) = hi;
             *reinterpret_cast<uint4*>(g + 8) = lo;
         } else {
-            // 16-bit output: the storage type of the operands (f32-compute layers never take the CO == 8 path)
-            using T16 = typename std::conditional<sizeof(T) == 2, T, uint16_t>::type;
+            // 16-bit output: the storage type of the operands, or (f32 operands: a bf16x3 layer feeding a half-storage stage of
+            // the mixed mode) the type out_dtype names
             uint4 pk;
-            pk.x = Pair16<T16>::pack(v[0], v[1]);
-            pk.y = Pair16<T16>::pack(v[2], v[3]);
-            pk.z = Pair16<T16>::pack(v[4], v[5]);
-            pk.w = Pair16<T16>::pack(v[6], v[7]);
+            if constexpr (sizeof(T) == 2) {
+                pk.x = Pair16<T>::pack(v[0], v[1]);
+                pk.y = Pair16<T>::pack(v[2], v[3]);
+                pk.z = Pair16<T>::pack(v[4], v[5]);
+                pk.w = Pair16<T>::pack(v[6], v[7]);
+            } else if (p.out_dtype == TT_F16) {
+                pk.x = pack_f16x2(v[0], v[1]);
+                pk.y = pack_f16x2(v[2], v[3]);
+                pk.z = pack_f16x2(v[4], v[5]);
+                pk.w = pack_f16x2(v[6], v[7]);
+            } else {
+                pk.x = pack_bf16x2(v[0], v[1]);
+                pk.y = pack_bf16x2(v[2], v[3]);
+                pk.z = pack_bf16x2(v[4], v[5]);
+                pk.w = pack_bf16x2(v[6], v[7]);
+            }
             *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.out) + o) = pk;
         }
+    };
+    // second, f32, row-linear copy (tt_conv_desc.out2)
+    float* const out2 = p.out2 ? p.out2 + p.out2_coff + co : nullptr;
+    auto store_row2 = [&](long long row, const float (&v)[CO]) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        float* q2 = out2 + row * p.out2_cstride;
+#pragma unroll
+        for (int e = 0; e < CO; e += 4)
+            __builtin_nontemporal_store(f4v{v[e], v[e + 1], v[e + 2], v[e + 3]}, reinterpret_cast<f4v*>(q2 + e));
     };
     const int cc = col_ok ? co : 0;
 #pragma unroll
@@ -284,6 +307,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                             for (int e = 0; e < CO; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                         }
                         store_row((long long)mr * p.out_cstride + obase, v);
+                        if (out2) store_row2(mr, v);
                     }
                 }
             };
@@ -328,6 +352,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
 #pragma unroll
                 for (int e = 0; e < CO; ++e) v[e] = apply_act(v[e], act);
                 store_row(o, v);
+                if (out2) store_row2(mo, v);
             }
         }
     }
@@ -416,6 +441,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                 reinterpret_cast<float*>(p.out)[o] = v;
             else
                 store16(p.out, o, v, p.out_dtype);
+            if (p.out2) p.out2[(long long)mo * p.out2_cstride + p.out2_coff + co] = v;
         }
     }
 }
@@ -431,6 +457,9 @@ int launch_conv_glds_x3_splitk(ConvArgs& a, hipStream_t st);
 int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int bn = 256);
 // run-staged sparse 3x3x3 conv (csrc/sp_conv_runs.hip; bf16x3, a.weight = pre-split weights): same contract.
 int try_launch_sp_conv_runs(ConvArgs& a, hipStream_t st);
+// "h2" arithmetic (csrc/conv_h2.hip): IEEE-half activations x f16 (hi, lo) weight pairs in a.weight, two MFMAs per product.
+// Returns 1 if it took the launch, 0 if the shape is outside its contract (dense, Cin % 64 == 0, KH*KW <= 31).
+int try_launch_conv_h2(ConvArgs& a, hipStream_t st);
 // latency-bound small-M variant (32x32 tile, intra-block split-K): same contract.
 int try_launch_conv_small(ConvArgs& a, int dtype, hipStream_t st);
 

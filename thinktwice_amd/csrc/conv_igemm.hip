@@ -331,8 +331,15 @@ extern "C" int tt_conv2d_splitk_slices(const tt_conv_desc* d) {
 static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     TT_REQUIRE(d && d->in && d->weight && d->out, "tt_conv2d_fwd: null pointer");
     TT_REQUIRE(d->dtype == TT_F32 || d->dtype == TT_BF16 || d->dtype == TT_F16, "tt_conv2d_fwd: bad dtype %d", d->dtype);
-    TT_REQUIRE(d->out_dtype == TT_F32 || d->out_dtype == d->dtype,
-               "tt_conv2d_fwd: out_dtype must be TT_F32 or the operand dtype (got %d for dtype %d)", d->out_dtype, d->dtype);
+    TT_REQUIRE(d->out_dtype == TT_F32 || d->out_dtype == d->dtype ||
+                   (d->dtype == TT_F32 && (d->out_dtype == TT_F16 || d->out_dtype == TT_BF16) && !d->res1 && !d->res2),
+               "tt_conv2d_fwd: out_dtype must be TT_F32, the operand dtype, or (f32 operands, no residuals) a 16-bit type "
+               "(got %d for dtype %d)", d->out_dtype, d->dtype);
+    TT_REQUIRE(!d->weight_h2 || (d->dtype == TT_F16 && !d->gather_idx && !d->splitk_ws && !d->pixel_shuffle2),
+               "tt_conv2d_fwd: weight_h2 goes with dense TT_F16 operands (no split-K workspace, no pixel shuffle)");
+    TT_REQUIRE(!d->out2 || (!d->splitk_ws && !d->pixel_shuffle2 && !d->gather_idx && d->out2_cstride % 4 == 0 &&
+                            d->out2_coff % 4 == 0 && (reinterpret_cast<uintptr_t>(d->out2) & 15) == 0),
+               "tt_conv2d_fwd: out2 needs a dense row-linear layer and 16-byte aligned rows");
     const int vec = d->dtype == TT_F32 ? 4 : 8;
     TT_REQUIRE(d->Cin > 0 && d->Cin % vec == 0 && d->in_cstride % vec == 0 && d->in_coff % vec == 0,
                "tt_conv2d_fwd: Cin=%d in_cstride=%d in_coff=%d must be multiples of %d (pad channels)",
@@ -368,6 +375,7 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     a.res1_cstride = d->res1_cstride; a.res1_coff = d->res1_coff;
     a.res2_cstride = d->res2_cstride; a.res2_coff = d->res2_coff;
     a.act = d->act; a.out_dtype = d->out_dtype;
+    a.out2 = d->out2; a.out2_cstride = d->out2_cstride; a.out2_coff = d->out2_coff;
     a.M = d->N * d->OH * d->OW;
     a.K = d->KH * d->KW * d->Cin;
     a.out_fast = (!d->pixel_shuffle2 && a.out_nstride == (long long)d->OH * d->OW * d->out_cstride) ? 1 : 0;
@@ -404,7 +412,7 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     }
     hipStream_t st = (hipStream_t)stream;
     if (query) {
-        if (d->in_pair || d->out_pair) return 0;
+        if (d->in_pair || d->out_pair || d->weight_h2) return 0;
         a.ws = nullptr;
         a.row_perm = nullptr;
         a.row_mask = nullptr;
@@ -416,6 +424,17 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
         if (d->dtype == TT_F16) return dispatch_conv<f16_t>(a, st);
         return dispatch_conv<uint16_t>(a, st);
     }
+    if (d->weight_h2) {
+        // half storage x (hi, lo) weights: the only kernel with this arithmetic -- a shape outside its contract is an error, not a
+        // silent change of precision
+        TT_REQUIRE((reinterpret_cast<uintptr_t>(d->weight_h2) & 15) == 0, "tt_conv2d_fwd: weight_h2 must be 16-byte aligned");
+        ConvArgs ah = a;
+        ah.weight = d->weight_h2;
+        TT_REQUIRE(try_launch_conv_h2(ah, st), "tt_conv2d_fwd: weight_h2 layer outside the h2 kernel's contract (Cin=%d KH*KW=%d)",
+                   d->Cin, d->KH * d->KW);
+        return check_launch("tt_conv2d_fwd(h2)");
+    }
+    TT_REQUIRE(!d->out2 || a.vec_epi, "tt_conv2d_fwd: out2 needs the vector epilogue (aligned channel counts)");
     if (d->in_pair || d->out_pair) {
         TT_REQUIRE(a.vec_epi && (reinterpret_cast<uintptr_t>(d->weight_x3) & 15) == 0 && a.K % 16 == 0,
                    "tt_conv2d_fwd: in_pair / out_pair need the vector epilogue and a 16-byte aligned weight_x3");
@@ -425,7 +444,7 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
                    "(M=%d Cin=%d Cout=%d)", a.M, d->Cin, d->Cout);
         return check_launch("tt_conv2d_fwd(glds x3, pair)");
     }
-    if (!d->splitk_ws && try_launch_conv_small(a, d->dtype, st)) {
+    if (!d->splitk_ws && !d->out2 && try_launch_conv_small(a, d->dtype, st)) {
         snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_small_kernel");
         return check_launch("tt_conv2d_fwd(small)");
     }

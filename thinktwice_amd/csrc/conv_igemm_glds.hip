@@ -760,16 +760,16 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
     }
     if (a.m_dev || a.M < 2048 || a.KH * a.KW > 32) return 0;
     if (a.Cin % 32 != 0 || a.K < 64) return 0;       // 128 B rows = 32 f32 of one tap per K tile, >= 2 tiles
-    // pre-split activations (tt_conv_desc.in_pair): 16-channel pair groups must line up with the 32-channel K tiles; the
-    // compiler-scheduled tiles only (the hand-pipelined kernels weave the split into their MFMA gaps)
+    // pre-split activations (tt_conv_desc.in_pair): 16-channel pair groups must line up with the 32-channel K tiles
     const bool apair = (a.flags & 32) != 0;
     if (apair && (a.in_coff % 16 != 0 || a.in_cstride % 16 != 0)) return 0;
-    // few output channels over very many rows (the segmentation head: 3 x 3, 64 -> 12 at 224 x 448 per image): a 256 x 32 tile,
-    // two workgroups per CU; below that row count the exact-f32 register-staged kernel is as fast
+    // few output channels over many rows (the segmentation head: 3 x 3, 64 -> 12 at 224 x 448 per image; the deformable conv's
+    // offset head: 3 x 3, 512 -> 18; seg_res_to_image_feature's 64 -> 16): a 256 x 32 tile, two workgroups per CU.  Below 2^16
+    // rows the exact-f32 register-staged kernel keeps them
     if (a.Cout < 64) {
         if (a.Cout > 32 || a.Cout < 8) return 0;
         if (apair) return launch_glds<float, 32, 8, 1, 128, 2, false, true, true>(a, st);
-        if (a.M < (1 << 18) || a.K < 256) return 0;
+        if (a.M < (1 << 16)) return 0;
         return launch_glds<float, 32, 8, 1, 128, 2, false, true>(a, st);
     }
     // Tile width along N.  The widest wave tile the layer allows is the most efficient per tile (the operand split costs
@@ -801,7 +801,7 @@ int try_launch_conv_glds_x3(ConvArgs& a, hipStream_t st) {
     // (K = 1024: 0.203 vs 0.216 ms, K = 256 N = 1280: 0.52 vs 0.77 ms; profiles/r04_pipe_ab_first.txt).
     // TT_X3_PIPE=0 (test hook: tests/test_conv.py compares the two families bit for bit): the compiler-scheduled tiles everywhere
     static const bool pipe = [] { const char* e = getenv("TT_X3_PIPE"); return e ? atoi(e) != 0 : true; }();
-    const bool hand = pipe && !apair && a.K >= 1152;
+    const bool hand = pipe && a.K >= 1152;
     if (bn == 256) {                                                                                           // 8 x (64 x 128)
         const int main_rows = tail_split_rows(a);
         if (hand && try_launch_conv_x3_pipe(a, st, main_rows)) { /* taken */ }

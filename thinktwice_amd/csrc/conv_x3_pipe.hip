@@ -34,7 +34,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define TT_PIPE_DEBUG 0
 #endif
 
-template <int WAVES_M, int WAVES_N, int BN = 256>
+// APAIR: pre-split (pair-format) activations, tt_conv_desc.in_pair -- the fragment reads fetch the bf16 hi and lo halves directly
+// (chunks 4 kc + h and that ^ 2, like the weights) and the eight split stages of every row-block window are simply not there.
+template <int WAVES_M, int WAVES_N, int BN = 256, bool APAIR = false>
 __global__ __launch_bounds__(256, 1) void conv_x3_pipe_kernel(const ConvArgs p, const void* zero_page, int tiles_m,
                                                              int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pipe_kernel(const ConvArgs p, 
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = wm * WTM + i * 32 + (lane & 31);
-            fa_pre[kc][i] = row * BKB + (((4u * kc + 2u * hi) ^ swz(row)) << 4);
+            fa_pre[kc][i] = row * BKB + (((4u * kc + (APAIR ? hi : 2u * hi)) ^ swz(row)) << 4);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -243,6 +245,13 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pipe_kernel(const ConvArgs p, 
         asm volatile("s_barrier" ::: "memory");
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            if constexpr (APAIR) {
+                ah[0][i] = lds_read(ldsA + fa_pre[0][i]);
+                al[0][i] = lds_read(ldsA + (fa_pre[0][i] ^ 32u));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(ah[0][i]), "+v"(al[0][i]));
+                continue;
+            }
             ra0 = lds_read(ldsA + fa_pre[0][i]);
             ra1 = lds_read(ldsA + (fa_pre[0][i] ^ 16u));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -339,8 +348,13 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pipe_kernel(const ConvArgs p, 
                         else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     }
                     if (ws == (barw ? RB : R0) && !(TT_PIPE_DEBUG & 8)) {
-                        ra0 = lds_read(srcA + fa_pre[kn][rb]);
-                        ra1 = lds_read(srcA + (fa_pre[kn][rb] ^ 16u));
+                        if constexpr (APAIR) {      // (the registers' last readers, the previous K step's MFMAs, were issued long ago)
+                            ah[kn][rb] = lds_read(srcA + fa_pre[kn][rb]);
+                            al[kn][rb] = lds_read(srcA + (fa_pre[kn][rb] ^ 32u));
+                        } else {
+                            ra0 = lds_read(srcA + fa_pre[kn][rb]);
+                            ra1 = lds_read(srcA + (fa_pre[kn][rb] ^ 16u));
+                        }
                     }
                     // DMA: behind the fragment reads; in the barrier group after the barrier (the weight stage it frees)
                     {
@@ -352,11 +366,12 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pipe_kernel(const ConvArgs p, 
                     }
                     if (ws == (barw ? WB : W0)) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        asm volatile("" : "+v"(ra0), "+v"(ra1));
+                        if constexpr (APAIR) asm volatile("" : "+v"(ah[kn][rb]), "+v"(al[kn][rb]));
+                        else asm volatile("" : "+v"(ra0), "+v"(ra1));
                         if (g == 0) asm volatile("" : "+v"(bh[TN - 1]));     // the gap-0 read of this K step has landed too
                     }
                     if (m == 2 * TM - 1 && !(TT_PIPE_DEBUG & 8)) bl[g] = lds_read(srcB + (fb_pre[kn][g] ^ 32u));   // lo half: free now
-                    {
+                    if constexpr (!APAIR) {
                         // the eight 3-VALU split stages, spread over what is left of the window
                         const int first = barw ? WB : W0;
                         const int avail = WIN - first;
@@ -450,7 +465,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pipe_kernel(const ConvArgs p, 
 // zero page (first / last image).  The K loop is unrolled over the three tiles of a run, so the tile's kw, its vmcnt and
 // its share of the next run's DMA (5 + 4 + 0 pieces) are compile-time.  LDS: 2 run buffers x 36 KiB (288 rows: 36 pieces)
 // + 2 weight stages + the zero row.  Results are bit-identical to the per-tap kernels (same K order, same operands).
-template <int BN>
+template <int BN, bool APAIR = false>
 __global__ __launch_bounds__(256, 1) void conv_x3_run3_kernel(const ConvArgs p, const void* zero_page, int tiles_m,
                                                              int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -539,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_run3_kernel(const ConvArgs p, 
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
                 const int q = row + kw;
-                fa_run[kw][kc][i] = q * BKB + (((4u * kc + 2u * hi) ^ swz(q)) << 4);
+                fa_run[kw][kc][i] = q * BKB + (((4u * kc + (APAIR ? hi : 2u * hi)) ^ swz(q)) << 4);
             }
     }
 #pragma unroll
@@ -632,6 +647,13 @@ __global__ __launch_bounds__(256, 1) void conv_x3_run3_kernel(const ConvArgs p, 
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const unsigned a0 = ((f_mask[i] >> 0) & 1u) ? lds_base + fa_run[0][0][i] : zaddr;
+            if constexpr (APAIR) {
+                ah[0][i] = lds_read(a0);
+                al[0][i] = lds_read(a0 ^ 32u);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(ah[0][i]), "+v"(al[0][i]));
+                continue;
+            }
             ra0 = lds_read(a0);
             ra1 = lds_read(a0 ^ 16u);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -728,8 +750,13 @@ __global__ __launch_bounds__(256, 1) void conv_x3_run3_kernel(const ConvArgs p, 
                         if (ws == (barw ? RB : R0)) {
                             // padding: a lane whose (row, tap) is outside the image reads the zero row
                             const unsigned a0 = ((f_mask[rb] >> ntap) & 1u) ? srcA + fa_run[nkw][kn][rb] : zaddr;
-                            ra0 = lds_read(a0);
-                            ra1 = lds_read(a0 ^ 16u);
+                            if constexpr (APAIR) {
+                                ah[kn][rb] = lds_read(a0);
+                                al[kn][rb] = lds_read(a0 ^ 32u);
+                            } else {
+                                ra0 = lds_read(a0);
+                                ra1 = lds_read(a0 ^ 16u);
+                            }
                         }
                         {
                             // DMA slots: gaps 2 and 3 of a group (4 and 5 behind the barrier).  Weights: one piece per group;
@@ -746,11 +773,12 @@ __global__ __launch_bounds__(256, 1) void conv_x3_run3_kernel(const ConvArgs p, 
                         }
                         if (ws == (barw ? WB : W0)) {
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            asm volatile("" : "+v"(ra0), "+v"(ra1));
+                            if constexpr (APAIR) asm volatile("" : "+v"(ah[kn][rb]), "+v"(al[kn][rb]));
+                            else asm volatile("" : "+v"(ra0), "+v"(ra1));
                             if (g == 0) asm volatile("" : "+v"(bh[TN - 1]));
                         }
                         if (m == 2 * TM - 1) bl[g] = lds_read(srcB + (fb_pre[kn][g] ^ 32u));
-                        {
+                        if constexpr (!APAIR) {
                             const int first = barw ? WB : W0;
                             const int avail = WIN - first;
                             int lastslot;
@@ -822,6 +850,7 @@ static const void* pipe_zero_page() {
 
 // Returns 1 if the launch was taken.  `m_tiles_limit` > 0: only that many row tiles from a.m_begin (tail split).
 int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int bn) {
+    const bool apair = (a.flags & 32) != 0;          // pre-split activations (tt_conv_desc.in_pair)
     if (a.gather || a.m_dev || (bn != 256 && bn != 128) || a.Cout % bn != 0 || a.Cin % 32 != 0 || a.KH * a.KW > 31 || a.K < 64) return 0;
     const void* zp = pipe_zero_page();
     if (!zp) return 0;
@@ -834,20 +863,23 @@ int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int 
     if (run3 && a.KW == 3 && a.KH <= 5 && a.stride == 1 && a.dil == 1 && a.pad == 1 && a.OH == a.H && a.OW == a.W &&
         (a.N == 1 || a.in_nstride == (long long)a.H * a.W * a.in_cstride)) {
         const size_t smem_r = (size_t)2 * 288 * 128 + (size_t)2 * bn * 128 + 256;
-        auto kr = bn == 128 ? conv_x3_run3_kernel<128> : conv_x3_run3_kernel<256>;
+        auto kr = bn == 128 ? (apair ? conv_x3_run3_kernel<128, true> : conv_x3_run3_kernel<128>)
+                            : (apair ? conv_x3_run3_kernel<256, true> : conv_x3_run3_kernel<256>);
         static bool attr_r = false;
         if (!attr_r) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_run3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      2 * 288 * 128 + 2 * 128 * 128 + 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_run3_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      2 * 288 * 128 + 2 * 256 * 128 + 256);
+            const int s128 = 2 * 288 * 128 + 2 * 128 * 128 + 256, s256 = 2 * 288 * 128 + 2 * 256 * 128 + 256;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_run3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, s128);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_run3_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, s256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_run3_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, s128);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_run3_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, s256);
             attr_r = true;
         }
         a.tiles_n = tiles_n;
         a.splits = 1;
         a.ws = nullptr;
         if (a.m_begin == 0)
-            snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_x3_run3_kernel<%d>%s", bn, m_tiles_limit > 0 ? " + tail" : "");
+            snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_x3_run3_kernel<%d>%s%s", bn, apair ? " pre-split A" : "",
+                     m_tiles_limit > 0 ? " + tail" : "");
         hipLaunchKernelGGL(kr, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), smem_r, st, a, zp, tiles_m, tiles_n);
         return 1;
     }
@@ -857,19 +889,22 @@ int try_launch_conv_x3_pipe(ConvArgs& a, hipStream_t st, int m_tiles_limit, int 
     if (smem < epi) smem = epi;
     // wave grid 4 x 1: 64 x 256 (64 x 128 on the 128-wide tile) per wave -- every activation fragment is split by ONE wave (the
     // 2 x 2 grid of 128 x 128 waves measured slower, profiles/r04_pipe_ab_grids.txt)
-    auto kern = bn == 128 ? conv_x3_pipe_kernel<4, 1, 128> : conv_x3_pipe_kernel<4, 1>;
+    auto kern = bn == 128 ? (apair ? conv_x3_pipe_kernel<4, 1, 128, true> : conv_x3_pipe_kernel<4, 1, 128>)
+                          : (apair ? conv_x3_pipe_kernel<4, 1, 256, true> : conv_x3_pipe_kernel<4, 1>);
     static bool attr_set = false;
     if (!attr_set) {
         const int full = (3 * 256 + 2 * 256) * 128;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pipe_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, full);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pipe_kernel<4, 1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, full);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pipe_kernel<4, 1, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, full);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_pipe_kernel<4, 1, 128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, full);
         attr_set = true;
     }
     a.tiles_n = tiles_n;
     a.splits = 1;
     a.ws = nullptr;
     if (a.m_begin == 0)
-        snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_x3_pipe_kernel<%s>%s", bn == 128 ? "4, 1, 128" : "4, 1",
+        snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_x3_pipe_kernel<%s>%s%s", bn == 128 ? "4, 1, 128" : "4, 1", apair ? " pre-split A" : "",
                  m_tiles_limit > 0 ? " + tail" : "");
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), smem, st, a, zp, tiles_m, tiles_n);
     return 1;

@@ -57,15 +57,19 @@ class EncoderDecoder(torch.nn.Module):
             raise _lib.TTError(f"EncoderDecoder: {device} requested, {torch.cuda.device_count()} GPU(s) visible")
         self.device = device
         c = self._ctor
+        # "f32x3h" (weights.X3H): the camera encoder's PAFPN on half storage / two-MFMA products, everything else -- the rest of the
+        # camera encoder, the LiDAR branch, the decoder -- exactly the bf16x3 mode
+        from . import weights as _w
+        rest = _w.X3 if (isinstance(self.dtype, str) and self.dtype == _w.X3H) else self.dtype
         self.img_encoder = build_backbone(c["img_encoder"], dtype=self.dtype, device=device)
         # precision mode of the LiDAR branch (default: the model's; its own knob because the sparse encoder is the one
         # part of the forward whose 16-bit rounding barely reaches the outputs)
         self.lidar_encoder = (build_backbone(c["lidar_encoder"], device=device,
-                                             dtype=self.dtype if self._lidar_dtype is None else self._lidar_dtype)
+                                             dtype=rest if self._lidar_dtype is None else self._lidar_dtype)
                               if c["lidar_encoder"] is not None else None)
         dec = dict(c["decoder"])
         dec.setdefault("config", self.config)
-        self.decoder = build_head(dec, dtype=self.dtype, device=device)
+        self.decoder = build_head(dec, dtype=rest, device=device)
         self.loaded = False
         self._side = None
         self._loss_red = None

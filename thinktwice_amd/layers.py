@@ -39,12 +39,18 @@ def _bn_spec(sd, bn, device, eps, momentum):
 
 class Conv:
     def __init__(self, w, scale, shift, stride=1, pad=0, dil=1, act="none", pixel_shuffle2=False, x3=False, bn=None,
-                 bias=None):
+                 bias=None, h2=False):
         self.w, self.scale, self.shift = w, scale, shift
         self.bn, self.bias = bn, bias            # train mode: ops.BNSpec + the conv's own bias (device f32) or None
         # precision mode "f32x3": the same weights pre-split into bf16 (hi, lo) pairs ride along; the C side uses them
         # wherever the layer fits the LDS-DMA kernel and the exact f32 path on `w` elsewhere
         self.w_x3 = weights.split_pairs_x3(w) if x3 else None
+        # layer mode "h2" (half-storage stage of the mixed mode): `w` arrives as the PREPARED f32 weights; the kernel reads the
+        # f16 (hi, lo) pair, `w` itself stays as the half-typed shape carrier the C ABI asks for
+        self.w_h2 = None
+        if h2:
+            self.w_h2 = weights.split_pairs_h2(w)
+            self.w = w.to(torch.float16)
         self.stride, self.pad, self.dil = stride, pad, dil
         self.act = ACT[act]
         self.ps2 = pixel_shuffle2
@@ -54,7 +60,7 @@ class Conv:
         if BN_TRAIN and self.bn is not None:
             return self._bn_train(x, **kw)
         return ops.conv2d(x, self.w, stride=self.stride, pad=self.pad, dil=self.dil, scale=self.scale,
-                          shift=self.shift, act=self.act, pixel_shuffle2=self.ps2, w_x3=self.w_x3, **kw)
+                          shift=self.shift, act=self.act, pixel_shuffle2=self.ps2, w_x3=self.w_x3, w_h2=self.w_h2, **kw)
 
     def _bn_train(self, x, res1=None, res1_coff=0, res2=None, res2_coff=0, out=None, out_coff=0, out_dtype=None, **kw):
         """model.train(): raw convolution (+ bias) into a dense buffer, then batch-statistics BatchNorm + residuals +
@@ -76,7 +82,8 @@ def conv_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, stride=1, pad=0, di
     [cin_lo, cin_lo + weight.shape[1]) of the layer's weight instead of the whole tensor."""
     w = sd[name + ".weight"] if weight is None else weight
     bias = sd.get(name + ".bias")
-    wq = weights.prep_conv_weight(w.to(device), dtype, cin_pad)
+    h2 = isinstance(dtype, str) and dtype == weights.H2
+    wq = weights.prep_conv_weight(w.to(device), torch.float32 if h2 else dtype, cin_pad)
     if bn is not None:
         scale, shift = weights.fold_bn(sd[bn + ".weight"], sd[bn + ".bias"], sd[bn + ".running_mean"],
                                        sd[bn + ".running_var"], eps, bias)
@@ -92,13 +99,13 @@ def conv_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, stride=1, pad=0, di
         kind="conv" if weight is None else "cin_slice", full_shape=tuple(full.shape), lo=cin_lo)
     if bn is not None:
         autodiff.CONV_META[wq].scale_ref = _dev(scale, device)
-    return Conv(wq, _dev(scale, device), _dev(shift, device), stride, pad, dil, act, x3=dtype == weights.X3,
-                bn=None if bn is None else _bn_spec(sd, bn, device, eps, bn_momentum), bias=_dev(bias, device))
+    return Conv(wq, _dev(scale, device), _dev(shift, device), stride, pad, dil, act, x3=weights.is_x3(dtype),
+                bn=None if bn is None else _bn_spec(sd, bn, device, eps, bn_momentum), bias=_dev(bias, device), h2=h2)
 
 
 def conv_from_weight(w, dtype, scale=None, shift=None, **kw):
     """Kernel-layout weight tensor [Cout,KH,KW,Cin_p] (storage dtype) -> Conv in the given precision mode."""
-    return Conv(w, scale, shift, x3=dtype == weights.X3, **kw)
+    return Conv(w, scale, shift, x3=weights.is_x3(dtype), **kw)
 
 
 def linear_from_sd(sd, name, device, act="none", in_pad=None, dtype=torch.float32, bn=None, eps=1e-5, bn_momentum=0.1):
@@ -117,7 +124,7 @@ def linear_from_sd(sd, name, device, act="none", in_pad=None, dtype=torch.float3
         None if bn is None else _dev(sd[bn + ".running_mean"], device),
         None if bn is None else torch.sqrt(_dev(sd[bn + ".running_var"], device) + eps), _dev(bias, device),
         kind="linear")
-    return Conv(wq, _dev(scale, device), _dev(shift, device), act=act, x3=dtype == weights.X3,
+    return Conv(wq, _dev(scale, device), _dev(shift, device), act=act, x3=weights.is_x3(dtype),
                 bn=None if bn is None else _bn_spec(sd, bn, device, eps, bn_momentum), bias=_dev(bias, device))
 
 
@@ -135,7 +142,7 @@ def deconv2x2_from_sd(sd, name, dtype, device, bn=None, eps=1e-5, act="none", bn
                                        sd[bn + ".running_var"], eps, bias)
     else:
         scale, shift = None, bias
-    return Conv(wq, _dev(scale, device), _dev(shift, device), act=act, pixel_shuffle2=True, x3=dtype == weights.X3,
+    return Conv(wq, _dev(scale, device), _dev(shift, device), act=act, pixel_shuffle2=True, x3=weights.is_x3(dtype),
                 bn=None if bn is None else _bn_spec(sd, bn, device, eps, bn_momentum), bias=_dev(bias, device))
 
 

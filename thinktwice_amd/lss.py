@@ -82,12 +82,12 @@ class _ResNet50:
         for stage in self.blocks:
             for blk in stage:
                 idt = blk["ds"](x) if blk["ds"] is not None else x
-                # conv1's output has one reader, the 3 x 3 conv2: pre-split (pair format) where conv2 runs on the compiler-scheduled
-                # LDS-DMA tile (64 output channels: layer1 -- the hand-pipelined kernels of the wider stages split in their MFMA gaps)
+                # conv1's output has one reader, the 3 x 3 conv2: produced pre-split (pair format, tt_conv_desc.in_pair) -- the
+                # operand split once per element in conv1's epilogue instead of nine times per column tile in conv2's K loop
                 c2 = blk["c2"]
                 rows2 = x.shape[0] * (x.shape[1] // c2.stride) * (x.shape[2] // c2.stride)
-                pr = (c2.w_x3 is not None and not layers.BN_TRAIN and c2.w.shape[0] == 64 and
-                      ops.pair_ok(rows2, c2.w.shape[-1], c2.w.shape[0]))
+                pr = (c2.w_x3 is not None and not layers.BN_TRAIN and
+                      ops.pair_ok(min(rows2, x.shape[0] * x.shape[1] * x.shape[2]), c2.w.shape[-1], c2.w.shape[0]))
                 y = c2(blk["c1"](x, out_pair=pr), in_pair=pr)
                 x = blk["c3"](y, res1=idt)          # relu(bn3(conv3) + identity)
             outs.append(x)
@@ -109,17 +109,50 @@ class PAFPN_fp32:
         assert start_level == 0 and end_level in (-1, len(in_channels)) and not add_extra_convs and \
             num_outs == len(in_channels), "PAFPN: only the thinktwice.py form (all levels, no extra convs) is built"
         self.in_channels, self.out_channels, self.num_outs = list(in_channels), out_channels, num_outs
-        self.wdtype, self.device = dtype, torch.device(device)
+        # dtype "f32x3h" (weights.X3H): the neck's own tensors -- laterals, top-down sums, intermediate maps -- live in IEEE half
+        # and its 3 x 3 convolutions run the two-MFMA h2 product (csrc/conv_h2.hip); inputs and outputs stay f32
+        self.half = isinstance(dtype, str) and dtype == weights.X3H
+        self.wdtype, self.device = (weights.X3 if self.half else dtype), torch.device(device)
         self.loaded = False
 
     def load_state_dict(self, sd, prefix):
         n, dt, dev, L = prefix, self.wdtype, self.device, self.num_outs
-        self.lat = [conv_from_sd(sd, f"{n}.lateral_convs.{i}.conv", dt, dev) for i in range(L)]
-        self.fpn = [conv_from_sd(sd, f"{n}.fpn_convs.{i}.conv", dt, dev, pad=1) for i in range(L)]
-        self.down = [conv_from_sd(sd, f"{n}.downsample_convs.{i}.conv", dt, dev, stride=2, pad=1) for i in range(L - 1)]
-        self.paf = [conv_from_sd(sd, f"{n}.pafpn_convs.{i}.conv", dt, dev, pad=1) for i in range(L - 1)]
+        inner = weights.H2 if self.half else dt       # layers whose INPUT is one of the neck's own (half) tensors
+        self.lat = [conv_from_sd(sd, f"{n}.lateral_convs.{i}.conv", dt, dev) for i in range(L)]     # read the backbone's f32 maps
+        self.fpn = [conv_from_sd(sd, f"{n}.fpn_convs.{i}.conv", inner, dev, pad=1) for i in range(L)]
+        self.down = [conv_from_sd(sd, f"{n}.downsample_convs.{i}.conv", inner, dev, stride=2, pad=1) for i in range(L - 1)]
+        self.paf = [conv_from_sd(sd, f"{n}.pafpn_convs.{i}.conv", inner, dev, pad=1) for i in range(L - 1)]
+        if self.half:
+            assert all(c % 64 == 0 for c in [self.out_channels]), "half-storage PAFPN: out_channels must be a multiple of 64"
         self.loaded = True
         return self
+
+    def _call_half(self, inputs, targets):
+        """The same data flow with the neck's own tensors in IEEE half: laterals written as half by the bf16x3 1 x 1 convs
+        (f32 backbone maps in), top-down and bottom-up sums rounded to half once, every 3 x 3 on the h2 kernel; the four OUTPUT
+        maps leave in f32 -- level 0 as the f32 twin of the half map downsample_convs.0 reads (tt_conv_desc.out2)."""
+        L, C, f16, f32 = self.num_outs, self.out_channels, torch.float16, torch.float32
+        lat = [self.lat[i](inputs[i], out_dtype=f16) for i in range(L)]
+        for i in range(L - 1, 0, -1):
+            ops.upsample_nearest_add_(lat[i - 1], lat[i])
+        NI, H0, W0, _ = lat[0].shape
+        if targets[0] is not None:
+            buf0, off0 = targets[0]
+        else:
+            buf0, off0 = torch.empty(NI, H0, W0, C, dtype=f32, device=lat[0].device), 0
+        inter0 = self.fpn[0](lat[0], out2=buf0, out2_coff=off0)                   # half map + its f32 twin in the consumer's buffer
+        inter = [inter0] + [self.fpn[i](lat[i]) for i in range(1, L)]
+        for i in range(L - 1):
+            self.down[i](inter[i], res1=inter[i + 1], out=inter[i + 1])
+        outs = [(buf0, off0, C)]
+        for i in range(1, L):
+            if targets[i] is not None:
+                buf, off = targets[i]
+                self.paf[i - 1](inter[i], out=buf, out_coff=off)
+            else:
+                buf, off = self.paf[i - 1](inter[i], out_dtype=f32), 0
+            outs.append((buf, off, C))
+        return outs
 
     def __call__(self, inputs, targets=None):
         """inputs: the backbone's maps (channel-last).  Returns [(tensor, channel offset, channels)] per level."""
@@ -127,6 +160,11 @@ class PAFPN_fp32:
         assert len(inputs) == len(self.in_channels)
         targets = list(targets) if targets is not None else [None] * L
         C = self.out_channels
+        if self.half:
+            from . import autodiff
+            if autodiff.TAPE is not None or layers.BN_TRAIN:
+                raise _lib.TTError("PAFPN: the half-storage mode ('f32x3h') is an inference mode; train in 'f32x3' or float32")
+            return self._call_half(inputs, targets)
         lat = [self.lat[i](inputs[i]) for i in range(L)]
         for i in range(L - 1, 0, -1):
             ops.upsample_nearest_add_(lat[i - 1], lat[i])
@@ -165,6 +203,10 @@ class LSS:
         self.queue_len = queue_len
         self.img_neck_conf = dict(img_neck_conf) if img_neck_conf else dict(type="PAFPN", in_channels=[256, 512, 1024, 2048],
                                                                               num_outs=4, out_channels=256)
+        # "f32x3h": bf16x3 with the PAFPN on half storage (weights.X3H); every other layer of this module sees plain bf16x3
+        self.half_neck = isinstance(dtype, str) and dtype == weights.X3H
+        if self.half_neck:
+            dtype = weights.X3
         self.wdtype = dtype                               # precision mode of the conv weights (may be weights.X3)
         self.dtype = weights.storage_dtype(dtype)         # storage type of the activations
         self.device = torch.device(device)
@@ -181,7 +223,8 @@ class LSS:
         f32 = torch.float32
         self.backbone = _ResNet50(sd, p + ".img_backbone", dt, dev)
         # lss.py:402 `self.img_neck = build_neck(img_neck_conf)`: the NECKS registry ('PAFPN' / 'PAFPN_fp32')
-        self.img_neck = build_neck(self.img_neck_conf, dtype=dt, device=dev).load_state_dict(sd, p + ".img_neck")
+        self.img_neck = build_neck(self.img_neck_conf, dtype=weights.X3H if self.half_neck else dt,
+                                   device=dev).load_state_dict(sd, p + ".img_neck")
         self.neck_conv = conv_from_sd(sd, p + ".neck_conv", dt, dev)
         d = p + ".depth_net"
         self.bn22 = layers.bn_affine(sd, d + ".bn", dev)
@@ -307,19 +350,22 @@ class LSS:
         d = ops.channel_gate(x, g_dep)
         if dbg is not None:
             dbg.update(se_depth=d)
+        x3 = self.bb[0][0].w_x3 is not None and not layers.BN_TRAIN
+        pr = x3 and ops.pair_ok(NI * h * w, d.shape[-1], d.shape[-1])    # conv1's output: one reader, conv2 (pair format)
         for c1, c2 in self.bb:
-            d = c2(c1(d), res1=d)
+            d = c2(c1(d, out_pair=pr), res1=d, in_pair=pr)
         if dbg is not None:
             dbg.update(blocks=d)
         mid = d.shape[-1]
         cat = torch.empty(NI, h, w, 4 * mid, dtype=dt, device=dev)
+        pr_cat = x3 and mid % 16 == 0 and ops.pair_ok(NI * h * w, 4 * mid, mid)   # the branch concat: one reader, conv1 of the ASPP
         for i, br in enumerate(self.aspp):
-            br(d, out=cat, out_coff=i * mid)
+            br(d, out=cat, out_coff=i * mid, out_pair=pr_cat)
         x5 = self.aspp_gap(rows(ops.spatial_pool(d, 0)))                 # (NI,1,1,mid) f32
         # eval: bn_scale * (W5 @ x5) joins the folded epilogue; train: the raw W5 @ x5 joins the raw conv in front of the BN
         self.aspp_gapw.scale = None if layers.BN_TRAIN else self.aspp_out.scale
         shift_n = unrows(self.aspp_gapw(x5)).contiguous()
-        d = self.aspp_out(cat, shift_n=shift_n, shift_n_mod=NI)
+        d = self.aspp_out(cat, shift_n=shift_n, shift_n_mod=NI, in_pair=pr_cat)
         if dbg is not None:
             dbg.update(aspp_cat=cat, x5=x5, aspp_pre_dropout=d)
         if layers.BN_TRAIN:

@@ -116,6 +116,7 @@ class _ConvDesc(ctypes.Structure):
         ("gather_idx", ctypes.c_void_p), ("m_dev", ctypes.c_void_p), ("splitk_ws", ctypes.c_void_p),
         ("weight_x3", ctypes.c_void_p), ("row_perm", ctypes.c_void_p), ("row_mask", ctypes.c_void_p),
         ("splitk_slices", _c), ("in_pair", _c), ("out_pair", _c),
+        ("weight_h2", ctypes.c_void_p), ("out2", ctypes.c_void_p), ("out2_cstride", _c), ("out2_coff", _c),
     ]
 
 
@@ -243,12 +244,15 @@ def sp_from_dense(gdense, coords, rows, max_rows, dims, grows):
 def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=None, res1_coff=0,
            res2=None, res2_coff=0, out=None, out_coff=0, in_coff=0, cin=None, pixel_shuffle2=False,
            shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None, splitk_ws=None,
-           in_cstride=None, w_x3=None, _no_tape=False, stop_grad=False, bn_raw=False, in_pair=False, out_pair=False):
+           in_cstride=None, w_x3=None, _no_tape=False, stop_grad=False, bn_raw=False, in_pair=False, out_pair=False,
+           w_h2=None, out2=None, out2_coff=0):
     """Channel-last implicit-GEMM convolution on MFMA (tt_conv2d_fwd).
 
     x   [N,H,W,Cs]  (f32 or bf16); channels [in_coff, in_coff+cin) are convolved
     w   [Cout,KH,KW,cin] same dtype (for pixel_shuffle2: [4*Cout_real,1,1,cin])
     out [N,OH,OW,Ct] written at channel offset out_coff (allocated if None)
+    w_h2: (x, w half) the f16 (hi, lo) weight pair of weights.split_pairs_h2 -- the layer runs the two-MFMA "h2" product
+    out2 / out2_coff: optional second, f32, copy of the output rows at channel offset out2_coff of a [.., Ct2] tensor
     in_pair / out_pair (bf16x3 layers only): x is / out becomes a PAIR-format tensor (an f32-typed container holding, per 16
     channels, the bf16 hi and lo halves the kernel's operand split would produce: tt_conv_desc.in_pair).  Only for tensors whose
     every reader is a bf16x3 convolution (`pair_ok(rows)` says whether a layer of that many output rows takes one).
@@ -287,6 +291,15 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     d.res2 = _dp(res2); d.res2_cstride = 0 if res2 is None else res2.shape[-1]; d.res2_coff = res2_coff
     d.act = act; d.dtype = dtype_code(x); d.out_dtype = dtype_code(out)
     from . import autodiff
+    if w_h2 is not None:
+        assert x.dtype == torch.float16 and w.dtype == torch.float16 and w_h2.dtype == torch.float16 and w_h2.is_contiguous() \
+            and w_h2.numel() == 2 * w.numel() and w_x3 is None and splitk_ws is None
+        if autodiff.TAPE is not None:
+            raise _lib.TTError("conv2d: half-storage (h2) layers have no backward; train in dtype torch.float32 or 'f32x3'")
+        d.weight_h2 = w_h2.data_ptr()
+    if out2 is not None:
+        assert out2.dtype == torch.float32 and out2.numel() // out2.shape[-1] == N * OH * OW and out2.stride(-1) == 1
+        d.out2 = out2.data_ptr(); d.out2_cstride = out2.shape[-1]; d.out2_coff = out2_coff
     if in_pair or out_pair:
         assert w_x3 is not None and x.dtype == torch.float32 and out.dtype == torch.float32 and splitk_ws is None
         if autodiff.TAPE is not None:
@@ -300,7 +313,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
         x3_splitk = autodiff.TAPE is None and not _no_tape
         if x3_splitk:
             d.weight_x3 = w_x3.data_ptr()
-    if _AUTO_SPLITK and splitk_ws is None and not (in_pair or out_pair) and N * OH * OW <= 4096 and KH * KW * Cin >= 2048:
+    if _AUTO_SPLITK and splitk_ws is None and not (in_pair or out_pair) and w_h2 is None and N * OH * OW <= 4096 and KH * KW * Cin >= 2048:
         # few rows, very long K (BEV-update conv K=18720, flatten MLPs): cross-workgroup split-K with an f32 workspace
         # beats conv_small.hip's in-workgroup split there (277 vs 416 us on the BEV-update conv: the direct 32 B/row
         # operand loads of the small kernel waste L2 sectors on a 10 MB weight matrix).  TT_CONV_AUTO_SPLITK=0 disables.
@@ -330,8 +343,10 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
             esz, osz = x.element_size(), out.element_size()
             m_out = N * OH * OW
             in_px = min(N * H * W, m_out * KH * KW)           # a strided 1x1 layer only touches the pixels it samples
-            CONV_BYTES.append(in_px * (in_cstride or Cin) * esz + m_out * Cout * osz + w.numel() * w.element_size() +
-                              m_out * Cout * esz * ((res1 is not None) + (res2 is not None)))
+            wsz = w.numel() * w.element_size() * (2 if w_h2 is not None else 1)
+            CONV_BYTES.append(in_px * (in_cstride or Cin) * esz + m_out * Cout * osz + wsz +
+                              m_out * Cout * esz * ((res1 is not None) + (res2 is not None)) +
+                              (m_out * Cout * 4 if out2 is not None else 0))
     if not _no_tape:
         from . import autodiff
         if autodiff.TAPE is not None:

@@ -11,9 +11,36 @@ import torch
 X3 = "f32x3"      # precision mode: f32 storage, bf16x3 MFMA arithmetic (pre-split weights beside the f32 ones)
 
 
+# precision mode of the MODEL: bf16x3 everywhere except the PAFPN, which keeps its activations in IEEE half and runs the two-MFMA
+# "h2" product (the one stage whose half storage the storage-level emulation clears).  Every module but LSS treats it as X3.
+X3H = "f32x3h"
+# precision mode of ONE layer: half activation storage x f16 (hi, lo) weight pair (csrc/conv_h2.hip)
+H2 = "h2"
+
+
+def is_x3(dtype):
+    return isinstance(dtype, str) and dtype in (X3, X3H)
+
+
 def storage_dtype(dtype):
     """torch dtype activations / plain weights are stored in for a precision mode."""
-    return torch.float32 if dtype == X3 else dtype
+    if is_x3(dtype):
+        return torch.float32
+    return torch.float16 if (isinstance(dtype, str) and dtype == H2) else dtype
+
+
+def split_pairs_h2(w):
+    """f32 weights [Cout, ..., K-contiguous] with K % 16 == 0 -> f16 tensor with a doubled last dimension holding, per 16 K
+    elements, 64 B = [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] with hi = f16(w), lo = f16(w - hi) (round to nearest even both):
+    the B operand of conv_h2_kernel (tt_conv_desc.weight_h2)."""
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.shape[-1] % 16 == 0
+    co = w.shape[0]
+    k = w.numel() // co
+    flat = w.reshape(co, k // 16, 16)
+    hi = flat.to(torch.float16)
+    lo = (flat - hi.float()).to(torch.float16)
+    pair = torch.stack([hi, lo], 2).contiguous()            # (co, k/16, 2, 16) f16 = 64 B per group
+    return pair.reshape(*w.shape[:-1], 2 * w.shape[-1]).contiguous()
 
 
 def vec_of(dtype):
