@@ -120,11 +120,11 @@ class VoxelPoolWorkload:
 
     def _pmc_traffic(self):
         """HBM bytes per launch of the op's kernels from the committed rocprofv3 counter passes of this workload
-        (profiles/r05_voxel_pool_pmc.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KB), if they were taken from this build."""
+        (profiles/r06_voxel_pool_pmc.json: FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KB), if they were taken from this build."""
         import json
         try:
             from thinktwice_amd import build
-            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_voxel_pool_pmc.json")
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_voxel_pool_pmc.json")
             data = json.load(open(path))
             if data.get("_stamp", {}).get("csrc_sha") != build.source_fingerprint() or self.B != 8:
                 return None
@@ -237,7 +237,8 @@ def main():
                        "frames_per_gpu_per_step": args.batch,
                        "global_frames_per_step": args.batch * world,
                        "parallelism": f"replicas x{world} (no data-path collective)",
-                       "launch": getattr(wl, "launch_note", "eager launches")},
+                       "launch": getattr(wl, "launch_note", "eager launches"),
+                       "batches_in_flight": getattr(wl, "pipeline", 1)},
             "roofline": wl.roofline(),
         }
         extra = getattr(wl, "extra", None)

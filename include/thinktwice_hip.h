@@ -379,7 +379,16 @@ int tt_look_query_ln(int B, const int* query_of_slot, const float* ref_packed, c
 int tt_msda_sample_ln(int B, const void* value, int value_dtype, int value_cstride, int value_coff,
                       const float* offsets, const float* logits, const float* ref_packed, const int* level_hw,
                       const float* gamma, const float* beta, float eps, float* out, float* out_ln,
-                      const int* max_len_or_null, void* stream);   /* max_len (device, from tt_look_project_pack): rows of
+                      const int* max_len_or_null, void* stream);
+/* The same rows WITHOUT a projected value tensor ("sample first, project after"): level_maps = the four fpn_linear maps
+ * [B*4][H_l][W_l][256] f32, wvT = value_proj.weight transposed [in 256][out 256], bias [256], vshift [level 4][camera 4][256] =
+ * W (cams_embeds + level_embeds) (thinktwice_decoder.py:392-393).  value_proj is applied to the attention-weighted sum of the raw
+ * rows; the bias / embedding terms enter through the in-bounds weight of each level (zero padding).  Replaces
+ * multi_scale_deformable_attn_function.py:474 (value_proj over every position) + :497-525 in the composite decoder. */
+int tt_msda_sample_proj_ln(int B, const void* const* level_maps, const int* level_hw, const float* offsets,
+                           const float* logits, const float* ref_packed, const float* wvT, const float* bias,
+                           const float* vshift, const float* gamma, const float* beta, float eps, float* out,
+                           float* out_ln, const int* max_len_or_null, void* stream);   /* max_len (device, from tt_look_project_pack): rows of
                       slots >= *max_len are skipped and left unwritten -- tt_sca_reduce_ln never reads them */
 int tt_sca_reduce_ln(int B, const float* x, const int* max_len, const float* gamma, const float* beta, float eps,
                      float* out, void* stream);

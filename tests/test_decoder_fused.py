@@ -119,3 +119,41 @@ def test_msda_sample_ln_skips_only_the_slots_no_one_reads():
                           torch.zeros(1024).cuda())
     b = ops.sca_reduce_ln(y, ml, B, torch.ones(1024).cuda(), torch.zeros(1024).cuda())
     assert torch.equal(a, b)                                                # the consumer never touches the skipped rows
+
+
+def test_sample_first_project_after_equals_projecting_every_position():
+    """tt_msda_sample_proj_ln (round 6): the attention rows from the RAW fpn_linear maps -- weighted sum of the sampled 256-channel
+    rows per head, then the head's slice of value_proj, bias and (level, camera) embedding shift weighted by the in-bounds corner
+    weight -- against the reference's order (multi_scale_deformable_attn_function.py:474: value_proj of every position, then
+    sample): tt_conv2d_fwd (exact f32) + tt_msda_sample_ln.  Offsets large enough that many corners fall outside (zero padding,
+    where the bias must NOT contribute); exact-f32 arithmetic on both sides, different summation order: 2e-5 of the max."""
+    from thinktwice_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(7)
+    level_hw = [(16, 32), (8, 16), (4, 8), (2, 4)]
+    maps = [torch.randn(B * 4, h, w, 256, generator=g).cuda() for h, w in level_hw]
+    W = (torch.randn(256, 256, generator=g) * 256 ** -0.5).cuda()
+    bias = torch.randn(256, generator=g).cuda()
+    vshift = torch.randn(4, 4, 256, generator=g).cuda()                     # (level, camera, channel)
+    R = B * 4 * 120
+    off = (torch.randn(R, 512, generator=g) * 3).cuda()
+    aw = torch.randn(R, 256, generator=g).cuda()
+    ref = torch.rand(B, 4, 120, 2, generator=g).cuda()
+    gamma, beta = torch.randn(256, generator=g).cuda(), torch.randn(256, generator=g).cuda()
+    # reference order: project every position (+ bias + per-(level, camera) shift), then sample
+    S = sum(h * w for h, w in level_hw)
+    value = torch.empty(B * 4, S, 256, device="cuda")
+    start = 0
+    for l, (m, (h, w)) in enumerate(zip(maps, level_hw)):
+        ops.conv2d(m, W.view(256, 1, 1, 256).contiguous(), shift=bias, shift_n=vshift[l].contiguous(), shift_n_mod=4,
+                   out=value[:, start:start + h * w].unflatten(1, (h, w)), out_nstride=S * 256)
+        start += h * w
+    want, want_ln = ops.msda_sample_ln(value, off, aw, ref, level_hw, B, 0, gamma, beta)
+    got, got_ln = ops.msda_sample_proj_ln(maps, off, aw, ref, B, W.t().contiguous(), bias, vshift.contiguous(), gamma, beta)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) < 2e-5 * scale, float((got - want).abs().max()) / scale
+    assert float((got_ln - want_ln).abs().max()) < 1e-3 * float(want_ln.abs().max())      # (LayerNorm amplifies by 1 / std of a row)
+    ml = torch.tensor([29], dtype=torch.int32, device="cuda")
+    part, _ = ops.msda_sample_proj_ln(maps, off, aw, ref, B, W.t().contiguous(), bias, vshift.contiguous(), gamma, beta, max_len=ml)
+    live = (torch.arange(R, device="cuda") % 120) < 29
+    assert torch.equal(part[live], got[live])

@@ -12,7 +12,7 @@ from . import ops, params, synth
 MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "bf16x3h": 2500.0}
 TORCH_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "bf16x3": "f32x3", "bf16x3h": "f32x3h"}
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = "r05"            # profiles/<tag>_forward_<dtype>_{kernel_stats.csv,pmc.json}: the committed rocprofv3 passes of this build
+PROFILE_TAG = "r06"            # profiles/<tag>_forward_<dtype>_{kernel_stats.csv,pmc.json}: the committed rocprofv3 passes of this build
 
 
 def mfma_per_product(kernel_label, dtype):
@@ -42,6 +42,9 @@ class ForwardWorkload:
                      f"65536-pt LiDAR), ResNet50+PAFPN+DepthNet+UNet+LSS splat, LidarNet, fusion, 5-stage decoder")
         self.precision_note = {
             "f32": "f32 everywhere (exact-f32 MFMA), parity mode",
+            "bf16x3h": "the bf16x3 mode with the PAFPN's own tensors in IEEE half and its 3 x 3 layers on two f16 MFMAs per product "
+                       "(half activation x f16 (hi, lo) weights, csrc/conv_h2.hip).  Outputs within 1e-3 of each tensor's max, "
+                       "waypoint L2 1.19 mm at B = 8 (tests/test_forward.py MODES): opt-in, not the headline",
             "bf16x3": "f32 storage everywhere; the camera + LiDAR trunks and the value projections multiply in bf16x3 "
                       "(operands split into bf16 hi+lo pairs, three v_mfma_f32_32x32x16_bf16 per product, f32 "
                       "accumulate: ~1e-5 relative error); layers outside the LDS-DMA kernel, BEV fusion, lift-splat and "
@@ -62,8 +65,10 @@ class ForwardWorkload:
         # TT_BENCH_GRAPH=1 replays one captured HIP graph per forward.  The graph pays at batch 1: see tick_latency.
         self.graph = None
         self.launch_note = "eager launches"
-        # TT_BENCH_PIPELINE=n: batches in flight (n streams, round-robin); 1 = one batch at a time on the current stream
-        self.pipeline = int(os.environ.get("TT_BENCH_PIPELINE", "1"))
+        # TT_BENCH_PIPELINE=n: batches in flight (n streams, round-robin; default 3: 88.1 / 87.3 / 84.7 ms per step for 1 / 2 / 3,
+        # profiles/r06_pipeline_ab.txt); 1 = one batch at a time on the current stream (reported beside the headline as
+        # `one_batch_at_a_time`)
+        self.pipeline = int(os.environ.get("TT_BENCH_PIPELINE", "3"))
         self._streams, self._tick = None, 0
         if self.pipeline > 1:
             self.launch_note = f"eager launches, {self.pipeline} batches in flight on alternating streams"
@@ -198,7 +203,7 @@ class ForwardWorkload:
                             "second stream there"}
         traffic, traffic_note = self._pmc_traffic()
         x3 = {}
-        if self.dtype == "bf16x3":
+        if self.dtype in ("bf16x3", "bf16x3h"):
             # `achieved` / `frac` count ALGORITHMIC flops (2 M N K) against the dense bf16 MFMA peak; every product costs
             # three bf16 MFMAs in this mode, so frac is bounded by 1/3 -- the matrix pipe itself is at 3x that
             x3 = {"mfma_per_product": 3, "executed_mfma_tflops": round(3 * ach, 1),
@@ -246,6 +251,25 @@ class ForwardWorkload:
 
     def extra(self):
         out = {}
+        if self.pipeline > 1 and self.graph is None and os.environ.get("TT_BENCH_SERIAL", "1") != "0":
+            # the same steps with ONE batch in flight (every forward starts when the previous one has been issued on the same
+            # stream): what a caller that needs each result before the next frame sees
+            import time
+            keep, self.pipeline = self.pipeline, 1
+            try:
+                for _ in range(2):
+                    self.step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n = 6
+                for _ in range(n):
+                    self.step()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / n
+            finally:
+                self.pipeline = keep
+            out["one_batch_at_a_time"] = {"value": round(self.B / dt, 3), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3),
+                                          "steps": n}
         if getattr(self, "_decoder_gemm", None):
             out["decoder_gemm"] = self._decoder_gemm
         if os.environ.get("TT_BENCH_TICK", "1") != "0" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
@@ -265,7 +289,10 @@ class ForwardWorkload:
         single = int(os.environ.get("WORLD_SIZE", "1")) == 1
         # the same workload in the other precision modes, a few timed steps each: the exact-f32 parity mode and the
         # bf16-storage speed mode (whose outputs are NOT inside the 1e-3 tolerance: tests/test_forward.py MODES)
-        legs = [("f32", "f32_parity_mode", "TT_BENCH_F32"), ("bf16", "bf16_speed_mode", "TT_BENCH_BF16")]
+        # ... and the opt-in "f32x3h" mode (bf16x3 + the PAFPN on half storage / two-MFMA products): every output inside the
+        # relative 1e-3, but its waypoint distance at B = 8 (1.19 mm) misses the 1 mm this repo asks of a parity mode
+        legs = [("f32", "f32_parity_mode", "TT_BENCH_F32"), ("bf16x3h", "bf16x3h_mode", "TT_BENCH_X3H"),
+                ("bf16", "bf16_speed_mode", "TT_BENCH_BF16")]
         for dt_name, key, env in legs:
             if not single or dt_name == self.dtype or os.environ.get(env, "1") == "0":
                 continue

@@ -327,6 +327,103 @@ __global__ __launch_bounds__(256) void msda_sample_ln_kernel(const T* __restrict
     out_ln[row * 256 + t] = d * rstd * gamma[t] + beta[t];
 }
 
+// "Sample first, project after" (round 6): the same attention rows WITHOUT the value tensor.  value_proj is linear and the
+// bilinear sample with zero padding is linear in the map, so for head h
+//     sum_s w_s * sample(W_h x + b_h + e_{level, cam}, loc_s)  =  W_h . z_h  +  sum_level beta_{h, level} * (b_h + e_{level, cam}),
+//     z_h = sum_s w_s * sample(x, loc_s)  (256 raw FPN channels),   beta_{h, level} = sum_{s in level} w_s * (in-bounds corner weight)
+// (multi_scale_deformable_attn_function.py:474 projects all 33,320 positions x 4 cameras x B of every layer -- 5.5 GB of f32 at
+// B = 8 of which the sampler reads a few per cent; here a row gathers the raw 1 KiB FPN rows of its 8 x 32 x 4 corners and applies
+// the head's 32 x 256 slice once).  One block per (b, cam, slot); phase 0: thread = (head, sample) -> softmax weight, corner
+// positions and weights into LDS; phase 1: thread = input channel, eight accumulators z_h[k] over the 1024 corner rows (coalesced
+// 1 KiB loads); phase 2: thread = output channel, a 256-long dot product with the transposed weight (coalesced) + the bias terms;
+// then the LayerNorm of msda_sample_ln_kernel.  Exact f32 FMAs.
+__global__ __launch_bounds__(256) void msda_sample_proj_ln_kernel(LevelMaps lv, const float* __restrict__ offsets,
+                                                                  const float* __restrict__ logits,
+                                                                  const float* __restrict__ ref, const float* __restrict__ wvT,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ vshift,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float eps,
+                                                                  float* __restrict__ out, float* __restrict__ out_ln,
+                                                                  const int* __restrict__ max_len) {
+    __shared__ float red[4];
+    __shared__ int cidx[8 * 32 * 4];          // corner position inside its level map, -1 = outside (zero padding)
+    __shared__ float cwt[8 * 32 * 4];         // attention weight x bilinear corner weight
+    __shared__ float sbeta[8 * 4];
+    __shared__ float z[8 * 256];
+    const long long row = blockIdx.x;
+    const int bc = (int)(row / kQ);
+    if (max_len && (int)(row - (long long)bc * kQ) >= *max_len) return;          // block-uniform: slots nobody reads
+    const int t = threadIdx.x, head = t >> 5, i = t & 31, l = i >> 3;
+    {
+        const float lg = logits[row * 256 + t];
+        float mx = lg;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));      // (xor < 32: stays inside the head's 32 lanes)
+        const float e = expf(lg - mx);
+        float den = e;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) den += __shfl_xor(den, o);
+        const float w = e / den;
+        const int H = lv.H[l], W = lv.W[l];
+        const float nx = ref[row * 2 + 0] + offsets[row * 512 + t * 2 + 0] / (float)W;
+        const float ny = ref[row * 2 + 1] + offsets[row * 512 + t * 2 + 1] / (float)H;
+        const float x = nx * (float)W - 0.5f, y = ny * (float)H - 0.5f;
+        const float fx = floorf(x), fy = floorf(y);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float lx = x - fx, ly = y - fy;
+        float inb = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int xx = x0 + (c & 1), yy = y0 + (c >> 1);
+            const bool ok = xx >= 0 && xx < W && yy >= 0 && yy < H;
+            const float cw = ((c >> 1) ? ly : 1.f - ly) * ((c & 1) ? lx : 1.f - lx);
+            cidx[t * 4 + c] = ok ? yy * W + xx : -1;
+            cwt[t * 4 + c] = w * cw;
+            inb += ok ? w * cw : 0.f;
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) inb += __shfl_xor(inb, o);               // the level's 8 points
+        if ((i & 7) == 0) sbeta[head * 4 + l] = inb;
+    }
+    __syncthreads();
+    // ---- phase 1: z[h][t] over the head's 32 samples x 4 corners; thread = raw FPN channel
+    const float* base[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        base[q] = reinterpret_cast<const float*>(lv.p[q]) + (long long)bc * lv.H[q] * lv.W[q] * 256 + t;
+#pragma unroll 1
+    for (int h = 0; h < 8; ++h) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll 8
+            for (int sidx = 0; sidx < 32; ++sidx) {                              // 8 points x 4 corners of level q
+                const int e = (h * 32 + q * 8 + (sidx >> 2)) * 4 + (sidx & 3);
+                const int ci = cidx[e];
+                const float v = ci >= 0 ? base[q][(long long)ci * 256] : 0.f;
+                acc += cwt[e] * v;
+            }
+        }
+        z[h * 256 + t] = acc;
+    }
+    __syncthreads();
+    // ---- phase 2: thread = output channel (head = t >> 5)
+    float acc = 0.f;
+    const float* zh = z + head * 256;
+#pragma unroll 8
+    for (int k = 0; k < 256; ++k) acc += wvT[k * 256 + t] * zh[k];
+    const int cam = bc & 3;
+    const float b0 = bias[t];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc += sbeta[head * 4 + q] * (b0 + vshift[(q * 4 + cam) * 256 + t]);
+    out[row * 256 + t] = acc;
+    const float mean = block_sum256(acc, red) / 256.f;
+    const float d = acc - mean;
+    const float rstd = 1.f / sqrtf(block_sum256(d * d, red) / 256.f + eps);
+    out_ln[row * 256 + t] = d * rstd * gamma[t] + beta[t];
+}
+
 // sca_reduce + LayerNorm(1024) (output_proj.0): one block of 1024 threads per sample, thread = (camera, channel)
 __global__ __launch_bounds__(1024) void sca_reduce_ln_kernel(const float* __restrict__ x, const int* __restrict__ max_len,
                                                              int B, const float* __restrict__ gamma,
@@ -514,6 +611,20 @@ extern "C" int tt_msda_sample_ln(int B, const void* value, int value_dtype, int 
     else MLN(uint16_t);
 #undef MLN
     return check_launch("tt_msda_sample_ln");
+}
+
+extern "C" int tt_msda_sample_proj_ln(int B, const void* const* level_maps, const int* level_hw, const float* offsets,
+                                      const float* logits, const float* ref_packed, const float* wvT, const float* bias,
+                                      const float* vshift, const float* gamma, const float* beta, float eps, float* out,
+                                      float* out_ln, const int* max_len_or_null, void* stream) {
+    TT_REQUIRE(level_maps && level_hw && offsets && logits && ref_packed && wvT && bias && vshift && gamma && beta && out && out_ln,
+               "tt_msda_sample_proj_ln: null");
+    LevelMaps m;
+    fill_levels(m, level_maps, level_hw);
+    const long long rows_n = (long long)B * kCams * kQ;
+    hipLaunchKernelGGL(msda_sample_proj_ln_kernel, dim3((unsigned)rows_n), dim3(256), 0, (hipStream_t)stream, m, offsets, logits,
+                       ref_packed, wvT, bias, vshift, gamma, beta, eps, out, out_ln, max_len_or_null);
+    return check_launch("tt_msda_sample_proj_ln");
 }
 
 extern "C" int tt_sca_reduce_ln(int B, const float* x, const int* max_len, const float* gamma, const float* beta,

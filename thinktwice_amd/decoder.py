@@ -114,6 +114,12 @@ class _Layer:
         self.flat2 = linear_from_sd(sd, p + ".flattened_BEV_feat_update_module.2", dev)
 
 
+# Composite decoder: "sample first, project after" (csrc/look_module.hip msda_sample_proj_ln_kernel) instead of projecting every
+# position of every level for all five layers up front.  TT_DEC_SAMPLE_FIRST=0 (test hook: tests/test_decoder_fused.py compares
+# the two forms): the value GEMM + tt_msda_sample_ln
+SAMPLE_FIRST = os.environ.get("TT_DEC_SAMPLE_FIRST", "1") != "0"
+
+
 @HEADS.register_module()
 class ThinkTwiceDecoder:
     def __init__(self, config=None, bev_h=None, bev_w=None, BEV_feat_dim=256, flattened_BEV_feat_dim=256,
@@ -158,6 +164,10 @@ class ThinkTwiceDecoder:
             w_e = conv_from_weight(lay.vproj_w.reshape(256, 1, 1, 256).clone(), F32)    # (a 16 B aligned copy: under the trainer
             # vproj_w is a view into the flat master buffer at an arbitrary offset)
             lay.vshift = [unrows(w_e(rows(emb[l].contiguous()))).contiguous() for l in range(4)]
+            # operands of the sample-first form (tt_msda_sample_proj_ln): W^T [in][out], W e per (level, camera)
+            lay.vproj_wT = lay.vproj_w.t().contiguous()
+            lay.vproj_b = lay.vproj_b.contiguous()
+            lay.vshift_lc = torch.stack(lay.vshift, 0).contiguous()                  # (level, cam, 256)
         self.vproj_all_shift = torch.cat([lay.vproj.shift for lay in self.layers], 0).contiguous()  # (L*256,)
         self.vproj_all = conv_from_weight(torch.cat([lay.vproj.w for lay in self.layers], 0).contiguous(),
                                           self.wdtype, shift=self.vproj_all_shift)                  # (L*256,1,1,256)
@@ -476,11 +486,16 @@ class ThinkTwiceDecoder:
         main = torch.cuda.current_stream(dev)
         fork = getattr(parent_module, "use_side_stream", True)
         vready = None
-        if fork:
+        if fork and self._branch is None:
+            self._branch = torch.cuda.Stream(dev)
+        if SAMPLE_FIRST and all(m.dtype == F32 for m in mlvl):
+            # (f32 maps: the 16-bit storage modes keep the projected-value form, whose sampler reads 16-bit rows)
+            # the composite decoder samples the raw fpn_linear maps and applies value_proj to the weighted sums
+            # (tt_msda_sample_proj_ln): the (B*4, 33320, 5*256) value tensor and its GEMM do not exist
+            value_all = None
+        elif fork:
             if self._vstream is None:
                 self._vstream = torch.cuda.Stream(dev)
-            if self._branch is None:
-                self._branch = torch.cuda.Stream(dev)
             self._vstream.wait_stream(main)
             with torch.cuda.stream(self._vstream):
                 value_all = self._project_values(mlvl, B, S)

@@ -220,9 +220,15 @@ class FusedDecoder:
         a = lay.chain_a
         ops.mlp_chain(qn, [{"lin": a[0], "src": -1}, {"lin": a[1], "src": 0}, {"lin": a[2], "src": 1, "out": (off, 0)},
                            {"lin": a[3], "src": 1, "out": (aw, 0)}])
-        if vready is not None and wait_values:
-            torch.cuda.current_stream(dev).wait_stream(vready)
-        att, an = ops.msda_sample_ln(value_all, off, aw, ref, level_hw, B, L * 256, *lay.ffn_ln, max_len=max_len)
+        if value_all is None:
+            # sample first, project after: no projected value tensor (decoder.py SAMPLE_FIRST)
+            dl = dec.layers[L]               # the layer-wise decoder's prepared value_proj operands (decoder.py load_state_dict)
+            att, an = ops.msda_sample_proj_ln(mlvl, off, aw, ref, B, dl.vproj_wT, dl.vproj_b, dl.vshift_lc, *lay.ffn_ln,
+                                              max_len=max_len)
+        else:
+            if vready is not None and wait_values:
+                torch.cuda.current_stream(dev).wait_stream(vready)
+            att, an = ops.msda_sample_ln(value_all, off, aw, ref, level_hw, B, L * 256, *lay.ffn_ln, max_len=max_len)
         y = torch.empty(R, 256, dtype=F32, device=dev)
         b_ = lay.chain_b
         ops.mlp_chain(an, [{"lin": b_[0], "src": -1}, {"lin": b_[1], "src": 0, "res": (att, 0), "out": (y, 0)}])

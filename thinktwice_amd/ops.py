@@ -305,6 +305,10 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
         if autodiff.TAPE is not None:
             raise _lib.TTError("conv2d: pair-format activations are an inference-path layout (the tape reads f32 tensors)")
         d.in_pair, d.out_pair = int(bool(in_pair)), int(bool(out_pair))
+    if w_x3 is not None and Cout < 64 and (autodiff.TAPE is not None or _no_tape):
+        # training step (taped forward, recomputations, input-gradient convolutions): the layers with fewer than 64 output channels
+        # keep the exact-f32 kernels the gradient goldens were taken with (inference runs them on the 256 x 32 bf16x3 tile)
+        w_x3 = None
     if w_x3 is not None:       # (before the split-K query: with a bf16x3 operand the query answers for the bf16x3 split-K tile)
         assert x.dtype == torch.float32 and w_x3.shape == w.shape and w_x3.is_contiguous()
         # the training step (forward under the tape, and the backward's recomputations / input-gradient convolutions, which
@@ -1163,6 +1167,23 @@ def msda_sample_ln(value, offsets, logits, ref, level_hw, B, coff, gamma, beta, 
     check(lib().tt_msda_sample_ln(_c(B), ptr(value), _c(dtype_code(value)), _c(value.shape[-1]), _c(coff), ptr(offsets),
                                   ptr(logits), ptr(ref), hw, ptr(gamma), ptr(beta), _f(eps), ptr(out), ptr(out_ln),
                                   ptr(max_len), _st(value)), "tt_msda_sample_ln")
+    return out, out_ln
+
+
+def msda_sample_proj_ln(maps, offsets, logits, ref, B, wvT, bias, vshift, gamma, beta, eps=1e-5, max_len=None):
+    """msda_sample_ln without a projected value tensor (tt_msda_sample_proj_ln): `maps` = the four fpn_linear maps (B*4, H_l, W_l,
+    256) f32, wvT (256 in, 256 out) = value_proj.weight^T, bias (256), vshift (4 levels, 4 cameras, 256) -> (raw rows, normalised
+    rows), both (B*4*120, 256) f32."""
+    R = B * 4 * 120
+    dev = offsets.device
+    assert all(m.dtype == torch.float32 and m.is_contiguous() and m.shape[-1] == 256 for m in maps)
+    assert tuple(wvT.shape) == (256, 256) and wvT.is_contiguous() and tuple(vshift.shape) == (4, 4, 256) and vshift.is_contiguous()
+    out = torch.empty(R, 256, dtype=torch.float32, device=dev)
+    out_ln = torch.empty(R, 256, dtype=torch.float32, device=dev)
+    arr, hw = _level_args(maps)
+    check(lib().tt_msda_sample_proj_ln(_c(B), arr, hw, ptr(offsets), ptr(logits), ptr(ref), ptr(wvT), ptr(bias), ptr(vshift),
+                                       ptr(gamma), ptr(beta), _f(eps), ptr(out), ptr(out_ln), ptr(max_len), _st(offsets)),
+          "tt_msda_sample_proj_ln")
     return out, out_ln
 
 
