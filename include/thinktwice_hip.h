@@ -195,6 +195,11 @@ typedef struct tt_conv_desc {
      * (row-linear outputs only): a layer whose result is read both by a half-storage consumer and by an f32 one
      * (PAFPN fpn_convs.0: downsample_convs.0 reads the f16 copy, the UNet concat buffer takes the f32 one) */
     float* out2; int out2_cstride, out2_coff;
+    /* optional: res1 is a coarser map [N][res1_up_h][res1_up_w][res1_cstride] read through NEAREST upsampling to (OH, OW)
+     * (pixel (oh, ow) adds pixel (oh * res1_up_h / OH, ow * res1_up_w / OW)): `lat[i-1] += F.interpolate(lat[i], size=...)` of the
+     * PAFPN top-down path (backbones/lss.py:301-305) inside the lateral conv.  0 = res1 has the output's own geometry.  Needs the
+     * vector epilogue and more than 4096 output rows. */
+    int res1_up_h, res1_up_w;
 } tt_conv_desc;
 
 int tt_conv2d_fwd(const tt_conv_desc* d, void* stream);

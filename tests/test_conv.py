@@ -657,3 +657,26 @@ def test_bf16x3_layer_can_store_half():
         got = out.float().cpu().permute(0, 3, 1, 2)
         assert float((got - ref).abs().max() / ref.abs().max()) < 6e-4
         assert float((got != ref.half().float()).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("shape", [(2, 56, 100, 28, 50), (3, 45, 37, 23, 19)], ids=["x2", "odd"])
+@pytest.mark.parametrize("mode", ["f32", "x3"])
+def test_conv_with_an_upsampled_residual_equals_conv_then_upsample_add(shape, mode):
+    """tt_conv_desc.res1_up_h / _w: the PAFPN top-down sum `lat[i-1] += F.interpolate(lat[i], size=..., mode='nearest')`
+    (backbones/lss.py:301-305) inside the lateral conv's epilogue is bit-identical to the conv followed by tt_upsample_nearest_add,
+    and both equal torch's interpolate."""
+    from thinktwice_amd import ops, weights
+    N, H, W, h, w = shape
+    g = torch.Generator().manual_seed(H + W)
+    x = _mk((N, H, W, 64), g).cuda()
+    wt = _mk((256, 1, 1, 64), g, 64 ** -0.5).cuda()
+    b = _mk((256,), g, 0.2).cuda()
+    coarse = _mk((N, h, w, 256), g).cuda()
+    wx = weights.split_pairs_x3(wt) if mode == "x3" else None
+    fused = ops.conv2d(x, wt, shift=b, w_x3=wx, res1=coarse, res1_up=True)
+    plain = ops.conv2d(x, wt, shift=b, w_x3=wx)
+    want = plain.clone()
+    ops.upsample_nearest_add_(want, coarse)
+    assert torch.equal(fused, want)
+    up = F.interpolate(coarse.permute(0, 3, 1, 2), size=(H, W), mode="nearest").permute(0, 2, 3, 1)
+    assert torch.equal(want, plain + up)

@@ -376,3 +376,31 @@ def test_module_shell_init_weights_and_device_placement():
     assert m.training and m.lidar_encoder.training
     m.eval()
     assert not m.training and not m.lidar_encoder.training
+
+
+def test_forwards_in_flight_on_alternating_streams_are_bit_equal_to_serial():
+    """bench.py keeps three batches in flight (consecutive forwards on alternating streams, so that the decoder's per-sample kernels
+    run under the next batch's camera trunk): the model holds no per-call state that two forwards in flight could share (the
+    bordered image buffer is per stream, the wide chains' ticket slots are claimed per launch), so every forward equals the
+    serial one bit for bit."""
+    from thinktwice_amd import model as tm, params, synth
+    hw = (128, 256)
+    m, cfg = tm.build_thinktwice(dtype="f32x3", final_dim=hw)
+    m.load_state_dict(params.init_params(cfg, seed=5))
+    batches = [tm.batch_to_device(synth.make_batch(2, img_hw=hw, num_points=3000, seed=40 + i)) for i in range(2)]
+    serial = []
+    for b in batches:
+        out = m.forward_inference(b)
+        serial.append({k: out[k].clone() for k in KEYS})
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    outs = []
+    for i in range(9):
+        with torch.cuda.stream(streams[i % 3]):
+            outs.append((i % 2, m.forward_inference(batches[i % 2])))
+    torch.cuda.synchronize()
+    for which, out in outs:
+        for k in KEYS:
+            assert torch.equal(out[k], serial[which][k]), (which, k)

@@ -44,6 +44,7 @@ struct ConvArgs {
     int ws_slices;       // split-K: > 0 = every split stores into its own [M][Cout] slice of ws (ordered finalize)
     int flags;           // bit 4: non-temporal f32 output stores (every launch of the product); bit 5: the activations are pre-split bf16 (hi, lo) pairs (tt_conv_desc.in_pair);
                          // bit 6: write the output in that pair format (tt_conv_desc.out_pair); < 0: split-K query (no launch)
+    int res1_up_h, res1_up_w;   // > 0: res1 is a [N][res1_up_h][res1_up_w][..] map read through nearest upsampling (tt_conv_desc)
     float* out2;         // optional second, f32, row-linear copy of the output (tt_conv_desc.out2): [M][out2_cstride] at out2_coff
     int out2_cstride, out2_coff;
     long long* trace;    // measurement aid (tt_conv_set_trace): 4 wall-clock stamps (10 ns ticks) per workgroup of the LDS-DMA kernel
@@ -163,6 +164,15 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
         }
     };
     const bool fast_act = (act == TT_ACT_NONE || act == TT_ACT_RELU);
+    // residual 1 through nearest upsampling (PAFPN top-down path fused into the lateral conv, lss.py:301-305): output pixel
+    // (n, oh, ow) reads residual pixel (n, oh * rh / OH, ow * rw / OW) -- F.interpolate(mode='nearest') with an explicit size
+    const bool r1_up = p.res1_up_w > 0;
+    auto res1_row = [&](int m) -> long long {
+        if (!r1_up) return (long long)m;
+        const int n = m / ohw, rem = m - n * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        return ((long long)n * p.res1_up_h + (oh * p.res1_up_h) / p.OH) * p.res1_up_w + (ow * p.res1_up_w) / p.OW;
+    };
     auto out_offset = [&](int m, int cc, int& n) -> long long {
         if (p.out_fast) {
             if (has_sn) n = m / ohw;
@@ -289,7 +299,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
 #pragma unroll
                         for (int q = 0; q < PG; ++q)
                             r1[q] = *reinterpret_cast<const RV*>(reinterpret_cast<const T*>(p.res1) +
-                                                                (long long)mrow[q] * p.res1_cstride + p.res1_coff + co);
+                                                                res1_row(mrow[q]) * p.res1_cstride + p.res1_coff + co);
                     }
 #pragma unroll
                     for (int q = 0; q < PG; ++q) {
@@ -340,7 +350,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                     const void* rb = which ? p.res2 : p.res1;
                     if (!rb) continue;
                     const T* rp = reinterpret_cast<const T*>(rb) +
-                                  (long long)mo * (which ? p.res2_cstride : p.res1_cstride) +
+                                  (which ? (long long)mo : res1_row(mo)) * (which ? p.res2_cstride : p.res1_cstride) +
                                   (which ? p.res2_coff : p.res1_coff) + co;
                     if (rvec) {
                         add_rv(v, *reinterpret_cast<const RV*>(rp));

@@ -376,6 +376,10 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     a.res2_cstride = d->res2_cstride; a.res2_coff = d->res2_coff;
     a.act = d->act; a.out_dtype = d->out_dtype;
     a.out2 = d->out2; a.out2_cstride = d->out2_cstride; a.out2_coff = d->out2_coff;
+    a.res1_up_h = d->res1_up_h; a.res1_up_w = d->res1_up_w;
+    TT_REQUIRE((d->res1_up_h > 0) == (d->res1_up_w > 0) && (d->res1_up_w <= 0 || (d->res1 && !d->gather_idx && !d->splitk_ws &&
+                                                                                 !d->pixel_shuffle2)),
+               "tt_conv2d_fwd: res1_up_h / res1_up_w come together, with a dense layer's res1");
     a.M = d->N * d->OH * d->OW;
     a.K = d->KH * d->KW * d->Cin;
     a.out_fast = (!d->pixel_shuffle2 && a.out_nstride == (long long)d->OH * d->OW * d->out_cstride) ? 1 : 0;
@@ -412,7 +416,7 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     }
     hipStream_t st = (hipStream_t)stream;
     if (query) {
-        if (d->in_pair || d->out_pair || d->weight_h2) return 0;
+        if (d->in_pair || d->out_pair || d->weight_h2 || d->res1_up_w > 0) return 0;
         a.ws = nullptr;
         a.row_perm = nullptr;
         a.row_mask = nullptr;
@@ -435,6 +439,7 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
         return check_launch("tt_conv2d_fwd(h2)");
     }
     TT_REQUIRE(!d->out2 || a.vec_epi, "tt_conv2d_fwd: out2 needs the vector epilogue (aligned channel counts)");
+    TT_REQUIRE(d->res1_up_w <= 0 || a.vec_epi, "tt_conv2d_fwd: an upsampled res1 needs the vector epilogue (aligned channel counts)");
     if (d->in_pair || d->out_pair) {
         TT_REQUIRE(a.vec_epi && (reinterpret_cast<uintptr_t>(d->weight_x3) & 15) == 0 && a.K % 16 == 0,
                    "tt_conv2d_fwd: in_pair / out_pair need the vector epilogue and a 16-byte aligned weight_x3");
@@ -444,7 +449,7 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
                    "(M=%d Cin=%d Cout=%d)", a.M, d->Cin, d->Cout);
         return check_launch("tt_conv2d_fwd(glds x3, pair)");
     }
-    if (!d->splitk_ws && !d->out2 && try_launch_conv_small(a, d->dtype, st)) {
+    if (!d->splitk_ws && !d->out2 && d->res1_up_w <= 0 && try_launch_conv_small(a, d->dtype, st)) {
         snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_small_kernel");
         return check_launch("tt_conv2d_fwd(small)");
     }

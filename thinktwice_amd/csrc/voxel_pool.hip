@@ -1418,10 +1418,7 @@ static bool v3_lds_ready(size_t lds_needed) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     if (state[dev] == 0) {
-        int lim = 0;
-        const bool ok = hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess;
-        int want = 160 * 1024;
-        if (ok && lim > 0 && lim < want) want = lim;
+        const int want = 160 * 1024;            // the whole CU's LDS: 1024 cells need all of it
         state[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(vp_cs_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          want) == hipSuccess ? want : -1;
         (void)hipGetLastError();

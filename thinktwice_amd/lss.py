@@ -165,9 +165,18 @@ class PAFPN_fp32:
             if autodiff.TAPE is not None or layers.BN_TRAIN:
                 raise _lib.TTError("PAFPN: the half-storage mode ('f32x3h') is an inference mode; train in 'f32x3' or float32")
             return self._call_half(inputs, targets)
-        lat = [self.lat[i](inputs[i]) for i in range(L)]
-        for i in range(L - 1, 0, -1):
-            ops.upsample_nearest_add_(lat[i - 1], lat[i])
+        from . import autodiff
+        lat = [None] * L
+        lat[L - 1] = self.lat[L - 1](inputs[L - 1])
+        for i in range(L - 2, -1, -1):
+            n, h, w, _ = inputs[i].shape
+            if autodiff.TAPE is None and not layers.BN_TRAIN and n * h * w > 4096:
+                # top-down path inside the lateral conv's epilogue: lat[i] = conv(C_i) + nearest_up(lat[i+1]) -- the same two f32
+                # additions per element as the separate kernel (bit-identical), without re-reading and re-writing lat[i]
+                lat[i] = self.lat[i](inputs[i], res1=lat[i + 1], res1_up=True)
+            else:
+                lat[i] = self.lat[i](inputs[i])
+                ops.upsample_nearest_add_(lat[i], lat[i + 1])
         # out[0] == inter[0] (pafpn.py: outs = [inter_outs[0]] + ...): produced where its consumer wants it
         if targets[0] is not None:
             buf0, off0 = targets[0]

@@ -117,6 +117,7 @@ class _ConvDesc(ctypes.Structure):
         ("weight_x3", ctypes.c_void_p), ("row_perm", ctypes.c_void_p), ("row_mask", ctypes.c_void_p),
         ("splitk_slices", _c), ("in_pair", _c), ("out_pair", _c),
         ("weight_h2", ctypes.c_void_p), ("out2", ctypes.c_void_p), ("out2_cstride", _c), ("out2_coff", _c),
+        ("res1_up_h", _c), ("res1_up_w", _c),
     ]
 
 
@@ -245,12 +246,13 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
            res2=None, res2_coff=0, out=None, out_coff=0, in_coff=0, cin=None, pixel_shuffle2=False,
            shift_n=None, shift_n_mod=1, out_dtype=None, out_nstride=0, out_hw=None, splitk_ws=None,
            in_cstride=None, w_x3=None, _no_tape=False, stop_grad=False, bn_raw=False, in_pair=False, out_pair=False,
-           w_h2=None, out2=None, out2_coff=0):
+           w_h2=None, out2=None, out2_coff=0, res1_up=False):
     """Channel-last implicit-GEMM convolution on MFMA (tt_conv2d_fwd).
 
     x   [N,H,W,Cs]  (f32 or bf16); channels [in_coff, in_coff+cin) are convolved
     w   [Cout,KH,KW,cin] same dtype (for pixel_shuffle2: [4*Cout_real,1,1,cin])
     out [N,OH,OW,Ct] written at channel offset out_coff (allocated if None)
+    res1_up: res1 is a coarser [N, h, w, C] map added through nearest upsampling to the output size (PAFPN top-down path)
     w_h2: (x, w half) the f16 (hi, lo) weight pair of weights.split_pairs_h2 -- the layer runs the two-MFMA "h2" product
     out2 / out2_coff: optional second, f32, copy of the output rows at channel offset out2_coff of a [.., Ct2] tensor
     in_pair / out_pair (bf16x3 layers only): x is / out becomes a PAIR-format tensor (an f32-typed container holding, per 16
@@ -288,6 +290,9 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     d.pixel_shuffle2 = 1 if pixel_shuffle2 else 0
     d.scale = _dp(scale); d.shift = _dp(shift); d.shift_n = _dp(shift_n); d.shift_n_mod = shift_n_mod
     d.res1 = _dp(res1); d.res1_cstride = 0 if res1 is None else res1.shape[-1]; d.res1_coff = res1_coff
+    if res1_up:
+        assert res1 is not None and res1.dim() == 4 and res1.is_contiguous() and res1.shape[0] == N and splitk_ws is None
+        d.res1_up_h, d.res1_up_w = res1.shape[1], res1.shape[2]
     d.res2 = _dp(res2); d.res2_cstride = 0 if res2 is None else res2.shape[-1]; d.res2_coff = res2_coff
     d.act = act; d.dtype = dtype_code(x); d.out_dtype = dtype_code(out)
     from . import autodiff
@@ -317,7 +322,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
         x3_splitk = autodiff.TAPE is None and not _no_tape
         if x3_splitk:
             d.weight_x3 = w_x3.data_ptr()
-    if _AUTO_SPLITK and splitk_ws is None and not (in_pair or out_pair) and w_h2 is None and N * OH * OW <= 4096 and KH * KW * Cin >= 2048:
+    if _AUTO_SPLITK and splitk_ws is None and not (in_pair or out_pair) and w_h2 is None and not res1_up and N * OH * OW <= 4096 and KH * KW * Cin >= 2048:
         # few rows, very long K (BEV-update conv K=18720, flatten MLPs): cross-workgroup split-K with an f32 workspace
         # beats conv_small.hip's in-workgroup split there (277 vs 416 us on the BEV-update conv: the direct 32 B/row
         # operand loads of the small kernel waste L2 sectors on a 10 MB weight matrix).  TT_CONV_AUTO_SPLITK=0 disables.
