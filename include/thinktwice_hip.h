@@ -200,6 +200,9 @@ typedef struct tt_conv_desc {
      * PAFPN top-down path (backbones/lss.py:301-305) inside the lateral conv.  0 = res1 has the output's own geometry.  Needs the
      * vector epilogue and more than 4096 output rows. */
     int res1_up_h, res1_up_w;
+    /* 1: res1 is an f32 tensor although the operands are 16-bit (dtype TT_F16 / TT_BF16): the f32 sum chains of the mixed mode's
+     * PAFPN beside its half conv inputs.  Vector epilogue only. */
+    int res1_f32;
 } tt_conv_desc;
 
 int tt_conv2d_fwd(const tt_conv_desc* d, void* stream);

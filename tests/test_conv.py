@@ -680,3 +680,45 @@ def test_conv_with_an_upsampled_residual_equals_conv_then_upsample_add(shape, mo
     assert torch.equal(fused, want)
     up = F.interpolate(coarse.permute(0, 3, 1, 2), size=(H, W), mode="nearest").permute(0, 2, 3, 1)
     assert torch.equal(want, plain + up)
+
+
+@pytest.mark.parametrize("out_half", [True, False], ids=["half-out", "f32-out"])
+def test_conv_h2_with_an_f32_residual(out_half):
+    """tt_conv_desc.res1_f32: the mixed mode's PAFPN keeps its bottom-up SUM in f32 and feeds the 3 x 3 convolutions half copies --
+    the h2 layer adds an f32 residual and writes half (the next conv's input) or f32 (the sum itself)."""
+    from thinktwice_amd import ops, weights
+    g = torch.Generator().manual_seed(21)
+    x = _mk((3, 64, 40, 48), g)
+    w = _mk((256, 64, 3, 3), g, (64 * 9) ** -0.5)
+    b = _mk((256,), g, 0.3)
+    res = _mk((3, 20, 24, 256), g).cuda()                                        # f32, stride-2 output geometry
+    xq = weights.to_channel_last(x, torch.float16).cuda()
+    w32 = weights.prep_conv_weight(w, torch.float32).cuda()
+    ref = F.conv2d(x.half().float(), w, b, 2, 1) + res.cpu().permute(0, 3, 1, 2)
+    out = ops.conv2d(xq, w32.half(), stride=2, pad=1, shift=b.cuda(), res1=res, w_h2=weights.split_pairs_h2(w32),
+                     out_dtype=torch.float16 if out_half else torch.float32)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    scale = float(ref.abs().max())
+    if out_half:
+        assert out.dtype == torch.float16 and float((got != ref.half().float()).float().mean()) < 0.02
+        assert float((got - ref).abs().max()) < 6e-4 * scale
+    else:
+        assert float((got - ref).abs().max()) < 2e-5 * scale
+
+
+def test_bf16x3_layer_with_residual_can_store_half_and_an_f32_twin():
+    """PAFPN lateral of the mixed mode: a bf16x3 1 x 1 conv (f32 in) adds the upsampled f32 top-down residual and writes BOTH the
+    half copy the next 3 x 3 reads (primary output) and the f32 sum the next level's residual reads (tt_conv_desc.out2)."""
+    from thinktwice_amd import ops, weights
+    g = torch.Generator().manual_seed(22)
+    x = _mk((2, 56, 100, 64), g).cuda()
+    wt = _mk((256, 1, 1, 64), g, 64 ** -0.5).cuda()
+    b = _mk((256,), g, 0.2).cuda()
+    coarse = _mk((2, 28, 50, 256), g).cuda()
+    wx = weights.split_pairs_x3(wt)
+    want = ops.conv2d(x, wt, shift=b, w_x3=wx, res1=coarse, res1_up=True)        # the f32 form (tested above)
+    twin = torch.empty_like(want)
+    half = ops.conv2d(x, wt, shift=b, w_x3=wx, res1=coarse, res1_up=True, out_dtype=torch.float16, out2=twin)
+    assert half.dtype == torch.float16
+    assert torch.equal(twin, want)
+    assert torch.equal(half, want.half())

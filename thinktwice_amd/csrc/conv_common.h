@@ -140,9 +140,23 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
     const bool has_sn = p.shift_n != nullptr;
     const bool has_r1 = p.res1 != nullptr, has_r2 = p.res2 != nullptr;
     const bool rvec = p.res_vec != 0;
+    struct F8 {
+        float4 a, b;
+    };
+    // residual vectors of CO channels: the operand type T (8 / 4 halves, or f32: one or two float4)
     using RV = typename std::conditional<sizeof(T) == 2 && CO == 8, uint4,
-                                         typename std::conditional<sizeof(T) == 2, uint2, float4>::type>::type;
-    auto add_rv = [](float (&v)[CO], const RV& u) {
+                                         typename std::conditional<sizeof(T) == 2, uint2,
+                                                                   typename std::conditional<CO == 8, F8, float4>::type>::type>::type;
+    using RVF = typename std::conditional<CO == 8, F8, float4>::type;        // ... of an f32 residual whatever T is (flags bit 7)
+    auto add_rvf = [](float (&v)[CO], const RVF& u) {
+        if constexpr (CO == 8) {
+            v[0] += u.a.x; v[1] += u.a.y; v[2] += u.a.z; v[3] += u.a.w;
+            v[4] += u.b.x; v[5] += u.b.y; v[6] += u.b.z; v[7] += u.b.w;
+        } else {
+            v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w;
+        }
+    };
+    auto add_rv = [&](float (&v)[CO], const RV& u) {
         if constexpr (sizeof(T) == 2 && CO == 8) {
             const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -160,9 +174,12 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                 v[2 * e] += a; v[2 * e + 1] += b;
             }
         } else {
-            v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w;
+            add_rvf(v, u);
         }
     };
+    // flags bit 7 (tt_conv_desc.res1_f32): residual 1 of a 16-bit-operand layer is an f32 tensor (the PAFPN's f32 sum chains beside
+    // its half conv inputs)
+    const bool r1_f32 = sizeof(T) == 2 && (p.flags & 128) != 0;
     const bool fast_act = (act == TT_ACT_NONE || act == TT_ACT_RELU);
     // residual 1 through nearest upsampling (PAFPN top-down path fused into the lateral conv, lss.py:301-305): output pixel
     // (n, oh, ow) reads residual pixel (n, oh * rh / OH, ow * rw / OW) -- F.interpolate(mode='nearest') with an explicit size
@@ -281,14 +298,17 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
             // together.  vmcnt counts stores on gfx950 and is in-order: a load issued between two stores -- or a
             // predicated store, which makes the compiler's count conservative -- serialises the passes on the store
             // latency, which capped these layers at 1.4 TB/s of output.
-            auto hot = [&](auto with_r1) {
-                constexpr bool R1 = decltype(with_r1)::value;
+            auto hot = [&](auto mode_c) {
+                constexpr int RM = decltype(mode_c)::value;      // 0: no residual, 1: residual of the operand type, 2: f32 residual
+                constexpr bool R1 = RM != 0;
+                using R1T = typename std::conditional<RM == 2, RVF, RV>::type;
+                using RES = typename std::conditional<RM == 2, float, T>::type;
                 // residual reads are batched ahead of the stores, at most PG passes at a time (a 128-wide f32 wave
-                // block has 16 passes: all 16 residual vectors at once would not fit beside the accumulators)
-                constexpr int PG = NPASS > 8 ? 8 : NPASS;
+                // block has 16 passes: all 16 residual vectors at once would not fit beside the accumulators; 32 B vectors: 4)
+                constexpr int PG = (sizeof(R1T) > 16 && NPASS > 4) ? 4 : (NPASS > 8 ? 8 : NPASS);
 #pragma unroll
                 for (int g0 = 0; g0 < NPASS; g0 += PG) {
-                    RV r1[R1 ? PG : 1];
+                    R1T r1[R1 ? PG : 1];
                     int mrow[PG];             // actual output row (sparse tile plan: tile slot -> row_perm[slot])
 #pragma unroll
                     for (int q = 0; q < PG; ++q) {
@@ -298,8 +318,8 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                     if constexpr (R1) {
 #pragma unroll
                         for (int q = 0; q < PG; ++q)
-                            r1[q] = *reinterpret_cast<const RV*>(reinterpret_cast<const T*>(p.res1) +
-                                                                res1_row(mrow[q]) * p.res1_cstride + p.res1_coff + co);
+                            r1[q] = *reinterpret_cast<const R1T*>(reinterpret_cast<const RES*>(p.res1) +
+                                                                 res1_row(mrow[q]) * p.res1_cstride + p.res1_coff + co);
                     }
 #pragma unroll
                     for (int q = 0; q < PG; ++q) {
@@ -311,7 +331,8 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                             const float4 t0 = *reinterpret_cast<const float4*>(sC + rl * LDC + col_l + e);
                             v[e] = t0.x; v[e + 1] = t0.y; v[e + 2] = t0.z; v[e + 3] = t0.w;
                         }
-                        if constexpr (R1) add_rv(v, r1[q]);
+                        if constexpr (RM == 2) add_rvf(v, r1[q]);
+                        else if constexpr (RM == 1) add_rv(v, r1[q]);
                         if (act == TT_ACT_RELU) {
 #pragma unroll
                             for (int e = 0; e < CO; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
@@ -321,8 +342,9 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                     }
                 }
             };
-            if (has_r1) hot(std::true_type{});
-            else hot(std::false_type{});
+            if (!has_r1) hot(std::integral_constant<int, 0>{});
+            else if (r1_f32) hot(std::integral_constant<int, 2>{});
+            else hot(std::integral_constant<int, 1>{});
         } else {
             // Everything else (sigmoid/GELU/softplus, strided or pixel-shuffled outputs, per-image shifts, two
             // residuals: the small and mid-size layers): one pass at a time, rolled
@@ -352,7 +374,11 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                     const T* rp = reinterpret_cast<const T*>(rb) +
                                   (which ? (long long)mo : res1_row(mo)) * (which ? p.res2_cstride : p.res1_cstride) +
                                   (which ? p.res2_coff : p.res1_coff) + co;
-                    if (rvec) {
+                    if (which == 0 && r1_f32) {
+                        const float* rf = reinterpret_cast<const float*>(rb) + res1_row(mo) * p.res1_cstride + p.res1_coff + co;
+#pragma unroll
+                        for (int e = 0; e < CO; ++e) v[e] += rf[e];
+                    } else if (rvec) {
                         add_rv(v, *reinterpret_cast<const RV*>(rp));
                     } else {
 #pragma unroll

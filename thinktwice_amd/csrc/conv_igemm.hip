@@ -332,9 +332,11 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     TT_REQUIRE(d && d->in && d->weight && d->out, "tt_conv2d_fwd: null pointer");
     TT_REQUIRE(d->dtype == TT_F32 || d->dtype == TT_BF16 || d->dtype == TT_F16, "tt_conv2d_fwd: bad dtype %d", d->dtype);
     TT_REQUIRE(d->out_dtype == TT_F32 || d->out_dtype == d->dtype ||
-                   (d->dtype == TT_F32 && (d->out_dtype == TT_F16 || d->out_dtype == TT_BF16) && !d->res1 && !d->res2),
-               "tt_conv2d_fwd: out_dtype must be TT_F32, the operand dtype, or (f32 operands, no residuals) a 16-bit type "
+                   (d->dtype == TT_F32 && (d->out_dtype == TT_F16 || d->out_dtype == TT_BF16) && !d->res2),
+               "tt_conv2d_fwd: out_dtype must be TT_F32, the operand dtype, or (f32 operands, at most res1) a 16-bit type "
                "(got %d for dtype %d)", d->out_dtype, d->dtype);
+    TT_REQUIRE(!d->res1_f32 || (d->dtype != TT_F32 && d->res1 && !d->gather_idx && !d->splitk_ws),
+               "tt_conv2d_fwd: res1_f32 goes with a dense 16-bit-operand layer's res1");
     TT_REQUIRE(!d->weight_h2 || (d->dtype == TT_F16 && !d->gather_idx && !d->splitk_ws && !d->pixel_shuffle2),
                "tt_conv2d_fwd: weight_h2 goes with dense TT_F16 operands (no split-K workspace, no pixel shuffle)");
     TT_REQUIRE(!d->out2 || (!d->splitk_ws && !d->pixel_shuffle2 && !d->gather_idx && d->out2_cstride % 4 == 0 &&
@@ -400,6 +402,7 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
         if (d->in_pair) a.flags |= 32;
         if (d->out_pair) a.flags |= 64;
     }
+    if (d->res1_f32) a.flags |= 128;
     if (query) a.flags = -1;       // launch_conv returns the split count instead of launching
     {
         const int co_vec = (d->out_dtype == TT_F32 && !d->out_pair) ? 4 : 8;
@@ -440,6 +443,9 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
     }
     TT_REQUIRE(!d->out2 || a.vec_epi, "tt_conv2d_fwd: out2 needs the vector epilogue (aligned channel counts)");
     TT_REQUIRE(d->res1_up_w <= 0 || a.vec_epi, "tt_conv2d_fwd: an upsampled res1 needs the vector epilogue (aligned channel counts)");
+    TT_REQUIRE(!d->res1_f32 || (a.vec_epi && a.res_vec), "tt_conv2d_fwd: an f32 res1 needs the vector epilogue and aligned residual rows");
+    TT_REQUIRE(!(d->dtype == TT_F32 && d->out_dtype != TT_F32 && d->res1) || (a.vec_epi && a.res_vec),
+               "tt_conv2d_fwd: a 16-bit output of an f32 layer with a residual needs the vector epilogue");
     if (d->in_pair || d->out_pair) {
         TT_REQUIRE(a.vec_epi && (reinterpret_cast<uintptr_t>(d->weight_x3) & 15) == 0 && a.K % 16 == 0,
                    "tt_conv2d_fwd: in_pair / out_pair need the vector epilogue and a 16-byte aligned weight_x3");
@@ -449,7 +455,7 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
                    "(M=%d Cin=%d Cout=%d)", a.M, d->Cin, d->Cout);
         return check_launch("tt_conv2d_fwd(glds x3, pair)");
     }
-    if (!d->splitk_ws && !d->out2 && d->res1_up_w <= 0 && try_launch_conv_small(a, d->dtype, st)) {
+    if (!d->splitk_ws && !d->out2 && d->res1_up_w <= 0 && !d->res1_f32 && try_launch_conv_small(a, d->dtype, st)) {
         snprintf(g_conv_kernel, sizeof(g_conv_kernel), "conv_small_kernel");
         return check_launch("tt_conv2d_fwd(small)");
     }

@@ -117,40 +117,76 @@ class PAFPN_fp32:
 
     def load_state_dict(self, sd, prefix):
         n, dt, dev, L = prefix, self.wdtype, self.device, self.num_outs
-        inner = weights.H2 if self.half else dt       # layers whose INPUT is one of the neck's own (half) tensors
-        self.lat = [conv_from_sd(sd, f"{n}.lateral_convs.{i}.conv", dt, dev) for i in range(L)]     # read the backbone's f32 maps
-        self.fpn = [conv_from_sd(sd, f"{n}.fpn_convs.{i}.conv", inner, dev, pad=1) for i in range(L)]
-        self.down = [conv_from_sd(sd, f"{n}.downsample_convs.{i}.conv", inner, dev, stride=2, pad=1) for i in range(L - 1)]
-        self.paf = [conv_from_sd(sd, f"{n}.pafpn_convs.{i}.conv", inner, dev, pad=1) for i in range(L - 1)]
+        self.lat = [conv_from_sd(sd, f"{n}.lateral_convs.{i}.conv", dt, dev) for i in range(L)]
+        self.fpn = [conv_from_sd(sd, f"{n}.fpn_convs.{i}.conv", dt, dev, pad=1) for i in range(L)]
+        self.down = [conv_from_sd(sd, f"{n}.downsample_convs.{i}.conv", dt, dev, stride=2, pad=1) for i in range(L - 1)]
+        self.paf = [conv_from_sd(sd, f"{n}.pafpn_convs.{i}.conv", dt, dev, pad=1) for i in range(L - 1)]
         if self.half:
-            assert all(c % 64 == 0 for c in [self.out_channels]), "half-storage PAFPN: out_channels must be a multiple of 64"
+            # the same 3 x 3 layers on the h2 kernel (half input copy x f16 (hi, lo) weights); a level with <= 4096 pixel rows in
+            # the batch keeps the bf16x3 forms above (the latency kernels have no half / two-output epilogue)
+            assert self.out_channels % 64 == 0, "half-storage PAFPN: out_channels must be a multiple of 64"
+            h2 = weights.H2
+            self.fpn_h = [conv_from_sd(sd, f"{n}.fpn_convs.{i}.conv", h2, dev, pad=1) for i in range(L)]
+            self.down_h = [conv_from_sd(sd, f"{n}.downsample_convs.{i}.conv", h2, dev, stride=2, pad=1) for i in range(L - 1)]
+            self.paf_h = [conv_from_sd(sd, f"{n}.pafpn_convs.{i}.conv", h2, dev, pad=1) for i in range(L - 1)]
         self.loaded = True
         return self
 
     def _call_half(self, inputs, targets):
-        """The same data flow with the neck's own tensors in IEEE half: laterals written as half by the bf16x3 1 x 1 convs
-        (f32 backbone maps in), top-down and bottom-up sums rounded to half once, every 3 x 3 on the h2 kernel; the four OUTPUT
-        maps leave in f32 -- level 0 as the f32 twin of the half map downsample_convs.0 reads (tt_conv_desc.out2)."""
+        """"f32x3h": the neck's SUMS stay in f32 -- laterals, the top-down chain, the bottom-up chain, exactly the tensors of the
+        f32 flow below -- and every 3 x 3 convolution reads an IEEE-half COPY of its input on the h2 kernel (two f16 MFMAs per
+        product).  One rounding per conv input, none accumulating along the chains (tools/precision_mix_emul.py plan `neckop`:
+        waypoint L2 0.62 mm on F14, against 1.08 mm with the chains themselves in half).  The copies cost no extra launch: the
+        producing epilogue writes the half tensor as its primary output and the f32 one through tt_conv_desc.out2; a level with
+        <= 4096 rows runs the plain bf16x3 layers."""
         L, C, f16, f32 = self.num_outs, self.out_channels, torch.float16, torch.float32
-        lat = [self.lat[i](inputs[i], out_dtype=f16) for i in range(L)]
-        for i in range(L - 1, 0, -1):
-            ops.upsample_nearest_add_(lat[i - 1], lat[i])
-        NI, H0, W0, _ = lat[0].shape
+        dev = inputs[0].device
+        rows = [t.shape[0] * t.shape[1] * t.shape[2] for t in inputs]
+        half = [r > 4096 for r in rows]
+        lat32, lat16 = [None] * L, [None] * L
+        for i in range(L - 1, -1, -1):
+            n, h, w, _ = inputs[i].shape
+            up = dict(res1=lat32[i + 1], res1_up=True) if i < L - 1 else {}
+            if half[i]:
+                lat32[i] = torch.empty(n, h, w, C, dtype=f32, device=dev)
+                lat16[i] = self.lat[i](inputs[i], out_dtype=f16, out2=lat32[i], **up)       # half copy + the f32 sum
+            else:
+                lat32[i] = self.lat[i](inputs[i])
+                if i < L - 1:
+                    ops.upsample_nearest_add_(lat32[i], lat32[i + 1])
+        # fpn convs.  Level 0's output IS the neck's first output (f32, in the consumer's buffer) and feeds downsample_convs.0
         if targets[0] is not None:
             buf0, off0 = targets[0]
         else:
-            buf0, off0 = torch.empty(NI, H0, W0, C, dtype=f32, device=lat[0].device), 0
-        inter0 = self.fpn[0](lat[0], out2=buf0, out2_coff=off0)                   # half map + its f32 twin in the consumer's buffer
-        inter = [inter0] + [self.fpn[i](lat[i]) for i in range(1, L)]
+            buf0, off0 = torch.empty(inputs[0].shape[0], inputs[0].shape[1], inputs[0].shape[2], C, dtype=f32, device=dev), 0
+        inter32, inter16 = [None] * L, [None] * L
+        if half[0]:
+            inter16[0] = self.fpn_h[0](lat16[0], out2=buf0, out2_coff=off0)
+        else:
+            self.fpn[0](lat32[0], out=buf0, out_coff=off0)
+        for i in range(1, L):
+            inter32[i] = self.fpn_h[i](lat16[i], out_dtype=f32) if half[i] else self.fpn[i](lat32[i])
+        # bottom-up: inter[i+1] += down(inter[i]); the sum is only read by 3 x 3 convs, so a half level keeps just its half copy
         for i in range(L - 1):
-            self.down[i](inter[i], res1=inter[i + 1], out=inter[i + 1])
+            if half[i]:
+                src = inter16[i]
+                if half[i + 1]:
+                    inter16[i + 1] = self.down_h[i](src, res1=inter32[i + 1], out_dtype=f16)
+                    inter32[i + 1] = None
+                else:
+                    self.down_h[i](src, res1=inter32[i + 1], out=inter32[i + 1])
+            elif i == 0:
+                self.down[0](buf0, in_coff=off0, cin=C, res1=inter32[1], out=inter32[1])
+            else:
+                self.down[i](inter32[i], res1=inter32[i + 1], out=inter32[i + 1])
         outs = [(buf0, off0, C)]
         for i in range(1, L):
+            conv, src = (self.paf_h[i - 1], inter16[i]) if half[i] else (self.paf[i - 1], inter32[i])
             if targets[i] is not None:
                 buf, off = targets[i]
-                self.paf[i - 1](inter[i], out=buf, out_coff=off)
+                conv(src, out=buf, out_coff=off)
             else:
-                buf, off = self.paf[i - 1](inter[i], out_dtype=f32), 0
+                buf, off = conv(src, out_dtype=f32), 0
             outs.append((buf, off, C))
         return outs
 

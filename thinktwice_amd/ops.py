@@ -117,7 +117,7 @@ class _ConvDesc(ctypes.Structure):
         ("weight_x3", ctypes.c_void_p), ("row_perm", ctypes.c_void_p), ("row_mask", ctypes.c_void_p),
         ("splitk_slices", _c), ("in_pair", _c), ("out_pair", _c),
         ("weight_h2", ctypes.c_void_p), ("out2", ctypes.c_void_p), ("out2_cstride", _c), ("out2_coff", _c),
-        ("res1_up_h", _c), ("res1_up_w", _c),
+        ("res1_up_h", _c), ("res1_up_w", _c), ("res1_f32", _c),
     ]
 
 
@@ -290,6 +290,8 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, act=0, res1=
     d.pixel_shuffle2 = 1 if pixel_shuffle2 else 0
     d.scale = _dp(scale); d.shift = _dp(shift); d.shift_n = _dp(shift_n); d.shift_n_mod = shift_n_mod
     d.res1 = _dp(res1); d.res1_cstride = 0 if res1 is None else res1.shape[-1]; d.res1_coff = res1_coff
+    if res1 is not None and res1.dtype == torch.float32 and x.dtype != torch.float32:
+        d.res1_f32 = 1                  # an f32 sum chain beside half conv inputs (mixed mode's PAFPN)
     if res1_up:
         assert res1 is not None and res1.dim() == 4 and res1.is_contiguous() and res1.shape[0] == N and splitk_ws is None
         d.res1_up_h, d.res1_up_w = res1.shape[1], res1.shape[2]

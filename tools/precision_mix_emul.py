@@ -72,7 +72,24 @@ def make_patches(plan):
             outs.append(x)
         return outs
 
+    def pafpn_operand_only(sd, p, feats):
+        """plan `neckop`: the PAFPN's sums stay in f32 (laterals, top-down and bottom-up chains); only the INPUT of each 3 x 3
+        conv is a half copy (one rounding per conv input, none accumulating along the chains)."""
+        n = len(feats)
+        lat = [conv(sd, f"{p}.lateral_convs.{i}.conv", feats[i]) for i in range(n)]
+        for i in range(n - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
+        inter = [conv(sd, f"{p}.fpn_convs.{i}.conv", q(lat[i]), 1, 1) for i in range(n)]
+        for i in range(n - 1):
+            inter[i + 1] = inter[i + 1] + conv(sd, f"{p}.downsample_convs.{i}.conv", q(inter[i]), 2, 1)
+        outs = [inter[0]]
+        for i in range(1, n):
+            outs.append(conv(sd, f"{p}.pafpn_convs.{i - 1}.conv", q(inter[i]), 1, 1))
+        return outs
+
     def pafpn(sd, p, feats):
+        if "neckop" in plan:
+            return pafpn_operand_only(sd, p, feats)
         if not h_neck:
             return M_ORIG["pafpn"](sd, p, feats)
         n = len(feats)
@@ -114,6 +131,8 @@ def score(pack, out):
             idx = torch.from_numpy(pack[f"inter__{name}__idx"])
             want = torch.from_numpy(pack[f"inter__{name}__val"])
             inter[name] = float((v[idx] - want).abs().max() / float(pack[f"inter__{name}__stats"][2]))
+    if "pred_wp" in pack.files:
+        inter["wp_L2_mm"] = 1e3 * float((out["pred_wp"].float() - torch.from_numpy(pack["pred_wp"])).norm(dim=-1).max())
     flips = None
     return errs, inter, flips
 
