@@ -207,10 +207,12 @@ class ForwardWorkload:
         traffic, traffic_note = self._pmc_traffic()
         x3 = {}
         if self.dtype in ("bf16x3", "bf16x3h"):
-            # `achieved` / `frac` count ALGORITHMIC flops (2 M N K) against the dense bf16 MFMA peak; every product costs
-            # three bf16 MFMAs in this mode, so frac is bounded by 1/3 -- the matrix pipe itself is at 3x that
-            x3 = {"mfma_per_product": 3, "executed_mfma_tflops": round(3 * ach, 1),
-                  "executed_mfma_frac": round(3 * ach / peak, 4)}
+            # `achieved` / `frac` count ALGORITHMIC flops (2 M N K) against the dense 16-bit MFMA peak; a product costs three bf16
+            # MFMAs on the bf16x3 kernels and two f16 MFMAs on the h2 kernel (1 on the exact-f32 latency kernels, whose peak is
+            # lower: counted as 1), so frac is bounded by ~1/3 -- the matrix pipe itself is at `executed_mfma_frac`
+            ex = sum(mfma_per_product(k, self.dtype) * r[0] for r, k in zip(rec, kernels)) / (ms * 1e-3) / 1e12
+            x3 = {"mfma_per_product": round(ex / ach, 3), "executed_mfma_tflops": round(ex, 1),
+                  "executed_mfma_frac": round(ex / peak, 4)}
         return {"kernel": "conv_igemm_glds_kernel (all conv/linear launches of one forward)", "bound": "mfma",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), **x3,
                 "dominant_kernel": dominant,
