@@ -474,3 +474,28 @@ def test_round5_host_side_contracts():
         got_t = agent_tick.offset_then_rotate((tgt[1], -tgt[0]), (pos[1], -pos[0]), yaw)
         np.testing.assert_allclose(got_t, want_t, rtol=0, atol=1e-12)
     assert L.tt_clear_device_faults() in (0, -2) and L.tt_device_faults() in (0, -2)
+
+
+def test_pair_formats_hold_hi_and_lo_halves_in_the_documented_places():
+    """weights.split_pairs_x3 / split_pairs_h2: per 16 K elements [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] with hi = rne(v), lo = rne(v - hi)
+    (bf16 / IEEE half) -- the layout tt_conv_desc.weight_x3 / in_pair / out_pair / weight_h2 document and the kernels' fragment reads
+    assume (hi chunk 4 kc + h, lo chunk that + 2)."""
+    import torch
+    from thinktwice_amd import weights
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(6, 3, 3, 32, generator=g)
+    px = weights.split_pairs_x3(w)
+    assert px.shape == w.shape and px.dtype == torch.float32
+    pairs = px.reshape(6, 9 * 32 // 16, 16).view(torch.bfloat16).reshape(6, 18, 2, 16)      # [row][group][hi | lo][16]
+    flat = w.reshape(6, 18, 16)
+    hi = flat.to(torch.bfloat16)
+    assert torch.equal(pairs[:, :, 0], hi) and torch.equal(pairs[:, :, 1], (flat - hi.float()).to(torch.bfloat16))
+    assert float((pairs[:, :, 0].float() + pairs[:, :, 1].float() - flat).abs().max()) < 2 ** -15 * float(flat.abs().max())
+    ph = weights.split_pairs_h2(w)
+    assert ph.dtype == torch.float16 and tuple(ph.shape) == (6, 3, 3, 64)
+    ph = ph.reshape(6, 18, 2, 16)
+    h16 = flat.to(torch.float16)
+    assert torch.equal(ph[:, :, 0], h16) and torch.equal(ph[:, :, 1], (flat - h16.float()).to(torch.float16))
+    assert float((ph[:, :, 0].float() + ph[:, :, 1].float() - flat).abs().max()) < 2 ** -20 * float(flat.abs().max())
+    assert weights.is_x3("f32x3") and weights.is_x3("f32x3h") and not weights.is_x3(torch.float32)
+    assert weights.storage_dtype("f32x3h") == torch.float32 and weights.storage_dtype("h2") == torch.float16

@@ -116,7 +116,11 @@ __device__ __forceinline__ void load_scale_shift(const ConvArgs& p, float (&sc)[
 // 128 B lines).  Everything is compile-time indexed so it stays in registers: an earlier version with runtime CO and
 // by-reference lambdas put its small arrays in scratch, and every scratch reload carried an `s_waitcnt vmcnt(0)` that
 // also waited for the in-flight global stores (1.4 TB/s ceiling on every memory-bound layer).
-template <typename T, int CO, int TM, int TN, int WTM, int WTN>
+// EXT: the round-6 extras -- a second f32 copy of the output (out2), residual 1 read through nearest upsampling (res1_up_*), an f32
+// residual beside 16-bit operands (res1_f32).  Compiled into the f32-operand kernels and the h2 kernel only: in the 16-bit tiles with
+// 128 x 64 waves they cost the 34 registers that push the epilogue's arrays into scratch (576 B; every scratch reload waits for the
+// stores in flight: the bf16 mode's convs went 40.7 -> 63.5 ms before this switch).
+template <typename T, int CO, int TM, int TN, int WTM, int WTN, bool EXT>
 __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&acc)[TM][TN], float* sC, int lane, int wm,
                                                   int wn, int m0, int n0, int Mlim) {
     constexpr int LDC = WTN + 4;
@@ -179,11 +183,11 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
     };
     // flags bit 7 (tt_conv_desc.res1_f32): residual 1 of a 16-bit-operand layer is an f32 tensor (the PAFPN's f32 sum chains beside
     // its half conv inputs)
-    const bool r1_f32 = sizeof(T) == 2 && (p.flags & 128) != 0;
+    const bool r1_f32 = EXT && sizeof(T) == 2 && (p.flags & 128) != 0;
     const bool fast_act = (act == TT_ACT_NONE || act == TT_ACT_RELU);
     // residual 1 through nearest upsampling (PAFPN top-down path fused into the lateral conv, lss.py:301-305): output pixel
     // (n, oh, ow) reads residual pixel (n, oh * rh / OH, ow * rw / OW) -- F.interpolate(mode='nearest') with an explicit size
-    const bool r1_up = p.res1_up_w > 0;
+    const bool r1_up = EXT && p.res1_up_w > 0;
     auto res1_row = [&](int m) -> long long {
         if (!r1_up) return (long long)m;
         const int n = m / ohw, rem = m - n * ohw;
@@ -252,7 +256,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
         }
     };
     // second, f32, row-linear copy (tt_conv_desc.out2)
-    float* const out2 = p.out2 ? p.out2 + p.out2_coff + co : nullptr;
+    float* const out2 = (EXT && p.out2) ? p.out2 + p.out2_coff + co : nullptr;
     auto store_row2 = [&](long long row, const float (&v)[CO]) {
         typedef float f4v __attribute__((ext_vector_type(4)));
         float* q2 = out2 + row * p.out2_cstride;
@@ -343,8 +347,9 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
                 }
             };
             if (!has_r1) hot(std::integral_constant<int, 0>{});
-            else if (r1_f32) hot(std::integral_constant<int, 2>{});
-            else hot(std::integral_constant<int, 1>{});
+            else if (EXT && sizeof(T) == 2 && r1_f32) {
+                if constexpr (EXT && sizeof(T) == 2) hot(std::integral_constant<int, 2>{});
+            } else hot(std::integral_constant<int, 1>{});
         } else {
             // Everything else (sigmoid/GELU/softplus, strided or pixel-shuffled outputs, per-image shifts, two
             // residuals: the small and mid-size layers): one pass at a time, rolled
@@ -396,7 +401,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvArgs& p, f32x16 (&ac
 
 // Fused epilogue shared by both kernels.  C/D map of the 32x32 MFMA: col = lane&31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-template <typename T, int TM, int TN, int WTM, int WTN>
+template <typename T, int TM, int TN, int WTM, int WTN, bool EXT = (sizeof(T) == 4)>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], unsigned char* smem,
                                               int wave, int lane, int wm, int wn, int m0, int n0, int Mlim) {
     // ---- epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -425,9 +430,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
     __syncthreads();   // every wave is done with the K-loop tiles before LDS is reused
     if (p.vec_epi) {
         if (p.out_dtype == TT_F32 && !(p.flags & 64))
-            conv_epilogue_vec<T, 4, TM, TN, WTM, WTN>(p, acc, sC, lane, wm, wn, m0, n0, Mlim);
+            conv_epilogue_vec<T, 4, TM, TN, WTM, WTN, EXT>(p, acc, sC, lane, wm, wn, m0, n0, Mlim);
         else
-            conv_epilogue_vec<T, 8, TM, TN, WTM, WTN>(p, acc, sC, lane, wm, wn, m0, n0, Mlim);
+            conv_epilogue_vec<T, 8, TM, TN, WTM, WTN, EXT>(p, acc, sC, lane, wm, wn, m0, n0, Mlim);
         return;
     }
     // Scalar path (channel counts / offsets that are not 16 B friendly: the 3-channel stem input side, heads with

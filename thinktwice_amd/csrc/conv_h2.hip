@@ -274,7 +274,7 @@ void conv_h2_kernel(const ConvArgs p, const void* zero_page, int tiles_m, int ti
         }
     }
     __syncthreads();   // all waves done with the last stage before the epilogue reuses LDS
-    conv_epilogue<f16_t, TM, TN, WTM, WTN>(p, acc, smem, wave, lane, wm, wn, m0, n0, Mlim);
+    conv_epilogue<f16_t, TM, TN, WTM, WTN, true>(p, acc, smem, wave, lane, wm, wn, m0, n0, Mlim);     // (with out2 / res1_f32)
 #endif
 }
 

@@ -335,8 +335,10 @@ static int conv2d_run(const tt_conv_desc* d, void* stream, bool query) {
                    (d->dtype == TT_F32 && (d->out_dtype == TT_F16 || d->out_dtype == TT_BF16) && !d->res2),
                "tt_conv2d_fwd: out_dtype must be TT_F32, the operand dtype, or (f32 operands, at most res1) a 16-bit type "
                "(got %d for dtype %d)", d->out_dtype, d->dtype);
-    TT_REQUIRE(!d->res1_f32 || (d->dtype != TT_F32 && d->res1 && !d->gather_idx && !d->splitk_ws),
-               "tt_conv2d_fwd: res1_f32 goes with a dense 16-bit-operand layer's res1");
+    TT_REQUIRE(!d->res1_f32 || (d->weight_h2 && d->res1),
+               "tt_conv2d_fwd: res1_f32 goes with an h2 layer's res1 (the other 16-bit kernels read residuals of their operand type)");
+    TT_REQUIRE(d->dtype == TT_F32 || d->weight_h2 || (!d->out2 && d->res1_up_w <= 0),
+               "tt_conv2d_fwd: out2 / res1_up_* exist in the f32-operand kernels and the h2 kernel only");
     TT_REQUIRE(!d->weight_h2 || (d->dtype == TT_F16 && !d->gather_idx && !d->splitk_ws && !d->pixel_shuffle2),
                "tt_conv2d_fwd: weight_h2 goes with dense TT_F16 operands (no split-K workspace, no pixel shuffle)");
     TT_REQUIRE(!d->out2 || (!d->splitk_ws && !d->pixel_shuffle2 && !d->gather_idx && d->out2_cstride % 4 == 0 &&

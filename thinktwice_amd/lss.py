@@ -206,7 +206,7 @@ class PAFPN_fp32:
         lat[L - 1] = self.lat[L - 1](inputs[L - 1])
         for i in range(L - 2, -1, -1):
             n, h, w, _ = inputs[i].shape
-            if autodiff.TAPE is None and not layers.BN_TRAIN and n * h * w > 4096:
+            if autodiff.TAPE is None and not layers.BN_TRAIN and n * h * w > 4096 and inputs[i].dtype == torch.float32:
                 # top-down path inside the lateral conv's epilogue: lat[i] = conv(C_i) + nearest_up(lat[i+1]) -- the same two f32
                 # additions per element as the separate kernel (bit-identical), without re-reading and re-writing lat[i]
                 lat[i] = self.lat[i](inputs[i], res1=lat[i + 1], res1_up=True)
