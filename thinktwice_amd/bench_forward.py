@@ -117,7 +117,11 @@ class ForwardWorkload:
         ops.CONV_BYTES = []
         ops.CONV_KERNELS = []
         self.model.use_side_stream = False     # per-launch timing needs the launches serialised on one stream
-        self.model.forward_inference(self.batch, channel_last_out=True)   # eager: the graph replay bypasses the hook
+        # on a stream the timed steps have already run on: the first forward on a NEW stream pays tens of milliseconds of allocator
+        # work inside whatever launch bracket it falls into (measured: 63 - 82 ms on one stride-2 layer, profiles/r06_roofline_warm.txt)
+        st = self._streams[0] if self._streams else torch.cuda.current_stream()
+        with torch.cuda.stream(st):
+            self.model.forward_inference(self.batch, channel_last_out=True)   # eager: the graph replay bypasses the hook
         torch.cuda.synchronize()
         self.model.use_side_stream = True
         rec = []
