@@ -171,6 +171,24 @@ class ForwardWorkload:
         nv = 256 * self.cfg["cfg"]["refine_num"]
         dec = [r for r in rec if f" N={nv} K=256 k1x1s1" in r[3] and not r[3].startswith("sparse")]
         self._decoder_gemm = None
+        if not dec:
+            # "sample first, project after" (round 6): the value_proj GEMM does not exist.  The decoder's remaining dense GEMMs are
+            # fpn_linear0-3 (thinktwice_decoder.py:330-333, 388-391): one 256 -> 256 linear per FPN level over the key sweep's
+            # B*4 images -- HBM-shaped (K = N = 256: 128 FLOP per byte moved at f32)
+            H, W = tuple(self.cfg["img_encoder"]["final_dim"])
+            lv = {f"M={self.B * 4 * (H // s) * (W // s)} N=256 K=256 k1x1s1" for s in (4, 8, 16, 32)}
+            fl = [r for r in rec if r[3] in lv]
+            if fl:
+                gf = sum(r[0] for r in fl)
+                gms = sum(r[1].elapsed_time(r[2]) for r in fl)
+                by = sum(int(r[3].split()[0][2:]) * (256 + 256) * 4 for r in fl)
+                self._decoder_gemm = {"shape": max(fl, key=lambda r: r[0])[3], "launches": len(fl), "what": "fpn_linear0-3",
+                                      "tflops": round(gf / (gms * 1e-3) / 1e12, 1), "mfma_frac": round(gf / (gms * 1e-3) / 1e12 / peak, 4),
+                                      "ms": round(gms, 4), "hbm_gbs": round(by / (gms * 1e-3) / 1e9, 1),
+                                      "hbm_frac": round(by / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "note": "the value_proj GEMM of rounds 1-5 is gone (tt_msda_sample_proj_ln applies value_proj to "
+                                              "the sampled sums); what is left of the decoder's dense GEMMs is bound by HBM: read M*256 + "
+                                              "write M*256 f32 once"}
         if dec:
             esz = 4 if self.dtype in ("f32", "bf16x3", "bf16x3h") else 2
             gf = sum(r[0] for r in dec)
