@@ -333,29 +333,33 @@ __global__ __launch_bounds__(256) void msda_sample_ln_kernel(const T* __restrict
 //     z_h = sum_s w_s * sample(x, loc_s)  (256 raw FPN channels),   beta_{h, level} = sum_{s in level} w_s * (in-bounds corner weight)
 // (multi_scale_deformable_attn_function.py:474 projects all 33,320 positions x 4 cameras x B of every layer -- 5.5 GB of f32 at
 // B = 8 of which the sampler reads a few per cent; here a row gathers the raw 1 KiB FPN rows of its 8 x 32 x 4 corners and applies
-// the head's 32 x 256 slice once).  One block per (b, cam, slot); phase 0: thread = (head, sample) -> softmax weight, corner
+// the head's 32 x 256 slice once).  One block (four groups of 256 threads) per (b, cam, slot); phase 0: thread = (head, sample) -> softmax weight, corner
 // positions and weights into LDS; phase 1: thread = input channel, eight accumulators z_h[k] over the 1024 corner rows (coalesced
 // 1 KiB loads); phase 2: thread = output channel, a 256-long dot product with the transposed weight (coalesced) + the bias terms;
 // then the LayerNorm of msda_sample_ln_kernel.  Exact f32 FMAs.
-__global__ __launch_bounds__(256) void msda_sample_proj_ln_kernel(LevelMaps lv, const float* __restrict__ offsets,
-                                                                  const float* __restrict__ logits,
-                                                                  const float* __restrict__ ref, const float* __restrict__ wvT,
-                                                                  const float* __restrict__ bias,
-                                                                  const float* __restrict__ vshift,
-                                                                  const float* __restrict__ gamma,
-                                                                  const float* __restrict__ beta, float eps,
-                                                                  float* __restrict__ out, float* __restrict__ out_ln,
-                                                                  const int* __restrict__ max_len) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void msda_sample_proj_ln_kernel(LevelMaps lv, const float* __restrict__ offsets,
+                                                                   const float* __restrict__ logits,
+                                                                   const float* __restrict__ ref, const float* __restrict__ wvT,
+                                                                   const float* __restrict__ bias,
+                                                                   const float* __restrict__ vshift,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float eps,
+                                                                   float* __restrict__ out, float* __restrict__ out_ln,
+                                                                   const int* __restrict__ max_len) {
+    // 1024 threads = 4 groups of 256: a row's 1 MiB of corner rows is latency-bound on ONE workgroup (184 rows per tick at batch 1),
+    // so the heads (phase 1) and the K range of the projection (phase 2) are dealt over four groups
+    __shared__ float red[16];
     __shared__ int cidx[8 * 32 * 4];          // corner position inside its level map, -1 = outside (zero padding)
     __shared__ float cwt[8 * 32 * 4];         // attention weight x bilinear corner weight
     __shared__ float sbeta[8 * 4];
     __shared__ float z[8 * 256];
+    __shared__ float part[4 * 256];
     const long long row = blockIdx.x;
     const int bc = (int)(row / kQ);
     if (max_len && (int)(row - (long long)bc * kQ) >= *max_len) return;          // block-uniform: slots nobody reads
-    const int t = threadIdx.x, head = t >> 5, i = t & 31, l = i >> 3;
-    {
+    const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255;
+    if (grp == 0) {                                                              // phase 0: thread = (head, sample)
+        const int head = t >> 5, i = t & 31, l = i >> 3;
         const float lg = logits[row * 256 + t];
         float mx = lg;
 #pragma unroll
@@ -387,13 +391,14 @@ __global__ __launch_bounds__(256) void msda_sample_proj_ln_kernel(LevelMaps lv, 
         if ((i & 7) == 0) sbeta[head * 4 + l] = inb;
     }
     __syncthreads();
-    // ---- phase 1: z[h][t] over the head's 32 samples x 4 corners; thread = raw FPN channel
+    // ---- phase 1: z[h][t] over the head's 32 samples x 4 corners; thread = raw FPN channel, group g takes heads 2 g, 2 g + 1
     const float* base[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         base[q] = reinterpret_cast<const float*>(lv.p[q]) + (long long)bc * lv.H[q] * lv.W[q] * 256 + t;
-#pragma unroll 1
-    for (int h = 0; h < 8; ++h) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int h = 2 * grp + hh;
         float acc = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -408,20 +413,39 @@ __global__ __launch_bounds__(256) void msda_sample_proj_ln_kernel(LevelMaps lv, 
         z[h * 256 + t] = acc;
     }
     __syncthreads();
-    // ---- phase 2: thread = output channel (head = t >> 5)
-    float acc = 0.f;
-    const float* zh = z + head * 256;
+    // ---- phase 2: output channel t (head = t >> 5); group g sums K in [64 g, 64 g + 64), group 0 adds the partial sums in order
+    {
+        const float* zh = z + (t >> 5) * 256 + 64 * grp;
+        const float* wk = wvT + (long long)(64 * grp) * 256 + t;
+        float pa = 0.f;
 #pragma unroll 8
-    for (int k = 0; k < 256; ++k) acc += wvT[k * 256 + t] * zh[k];
-    const int cam = bc & 3;
-    const float b0 = bias[t];
+        for (int k = 0; k < 64; ++k) pa += wk[k * 256] * zh[k];
+        part[grp * 256 + t] = pa;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    if (grp == 0) {
+        const int head = t >> 5;
+        acc = (part[t] + part[256 + t]) + (part[512 + t] + part[768 + t]);
+        const int cam = bc & 3;
+        const float b0 = bias[t];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc += sbeta[head * 4 + q] * (b0 + vshift[(q * 4 + cam) * 256 + t]);
-    out[row * 256 + t] = acc;
-    const float mean = block_sum256(acc, red) / 256.f;
+        for (int q = 0; q < 4; ++q) acc += sbeta[head * 4 + q] * (b0 + vshift[(q * 4 + cam) * 256 + t]);
+        out[row * 256 + t] = acc;
+    }
+    // LayerNorm over the 256 outputs (groups 1-3 contribute zeros to the block sums)
+    auto block_sum = [&](float v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);                            // group 0's four waves
+    };
+    const float mean = block_sum(grp == 0 ? acc : 0.f) / 256.f;
     const float d = acc - mean;
-    const float rstd = 1.f / sqrtf(block_sum256(d * d, red) / 256.f + eps);
-    out_ln[row * 256 + t] = d * rstd * gamma[t] + beta[t];
+    const float rstd = 1.f / sqrtf(block_sum(grp == 0 ? d * d : 0.f) / 256.f + eps);
+    if (grp == 0) out_ln[row * 256 + t] = d * rstd * gamma[t] + beta[t];
 }
 
 // sca_reduce + LayerNorm(1024) (output_proj.0): one block of 1024 threads per sample, thread = (camera, channel)
@@ -622,7 +646,7 @@ extern "C" int tt_msda_sample_proj_ln(int B, const void* const* level_maps, cons
     LevelMaps m;
     fill_levels(m, level_maps, level_hw);
     const long long rows_n = (long long)B * kCams * kQ;
-    hipLaunchKernelGGL(msda_sample_proj_ln_kernel, dim3((unsigned)rows_n), dim3(256), 0, (hipStream_t)stream, m, offsets, logits,
+    hipLaunchKernelGGL(msda_sample_proj_ln_kernel, dim3((unsigned)rows_n), dim3(1024), 0, (hipStream_t)stream, m, offsets, logits,
                        ref_packed, wvT, bias, vshift, gamma, beta, eps, out, out_ln, max_len_or_null);
     return check_launch("tt_msda_sample_proj_ln");
 }
