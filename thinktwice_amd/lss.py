@@ -109,8 +109,8 @@ class PAFPN_fp32:
         assert start_level == 0 and end_level in (-1, len(in_channels)) and not add_extra_convs and \
             num_outs == len(in_channels), "PAFPN: only the thinktwice.py form (all levels, no extra convs) is built"
         self.in_channels, self.out_channels, self.num_outs = list(in_channels), out_channels, num_outs
-        # dtype "f32x3h" (weights.X3H): the neck's own tensors -- laterals, top-down sums, intermediate maps -- live in IEEE half
-        # and its 3 x 3 convolutions run the two-MFMA h2 product (csrc/conv_h2.hip); inputs and outputs stay f32
+        # dtype "f32x3h" (weights.X3H): the neck's 3 x 3 convolutions read IEEE-half COPIES of their inputs on the two-MFMA h2 product
+        # (csrc/conv_h2.hip); its sums (laterals, top-down, bottom-up), inputs and outputs stay f32 (_call_half)
         self.half = isinstance(dtype, str) and dtype == weights.X3H
         self.wdtype, self.device = (weights.X3 if self.half else dtype), torch.device(device)
         self.loaded = False

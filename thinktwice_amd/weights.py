@@ -11,8 +11,8 @@ import torch
 X3 = "f32x3"      # precision mode: f32 storage, bf16x3 MFMA arithmetic (pre-split weights beside the f32 ones)
 
 
-# precision mode of the MODEL: bf16x3 everywhere except the PAFPN, which keeps its activations in IEEE half and runs the two-MFMA
-# "h2" product (the one stage whose half storage the storage-level emulation clears).  Every module but LSS treats it as X3.
+# precision mode of the MODEL: bf16x3 everywhere except the PAFPN's 3 x 3 convolutions, which read IEEE-half copies of their inputs and
+# run the two-MFMA "h2" product (the one stage the storage-level emulation clears).  Every module but LSS treats it as X3.
 X3H = "f32x3h"
 # precision mode of ONE layer: half activation storage x f16 (hi, lo) weight pair (csrc/conv_h2.hip)
 H2 = "h2"
