@@ -27,7 +27,11 @@ def main():
     wx = weights.split_pairs_x3(w) if mode in ("x3", "x3p") else None
     if mode == "x3p":       # pre-split (pair-format) activations: tt_conv_desc.in_pair
         x = weights.split_pairs_x3(x)
-    conv = lambda: ops.conv2d(x, w, stride=stride, pad=pad, act=act, res1=res, w_x3=wx, in_pair=mode == "x3p")
+    if mode == "h2":        # half activations x f16 (hi, lo) weights (csrc/conv_h2.hip), f32 output
+        wh, x, w = weights.split_pairs_h2(w), x.half(), w.half()
+        conv = lambda: ops.conv2d(x, w, stride=stride, pad=pad, act=act, w_h2=wh, out_dtype=torch.float32)
+    else:
+        conv = lambda: ops.conv2d(x, w, stride=stride, pad=pad, act=act, res1=res, w_x3=wx, in_pair=mode == "x3p")
     for _ in range(3):
         y = conv()
     torch.cuda.synchronize()
