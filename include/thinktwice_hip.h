@@ -272,8 +272,10 @@ int tt_dec_gru(int B, const float* inp6, const float* state, float* fut, float* 
                const float* const* wx, const float* const* b0, const void* const* w2, const float* const* b2,
                const void* wd0, const float* bd0, const void* wd2, const float* bd2, void* stream);
 /* grid2feat (encoder_decoder_framework.py:228-234, thinktwice_decoder.py:405-415): maps x [441][32] -> [256];
- * 17 weight sets in the order documented in dec_spatial.hip; mids (nullable): the three SE-block outputs. */
-int tt_dec_flatten(int maps, const float* in, float* out, float* mids_or_null, const void* const* w,
+ * 17 weight sets in the order documented in dec_spatial.hip; mids (nullable): the three SE-block outputs;
+ * scratch: tt_dec_flatten_scratch_floats(maps) floats (the tensors between the per-layer launches of the 4x4 level on). */
+long long tt_dec_flatten_scratch_floats(int maps);
+int tt_dec_flatten(int maps, const float* in, float* out, float* mids_or_null, float* scratch, const void* const* w,
                    const float* const* b, const float* bn_scale, const float* bn_shift, void* stream);
 /* debug: while set, workgroup 0 of tt_dec_gru / tt_dec_flatten writes a wall-clock stamp (10 ns ticks) after every phase (<= 64) */
 int tt_dec_set_trace(void* stamps_or_null);

@@ -402,7 +402,8 @@ __global__ __launch_bounds__(kGruWaves * 64) void dec_gru_kernel(const GruArgs a
 }
 
 // ------------------------------------------------------------------------------------------------ grid2feat
-// One workgroup per 21x21x32 map.  Weight sets (pair format, eval BatchNorm scale folded into the rows, shift = bias):
+// tt_dec_flatten = dec_flatten_kernel (one workgroup per 21x21x32 map: conv21_10, MLP10, conv10_4) + eleven launches of
+// dec_tail_conv_kernel (everything from the 4x4 level on, rows of all maps packed, columns dealt over workgroups).  Weight sets (pair format, eval BatchNorm scale folded into the rows, shift = bias):
 //   0 conv21_10 | 1 2 MLP10.conv1/2 | 3 4 MLP10.se.fc1/2 | 5 conv10_4 | 6 7 MLP4.conv1/2 | 8 9 MLP4.se.fc1/2 |
 //   10 conv4_2 | 11 12 MLP2.conv1/2 | 13 14 MLP2.se.fc1/2 | 15 output_fc.0 (as a 2x2 conv over the 2x2x256 map) |
 //   16 output_fc.3
@@ -413,6 +414,7 @@ struct FlatArgs {
     const float* in;          // [maps][441][32] f32 channel-last
     float* out;               // [maps][256] f32
     float* mids;              // optional [maps][(100*64 + 16*128 + 4*256)] f32: the 10x10, 4x4, 2x2 block outputs
+    float* x4;                // [maps][16][128] f32: conv10_4's output, where the kernel hands over to the column-split tail
     const unsigned char* w[kFlatSets];
     const float* b[kFlatSets];
     const float* bn_scale;    // output_fc.2 (eval BatchNorm1d) scale / shift [512]
@@ -425,35 +427,52 @@ __device__ __forceinline__ int ps_of(int C) { return C * 4 + 16; }
 // SEBasicBlock (code/utils.py:99-121) on an LDS map, IN PLACE: X (C channels; input, residual and output) ->
 // Y1 = relu(bn1(conv1 X)) (2C channels) -> Y2 = relu(bn2(conv2 Y1)) (C) -> gate = sigmoid(fc2 relu(fc1 pool(Y2))) ->
 // X = relu(Y2 * gate + X).  `vec`: scratch for two 1-pixel maps of C channels + C floats of gate.
+template <typename Stamp>
 __device__ __forceinline__ void se_block(const FlatArgs& a, int set, int HW, int C, unsigned char* X, unsigned char* Y1,
                                          unsigned char* Y2, unsigned char* vec, const unsigned char* zero, int wave,
-                                         int lane, int tid) {
+                                         int lane, int tid, Stamp stamp) {
     const int PS = ps_of(C), PS1 = ps_of(2 * C), M = HW * HW;
     conv_lds<1, 4>(X, HW, HW, C, PS, zero, 1, 1, 3, 3, a.w[set], 2 * C, HW, HW, wave, kFlatWaves, lane,
                    [&](int m, int n, float v, int) { v += a.b[set][n]; pair_store(Y1, PS1, m, n, v > 0.f ? v : 0.f); });
     __syncthreads();
+    stamp();
     conv_lds<1, 4>(Y1, HW, HW, 2 * C, PS1, zero, 1, 1, 3, 3, a.w[set + 1], C, HW, HW, wave, kFlatWaves, lane,
                    [&](int m, int n, float v, int) { v += a.b[set + 1][n]; pair_store(Y2, PS, m, n, v > 0.f ? v : 0.f); });
     __syncthreads();
+    stamp();
     unsigned char* s0 = vec;                       // pooled vector as a 1-pixel map
     unsigned char* s1 = vec + ps_of(C);            // fc1 output
     float* gate = reinterpret_cast<float*>(vec + 2 * ps_of(C));
-    for (int c = tid; c < C; c += kFlatWaves * 64) {
+    float* red = gate + C;                         // [threads / C][C][2] partial (sum, max)
+    {
+        // every thread takes a slice of the pixels of one channel (one thread per channel walked all M pixels alone: ~10 us)
+        const int nparts = kFlatWaves * 64 / C, c = tid % C, part = tid / C;
         float sum = 0.f, mx = -INFINITY;
-        for (int m = 0; m < M; ++m) {
+        for (int m = part; m < M; m += nparts) {
             const float v = pair_load(Y2, PS, m, c);
             sum += v;
             mx = fmaxf(mx, v);
         }
-        pair_store(s0, PS, 0, c, 0.5f * (sum / (float)M) + 0.5f * mx);
+        red[(part * C + c) * 2] = sum;
+        red[(part * C + c) * 2 + 1] = mx;
+        __syncthreads();
+        if (tid < C) {
+            for (int q = 1; q < nparts; ++q) {
+                sum += red[(q * C + tid) * 2];
+                mx = fmaxf(mx, red[(q * C + tid) * 2 + 1]);
+            }
+            pair_store(s0, PS, 0, tid, 0.5f * (sum / (float)M) + 0.5f * mx);
+        }
     }
     __syncthreads();
+    stamp();
     conv_lds<1, 4>(s0, 1, 1, C, PS, zero, 1, 0, 1, 1, a.w[set + 2], C, 1, 1, wave, kFlatWaves, lane,
                    [&](int, int n, float v, int) { v += a.b[set + 2][n]; pair_store(s1, PS, 0, n, v > 0.f ? v : 0.f); });
     __syncthreads();
     conv_lds<1, 4>(s1, 1, 1, C, PS, zero, 1, 0, 1, 1, a.w[set + 3], C, 1, 1, wave, kFlatWaves, lane,
                    [&](int, int n, float v, int) { gate[n] = 1.f / (1.f + expf(-(v + a.b[set + 3][n]))); });
     __syncthreads();
+    stamp();
     for (int e = tid; e < M * C; e += kFlatWaves * 64) {
         const int m = e / C, c = e - m * C;
         const float v = pair_load(Y2, PS, m, c) * gate[c] + pair_load(X, PS, m, c);
@@ -472,28 +491,18 @@ __global__ __launch_bounds__(kFlatWaves * 64) void dec_flatten_kernel(const Flat
     };
     stamp();
     // LDS plan (bytes).  Region A [0, 63504): the input map; once conv21_10 has consumed it, MLP10's 128-channel hidden
-    // map; after MLP10 the 4x4 and 2x2 maps.  Region B: the 10x10x64 map X10 and MLP10's Y2.  Then zero page, vectors.
+    // map.  Region B: the 10x10x64 map X10 and MLP10's Y2.  Then zero page, vectors.
     constexpr int kIn = kMapPix * kPS32;                               // 63504
     constexpr int kOffB = (kIn + 15) / 16 * 16;
     constexpr int kSz10 = 100 * (64 * 4 + 16);                         // 27200
     constexpr int kZero = kOffB + 2 * kSz10;
-    constexpr int kVec = kZero + 64;                                   // 2 x (256*4+16) + 256*4
+    constexpr int kVec = kZero + 64;                                   // 2 x (64*4+16) + 64*4 + 8*64*2*4
     unsigned char* Rin = smem;
     unsigned char* X10 = smem + kOffB;
     unsigned char* Y10b = X10 + kSz10;
     unsigned char* Y10a = smem;                                        // 100 x (128*4+16) = 52800 B, in region A
     unsigned char* zero = smem + kZero;
     unsigned char* vec = smem + kVec;
-    constexpr int kSz4 = 16 * (128 * 4 + 16), kSz4h = 16 * (256 * 4 + 16);     // 8448, 16640
-    constexpr int kSz2 = 4 * (256 * 4 + 16), kSz2h = 4 * (512 * 4 + 16);       // 4160, 8256
-    unsigned char* X4 = smem;                                          // region A again (MLP10 is finished by then)
-    unsigned char* Y4a = X4 + kSz4;
-    unsigned char* Y4b = Y4a + kSz4h;
-    unsigned char* X2 = Y4b + kSz4;
-    unsigned char* Y2a = X2 + kSz2;
-    unsigned char* Y2b = Y2a + kSz2h;
-    unsigned char* H512 = Y2b + kSz2;                                  // 1-pixel map of 512 channels (2064 B)
-    static_assert(2 * kSz4 + kSz4h + 2 * kSz2 + kSz2h + 2064 <= kIn, "region A overflow");
 
     if (tid < 16) reinterpret_cast<uint32_t*>(zero)[tid] = 0u;
     const float* src = a.in + (size_t)map * kMapPix * kMapC;
@@ -505,43 +514,203 @@ __global__ __launch_bounds__(kFlatWaves * 64) void dec_flatten_kernel(const Flat
                    [&](int m, int n, float v, int) { v += a.b[0][n]; pair_store(X10, ps_of(64), m, n, v > 0.f ? v : 0.f); });
     __syncthreads();
     stamp();
-    se_block(a, 1, 10, 64, X10, Y10a, Y10b, vec, zero, wave, lane, tid);            // X10 updated in place
+    se_block(a, 1, 10, 64, X10, Y10a, Y10b, vec, zero, wave, lane, tid, stamp);     // X10 updated in place
     stamp();
     float* mid = a.mids ? a.mids + (size_t)map * (100 * 64 + 16 * 128 + 4 * 256) : nullptr;
     if (mid)
         for (int e = tid; e < 100 * 64; e += kFlatWaves * 64) mid[e] = pair_load(X10, ps_of(64), e >> 6, e & 63);
-    // conv10_4: 3x3 stride 2, no padding, 64 -> 128, ReLU (region A is free again)
+    // conv10_4: 3x3 stride 2, no padding, 64 -> 128, ReLU -- straight to global memory: the 4x4 and 2x2 levels and the two
+    // linears are weight streams (15.6 of the network's 16.8 MB) and run as the column-split stages below
+    float* x4 = a.x4 + (size_t)map * 16 * 128;
     conv_lds<1, 4>(X10, 10, 10, 64, ps_of(64), zero, 2, 0, 3, 3, a.w[5], 128, 4, 4, wave, kFlatWaves, lane,
-                   [&](int m, int n, float v, int) { v += a.b[5][n]; pair_store(X4, ps_of(128), m, n, v > 0.f ? v : 0.f); });
+                   [&](int m, int n, float v, int) { v += a.b[5][n]; x4[m * 128 + n] = v > 0.f ? v : 0.f; });
+    stamp();
+}
+
+// ------------------------------------------------------------------------------------------------ grid2feat, 4x4 level on
+// One workgroup streamed all 16.8 MB of grid2feat's weights for its map at the ~64 GB/s a single CU gets out of the L2 (267 us
+// at 4 maps, 340 us at 32: 15.6 MB of it for the 16-, 4- and 1-pixel levels).  From conv10_4's output on, the ROWS of all maps
+// are packed into one GEMM per layer (rows = maps x output pixels: a 32-row block holds 2 / 8 / 32 maps) and the COLUMNS are
+// dealt over workgroups, so a layer's weights are streamed once per 32 / 64 rows by N / 32 CUs at a time.  One launch per
+// layer (the stream order is the barrier); a workgroup = one 32-column block x one group of maps:
+//   * the group's input maps are staged in LDS in pair format (as in the kernel above).  Three staging modes: the stored
+//     tensor; the SE block's pooled vector 0.5 mean + 0.5 max over the pixels (input of se.fc1); the SE block's output
+//     relu(y * gate + x) (input of the layer after the block -- column block 0 also stores it, for `mids`);
+//   * the eight waves split the K steps (wave w: steps w, w + 8, ...: a ring of 8 x 2 KiB of weights in flight per wave), each
+//     against all row blocks of the group; the partial tiles are summed through LDS in wave order (deterministic).
+constexpr int kTailWaves = 8, kTailPF = 8;
+
+struct TailArgs {
+    const float* in;          // mode 0: [maps][HW * HW][C]; modes 1, 2: the block's y [maps][P_in][C]
+    const float* gate;        // mode 2: [maps][C]
+    const float* res;         // mode 2: the block's input x [maps][P_in][C]
+    float* stage_out;         // mode 2, optional: relu(y * gate + x), map stride stage_out_ms floats
+    long long stage_out_ms;
+    int mode, maps, MG;       // MG maps per workgroup (gridDim.y = ceil(maps / MG)); MG * OHW * OHW <= 32 * MBG
+    int HW, C, KH, KW, pad, OHW, P_in;
+    const unsigned char* w;   // fragment-major pair format, as in conv_lds
+    const float* bias;
+    const float* bn_scale;    // optional affine after the activation (output_fc.2)
+    const float* bn_shift;
+    int N, act;               // act: 0 ReLU, 1 sigmoid
+    float* out;               // [maps * OHW * OHW][N]
+};
+
+template <int MBG>
+__global__ __launch_bounds__(kTailWaves * 64) void dec_tail_conv_kernel(const TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = blockIdx.x, map0 = blockIdx.y * a.MG;
+    const int nm = min(a.MG, a.maps - map0);
+    const int C = a.C, PS = C * 4 + 16, HW2 = a.HW * a.HW;
+    unsigned char* Xs = smem;
+    unsigned char* zero = smem + (size_t)a.MG * HW2 * PS;
+    float(*part)[MBG][32][32] = reinterpret_cast<float(*)[MBG][32][32]>(zero + 64);
+    if (tid < 16) reinterpret_cast<uint32_t*>(zero)[tid] = 0u;
+    // ---- stage the group's maps: four channels per thread and step, kStageUn independent loads in flight per thread (one
+    // element per step left every step waiting for its own L2 round trip: 22 us for the 16 K elements of MLP4.conv2's input)
+    constexpr int kStageUn = 4, kStep = kTailWaves * 64;
+    const int C4 = C >> 2, per_map4 = HW2 * C4, ngr = nm * per_map4;
+    auto put4 = [&](int ml, int q4, float4 v) {
+        const int pix = q4 / C4, c = (q4 - pix * C4) * 4;
+        unsigned char* p = Xs + (size_t)(ml * HW2 + pix) * PS + (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
+        const uint16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
+        const uint16_t l0 = f32_to_bf16(v.x - bf16_to_f32(h0)), l1 = f32_to_bf16(v.y - bf16_to_f32(h1));
+        const uint16_t l2 = f32_to_bf16(v.z - bf16_to_f32(h2)), l3 = f32_to_bf16(v.w - bf16_to_f32(h3));
+        *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+        *reinterpret_cast<uint2*>(p + 32) = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+    };
+    const float4* in4 = reinterpret_cast<const float4*>(a.in);
+    for (int e0 = tid; e0 < ngr; e0 += kStep * kStageUn) {
+        int ml[kStageUn], q4[kStageUn];
+        float4 v[kStageUn];
+#pragma unroll
+        for (int u = 0; u < kStageUn; ++u) {
+            const int e = e0 + u * kStep < ngr ? e0 + u * kStep : e0;
+            ml[u] = e / per_map4;
+            q4[u] = e - ml[u] * per_map4;
+        }
+        if (a.mode == 0) {
+#pragma unroll
+            for (int u = 0; u < kStageUn; ++u) v[u] = in4[(size_t)(map0 + ml[u]) * per_map4 + q4[u]];
+        } else if (a.mode == 1) {                                   // HW = 1: q4 = channel group; pool the P_in pixels
+#pragma unroll
+            for (int u = 0; u < kStageUn; ++u) {
+                const float4* y = in4 + (size_t)(map0 + ml[u]) * a.P_in * C4 + q4[u];
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll 4
+                for (int p = 0; p < a.P_in; ++p) {
+                    const float4 t = y[(size_t)p * C4];
+                    sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+                    mx.x = fmaxf(mx.x, t.x); mx.y = fmaxf(mx.y, t.y); mx.z = fmaxf(mx.z, t.z); mx.w = fmaxf(mx.w, t.w);
+                }
+                const float inv = 1.f / (float)a.P_in;
+                v[u] = make_float4(0.5f * (sum.x * inv) + 0.5f * mx.x, 0.5f * (sum.y * inv) + 0.5f * mx.y,
+                                   0.5f * (sum.z * inv) + 0.5f * mx.z, 0.5f * (sum.w * inv) + 0.5f * mx.w);
+            }
+        } else {
+            float4 g[kStageUn], x[kStageUn];
+#pragma unroll
+            for (int u = 0; u < kStageUn; ++u) {
+                const size_t map = (size_t)(map0 + ml[u]);
+                v[u] = in4[map * per_map4 + q4[u]];
+                g[u] = reinterpret_cast<const float4*>(a.gate)[map * C4 + q4[u] % C4];
+                x[u] = reinterpret_cast<const float4*>(a.res)[map * per_map4 + q4[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < kStageUn; ++u) {
+                v[u] = make_float4(fmaxf(v[u].x * g[u].x + x[u].x, 0.f), fmaxf(v[u].y * g[u].y + x[u].y, 0.f),
+                                   fmaxf(v[u].z * g[u].z + x[u].z, 0.f), fmaxf(v[u].w * g[u].w + x[u].w, 0.f));
+                if (a.stage_out && nb == 0 && e0 + u * kStep < ngr)
+                    *reinterpret_cast<float4*>(a.stage_out + (size_t)(map0 + ml[u]) * a.stage_out_ms + (size_t)q4[u] * 4) = v[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kStageUn; ++u)
+            if (e0 + u * kStep < ngr) put4(ml[u], q4[u], v[u]);
+    }
     __syncthreads();
-    stamp();
-    se_block(a, 6, 4, 128, X4, Y4a, Y4b, vec, zero, wave, lane, tid);
-    stamp();
-    if (mid)
-        for (int e = tid; e < 16 * 128; e += kFlatWaves * 64) mid[100 * 64 + e] = pair_load(X4, ps_of(128), e >> 7, e & 127);
-    // conv4_2: 3x3 stride 1, no padding, 128 -> 256, ReLU
-    conv_lds<1, 4>(X4, 4, 4, 128, ps_of(128), zero, 1, 0, 3, 3, a.w[10], 256, 2, 2, wave, kFlatWaves, lane,
-                   [&](int m, int n, float v, int) { v += a.b[10][n]; pair_store(X2, ps_of(256), m, n, v > 0.f ? v : 0.f); });
+    // ---- K loop
+    const int r = lane & 31, h = lane >> 5;
+    const int P = a.OHW * a.OHW, rows = nm * P;
+    const int gpt = C >> 4, gsh = __builtin_ctz(gpt);
+    const int nsteps = a.KH * a.KW * gpt, last = nsteps - 1;
+    const int mine = (nsteps - wave + kTailWaves - 1) / kTailWaves;
+    int base[MBG];
+    unsigned mask[MBG];
+#pragma unroll
+    for (int q = 0; q < MBG; ++q) {
+        const int row = q * 32 + r;
+        const bool ok = row < rows;
+        const int ml = ok ? row / P : 0, pix = ok ? row - (row / P) * P : 0;
+        const int oy = pix / a.OHW, ox = pix - oy * a.OHW;
+        base[q] = (ml * HW2 + (oy - a.pad) * a.HW + (ox - a.pad)) * PS + h * 16;
+        unsigned mk = 0;
+        if (ok)
+            for (int kh = 0; kh < a.KH; ++kh)
+                for (int kw = 0; kw < a.KW; ++kw) {
+                    const int iy = oy - a.pad + kh, ix = ox - a.pad + kw;
+                    if (iy >= 0 && iy < a.HW && ix >= 0 && ix < a.HW) mk |= 1u << (kh * a.KW + kw);
+                }
+        mask[q] = mk;
+    }
+    f32x16 acc[MBG], acc2[MBG];
+#pragma unroll
+    for (int q = 0; q < MBG; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = acc2[q][i] = 0.f;
+    const unsigned char* bp = a.w + (size_t)nb * nsteps * 2048 + (h * 32 + r) * 16;
+    uint4 bh[kTailPF], bl[kTailPF];
+    auto load_b = [&](int step, int p) {
+        const int kk = step < last ? step : last;                  // unconditional loads (conv_lds): clamped to the last step
+        bh[p] = *reinterpret_cast<const uint4*>(bp + (size_t)kk * 2048);
+        bl[p] = *reinterpret_cast<const uint4*>(bp + (size_t)kk * 2048 + 1024);
+    };
+#pragma unroll
+    for (int p = 0; p < kTailPF; ++p) load_b(wave + kTailWaves * p, p);
+#pragma unroll 1
+    for (int i = 0; i < mine; i += kTailPF) {
+#pragma unroll
+        for (int p = 0; p < kTailPF; ++p) {
+            const int step = wave + kTailWaves * (i + p);
+            if (i + p < mine) {
+                const int tap = step >> gsh, g = step & (gpt - 1);
+                const int kh = tap / a.KW, kw = tap - kh * a.KW;
+                const int toff = (kh * a.HW + kw) * PS + g * 64;
+#pragma unroll
+                for (int q = 0; q < MBG; ++q) {
+                    const bool ok = (mask[q] >> tap) & 1u;
+                    const unsigned char* ap = ok ? Xs + base[q] + toff : zero + h * 16;
+                    const uint4 ah = *reinterpret_cast<const uint4*>(ap);
+                    const uint4 al = *reinterpret_cast<const uint4*>(ok ? ap + 32 : ap);
+                    mfma3s(ah, al, bh[p], bl[p], acc[q], acc2[q]);
+                }
+            }
+            if (i + kTailPF < mine) load_b(step + kTailWaves * kTailPF, p);    // wave-uniform: the last round reloads nothing
+        }
+    }
+    // ---- partial tiles -> LDS, summed in wave order.  C/D map: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int q = 0; q < MBG; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[wave][q][(i & 3) + 8 * (i >> 2) + 4 * h][r] = acc[q][i] + acc2[q][i];
     __syncthreads();
-    stamp();
-    se_block(a, 11, 2, 256, X2, Y2a, Y2b, vec, zero, wave, lane, tid);
-    stamp();
-    if (mid)
-        for (int e = tid; e < 4 * 256; e += kFlatWaves * 64)
-            mid[100 * 64 + 16 * 128 + e] = pair_load(X2, ps_of(256), e >> 8, e & 255);
-    // output_fc.0 over the pixel-major flattening of the 2x2x256 map = a 2x2 "valid" conv; ReLU; BatchNorm1d (eval)
-    conv_lds<1, 4>(X2, 2, 2, 256, ps_of(256), zero, 1, 0, 2, 2, a.w[15], 512, 1, 1, wave, kFlatWaves, lane,
-                   [&](int, int n, float v, int) {
-                       v += a.b[15][n];
-                       v = v > 0.f ? v : 0.f;
-                       pair_store(H512, ps_of(512), 0, n, v * a.bn_scale[n] + a.bn_shift[n]);
-                   });
-    __syncthreads();
-    stamp();
-    float* dst = a.out + (size_t)map * 256;
-    conv_lds<1, 4>(H512, 1, 1, 512, ps_of(512), zero, 1, 0, 1, 1, a.w[16], 256, 1, 1, wave, kFlatWaves, lane,
-                   [&](int, int n, float v, int) { v += a.b[16][n]; dst[n] = v > 0.f ? v : 0.f; });
-    stamp();
+    const int col = tid & 31, n = nb * 32 + col;
+    if (n >= a.N) return;
+    const float bias = a.bias[n];
+    const float sc = a.bn_scale ? a.bn_scale[n] : 1.f, sh = a.bn_scale ? a.bn_shift[n] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2 * MBG; ++j) {
+        const int rg = (tid >> 5) + 16 * j;
+        if (rg >= rows) break;
+        float v = part[0][rg >> 5][rg & 31][col];
+#pragma unroll
+        for (int q = 1; q < kTailWaves; ++q) v += part[q][rg >> 5][rg & 31][col];
+        v += bias;
+        v = a.act == 1 ? 1.f / (1.f + expf(-v)) : (v > 0.f ? v : 0.f);
+        a.out[((size_t)map0 * P + rg) * a.N + n] = v * sc + sh;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ BEV update
@@ -665,9 +834,15 @@ extern "C" int tt_dec_gru(int B, const float* inp6, const float* state, float* f
     return check_launch("tt_dec_gru");
 }
 
-extern "C" int tt_dec_flatten(int maps, const float* in, float* out, float* mids_or_null, const void* const* w,
-                              const float* const* b, const float* bn_scale, const float* bn_shift, void* stream) {
-    TT_REQUIRE(maps > 0 && in && out && w && b && bn_scale && bn_shift, "tt_dec_flatten: null");
+// floats of scratch per map: x4, MLP4's y1 / y2, its pooled fc1 output and gate, the block output, the 2x2 level likewise, fc0
+constexpr int kFlatScratch = 2048 + 4096 + 2048 + 128 + 128 + 2048 + 1024 + 2048 + 1024 + 256 + 256 + 1024 + 512;
+
+extern "C" long long tt_dec_flatten_scratch_floats(int maps) { return (long long)maps * kFlatScratch; }
+
+extern "C" int tt_dec_flatten(int maps, const float* in, float* out, float* mids_or_null, float* scratch,
+                              const void* const* w, const float* const* b, const float* bn_scale, const float* bn_shift,
+                              void* stream) {
+    TT_REQUIRE(maps > 0 && in && out && scratch && w && b && bn_scale && bn_shift, "tt_dec_flatten: null");
     FlatArgs a;
     a.in = in; a.out = out; a.mids = mids_or_null; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
     a.trace = g_dec_trace;
@@ -676,15 +851,58 @@ extern "C" int tt_dec_flatten(int maps, const float* in, float* out, float* mids
         a.w[i] = (const unsigned char*)w[i];
         a.b[i] = b[i];
     }
+    const size_t M = (size_t)maps;
+    float* x4 = scratch;                 float* y4a = x4 + M * 2048;      float* y4b = y4a + M * 4096;
+    float* s4 = y4b + M * 2048;          float* g4 = s4 + M * 128;        float* x4o = g4 + M * 128;
+    float* x2 = x4o + M * 2048;          float* y2a = x2 + M * 1024;      float* y2b = y2a + M * 2048;
+    float* s2 = y2b + M * 1024;          float* g2 = s2 + M * 256;        float* x2o = g2 + M * 256;
+    float* h512 = x2o + M * 1024;
+    a.x4 = x4;
     const size_t smem = (size_t)((kMapPix * kPS32 + 15) / 16 * 16) + 2 * 100 * (64 * 4 + 16) + 64 +
-                        2 * (256 * 4 + 16) + 256 * 4 + 64;
+                        2 * (64 * 4 + 16) + 64 * 4 + kFlatWaves * 64 * 2 * 4 + 64;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_flatten_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_tail_conv_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_tail_conv_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     hipLaunchKernelGGL(dec_flatten_kernel, dim3((unsigned)maps), dim3(kFlatWaves * 64), smem, (hipStream_t)stream, a);
+    // one column-split stage: `set` = weight set; input map HW x HW x C, KH x KW / pad -> OHW x OHW x N
+    auto stage = [&](int set, int mode, const float* src, const float* gate, const float* res, float* stage_out,
+                     long long stage_out_ms, int P_in, int HW, int C, int K, int pad, int OHW, int N, int act, bool bn,
+                     float* dst, int MG, int MBG) {
+        TailArgs t;
+        t.in = src; t.gate = gate; t.res = res; t.stage_out = stage_out; t.stage_out_ms = stage_out_ms;
+        t.mode = mode; t.maps = maps; t.MG = MG; t.HW = HW; t.C = C; t.KH = K; t.KW = K; t.pad = pad; t.OHW = OHW; t.P_in = P_in;
+        t.w = a.w[set]; t.bias = a.b[set]; t.bn_scale = bn ? bn_scale : nullptr; t.bn_shift = bn ? bn_shift : nullptr;
+        t.N = N; t.act = act; t.out = dst;
+        const size_t lds = (size_t)MG * HW * HW * (C * 4 + 16) + 64 + (size_t)kTailWaves * MBG * 32 * 32 * 4;
+        const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((maps + MG - 1) / MG));
+        if (MBG == 2) hipLaunchKernelGGL(dec_tail_conv_kernel<2>, grid, dim3(kTailWaves * 64), lds, (hipStream_t)stream, t);
+        else hipLaunchKernelGGL(dec_tail_conv_kernel<1>, grid, dim3(kTailWaves * 64), lds, (hipStream_t)stream, t);
+    };
+    const long long ms = 100 * 64 + 16 * 128 + 4 * 256;
+    float* mid4 = mids_or_null ? mids_or_null + 100 * 64 : nullptr;
+    float* mid2 = mids_or_null ? mids_or_null + 100 * 64 + 16 * 128 : nullptr;
+    // MLP4 (SEBasicBlock on the 4x4x128 map): conv1, conv2, se.fc1 on the pooled vector, se.fc2 -> gate
+    stage(6, 0, x4, nullptr, nullptr, nullptr, 0, 0, 4, 128, 3, 1, 4, 256, 0, false, y4a, 4, 2);
+    stage(7, 0, y4a, nullptr, nullptr, nullptr, 0, 0, 4, 256, 3, 1, 4, 128, 0, false, y4b, 4, 2);
+    stage(8, 1, y4b, nullptr, nullptr, nullptr, 0, 16, 1, 128, 1, 0, 1, 128, 0, false, s4, 32, 1);
+    stage(9, 0, s4, nullptr, nullptr, nullptr, 0, 0, 1, 128, 1, 0, 1, 128, 1, false, g4, 32, 1);
+    // conv4_2 on the block's output relu(y * gate + x): 3x3, no padding, 128 -> 256
+    stage(10, 2, y4b, g4, x4, mid4 ? mid4 : x4o, mid4 ? ms : 2048, 16, 4, 128, 3, 0, 2, 256, 0, false, x2, 8, 1);
+    // MLP2 on the 2x2x256 map
+    stage(11, 0, x2, nullptr, nullptr, nullptr, 0, 0, 2, 256, 3, 1, 2, 512, 0, false, y2a, 8, 1);
+    stage(12, 0, y2a, nullptr, nullptr, nullptr, 0, 0, 2, 512, 3, 1, 2, 256, 0, false, y2b, 8, 1);
+    stage(13, 1, y2b, nullptr, nullptr, nullptr, 0, 4, 1, 256, 1, 0, 1, 256, 0, false, s2, 32, 1);
+    stage(14, 0, s2, nullptr, nullptr, nullptr, 0, 0, 1, 256, 1, 0, 1, 256, 1, false, g2, 32, 1);
+    // output_fc.0 over the pixel-major flattening of the block's 2x2x256 output = a 2x2 "valid" conv; ReLU; BatchNorm1d (eval)
+    stage(15, 2, y2b, g2, x2, mid2 ? mid2 : x2o, mid2 ? ms : 1024, 4, 2, 256, 2, 0, 1, 512, 0, true, h512, 16, 1);
+    stage(16, 0, h512, nullptr, nullptr, nullptr, 0, 0, 1, 512, 1, 0, 1, 256, 0, false, out, 32, 1);
     return check_launch("tt_dec_flatten");
 }
 

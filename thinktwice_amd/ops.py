@@ -1227,7 +1227,10 @@ def dec_flatten(wts, maps, want_mids=False):
     assert maps.is_contiguous() and maps.dtype == torch.float32
     out = torch.empty(N, 256, dtype=torch.float32, device=maps.device)
     mids = torch.empty(N, 100 * 64 + 16 * 128 + 4 * 256, dtype=torch.float32, device=maps.device) if want_mids else None
-    check(lib().tt_dec_flatten(_c(N), ptr(maps), ptr(out), ptr(mids), wts["w"], wts["b"], ptr(wts["bn_scale"]),
+    L = lib()
+    L.tt_dec_flatten_scratch_floats.restype = ctypes.c_longlong
+    scratch = torch.empty(L.tt_dec_flatten_scratch_floats(_c(N)), dtype=torch.float32, device=maps.device)
+    check(L.tt_dec_flatten(_c(N), ptr(maps), ptr(out), ptr(mids), ptr(scratch), wts["w"], wts["b"], ptr(wts["bn_scale"]),
                                ptr(wts["bn_shift"]), _st(maps)), "tt_dec_flatten")
     return (out, mids) if want_mids else out
 

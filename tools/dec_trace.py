@@ -39,7 +39,7 @@ for B in (1, 8):
     traced(lambda: ops.dec_gru(w, inp6, state, fut), f"gru B={B} (entry, map load, then per step: class sums + 8 convs)")
     fw = DF.prep_flatten(sd, "cuda")
     maps = torch.randn(B * 4, 441, 32).cuda()
-    traced(lambda: ops.dec_flatten(fw, maps), f"flatten maps={B * 4} (load, conv21_10, MLP10, conv10_4, MLP4, conv4_2, MLP2, fc0, fc3)")
+    traced(lambda: ops.dec_flatten(fw, maps), f"flatten head maps={B * 4} (load, conv21_10, MLP10: conv1, conv2, pool, fc1+fc2, gate; conv10_4)")
 
 
 def timeit(fn, iters=50):
