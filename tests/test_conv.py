@@ -641,6 +641,18 @@ def test_conv_h2_matches_torch_f32(case):
         assert float(out2[..., :8].abs().max()) == 0.0
 
 
+def test_h2_pipelined_kernel_is_bit_identical_to_the_8wave_kernel():
+    """tools/h2_pipe_ab.py: conv_h2_pipe_kernel (long-K 128-wide layers: the PAFPN's 3 x 3 convolutions) against conv_h2_kernel
+    (TT_H2_PIPE=0), each arm in its own process, outputs compared bit for bit; plus repeatability and the distance to torch f32."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "h2_pipe_ab.py"), "1"], cwd=root, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, (r.stdout[-2500:], r.stderr[-500:])
+
+
 def test_bf16x3_layer_can_store_half():
     """A bf16x3 layer (f32 operands) feeding a half-storage stage writes IEEE half directly (stem -> layer1, PAFPN laterals 2 / 3)."""
     from thinktwice_amd import ops, weights
