@@ -267,7 +267,10 @@ int tt_mlp_chain_wide_set_trace(void* stamps_or_null);
 /* SpatialGRU (dense_heads/utils.py:53-106): inp6 [B][4][6] (waypoint xy, softplus ctrl), state [B][441][32] f32
  * channel-last -> fut [B][4][441][32].  w0/wx/b0/w2/b2: arrays of 3 (conv_update, conv_reset, conv_state_tilde):
  * w0 = state part of the .0 conv [32][9*32], wx = its constant-input part f32 [9][6][32], w2 = the .2 conv.
- * scratch: [B][2][448][32] f32 (the 441 pixels padded to 14 row blocks of 32). */
+ * scratch: tt_dec_gru_scratch_floats(B) floats ([B][3][448][32] f32 -- the 441 pixels padded to 14 row blocks of 32 -- + two flag
+ * words per sample: two workgroups per sample hand the state and the update gate over through it; a hand-over that times out
+ * sets the device fault word, tt_device_faults). */
+long long tt_dec_gru_scratch_floats(int B);
 int tt_dec_gru(int B, const float* inp6, const float* state, float* fut, float* scratch, const void* const* w0,
                const float* const* wx, const float* const* b0, const void* const* w2, const float* const* b2,
                const void* wd0, const float* bd0, const void* wd2, const float* bd2, void* stream);
@@ -280,10 +283,12 @@ int tt_dec_flatten(int maps, const float* in, float* out, float* mids_or_null, f
 /* debug: while set, workgroup 0 of tt_dec_gru / tt_dec_flatten writes a wall-clock stamp (10 ns ticks) after every phase (<= 64) */
 int tt_dec_set_trace(void* stamps_or_null);
 /* BEV_feat_update_module + residual (thinktwice_decoder.py:221-225,257): bev [B][441][32], G [B][9][128] = the
- * broadcast-channel term per tap (tt_mlp_chain over h), w0 [128][9*32] (bev part), w2[4] [32][9*32] per hidden chunk. */
+ * broadcast-channel term per tap (tt_mlp_chain over h), w0 [128][9*32] (bev part), w2[4] [32][9*32] per hidden chunk;
+ * scratch: tt_dec_bev_update_scratch_floats(B) floats (the four hidden-channel chunks' partial maps + a ticket per sample). */
+long long tt_dec_bev_update_scratch_floats(int B);
 int tt_dec_bev_update(int B, const float* bev, const float* G, float* out, long long out_bstride, float* out2,
-                      long long out2_bstride, const void* w0, const float* b0, const void* const* w2, const float* b2,
-                      void* stream);
+                      long long out2_bstride, float* scratch, const void* w0, const float* b0, const void* const* w2,
+                      const float* b2, void* stream);
 
 /* ------------------------------------------------------------------------
  * HBM-bound glue of the forward (channel-last; `dtype` = storage type of the activation).

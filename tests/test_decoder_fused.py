@@ -39,12 +39,13 @@ def test_gru_kernel_matches_oracle(sd_cfg, B):
     assert _rel(got, ref) < 1e-3, _rel(got, ref)
 
 
-def test_flatten_kernel_matches_oracle(sd_cfg):
+@pytest.mark.parametrize("N", [6, 35])      # 35 maps: more than one group of maps at every level of the column-split tail
+def test_flatten_kernel_matches_oracle(sd_cfg, N):
+    """tt_dec_flatten (one workgroup per map up to conv10_4, then dec_tail_conv_kernel per layer over all maps' rows)."""
     from oracle import model_ref as M
     from thinktwice_amd import decoder_fused as DF, ops
     sd, _ = sd_cfg
     g = torch.Generator().manual_seed(5)
-    N = 6
     f21 = torch.randn(N, 32, 21, 21, generator=g).abs() * 0.7
     with torch.no_grad():
         flat_r, (f10, f4, f2) = M.flatten_tail(sd, f21)

@@ -683,6 +683,15 @@ extern "C" int tt_clear_device_faults(void) {
     return 0;
 }
 
+int* tt::device_fault_word() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_wide_mutex);
+    return fault_word(dev);
+}
+
+int tt::pair_wait_max_spin() { return g_wide_max_spin.load(); }
+
 // The check every forward entry point makes first: a barrier time-out is sticky (like a device fault), because whatever ran
 // after it consumed poisoned data.
 int tt::refuse_after_fault(const char* what) {

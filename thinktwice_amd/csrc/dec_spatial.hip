@@ -44,6 +44,38 @@ __device__ __forceinline__ float pair_load(const unsigned char* map, int PS, int
     return bf16_to_f32(*reinterpret_cast<const uint16_t*>(p)) + bf16_to_f32(*reinterpret_cast<const uint16_t*>(p + 32));
 }
 
+// four consecutive channels c .. c + 3 (c % 4 == 0) of one pixel: two 8-byte LDS stores
+__device__ __forceinline__ void pair_store4(unsigned char* map, int PS, int pix, int c, const float4& v) {
+    unsigned char* p = map + (size_t)pix * PS + (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
+    const uint16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
+    const uint16_t l0 = f32_to_bf16(v.x - bf16_to_f32(h0)), l1 = f32_to_bf16(v.y - bf16_to_f32(h1));
+    const uint16_t l2 = f32_to_bf16(v.z - bf16_to_f32(h2)), l3 = f32_to_bf16(v.w - bf16_to_f32(h3));
+    *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+    *reinterpret_cast<uint2*>(p + 32) = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+}
+
+// a 441 x 32 f32 map (16 B aligned) from global memory into a pair-format LDS map: every load of a thread issued before its
+// first store (one element per step left each step waiting for its own L2 round trip)
+template <int NT>
+__device__ __forceinline__ void load_map32(unsigned char* map, const float* src, int tid) {
+    constexpr int kN4 = 441 * 32 / 4, kPer = (kN4 + NT - 1) / NT, kBatch = 4;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll 1
+    for (int u0 = 0; u0 < kPer; u0 += kBatch) {
+        float4 v[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int e = tid + (u0 + u) * NT;
+            v[u] = s4[e < kN4 ? e : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int e = tid + (u0 + u) * NT;
+            if (e < kN4) pair_store4(map, 144, e >> 3, (e & 7) * 4, v[u]);
+        }
+    }
+}
+
 // Implicit-GEMM convolution of an LDS-resident pair-format map by the whole workgroup.
 //   in_map: H x W pixels, Cp channels (multiple of 16), pixel stride PS; `zero`: >= 64 zeroed bytes (padding taps)
 //   w: fragment-major pair-format weights (weights.py::split_pairs_frag) of the [N rounded up to 32][KH*KW*Cp]
@@ -252,8 +284,8 @@ struct GruArgs {
     const float* inp6;        // [B][4][6]   (waypoint xy, softplus(ctrl) x4) per future step
     const float* state;       // [B][441][32] f32 channel-last BEV state
     float* fut;               // [B][4][441][32] f32
-    float* scratch;           // [B][2][448][32] f32: update gate and previous state of the running step (each element
-                              // is written and re-read by the SAME lane, so plain stores / loads need no fence)
+    float* scratch;           // [B][3][448][32] f32: update gate (role 1 -> role 0), previous state of the running step (written
+                              // and re-read by the SAME lane), new state (role 0 -> role 1); then [B][2] flag words
     const unsigned char* w0[3];   // conv_update.0 / conv_reset.0 / conv_state_tilde.0: state part, pair [32][9*32]
     const float* wx[3];           // ... constant-input part, f32 [9][6][32]
     const float* b0[3];
@@ -261,9 +293,45 @@ struct GruArgs {
     const float* b2[3];
     const unsigned char* wd0; const float* bd0;   // conv_decoder.0 / .2
     const unsigned char* wd2; const float* bd2;
+    unsigned* flags;          // [B][2], zero at launch: [0] states published by role 0, [1] update gates published by role 1
+    int* fault;               // the device's host-mapped fault word (dec_chain.hip): set if a wait gave up
+    int max_spin;
     long long* trace;         // debug (tt_dec_set_trace): wall-clock stamps of workgroup 0 after every phase, or null
 };
 
+// Flag hand-over between the two workgroups of a sample (agent scope: they may sit on different XCDs, whose L2s are not
+// coherent for plain stores).  post: every thread's stores of the phase, then thread 0 releases and bumps the flag.  wait:
+// thread 0 polls (bounded: a partner that is not running within max_spin polls makes the wait give up LOUDLY -- the device's
+// fault word is set and the caller poisons everything it writes from then on, as in tt_mlp_chain_wide), then acquires.
+__device__ __forceinline__ void flag_post(unsigned* f, unsigned value) {
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(f, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool flag_wait(const unsigned* f, unsigned target, int* fault, int max_spin, int* gave_up) {
+    if (threadIdx.x == 0) {
+        int spin = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spin > max_spin) {
+                __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                *gave_up = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    return *gave_up != 0;
+}
+
+// TWO workgroups per sample.  A step of the GRU is eight 441 x 32 x 288 convolutions, MFMA-bound on the one CU that ran them all
+// (~50 us a step on the batch-1 tick's critical path), but only four of them are on the recurrence:
+//   role 0 (blockIdx.x = 0): reset gate (conv_reset.0 / .2), candidate (conv_state_tilde.0 / .2 on (1 - r) * S), the blend
+//                            S' = (1 - u) * S + u * cand with the update gate it gets from role 1; publishes S';
+//   role 1:                  update gate (conv_update.0 / .2) of the state role 0 published, then -- off the recurrence -- the
+//                            decoder convs (conv_decoder.0 / .2) of that same state = the previous step's output map.
+// Every convolution is the one the single workgroup ran, on the same LDS image (pair(S) rebuilt from the published f32 state =
+// the pair the blend stored): results are bit-identical to it.
 __global__ __launch_bounds__(kGruWaves * 64) void dec_gru_kernel(const GruArgs a) {
     // LDS: two maps padded to 448 pixels (the epilogues store the 7 rows beyond pixel 440 of the last row block unguarded), the
     // zero page, the class sums [3 convs][16 class slots][32] (slot 15: rows beyond the map).
@@ -272,19 +340,18 @@ __global__ __launch_bounds__(kGruWaves * 64) void dec_gru_kernel(const GruArgs a
     unsigned char* Hmap = smem + kMapPixPad * kPS32;              // hidden map of the current two-conv block
     unsigned char* zero = Hmap + kMapPixPad * kPS32;              // 64 zero bytes
     float* Gc = reinterpret_cast<float*>(zero + 64);
+    __shared__ int gave_up;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
+    const int role = blockIdx.x, b = blockIdx.y;
     int tri = 0;
     auto stamp = [&]() {
-        if (a.trace && b == 0 && tid == 0 && tri < 64) a.trace[tri++] = (long long)wall_clock64();
+        if (a.trace && b == 0 && role == 0 && tid == 0 && tri < 64) a.trace[tri++] = (long long)wall_clock64();
     };
     stamp();
-    if (a.trace && b == 0 && tid == 0) a.trace[62] = (long long)clock64();      // shader-clock ticks (vs the 100 MHz stamps)
+    if (a.trace && b == 0 && role == 0 && tid == 0) a.trace[62] = (long long)clock64();      // shader-clock ticks (vs the 100 MHz stamps)
+    if (tid == 0) gave_up = 0;
     if (tid < 16) reinterpret_cast<uint32_t*>(zero)[tid] = 0u;
-    for (int e = tid; e < kMapPix * kMapC; e += kGruWaves * 64) {
-        const int pix = e >> 5, c = e & 31;
-        pair_store(Smap, kPS32, pix, c, a.state[(size_t)b * kMapPix * kMapC + e]);
-    }
+    load_map32<kGruWaves * 64>(Smap, a.state + (size_t)b * kMapPix * kMapC, tid);
     for (int e = tid; e < 3 * 16 * 32; e += kGruWaves * 64)
         if (((e >> 5) & 15) >= 9) Gc[e] = 0.f;      // slot 15 (rows beyond the map) and the unused slots: finite; 0-8 are written per step
     // The epilogues were the larger half of a conv (30-44 VALU instructions per accumulator element at 4 cycles each: pixel ->
@@ -316,13 +383,17 @@ __global__ __launch_bounds__(kGruWaves * 64) void dec_gru_kernel(const GruArgs a
     };
     auto row_of = [&](int q, int i) { return ml + q * 32 + (i & 3) + 8 * (i >> 2); };
     stamp();
-    float* ug = a.scratch + (size_t)b * 2 * kMapPixPad * kMapC;   // padded like the maps: written / read unguarded
+    float* ug = a.scratch + (size_t)b * 3 * kMapPixPad * kMapC;   // padded like the maps: written / read unguarded
     float* sg = ug + kMapPixPad * kMapC;
-    const float b2u = a.b2[0][r], b2r = a.b2[1][r], b2c = a.b2[2][r], bd0 = a.bd0[r], bd2 = a.bd2[r];
-    for (int t = 0; t < 4; ++t) {
-        // class sums of the constant-input contribution of the three first convs (+ their bias)
+    float* sn = sg + kMapPixPad * kMapC;
+    unsigned* f_state = a.flags + 2 * b;
+    unsigned* f_gate = f_state + 1;
+    bool poisoned = false;
+    const float kNaN = __builtin_nanf("");
+    // class sums of the constant-input contribution of the first convs cv0 .. cv1 (+ their bias) for step t
+    auto class_sums = [&](int t, int cv0, int cv1) {
         const float* x = a.inp6 + ((size_t)b * 4 + t) * 6;
-        for (int ge = tid; ge < 3 * 288; ge += kGruWaves * 64) {        // entry = (conv, class, n)
+        for (int ge = cv0 * 288 + tid; ge < (cv1 + 1) * 288; ge += kGruWaves * 64) {        // entry = (conv, class, n)
             const int cv = ge / 288, e = ge - cv * 288, cls = e >> 5, n = e & 31;
             const float* wxc = cv == 0 ? a.wx[0] : (cv == 1 ? a.wx[1] : a.wx[2]);
             const float* b0c = cv == 0 ? a.b0[0] : (cv == 1 ? a.b0[1] : a.b0[2]);
@@ -339,66 +410,88 @@ __global__ __launch_bounds__(kGruWaves * 64) void dec_gru_kernel(const GruArgs a
             }
             Gc[(cv * 16 + cls) * 32 + n] = s;
         }
-        __syncthreads();
-        stamp();
-        auto first_conv = [&](int cv) {    // H = relu(conv_cv.0([x, S]))
-            fresh_rows();
-            fresh_rows();
+    };
+    auto first_conv = [&](int cv) {    // H = relu(conv_cv.0([x, S]))
+        fresh_rows();
         conv3x3_map32<2>(Smap, zero, a.w0[cv], wave, kGruWaves, lane, [&](int, int q, int i, float v) {
-                v += Gc[(cv * 16 + cls_of(q, i)) * 32 + r];
-                pair_store(Hmap, kPS32, row_of(q, i), r, v > 0.f ? v : 0.f);
-            });
-        };
-        first_conv(0);
-        __syncthreads();
-        stamp();
-        fresh_rows();
-        conv3x3_map32<2>(Hmap, zero, a.w2[0], wave, kGruWaves, lane, [&](int, int q, int i, float v) {
-            ug[row_of(q, i) * kMapC + r] = sigmoid_fast(v + b2u);
-        });
-        __syncthreads();
-        stamp();
-        first_conv(1);
-        __syncthreads();
-        stamp();
-        fresh_rows();
-        conv3x3_map32<2>(Hmap, zero, a.w2[1], wave, kGruWaves, lane, [&](int, int q, int i, float v) {
-            const int m = row_of(q, i);
-            const float rg = sigmoid_fast(v + b2r);
-            const float s = pair_load(Smap, kPS32, m, r);
-            sg[m * kMapC + r] = s;
-            pair_store(Smap, kPS32, m, r, (1.f - rg) * s);        // own element only: no other reader now
-        });
-        __syncthreads();
-        stamp();
-        first_conv(2);
-        __syncthreads();
-        stamp();
-        fresh_rows();
-        conv3x3_map32<2>(Hmap, zero, a.w2[2], wave, kGruWaves, lane, [&](int, int q, int i, float v) {
-            const int m = row_of(q, i);
-            const float cand = v + b2c;
-            const float u = ug[m * kMapC + r];
-            pair_store(Smap, kPS32, m, r, (1.f - u) * sg[m * kMapC + r] + u * cand);
-        });
-        __syncthreads();
-        stamp();
-        fresh_rows();
-        conv3x3_map32<2>(Smap, zero, a.wd0, wave, kGruWaves, lane, [&](int, int q, int i, float v) {
-            v += bd0;
+            v += Gc[(cv * 16 + cls_of(q, i)) * 32 + r];
             pair_store(Hmap, kPS32, row_of(q, i), r, v > 0.f ? v : 0.f);
         });
-        __syncthreads();
-        stamp();
-        float* fo = a.fut + (((size_t)b * 4 + t) * kMapPix) * kMapC;
-        fresh_rows();
-        conv3x3_map32<2>(Hmap, zero, a.wd2, wave, kGruWaves, lane, [&](int, int q, int i, float v) {
-            if (cls_of(q, i) != 15) fo[(size_t)row_of(q, i) * kMapC + r] = v + bd2;      // global output: exactly 441 rows
-        });
-        __syncthreads();
-        stamp();
+    };
+    if (role == 0) {
+        // ---------------------------------------------------------------- the recurrence
+        const float b2r = a.b2[1][r], b2c = a.b2[2][r];
+        for (int t = 0; t < 4; ++t) {
+            class_sums(t, 1, 2);
+            __syncthreads();
+            stamp();
+            first_conv(1);
+            __syncthreads();
+            stamp();
+            fresh_rows();
+            conv3x3_map32<2>(Hmap, zero, a.w2[1], wave, kGruWaves, lane, [&](int, int q, int i, float v) {
+                const int m = row_of(q, i);
+                const float rg = sigmoid_fast(v + b2r);
+                const float s = pair_load(Smap, kPS32, m, r);
+                sg[m * kMapC + r] = s;
+                pair_store(Smap, kPS32, m, r, (1.f - rg) * s);        // own element only: no other reader now
+            });
+            __syncthreads();
+            stamp();
+            first_conv(2);
+            __syncthreads();
+            stamp();
+            poisoned = flag_wait(f_gate, (unsigned)(t + 1), a.fault, a.max_spin, &gave_up) || poisoned;     // update gate of step t
+            fresh_rows();
+            conv3x3_map32<2>(Hmap, zero, a.w2[2], wave, kGruWaves, lane, [&](int, int q, int i, float v) {
+                const int m = row_of(q, i);
+                const float cand = v + b2c;
+                const float u = ug[m * kMapC + r];
+                float ns = (1.f - u) * sg[m * kMapC + r] + u * cand;
+                if (poisoned) ns = kNaN;
+                pair_store(Smap, kPS32, m, r, ns);
+                sn[m * kMapC + r] = ns;
+            });
+            flag_post(f_state, (unsigned)(t + 1));
+            stamp();
+        }
+    } else {
+        // ---------------------------------------------------------------- update gate + decoder
+        const float b2u = a.b2[0][r], bd0 = a.bd0[r], bd2 = a.bd2[r];
+        for (int t = 0; t <= 4; ++t) {
+            if (t < 4) class_sums(t, 0, 0);
+            if (t > 0) {       // the state after step t - 1
+                poisoned = flag_wait(f_state, (unsigned)t, a.fault, a.max_spin, &gave_up) || poisoned;
+                load_map32<kGruWaves * 64>(Smap, sn, tid);
+            }
+            __syncthreads();
+            if (t < 4) {
+                first_conv(0);
+                __syncthreads();
+                fresh_rows();
+                conv3x3_map32<2>(Hmap, zero, a.w2[0], wave, kGruWaves, lane, [&](int, int q, int i, float v) {
+                    ug[row_of(q, i) * kMapC + r] = poisoned ? kNaN : sigmoid_fast(v + b2u);
+                });
+                flag_post(f_gate, (unsigned)(t + 1));
+            }
+            if (t > 0) {
+                __syncthreads();
+                fresh_rows();
+                conv3x3_map32<2>(Smap, zero, a.wd0, wave, kGruWaves, lane, [&](int, int q, int i, float v) {
+                    v += bd0;
+                    pair_store(Hmap, kPS32, row_of(q, i), r, v > 0.f ? v : 0.f);
+                });
+                __syncthreads();
+                float* fo = a.fut + (((size_t)b * 4 + (t - 1)) * kMapPix) * kMapC;
+                fresh_rows();
+                conv3x3_map32<2>(Hmap, zero, a.wd2, wave, kGruWaves, lane, [&](int, int q, int i, float v) {
+                    if (cls_of(q, i) != 15) fo[(size_t)row_of(q, i) * kMapC + r] = poisoned ? kNaN : v + bd2;      // exactly 441 rows
+                });
+                __syncthreads();
+            }
+        }
     }
-    if (a.trace && b == 0 && tid == 0) a.trace[63] = (long long)clock64();
+    if (a.trace && b == 0 && role == 0 && tid == 0) a.trace[63] = (long long)clock64();
 }
 
 // ------------------------------------------------------------------------------------------------ grid2feat
@@ -506,7 +599,7 @@ __global__ __launch_bounds__(kFlatWaves * 64) void dec_flatten_kernel(const Flat
 
     if (tid < 16) reinterpret_cast<uint32_t*>(zero)[tid] = 0u;
     const float* src = a.in + (size_t)map * kMapPix * kMapC;
-    for (int e = tid; e < kMapPix * kMapC; e += kFlatWaves * 64) pair_store(Rin, kPS32, e >> 5, e & 31, src[e]);
+    load_map32<kFlatWaves * 64>(Rin, src, tid);
     __syncthreads();
     stamp();
     // conv21_10: 3x3 stride 2, no padding, 32 -> 64, ReLU
@@ -727,26 +820,33 @@ struct BevArgs {
     const float* b0;          // [128]
     const unsigned char* w2[4];   // pair [32][9*32] each: BEV_feat_update_module.2 restricted to hidden channels 32c..32c+31
     const float* b2;          // [32]
+    float* part;              // scratch [B][4][448][32] f32: the four hidden-channel chunks' partial outputs
+    unsigned* tickets;        // [B], zero at launch
 };
 
+// One workgroup per (sample, chunk of 32 hidden channels): out = sum_c conv2_c(relu(conv0_c([bev, h]))) + b2 + bev.  A sample
+// is eight 441 x 32 x 288 convolutions, MFMA-bound on the ONE CU that ran them (58 us on the batch-1 tick's critical path);
+// dealt over four CUs, the last workgroup of a sample to finish adds the four partial maps IN CHUNK ORDER -- the order the
+// single workgroup accumulated them in its registers, so the result is bit-identical to it.
 __global__ __launch_bounds__(kBevWaves * 64) void dec_bev_update_kernel(const BevArgs a) {
     // (maps padded to 448 pixels, 16 class slots, packed border classes: see dec_gru_kernel)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Bmap = smem;
     unsigned char* Hmap = smem + kMapPixPad * kPS32;
     unsigned char* zero = Hmap + kMapPixPad * kPS32;
-    float* Gc = reinterpret_cast<float*>(zero + 64);              // [16 class slots][128], bias included
+    float* Gc = reinterpret_cast<float*>(zero + 64);              // [16 class slots][32], bias included
+    __shared__ unsigned s_old;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
+    const int c = blockIdx.x, b = blockIdx.y;
     if (tid < 16) reinterpret_cast<uint32_t*>(zero)[tid] = 0u;
     const float* src = a.bev + (size_t)b * kMapPix * kMapC;
-    for (int e = tid; e < kMapPix * kMapC; e += kBevWaves * 64) pair_store(Bmap, kPS32, e >> 5, e & 31, src[e]);
-    const float* g = a.G + (size_t)b * 9 * 128;
-    for (int e = tid; e < 16 * 128; e += kBevWaves * 64) {
-        const int cls = e >> 7, n = e & 127;
+    load_map32<kBevWaves * 64>(Bmap, src, tid);
+    const float* g = a.G + (size_t)b * 9 * 128 + c * 32;
+    for (int e = tid; e < 16 * 32; e += kBevWaves * 64) {
+        const int cls = e >> 5, n = e & 31;
         float s = 0.f;
         if (cls < 9) {
-            s = a.b0[n];
+            s = a.b0[c * 32 + n];
             for (int kh = 0; kh < 3; ++kh)
                 for (int kw = 0; kw < 3; ++kw)
                     if (tap_valid(cls, kh, kw)) s += g[(kh * 3 + kw) * 128 + n];
@@ -767,36 +867,39 @@ __global__ __launch_bounds__(kBevWaves * 64) void dec_bev_update_kernel(const Be
         }
     }
     __syncthreads();
-    f32x16 out_acc[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) out_acc[q][i] = 0.f;
-    for (int c = 0; c < 4; ++c) {
-        int ml = m_lane;
+    int ml = m_lane;
 #if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+v"(ml));
+    asm volatile("" : "+v"(ml));
 #endif
-        conv3x3_map32<2>(Bmap, zero, a.w0 + (size_t)c * 32 * (9 * 32 * 4), wave, kBevWaves, lane,
-                         [&](int, int q, int i, float v) {
-                             v += Gc[(int)((clsp[q] >> (4 * i)) & 15ull) * 128 + c * 32 + r];
-                             pair_store(Hmap, kPS32, ml + q * 32 + (i & 3) + 8 * (i >> 2), r, v > 0.f ? v : 0.f);
-                         });
-        __syncthreads();
-        conv3x3_map32<2>(Hmap, zero, a.w2[c], wave, kBevWaves, lane, [&](int, int q, int i, float v) { out_acc[q][i] += v; });
-        __syncthreads();
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = wave * 64 + q * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (m < kMapPix) {
-                const float v = out_acc[q][i] + a.b2[r] + src[(size_t)m * kMapC + r];
-                a.out[(size_t)b * a.out_bstride + (size_t)m * kMapC + r] = v;
-                if (a.out2) a.out2[(size_t)b * a.out2_bstride + (size_t)m * kMapC + r] = v;
-            }
-        }
+    conv3x3_map32<2>(Bmap, zero, a.w0 + (size_t)c * 32 * (9 * 32 * 4), wave, kBevWaves, lane,
+                     [&](int, int q, int i, float v) {
+                         v += Gc[(int)((clsp[q] >> (4 * i)) & 15ull) * 32 + r];
+                         pair_store(Hmap, kPS32, ml + q * 32 + (i & 3) + 8 * (i >> 2), r, v > 0.f ? v : 0.f);
+                     });
+    __syncthreads();
+    // the chunk's partial output: all 448 rows of the padded map (the buffer is padded likewise), read back by one workgroup
+    float* mine = a.part + ((size_t)b * 4 + c) * kMapPixPad * kMapC;
+    conv3x3_map32<2>(Hmap, zero, a.w2[c], wave, kBevWaves, lane, [&](int, int q, int i, float v) {
+        mine[(size_t)(ml + q * 32 + (i & 3) + 8 * (i >> 2)) * kMapC + r] = v;
+    });
+    // last workgroup of the sample: agent-scope release of the partial map, ticket, acquire (the XCDs' L2s are not coherent
+    // with each other for plain stores)
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_old = __hip_atomic_fetch_add(a.tickets + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_old != 3u) return;
+    __threadfence();
+    const float* p = a.part + (size_t)b * 4 * kMapPixPad * kMapC;
+    constexpr int kChunk = kMapPixPad * kMapC;
+    for (int e = tid; e < kMapPix * kMapC; e += kBevWaves * 64) {
+        float acc = __builtin_nontemporal_load(p + e);
+        acc += __builtin_nontemporal_load(p + kChunk + e);
+        acc += __builtin_nontemporal_load(p + 2 * kChunk + e);
+        acc += __builtin_nontemporal_load(p + 3 * kChunk + e);
+        const float v = acc + a.b2[e & 31] + src[e];
+        a.out[(size_t)b * a.out_bstride + e] = v;
+        if (a.out2) a.out2[(size_t)b * a.out2_bstride + e] = v;
     }
 }
 
@@ -810,10 +913,15 @@ extern "C" int tt_dec_set_trace(void* stamps_or_null) {
     return 0;
 }
 
+extern "C" long long tt_dec_gru_scratch_floats(int B) { return (long long)B * (3 * kMapPixPad * kMapC + 2); }
+
 extern "C" int tt_dec_gru(int B, const float* inp6, const float* state, float* fut, float* scratch, const void* const* w0,
                           const float* const* wx, const float* const* b0, const void* const* w2, const float* const* b2,
                           const void* wd0, const float* bd0, const void* wd2, const float* bd2, void* stream) {
     TT_REQUIRE(B > 0 && inp6 && state && fut && scratch && w0 && wx && b0 && w2 && b2 && wd0 && bd0 && wd2 && bd2, "tt_dec_gru: null");
+    TT_REQUIRE((reinterpret_cast<uintptr_t>(state) & 15) == 0 && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0,
+               "tt_dec_gru: state / scratch must be 16 B aligned");
+    if (int rc = refuse_after_fault("tt_dec_gru")) return rc;
     GruArgs a;
     a.inp6 = inp6; a.state = state; a.fut = fut; a.scratch = scratch;
     for (int c = 0; c < 3; ++c) {
@@ -823,6 +931,14 @@ extern "C" int tt_dec_gru(int B, const float* inp6, const float* state, float* f
     }
     a.wd0 = (const unsigned char*)wd0; a.bd0 = bd0; a.wd2 = (const unsigned char*)wd2; a.bd2 = bd2;
     a.trace = g_dec_trace;
+    // the two workgroups of a sample hand the state / the update gate over through flags behind the scratch maps (zeroed here,
+    // on the stream: recordable into a HIP graph); a wait that gives up sets the device's fault word (dec_chain.hip)
+    a.flags = reinterpret_cast<unsigned*>(scratch + (size_t)B * 3 * kMapPixPad * kMapC);
+    a.fault = device_fault_word();
+    TT_REQUIRE(a.fault, "tt_dec_gru: cannot allocate the host-mapped fault word");
+    a.max_spin = pair_wait_max_spin();
+    TT_REQUIRE(hipMemsetAsync(a.flags, 0, (size_t)B * 2 * sizeof(unsigned), (hipStream_t)stream) == hipSuccess,
+               "tt_dec_gru: hipMemsetAsync failed");
     const size_t smem = (size_t)2 * kMapPixPad * kPS32 + 64 + 3 * 16 * 32 * 4;
     static bool attr = false;
     if (!attr) {
@@ -830,7 +946,7 @@ extern "C" int tt_dec_gru(int B, const float* inp6, const float* state, float* f
                                   (int)smem);
         attr = true;
     }
-    hipLaunchKernelGGL(dec_gru_kernel, dim3((unsigned)B), dim3(kGruWaves * 64), smem, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(dec_gru_kernel, dim3(2u, (unsigned)B), dim3(kGruWaves * 64), smem, (hipStream_t)stream, a);
     return check_launch("tt_dec_gru");
 }
 
@@ -843,6 +959,8 @@ extern "C" int tt_dec_flatten(int maps, const float* in, float* out, float* mids
                               const void* const* w, const float* const* b, const float* bn_scale, const float* bn_shift,
                               void* stream) {
     TT_REQUIRE(maps > 0 && in && out && scratch && w && b && bn_scale && bn_shift, "tt_dec_flatten: null");
+    TT_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(mids_or_null) & 15) == 0, "tt_dec_flatten: in / scratch / mids must be 16 B aligned");
     FlatArgs a;
     a.in = in; a.out = out; a.mids = mids_or_null; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
     a.trace = g_dec_trace;
@@ -906,10 +1024,13 @@ extern "C" int tt_dec_flatten(int maps, const float* in, float* out, float* mids
     return check_launch("tt_dec_flatten");
 }
 
+extern "C" long long tt_dec_bev_update_scratch_floats(int B) { return (long long)B * (4 * kMapPixPad * kMapC + 1); }
+
 extern "C" int tt_dec_bev_update(int B, const float* bev, const float* G, float* out, long long out_bstride, float* out2,
-                                 long long out2_bstride, const void* w0, const float* b0, const void* const* w2,
-                                 const float* b2, void* stream) {
-    TT_REQUIRE(B > 0 && bev && G && out && w0 && b0 && w2 && b2, "tt_dec_bev_update: null");
+                                 long long out2_bstride, float* scratch, const void* w0, const float* b0,
+                                 const void* const* w2, const float* b2, void* stream) {
+    TT_REQUIRE(B > 0 && bev && G && out && scratch && w0 && b0 && w2 && b2, "tt_dec_bev_update: null");
+    TT_REQUIRE((reinterpret_cast<uintptr_t>(bev) & 15) == 0, "tt_dec_bev_update: bev must be 16 B aligned");
     BevArgs a;
     a.bev = bev; a.G = G; a.out = out; a.out2 = out2; a.out_bstride = out_bstride; a.out2_bstride = out2_bstride;
     a.w0 = (const unsigned char*)w0; a.b0 = b0; a.b2 = b2;
@@ -917,13 +1038,17 @@ extern "C" int tt_dec_bev_update(int B, const float* bev, const float* G, float*
         TT_REQUIRE(w2[c], "tt_dec_bev_update: null w2[%d]", c);
         a.w2[c] = (const unsigned char*)w2[c];
     }
-    const size_t smem = (size_t)2 * kMapPixPad * kPS32 + 64 + 16 * 128 * 4;
+    a.part = scratch;
+    a.tickets = reinterpret_cast<unsigned*>(scratch + (size_t)B * 4 * kMapPixPad * kMapC);
+    TT_REQUIRE(hipMemsetAsync(a.tickets, 0, (size_t)B * sizeof(unsigned), (hipStream_t)stream) == hipSuccess,
+               "tt_dec_bev_update: hipMemsetAsync failed");
+    const size_t smem = (size_t)2 * kMapPixPad * kPS32 + 64 + 16 * 32 * 4;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bev_update_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr = true;
     }
-    hipLaunchKernelGGL(dec_bev_update_kernel, dim3((unsigned)B), dim3(kBevWaves * 64), smem, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(dec_bev_update_kernel, dim3(4u, (unsigned)B), dim3(kBevWaves * 64), smem, (hipStream_t)stream, a);
     return check_launch("tt_dec_bev_update");
 }

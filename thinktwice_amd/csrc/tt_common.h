@@ -13,6 +13,10 @@ void set_error(const char* fmt, ...);
 // Non-zero (and the error text set) if a tt_mlp_chain_wide barrier has timed out on the current device since the last
 // tt_clear_device_faults(): forward entry points return it first (csrc/dec_chain.hip).
 int refuse_after_fault(const char* what);
+// The current device's host-mapped fault word (allocated on first use; null on failure) and the poll bound of a cross-workgroup
+// wait (tt_mlp_chain_wide_set_max_spin): for kernels whose workgroups wait for each other (tt_mlp_chain_wide, tt_dec_gru).
+int* device_fault_word();
+int pair_wait_max_spin();
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

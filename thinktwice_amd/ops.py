@@ -1214,10 +1214,12 @@ def dec_gru(wts, inp6, state, fut):
     """wts: dict from decoder_fused.prep_gru; inp6 (B,4,6), state (B,441,32), fut (B,4,441,32) all f32 contiguous."""
     B = state.shape[0]
     assert inp6.is_contiguous() and state.is_contiguous() and fut.is_contiguous()
-    scratch = torch.empty(B, 2, 448, 32, dtype=torch.float32, device=state.device)       # 441 pixels padded to 14 x 32 rows
-    check(lib().tt_dec_gru(_c(B), ptr(inp6), ptr(state), ptr(fut), ptr(scratch), wts["w0"], wts["wx"], wts["b0"],
-                           wts["w2"], wts["b2"], ptr(wts["wd0"]), ptr(wts["bd0"]), ptr(wts["wd2"]), ptr(wts["bd2"]),
-                           _st(state)), "tt_dec_gru")
+    L = lib()
+    L.tt_dec_gru_scratch_floats.restype = ctypes.c_longlong
+    scratch = torch.empty(L.tt_dec_gru_scratch_floats(_c(B)), dtype=torch.float32, device=state.device)
+    check(L.tt_dec_gru(_c(B), ptr(inp6), ptr(state), ptr(fut), ptr(scratch), wts["w0"], wts["wx"], wts["b0"],
+                       wts["w2"], wts["b2"], ptr(wts["wd0"]), ptr(wts["bd0"]), ptr(wts["wd2"]), ptr(wts["bd2"]),
+                       _st(state)), "tt_dec_gru")
     return fut
 
 
@@ -1239,6 +1241,9 @@ def dec_bev_update(wts, bev, G, out):
     """bev (B,441,32), G (B,1152) -> out (B,441,32) (all f32 contiguous)."""
     B = bev.shape[0]
     assert bev.is_contiguous() and G.is_contiguous() and out.is_contiguous()
-    check(lib().tt_dec_bev_update(_c(B), ptr(bev), ptr(G), ptr(out), _ll(441 * 32), None, _ll(0), ptr(wts["w0"]),
-                                  ptr(wts["b0"]), wts["w2"], ptr(wts["b2"]), _st(bev)), "tt_dec_bev_update")
+    L = lib()
+    L.tt_dec_bev_update_scratch_floats.restype = ctypes.c_longlong
+    scratch = torch.empty(L.tt_dec_bev_update_scratch_floats(_c(B)), dtype=torch.float32, device=bev.device)
+    check(L.tt_dec_bev_update(_c(B), ptr(bev), ptr(G), ptr(out), _ll(441 * 32), None, _ll(0), ptr(scratch), ptr(wts["w0"]),
+                              ptr(wts["b0"]), wts["w2"], ptr(wts["b2"]), _st(bev)), "tt_dec_bev_update")
     return out

@@ -3,9 +3,9 @@
 ROOT="$GRAFT_REPO_ROOT"; cd $ROOT; mkdir -p gpurun_out; O=$ROOT/gpurun_out/r06_t.txt; rm -f $O
 timeout 600 python -m pytest tests/test_decoder_fused.py -x -q -m gpu 2>&1 | tail -15 | tee -a $O
 timeout 300 python tools/dec_microbench.py 2>&1 | grep "flatten\|gru\|bev_update" | tee -a $O
-timeout 300 python tools/dec_trace.py 2>&1 | grep -A2 "flatten" | tee -a $O
+timeout 300 python tools/dec_trace.py 2>&1 | grep -A2 "flatten\|gru" | tee -a $O
 if [ "$QUICK" != "1" ]; then
-timeout 900 python -m pytest tests/test_decoder.py tests/test_agent_tick.py -x -q -m gpu 2>&1 | tail -3 | tee -a $O
+timeout 900 python -m pytest tests/test_decoder.py tests/test_agent_tick.py tests/test_plan.py -x -q -m gpu 2>&1 | tail -3 | tee -a $O
 timeout 300 python tools/pipeline_ab.py 20 1 2>&1 | grep "in flight" | head -2 | tee -a $O
 fi
 cd /tmp && export TMPDIR=/tmp
