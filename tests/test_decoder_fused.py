@@ -39,6 +39,43 @@ def test_gru_kernel_matches_oracle(sd_cfg, B):
     assert _rel(got, ref) < 1e-3, _rel(got, ref)
 
 
+def test_gru_handover_timeout_is_loud_and_recoverable(sd_cfg):
+    """tt_dec_gru runs two workgroups per sample that hand the state / the update gate over through flags.  With the wait bound
+    forced to 0 polls (tt_mlp_chain_wide_set_max_spin, shared with the wide chain) the first wait gives up: the future maps are
+    NaN, the device's fault word is set and the next launch is refused; after clear_device_faults() the results are the
+    earlier ones again, bit for bit."""
+    from thinktwice_amd import _lib, decoder_fused as DF, ops
+    sd, _ = sd_cfg
+    L = _lib.lib()
+    w = DF.prep_gru(sd, "decoder.decoder_layers.0.prediction_module.spatial_gru", "cuda")
+    g = torch.Generator().manual_seed(9)
+    B = 2
+    inp6 = torch.randn(B, 4, 6, generator=g).cuda()
+    state = (torch.randn(B, 441, 32, generator=g) * 0.5).cuda()
+
+    def run():
+        fut = torch.zeros(B, 4, 441, 32, device="cuda")
+        ops.dec_gru(w, inp6, state, fut)
+        torch.cuda.synchronize()
+        return fut.cpu()
+
+    assert ops.device_faults() == 0
+    good = run()
+    assert torch.isfinite(good).all()
+    try:
+        L.tt_mlp_chain_wide_set_max_spin(0)
+        bad = run()
+        assert torch.isnan(bad).any(), "a timed-out hand-over must poison the outputs"
+        assert ops.device_faults() == 1
+        with pytest.raises(_lib.TTError, match="gave up waiting"):
+            run()                                            # sticky: the next launch is refused
+    finally:
+        L.tt_mlp_chain_wide_set_max_spin(-1)
+        ops.clear_device_faults()
+    for _ in range(3):
+        assert torch.equal(run(), good)
+
+
 @pytest.mark.parametrize("N", [6, 35])      # 35 maps: more than one group of maps at every level of the column-split tail
 def test_flatten_kernel_matches_oracle(sd_cfg, N):
     """tt_dec_flatten (one workgroup per map up to conv10_4, then dec_tail_conv_kernel per layer over all maps' rows)."""
