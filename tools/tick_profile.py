@@ -1,4 +1,5 @@
-"""Batch-1 closed-loop tick under a profiler (tools only):  rocprofv3 --kernel-trace --stats -- python tools/tick_profile.py [dtype] [iters]"""
+"""Closed-loop tick (batch 1; or one forward of [batch] frames) under a profiler (tools only):
+rocprofv3 --kernel-trace --stats -- python tools/tick_profile.py [dtype] [iters] [batch]"""
 import os
 import sys
 import time
@@ -11,10 +12,11 @@ from thinktwice_amd import model as tm, params, synth  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "f32x3"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}.get(mode, mode)
 m, cfg = tm.build_thinktwice(dtype=dt)
 m.load_state_dict(params.init_params(cfg, seed=0))
-b1 = tm.batch_to_device(synth.make_batch(1, seed=4321))
+b1 = tm.batch_to_device(synth.make_batch(batch, seed=4321))
 for _ in range(2):
     m.forward_inference(b1, channel_last_out=True)
 torch.cuda.synchronize()
