@@ -499,3 +499,24 @@ def test_pair_formats_hold_hi_and_lo_halves_in_the_documented_places():
     assert float((ph[:, :, 0].float() + ph[:, :, 1].float() - flat).abs().max()) < 2 ** -20 * float(flat.abs().max())
     assert weights.is_x3("f32x3") and weights.is_x3("f32x3h") and not weights.is_x3(torch.float32)
     assert weights.storage_dtype("f32x3h") == torch.float32 and weights.storage_dtype("h2") == torch.float16
+
+
+def test_decoder_scratch_queries_and_null_scratch_refusals():
+    """Round 6: tt_dec_flatten / tt_dec_gru / tt_dec_bev_update run on more than one workgroup per sample and take a scratch buffer
+    sized by a host-side query (no GPU needed); a null scratch pointer is refused before anything is launched."""
+    import ctypes
+    from thinktwice_amd import _lib
+    L = _lib.lib()
+    for f in (L.tt_dec_flatten_scratch_floats, L.tt_dec_gru_scratch_floats, L.tt_dec_bev_update_scratch_floats):
+        f.restype = ctypes.c_longlong
+    # grid2feat tail: x4, MLP4's two hidden maps, pooled fc1 output, gate, block output; the 2x2 level likewise; fc0's output
+    per_map = 2048 + 4096 + 2048 + 128 + 128 + 2048 + 1024 + 2048 + 1024 + 256 + 256 + 1024 + 512
+    assert L.tt_dec_flatten_scratch_floats(4) == 4 * per_map and L.tt_dec_flatten_scratch_floats(35) == 35 * per_map
+    assert L.tt_dec_gru_scratch_floats(8) == 8 * (3 * 448 * 32 + 2)             # gate, previous state, new state + two flag words
+    assert L.tt_dec_bev_update_scratch_floats(8) == 8 * (4 * 448 * 32 + 1)      # four partial maps + a ticket
+    one = ctypes.c_void_p(16)                                                     # any non-null, 16 B aligned address: never dereferenced
+    assert L.tt_dec_flatten(ctypes.c_int(1), one, one, None, None, one, one, one, one, None) == -1
+    assert b"null" in L.tt_last_error()
+    assert L.tt_dec_gru(ctypes.c_int(1), one, one, one, None, one, one, one, one, one, one, one, one, one, None) == -1
+    assert L.tt_dec_bev_update(ctypes.c_int(1), one, one, one, ctypes.c_longlong(0), None, ctypes.c_longlong(0), None, one, one,
+                               one, one, None) == -1
